@@ -1,0 +1,76 @@
+"""Loader of the CPU parity oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg -- never by
+anything under stochqn_amd/ (the product path has no CPU fallback).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+from stochqn_amd import _abi  # noqa: E402  (declarations only; does not load the HIP library)
+
+SO = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "stochqn_oracle.c")
+    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return SO
+
+
+_lib = None
+_bound = None
+
+
+def cdll():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        d, vp, i, sz = C.c_double, C.c_void_p, C.c_int, C.c_size_t
+        _lib.oracle_set_threads.argtypes = [i]
+        _lib.oracle_get_threads.restype = i
+        _lib.oracle_two_loop.restype = None
+        _lib.oracle_two_loop.argtypes = [vp, i, vp, d, vp, vp, sz, sz, sz, vp, vp]
+        _lib.oracle_diag_rescale.restype = None
+        _lib.oracle_diag_rescale.argtypes = [vp, vp, vp, i, d, d]
+        _lib.oracle_fisher_product.restype = None
+        _lib.oracle_fisher_product.argtypes = [vp, sz, i, vp, vp, vp]
+        _lib.oracle_take_step.restype = None
+        _lib.oracle_take_step.argtypes = [d, i, vp, vp, C.POINTER(_abi.bfgs_mem), d, vp, d, vp, d, i, C.POINTER(i)]
+    return _lib
+
+
+def bound():
+    """The oracle's run_*/initialize_*/dealloc_* bound with the same prototypes as the product."""
+    global _bound
+    if _bound is None:
+        _bound = _abi.Bound(cdll(), prefix="oracle_")
+    return _bound
+
+
+def set_threads(n):
+    cdll().oracle_set_threads(int(n))
+
+
+def two_loop(q, H0, h0, Y, S, m, used, st):
+    """In-place two-loop on numpy arrays; returns (rho, alpha). Y, S are [m*n] row-major."""
+    import numpy as np
+    n = q.shape[0]
+    rho = np.zeros(m)
+    alpha = np.zeros(m)
+    cdll().oracle_two_loop(q.ctypes.data, n, None if H0 is None else H0.ctypes.data, float(h0),
+                           Y.ctypes.data, S.ctypes.data, m, used, st, rho.ctypes.data, alpha.ctypes.data)
+    return rho, alpha
+
+
+def fisher_product(F, fu, s):
+    import numpy as np
+    n = s.shape[0]
+    t = np.zeros(fu)
+    y = np.zeros(n)
+    cdll().oracle_fisher_product(F.ctypes.data, fu, n, s.ctypes.data, t.ctypes.data, y.ctypes.data)
+    return t, y

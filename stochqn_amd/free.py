@@ -1,0 +1,337 @@
+"""Free-mode optimiser objects over the C ABI -- the host-side mirror of the reference's Python layer.
+
+Mirrors reference stochqn/_optimizers.py:791-1364: the `_*_holder` classes that own every state
+array (sizes as in `_optimizers.py:791-879`, including the 1-element place-holders), and the
+`oLBFGS_free / SQN_free / adaQN_free` objects with `run_optimizer`, `update_gradient`,
+`update_hess_vec`, `update_function` and the same request dictionary.  Per call the C structs are
+rebuilt from the Python-side arrays and counters, and the counters are copied back afterwards,
+exactly as reference stochqn/pywrapper.pxi:89-207 does ("profile B" of SURVEY.md section 8b).
+
+Two memory spaces are supported:
+  * ``space="host"``   -- numpy arrays, what the reference's Python package passes;
+  * ``space="device"`` -- torch double tensors on the GPU; the library then works on them in place.
+
+The arithmetic is done by whatever library `backend` wraps: `stochqn_amd.lib()` (the HIP library;
+default) or, in the test-suite only, the CPU oracle.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+# ----------------------------------------------------------------------------------------------
+# array spaces
+# ----------------------------------------------------------------------------------------------
+class _HostSpace:
+    name = "host"
+
+    @staticmethod
+    def empty(n):
+        # the reference uses np.empty; zeros keeps runs reproducible and is a legal instance of it
+        return np.zeros(int(n), dtype=np.float64)
+
+    zeros = empty
+
+    @staticmethod
+    def ptr(a):
+        return a.ctypes.data
+
+    @staticmethod
+    def assign(dst, src):
+        dst[:] = np.asarray(src, dtype=np.float64).reshape(-1)
+
+    @staticmethod
+    def is_array(a):
+        return isinstance(a, np.ndarray) and a.dtype == np.float64
+
+
+class _DeviceSpace:
+    name = "device"
+
+    def __init__(self, device=None):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device if device is not None else "cuda")
+
+    def empty(self, n):
+        return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)
+
+    zeros = empty
+
+    @staticmethod
+    def ptr(a):
+        return a.data_ptr()
+
+    def assign(self, dst, src):
+        if not isinstance(src, self.torch.Tensor):
+            src = self.torch.as_tensor(np.asarray(src, dtype=np.float64))
+        dst.copy_(src.reshape(-1))
+
+    def is_array(self, a):
+        return isinstance(a, self.torch.Tensor) and a.dtype == self.torch.float64 and a.is_cuda
+
+
+def _space(space, device=None):
+    if space == "host":
+        return _HostSpace()
+    if space == "device":
+        return _DeviceSpace(device)
+    raise ValueError("space must be 'host' or 'device'")
+
+
+# ----------------------------------------------------------------------------------------------
+# state holders (reference stochqn/_optimizers.py:791-879)
+# ----------------------------------------------------------------------------------------------
+class _BFGS_mem_holder:
+    def __init__(self, sp, mem_size, n, min_curvature, y_reg, upd_freq):
+        self.s_mem = sp.empty(n * mem_size)
+        self.y_mem = sp.empty(n * mem_size)
+        self.buffer_rho = np.zeros(mem_size)      # tiny, always host: read back by callers
+        self.buffer_alpha = np.zeros(mem_size)
+        k = n if min_curvature > 0 else 1
+        self.s_bak = sp.empty(k)
+        self.y_bak = sp.empty(k)
+        self.mem_size, self.mem_used, self.mem_st_ix = int(mem_size), 0, 0
+        self.upd_freq = int(upd_freq)
+        self.y_reg, self.min_curvature = float(y_reg), float(min_curvature)
+
+    def c_struct(self, sp):
+        return _abi.bfgs_mem(sp.ptr(self.s_mem), sp.ptr(self.y_mem),
+                             self.buffer_rho.ctypes.data, self.buffer_alpha.ctypes.data,
+                             sp.ptr(self.s_bak), sp.ptr(self.y_bak),
+                             self.mem_size, self.mem_used, self.mem_st_ix, self.upd_freq,
+                             self.y_reg, self.min_curvature)
+
+
+class _Fisher_mem_holder:
+    def __init__(self, sp, mem_size, n):
+        self.F = sp.empty(n * mem_size)
+        self.buffer_y = np.zeros(mem_size)
+        self.mem_size, self.mem_used, self.mem_st_ix = int(mem_size), 0, 0
+
+    def c_struct(self, sp):
+        return _abi.fisher_mem(sp.ptr(self.F), self.buffer_y.ctypes.data,
+                               self.mem_size, self.mem_used, self.mem_st_ix)
+
+
+_TASK = _abi.TASKS
+_INFO = _abi.INFOS
+
+
+class _StochQN_free:
+    """Shared argument handling (reference stochqn/_optimizers.py:881-935)."""
+
+    def _take_common_inputs(self, mem_size, min_curvature, y_reg, check_nan, nthreads, space, device, backend):
+        assert isinstance(mem_size, int) and mem_size > 0
+        if min_curvature is not None:
+            assert min_curvature > 0
+        else:
+            min_curvature = 0
+        if y_reg is not None:
+            assert y_reg > 0
+        else:
+            y_reg = 0
+        if nthreads is None or nthreads <= 0:
+            nthreads = 1
+        self.mem_size = mem_size
+        self.min_curvature = min_curvature
+        self.y_reg = y_reg
+        self.check_nan = bool(check_nan)
+        self.nthreads = int(nthreads)
+        self._sp = _space(space, device)
+        if backend is None:
+            from . import lib
+            backend = lib()
+        self._be = backend
+        self.initialized = False
+
+    def update_gradient(self, gradient):
+        """Hand over the gradient that the last request asked for."""
+        self._sp.assign(self.gradient, gradient)
+
+    # -- helpers -----------------------------------------------------------------------------
+    def _check_x(self, x):
+        if not self._sp.is_array(x):
+            raise ValueError("'x' has wrong dtype or lives in the wrong memory space.")
+        if not self.initialized:
+            self._initialize(int(x.shape[0]))
+
+    def _resolve(self, ptr, x, candidates):
+        """Map a returned `*req` address back onto the array it aliases."""
+        n = self._n
+        if ptr == self._sp.ptr(x):
+            return x
+        for arr in candidates:
+            base = self._sp.ptr(arr)
+            size = arr.shape[0]
+            if base <= ptr < base + 8 * size:
+                off = (ptr - base) // 8
+                return arr[off:off + n]
+        raise RuntimeError("library returned a request pointer outside the caller's arrays")
+
+    @staticmethod
+    def _request(task, req, x_changed, niter, info):
+        return {"task": _TASK[task], "requested_on": req,
+                "info": {"x_changed_in_run": bool(x_changed), "iteration_number": int(niter),
+                         "iteration_info": _INFO[info]}}
+
+
+class oLBFGS_free(_StochQN_free):
+    """oLBFGS optimizer, free mode (reference stochqn/_optimizers.py:937-1044)."""
+
+    def __init__(self, mem_size=10, hess_init=None, min_curvature=1e-4, y_reg=None, check_nan=True,
+                 nthreads=-1, space="host", device=None, backend=None):
+        self._take_common_inputs(mem_size, min_curvature, y_reg, check_nan, nthreads, space, device, backend)
+        if hess_init is not None:
+            assert hess_init > 0
+        else:
+            hess_init = 0
+        self.hess_init = hess_init
+
+    def _initialize(self, n):
+        sp = self._sp
+        self._n = n
+        self.BFGS_mem = _BFGS_mem_holder(sp, self.mem_size, n, self.min_curvature, self.y_reg, 1)
+        self.grad_prev = sp.empty(n)
+        self.niter, self.section = 0, 0
+        self.gradient = sp.empty(n)
+        self.initialized = True
+
+    def run_optimizer(self, x, step_size):
+        self._check_x(x)
+        sp = self._sp
+        b = self.BFGS_mem.c_struct(sp)
+        w = _abi.workspace_oLBFGS(C.pointer(b), sp.ptr(self.grad_prev), self.hess_init, self.niter,
+                                  self.section, self.nthreads, int(self.check_nan), self._n)
+        req, task, info = C.c_void_p(), C.c_int(), C.c_int()
+        changed = self._be.run_oLBFGS(step_size, sp.ptr(x), sp.ptr(self.gradient), C.byref(req), C.byref(task),
+                                      C.byref(w), C.byref(info))
+        self.niter, self.section = w.niter, w.section
+        self.BFGS_mem.mem_used, self.BFGS_mem.mem_st_ix = b.mem_used, b.mem_st_ix
+        if changed == _abi.RECEIVED_INVALID_INPUT:
+            raise ValueError("oLBFGS got an invalid workspace as input.")
+        return self._request(task.value, self._resolve(req.value, x, []), changed, self.niter, info.value)
+
+
+class SQN_free(_StochQN_free):
+    """SQN optimizer, free mode (reference stochqn/_optimizers.py:1046-1190)."""
+
+    def __init__(self, mem_size=10, bfgs_upd_freq=20, min_curvature=1e-4, y_reg=None, use_grad_diff=False,
+                 check_nan=True, nthreads=-1, space="host", device=None, backend=None):
+        self._take_common_inputs(mem_size, min_curvature, y_reg, check_nan, nthreads, space, device, backend)
+        assert bfgs_upd_freq > 0
+        self.bfgs_upd_freq = int(bfgs_upd_freq)
+        self.use_grad_diff = bool(use_grad_diff)
+
+    def _initialize(self, n):
+        sp = self._sp
+        self._n = n
+        self.BFGS_mem = _BFGS_mem_holder(sp, self.mem_size, n, self.min_curvature, self.y_reg, self.bfgs_upd_freq)
+        self.grad_prev = sp.empty(n if self.use_grad_diff else 1)
+        self.x_sum = sp.zeros(n)
+        self.x_avg_prev = sp.empty(n)
+        self.niter, self.section = 0, 0
+        self.gradient = sp.empty(n)
+        self.hess_vec = sp.empty(1 if self.use_grad_diff else n)
+        self.initialized = True
+
+    def update_hess_vec(self, hess_vec):
+        """Hand over the Hessian-vector product that the last request asked for."""
+        self._sp.assign(self.hess_vec, hess_vec)
+
+    def run_optimizer(self, x, step_size):
+        self._check_x(x)
+        sp = self._sp
+        b = self.BFGS_mem.c_struct(sp)
+        w = _abi.workspace_SQN(C.pointer(b), sp.ptr(self.grad_prev), sp.ptr(self.x_sum), sp.ptr(self.x_avg_prev),
+                               int(self.use_grad_diff), self.niter, self.section, self.nthreads,
+                               int(self.check_nan), self._n)
+        req, req_vec, task, info = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
+        changed = self._be.run_SQN(step_size, sp.ptr(x), sp.ptr(self.gradient), sp.ptr(self.hess_vec),
+                                   C.byref(req), C.byref(req_vec), C.byref(task), C.byref(w), C.byref(info))
+        self.niter, self.section = w.niter, w.section
+        self.BFGS_mem.mem_used, self.BFGS_mem.mem_st_ix = b.mem_used, b.mem_st_ix
+        if changed == _abi.RECEIVED_INVALID_INPUT:
+            raise ValueError("SQN got an invalid workspace as input.")
+        cands = [self.x_sum, self.x_avg_prev]
+        r = self._resolve(req.value, x, cands)
+        if _TASK[task.value] == "calc_hess_vec":
+            r = (r, self._resolve(req_vec.value, x, [self.BFGS_mem.s_mem]))
+        return self._request(task.value, r, changed, self.niter, info.value)
+
+
+class adaQN_free(_StochQN_free):
+    """adaQN optimizer, free mode (reference stochqn/_optimizers.py:1192-1364)."""
+
+    def __init__(self, mem_size=10, fisher_size=100, bfgs_upd_freq=20, max_incr=1.01, min_curvature=1e-4,
+                 scal_reg=1e-4, rmsprop_weight=None, y_reg=None, use_grad_diff=False, check_nan=True,
+                 nthreads=-1, space="host", device=None, backend=None):
+        self._take_common_inputs(mem_size, min_curvature, y_reg, check_nan, nthreads, space, device, backend)
+        assert bfgs_upd_freq > 0
+        if not use_grad_diff:
+            assert fisher_size > 0
+            fisher_size = int(fisher_size)
+        else:
+            fisher_size = 0
+        if max_incr is not None:
+            assert max_incr > 0
+        else:
+            max_incr = 0
+        assert scal_reg > 0
+        if rmsprop_weight is not None:
+            assert 0 < rmsprop_weight < 1
+        else:
+            rmsprop_weight = 0
+        self.fisher_size = fisher_size
+        self.bfgs_upd_freq = int(bfgs_upd_freq)
+        self.max_incr = max_incr
+        self.scal_reg = scal_reg
+        self.rmsprop_weight = rmsprop_weight
+        self.use_grad_diff = bool(use_grad_diff)
+
+    def _initialize(self, n):
+        sp = self._sp
+        self._n = n
+        self.BFGS_mem = _BFGS_mem_holder(sp, self.mem_size, n, self.min_curvature, self.y_reg, self.bfgs_upd_freq)
+        if self.use_grad_diff:
+            self.Fisher_mem = _Fisher_mem_holder(sp, 1, 1)
+            self.grad_prev = sp.empty(n)
+        else:
+            self.Fisher_mem = _Fisher_mem_holder(sp, self.fisher_size, n)
+            self.grad_prev = sp.empty(1)
+        self.H0 = sp.empty(n)
+        self.x_sum = sp.zeros(n)
+        self.x_avg_prev = sp.empty(n)
+        self.grad_sum_sq = sp.zeros(n)
+        self.f_prev = 0.0
+        self.niter, self.section = 0, 0
+        self.gradient = sp.empty(n)
+        self.f = 0.0
+        self.initialized = True
+
+    def update_function(self, fun):
+        """Hand over the objective value that the last request asked for."""
+        self.f = float(fun)
+
+    def run_optimizer(self, x, step_size):
+        self._check_x(x)
+        sp = self._sp
+        b = self.BFGS_mem.c_struct(sp)
+        fm = self.Fisher_mem.c_struct(sp)
+        w = _abi.workspace_adaQN(C.pointer(b), C.pointer(fm), sp.ptr(self.H0), sp.ptr(self.grad_prev),
+                                 sp.ptr(self.x_sum), sp.ptr(self.x_avg_prev), sp.ptr(self.grad_sum_sq),
+                                 self.f_prev, self.max_incr, self.scal_reg, self.rmsprop_weight,
+                                 int(self.use_grad_diff), self.niter, self.section, self.nthreads,
+                                 int(self.check_nan), self._n)
+        req, task, info = C.c_void_p(), C.c_int(), C.c_int()
+        changed = self._be.run_adaQN(step_size, sp.ptr(x), self.f, sp.ptr(self.gradient), C.byref(req),
+                                     C.byref(task), C.byref(w), C.byref(info))
+        self.niter, self.section, self.f_prev = w.niter, w.section, w.f_prev
+        self.BFGS_mem.mem_used, self.BFGS_mem.mem_st_ix = b.mem_used, b.mem_st_ix
+        self.Fisher_mem.mem_used, self.Fisher_mem.mem_st_ix = fm.mem_used, fm.mem_st_ix
+        if changed == _abi.RECEIVED_INVALID_INPUT:
+            raise ValueError("adaQN got an invalid workspace as input.")
+        r = self._resolve(req.value, x, [self.x_sum, self.x_avg_prev])
+        return self._request(task.value, r, changed, self.niter, info.value)
