@@ -1,0 +1,77 @@
+/*  stochqn_hip.h -- device-side extras of libstochqn.so (MI355X build).
+ *
+ *  Nothing in here is needed by a caller of the reference ABI (stochqn.h); these entry points
+ *  exist for (a) callers that keep their vectors in HBM, (b) one-process-per-GPU sharding of the
+ *  n dimension over RCCL, (c) measurement, (d) checkpointing host-mirrored state.  All symbols
+ *  are plain C, pointers and sizes only.
+ */
+#ifndef STOCHQN_HIP_INCLUDE
+#define STOCHQN_HIP_INCLUDE
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 1 when a HIP device is usable from this process, else 0 (never aborts). */
+int stochqn_hip_available(void);
+
+/* ---- isolated two-loop recursion --------------------------------------------------------------
+ * Exposes what the reference keeps `static inline`: approx_inv_hess_grad (reference
+ * src/stochqn.c:663-708), same argument meaning.  `mem_st_ix` is the row of the OLDEST pair, as
+ * take_step passes it (reference src/stochqn.c:820).  grad/H0/y_mem/s_mem may be device or host
+ * pointers; buffer_rho/buffer_alpha receive rho_i and alpha_i by logical index.
+ * 1/(y_i's_i) and the newest pair's s'y / y'y are cached per (s_mem, row): after changing rows
+ * of s_mem / y_mem from outside the library call stochqn_hip_invalidate(s_mem).
+ * Returns 0 on success, -1000 on invalid input / no device. */
+int stochqn_hip_two_loop(double grad[], int n, double H0[], double h0, double y_mem[], double s_mem[],
+	size_t mem_size, size_t mem_used, size_t mem_st_ix, double buffer_rho[], double buffer_alpha[]);
+
+/* Empirical Fisher product y = F'(F s)/fu of reference src/stochqn.c:946-949 (update_y_fisher
+ * without the curvature check).  F is [fu][n] row-major.  Device or host pointers. */
+int stochqn_hip_fisher_product(double F[], size_t fu, int n, double s[], double buffer_y[], double y[]);
+
+/* ---- device-context management ------------------------------------------------------------------
+ * State that mirrors caller-owned HOST arrays lives in a context keyed by the address of
+ * `bfgs_mem.s_mem`.  R and Python never call dealloc_*, so contexts are released explicitly, or
+ * all together at process exit. */
+void stochqn_hip_invalidate(const void *s_mem);       /* forget cached rho / gamma             */
+void stochqn_hip_release(const void *s_mem);          /* free the context of this workspace    */
+void stochqn_hip_release_all(void);
+/* Copy every mirrored array back into the caller's host arrays (checkpoint / pickle / saveRDS
+ * support).  No-op for arrays the caller already keeps in device memory.  Returns 0 or -1000. */
+int stochqn_hip_export(const void *s_mem);
+
+/* ---- options -------------------------------------------------------------------------------------
+ * "nontemporal" (default 1)  stream pair / Fisher rows with non-temporal loads
+ * "grid_cap"    (default 2048) maximum workgroups per sweep
+ * "strict_grad" (default 1)  host callers: copy the search direction back into `grad`
+ * Returns 0, or -1 for an unknown name. Applies to contexts created afterwards and existing ones. */
+int stochqn_hip_set_option(const char *name, double value);
+
+/* ---- built-in HIP-event profiler -----------------------------------------------------------------
+ * When enabled every kernel launch is bracketed by two events on the library's stream; durations
+ * are accumulated per kernel id.  Ids 0..stochqn_hip_profile_kernels()-1. */
+void stochqn_hip_profile_enable(int on);
+void stochqn_hip_profile_reset(void);
+int stochqn_hip_profile_kernels(void);
+const char* stochqn_hip_profile_name(int kernel_id);
+int stochqn_hip_profile_get(int kernel_id, long long *launches, double *total_ms);
+
+/* ---- sharding n across GPUs (one process per GPU, RCCL over xGMI) ---------------------------------
+ * Every rank owns a contiguous slice of all n-vectors and of every row of S, Y, F and passes its
+ * LOCAL n to initialize_* / run_*.  After comm_init every dot product inside the library becomes
+ * local partial sums + one ncclAllReduce(sum, double) of 1..3 scalars (Fisher: fu scalars) on
+ * the library's stream, and all ranks take identical decisions.  RCCL is dlopen()ed on first use.
+ *   unique_id : NCCL_UNIQUE_ID_BYTES (128) bytes, produced on one rank and broadcast by the host
+ *               program (bench.py uses torch.distributed for that hand-shake only). */
+int stochqn_hip_comm_unique_id(void *out128);
+int stochqn_hip_comm_init(int rank, int nranks, const void *unique_id128);
+int stochqn_hip_comm_nranks(void);
+void stochqn_hip_comm_finalize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STOCHQN_HIP_INCLUDE */

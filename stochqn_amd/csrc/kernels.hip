@@ -1,0 +1,832 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the stochastic quasi-Newton step.
+//
+// Every kernel is one *sweep*: a grid-stride pass over n doubles that fuses an element-wise
+// update with the dot product the NEXT step of the recursion needs, so that each n-vector is
+// read once and written at most once per sweep.  The chain for one two-loop recursion
+// (reference src/stochqn.c:663-708) over k stored pairs is
+//
+//     first      p = s_{k-1}'q                                   (+ oLBFGS/adaQN side effects)
+//     bwd  i     alpha_i = rho_i p ; q -= alpha_i y_i ; p = s_{i-1}'q          i = k-1 .. 1
+//     mid        alpha_0 ; q -= alpha_0 y_0 ; r = H0 q ; p = y_0'r
+//     fwd  i     beta = rho_i p ; r += (alpha_i - beta) s_i ; p = y_{i+1}'r    i = 0 .. k-2
+//     fwd_last   r += (alpha_{k-1} - beta) s_{k-1} ; p = (r'r, #nonfinite)
+//     apply      guard (reference src/stochqn.c:825-835) ; x -= step r ; x_sum += x
+//
+// = 8*k*n words of compulsory HBM traffic for the two-loop.  A sweep's
+// reduction is NOT finished inside the sweep: every workgroup stores one partial per quantity
+// and every workgroup of the following kernel re-adds those partials in a fixed order
+// (`total_of`).  That removes the 1-block "finalise" launches from the dependency chain, needs
+// no atomics and no inter-workgroup hand-off, and is bit-reproducible for a given (n, grid).
+//
+// Memory access: 16-byte (double2) loads/stores per lane, fully coalesced (1 KiB per wave
+// instruction), `kUnroll` independent packs per lane in flight; correction-pair rows and Fisher
+// rows are streamed with non-temporal loads (they are dead until the next optimiser step) so
+// that q / r keep what cache residency they can.  These are BLAS-1 reductions at 0.25 flop/B:
+// no MFMA, no LDS tiling -- LDS only carries the per-workgroup reduction.
+#include "sqn_device.hpp"
+
+#include <cmath>
+
+namespace sqn {
+
+namespace {
+
+constexpr int kUnroll = 2;
+constexpr int kWaves = kBlock / 64;
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+template <int W> struct Pack { double v[W]; };
+
+template <int W, bool NT> __device__ __forceinline__ Pack<W> ld(const double* p, uint32_t i)
+{
+	Pack<W> r;
+	if constexpr (W == 2) {
+		d2 t = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2*>(p + i))
+		          : *reinterpret_cast<const d2*>(p + i);
+		r.v[0] = t.x; r.v[1] = t.y;
+	} else {
+		r.v[0] = NT ? __builtin_nontemporal_load(p + i) : p[i];
+	}
+	return r;
+}
+
+template <int W> __device__ __forceinline__ void st(double* p, uint32_t i, const Pack<W>& a)
+{
+	if constexpr (W == 2) { d2 t; t.x = a.v[0]; t.y = a.v[1]; *reinterpret_cast<d2*>(p + i) = t; }
+	else p[i] = a.v[0];
+}
+
+// write-once outputs (new s / y rows, Fisher row): keep them out of the caches
+template <int W> __device__ __forceinline__ void st_nt(double* p, uint32_t i, const Pack<W>& a)
+{
+	if constexpr (W == 2) { d2 t; t.x = a.v[0]; t.y = a.v[1]; __builtin_nontemporal_store(t, reinterpret_cast<d2*>(p + i)); }
+	else __builtin_nontemporal_store(a.v[0], p + i);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+	#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+	return v;
+}
+
+// Sum over the workgroup, returned to every thread.  Fixed tree: 6 shuffle steps per wave, then
+// the kWaves wave sums in wave order.
+__device__ __forceinline__ double block_sum(double v, double* sh)
+{
+	v = wave_sum(v);
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+	__syncthreads();
+	double t = sh[0];
+	#pragma unroll
+	for (int w = 1; w < kWaves; w++) t += sh[w];
+	return t;
+}
+
+// Total of the previous sweep's partials, identical in every workgroup of the grid.
+__device__ __forceinline__ double total_of(const double* parts, int count, double* sh)
+{
+	double a = 0;
+	for (int i = threadIdx.x; i < count; i += kBlock) a += parts[i];
+	return block_sum(a, sh);
+}
+
+// The sweep skeleton.  Op supplies `In<W> load<W>(i)` (loads only) and `apply<W>(i, in, acc)`
+// (arithmetic + stores) so that all loads of an unrolled group are issued before its first store.
+template <int W, int NP, class Op>
+__device__ __forceinline__ void sweep(uint32_t n, const Op& op, double (&acc)[NP > 0 ? NP : 1])
+{
+	const uint32_t packs = n / W;
+	const uint32_t stride = gridDim.x * kBlock;
+	uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+	// packs <= 2^31 and stride*(kUnroll) <= 2^21, so the sums below stay inside 32 bits
+	for (; p + (kUnroll - 1) * stride < packs; p += kUnroll * stride) {
+		typename Op::template In<W> in[kUnroll];
+		#pragma unroll
+		for (int u = 0; u < kUnroll; u++) in[u] = op.template load<W>((p + u * stride) * W);
+		#pragma unroll
+		for (int u = 0; u < kUnroll; u++) op.template apply<W>((p + u * stride) * W, in[u], acc);
+	}
+	for (; p < packs; p += stride) {
+		typename Op::template In<W> in = op.template load<W>(p * W);
+		op.template apply<W>(p * W, in, acc);
+	}
+	if constexpr (W > 1) {  // odd tail (n not a multiple of W): the last workgroup's first lanes
+		const uint32_t i = packs * W + threadIdx.x;
+		if (blockIdx.x == gridDim.x - 1 && i < n) {
+			typename Op::template In<1> in = op.template load<1>(i);
+			op.template apply<1>(i, in, acc);
+		}
+	}
+}
+
+template <int W, int NP, class Op>
+__global__ void __launch_bounds__(kBlock) k_sweep(Op op, uint32_t n, double* parts_out)
+{
+	__shared__ double sh[kWaves];
+	op.prologue(sh);
+	double acc[NP > 0 ? NP : 1] = {0};
+	sweep<W, NP>(n, op, acc);
+	#pragma unroll
+	for (int j = 0; j < NP; j++) {
+		double t = block_sum(acc[j], sh);
+		if (threadIdx.x == 0) parts_out[j * kMaxGrid + blockIdx.x] = t;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// first sweep (take_step prologue; reference src/stochqn.c:808-818, 996, 1174 + first dot of :677)
+// ------------------------------------------------------------------------------------------------
+template <bool NT> struct FirstOp {
+	FirstArgs a;
+	bool rms;
+	double w_old, w_new;
+	template <int W> struct In { Pack<W> q, s, G; };
+
+	__device__ void prologue(double*) {}
+	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
+	{
+		In<W> in;
+		in.q = ld<W, false>(a.q, i);
+		if (a.s_newest) in.s = ld<W, NT>(a.s_newest, i);
+		if (a.G) in.G = ld<W, false>(a.G, i);
+		return in;
+	}
+	template <int W> __device__ __forceinline__ void apply(uint32_t i, const In<W>& in, double (&acc)[2]) const
+	{
+		if (a.gprev_out) st<W>(a.gprev_out, i, in.q);
+		if (a.frow_out) st_nt<W>(a.frow_out, i, in.q);
+		Pack<W> dir = in.q;
+		if (a.G) {
+			Pack<W> Gn;
+			#pragma unroll
+			for (int k = 0; k < W; k++) {
+				const double g = in.q.v[k];
+				// reference src/stochqn.c:738 / :745, rounded as written (no contraction)
+				Gn.v[k] = rms ? (w_old * in.G.v[k] + w_new * (g * g)) : (in.G.v[k] + g * g);
+				dir.v[k] = g / sqrt(Gn.v[k] + a.scal_reg);               // :778 / :781
+			}
+			st<W>(a.G, i, Gn);
+			st<W>(a.H0_out ? a.H0_out : a.q, i, dir);
+		}
+		#pragma unroll
+		for (int k = 0; k < W; k++) {
+			if (a.s_newest) {
+				acc[0] = fma(in.s.v[k], in.q.v[k], acc[0]);              // s_{k-1}' q on the RAW gradient
+			} else {
+				acc[0] = fma(dir.v[k], dir.v[k], acc[0]);                 // guard: sum dir^2
+				acc[1] += (isfinite(dir.v[k]) ? 0.0 : 1.0);               //        #nonfinite
+			}
+		}
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// backward sweep (reference src/stochqn.c:676-678, fused with the next iteration's :677)
+// ------------------------------------------------------------------------------------------------
+template <bool NT> struct BwdOp {
+	Partials in;
+	const double* sy_row;     // s'y of pair i  (rho_i = 1 / s'y, :676)
+	double* alpha_out;        // &alpha[i]
+	double* rho_out;          // &rho[i]
+	const double* y;
+	double* q;
+	const double* s_prev;
+	double alpha;
+	template <int W> struct In { Pack<W> y, q, s; };
+
+	__device__ void prologue(double* sh)
+	{
+		const double p = total_of(in.parts, in.count, sh);
+		const double rho = 1.0 / *sy_row;
+		alpha = rho * p;
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *alpha_out = alpha; *rho_out = rho; }
+	}
+	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
+	{
+		return In<W>{ld<W, NT>(y, i), ld<W, false>(q, i), ld<W, NT>(s_prev, i)};
+	}
+	template <int W> __device__ __forceinline__ void apply(uint32_t i, const In<W>& in_, double (&acc)[1]) const
+	{
+		Pack<W> o;
+		#pragma unroll
+		for (int k = 0; k < W; k++) {
+			o.v[k] = fma(-alpha, in_.y.v[k], in_.q.v[k]);
+			acc[0] = fma(in_.s.v[k], o.v[k], acc[0]);
+		}
+		st<W>(q, i, o);
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// middle sweep: last backward update + initial scaling (:683-699) + first forward dot (:705)
+// ------------------------------------------------------------------------------------------------
+template <bool NT> struct MidOp {
+	Partials in;
+	const double* sy_row;
+	double* alpha_out;
+	double* rho_out;
+	const double* y;
+	double* q;
+	MidScale ms;
+	double alpha, scal;
+	template <int W> struct In { Pack<W> y, q, h; };
+
+	__device__ void prologue(double* sh)
+	{
+		const double p = total_of(in.parts, in.count, sh);
+		const double rho = 1.0 / *sy_row;
+		alpha = rho * p;
+		scal = (ms.sy_newest != nullptr) ? (*ms.sy_newest / *ms.yy_newest) : ms.h0;
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *alpha_out = alpha; *rho_out = rho; }
+	}
+	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
+	{
+		In<W> r;
+		r.y = ld<W, NT>(y, i);
+		r.q = ld<W, false>(q, i);
+		if (ms.H0) r.h = ld<W, false>(ms.H0, i);
+		return r;
+	}
+	template <int W> __device__ __forceinline__ void apply(uint32_t i, const In<W>& in_, double (&acc)[1]) const
+	{
+		Pack<W> o;
+		#pragma unroll
+		for (int k = 0; k < W; k++) {
+			const double qn = fma(-alpha, in_.y.v[k], in_.q.v[k]);
+			o.v[k] = ms.H0 ? qn * in_.h.v[k] : scal * qn;
+			acc[0] = fma(in_.y.v[k], o.v[k], acc[0]);
+		}
+		st<W>(q, i, o);
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward sweeps (reference src/stochqn.c:705-706, fused with the next iteration's :705)
+// ------------------------------------------------------------------------------------------------
+template <bool NT, bool LAST, bool FUSE> struct FwdOp {
+	Partials in;
+	const double* sy_row;
+	const double* alpha_i;
+	const double* s;
+	double* r;
+	const double* y_next;   // !LAST
+	ApplyArgs ap;           // FUSE
+	double coef;
+	template <int W> struct In { Pack<W> s, r, y, x, xs; };
+
+	__device__ void prologue(double* sh)
+	{
+		const double p = total_of(in.parts, in.count, sh);
+		const double beta = (1.0 / *sy_row) * p;
+		coef = *alpha_i - beta;
+	}
+	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
+	{
+		In<W> v;
+		v.s = ld<W, NT>(s, i);
+		v.r = ld<W, false>(r, i);
+		if constexpr (!LAST) v.y = ld<W, NT>(y_next, i);
+		if constexpr (FUSE) {
+			v.x = ld<W, false>(ap.x, i);
+			if (ap.x_sum) v.xs = ld<W, false>(ap.x_sum, i);
+		}
+		return v;
+	}
+	template <int W> __device__ __forceinline__ void apply(uint32_t i, const In<W>& v, double (&acc)[2]) const
+	{
+		Pack<W> o;
+		#pragma unroll
+		for (int k = 0; k < W; k++) {
+			o.v[k] = fma(coef, v.s.v[k], v.r.v[k]);
+			if constexpr (!LAST) acc[0] = fma(v.y.v[k], o.v[k], acc[0]);
+			else if constexpr (!FUSE) { acc[0] = fma(o.v[k], o.v[k], acc[0]); acc[1] += (isfinite(o.v[k]) ? 0.0 : 1.0); }
+		}
+		if constexpr (FUSE) {
+			Pack<W> xn, sg;
+			#pragma unroll
+			for (int k = 0; k < W; k++) {
+				xn.v[k] = fma(-ap.step, o.v[k], v.x.v[k]);                // :838
+				sg.v[k] = (-ap.step) * o.v[k];                            // :1006
+			}
+			st<W>(ap.x, i, xn);
+			if (ap.x_sum) {
+				Pack<W> t;
+				#pragma unroll
+				for (int k = 0; k < W; k++) t.v[k] = v.xs.v[k] + xn.v[k];  // :283
+				st<W>(ap.x_sum, i, t);
+			}
+			if (ap.s_slot) { st_nt<W>(ap.s_slot, i, sg); st<W>(r, i, sg); }
+			else st<W>(r, i, o);
+		} else {
+			st<W>(r, i, o);
+		}
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// guarded position update (reference src/stochqn.c:825-838, 1006-1007, 1067/1191)
+// ------------------------------------------------------------------------------------------------
+struct ApplyOp {
+	Partials guard;
+	bool guarded;
+	double n_global;
+	const double* r;
+	double* grad_out;   // oLBFGS: -step*r is written back here (and to s_slot)
+	ApplyArgs ap;
+	double* report;
+	bool bad;
+	template <int W> struct In { Pack<W> r, x, xs; };
+
+	__device__ void prologue(double* sh)
+	{
+		bad = false;
+		if (guarded) {
+			const double ss = total_of(guard.parts, guard.count, sh);
+			const double nf = total_of(guard.parts + guard.stride, guard.count, sh);
+			bad = (nf > 0.0) || !(sqrt(ss) <= 1e3 * n_global);
+			if (blockIdx.x == 0 && threadIdx.x == 0) { report[0] = bad ? 1.0 : 0.0; report[1] = ss; report[2] = nf; }
+		} else if (blockIdx.x == 0 && threadIdx.x == 0) {
+			report[0] = 0.0; report[1] = 0.0; report[2] = 0.0;
+		}
+	}
+	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
+	{
+		In<W> v;
+		if (!bad) v.r = ld<W, false>(r, i);
+		v.x = ld<W, false>(ap.x, i);
+		if (ap.x_sum) v.xs = ld<W, false>(ap.x_sum, i);
+		return v;
+	}
+	template <int W> __device__ __forceinline__ void apply(uint32_t i, const In<W>& v, double (&)[1]) const
+	{
+		Pack<W> xn = v.x;
+		if (!bad) {
+			Pack<W> sg;
+			#pragma unroll
+			for (int k = 0; k < W; k++) {
+				xn.v[k] = fma(-ap.step, v.r.v[k], v.x.v[k]);
+				sg.v[k] = (-ap.step) * v.r.v[k];
+			}
+			st<W>(ap.x, i, xn);
+			if (ap.s_slot) { st_nt<W>(ap.s_slot, i, sg); st<W>(grad_out, i, sg); }
+		}
+		if (ap.x_sum) {
+			Pack<W> t;
+			#pragma unroll
+			for (int k = 0; k < W; k++) t.v[k] = v.xs.v[k] + xn.v[k];
+			st<W>(ap.x_sum, i, t);
+		}
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// correction pairs
+// ------------------------------------------------------------------------------------------------
+// s = x_avg - x_avg_prev, with x_avg = x_sum * (1/L) written back first (:286-291, :861-870)
+struct PairSOp {
+	double* x_sum;
+	double inv_L;
+	bool scale;
+	const double* x_avg_prev;
+	double* s_out;
+	template <int W> struct In { Pack<W> xs, xp; };
+	__device__ void prologue(double*) {}
+	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
+	{
+		return In<W>{ld<W, false>(x_sum, i), ld<W, false>(x_avg_prev, i)};
+	}
+	template <int W> __device__ __forceinline__ void apply(uint32_t i, const In<W>& v, double (&)[1]) const
+	{
+		Pack<W> avg = v.xs, s;
+		#pragma unroll
+		for (int k = 0; k < W; k++) {
+			if (scale) avg.v[k] = v.xs.v[k] * inv_L;
+			s.v[k] = avg.v[k] - v.xp.v[k];
+		}
+		if (scale) st<W>(x_sum, i, avg);
+		st<W>(s_out, i, s);
+	}
+};
+
+__device__ __forceinline__ void three_dots(double s, double y, double (&acc)[3])
+{
+	acc[0] = fma(s, y, acc[0]);
+	acc[1] = fma(s, s, acc[1]);
+	acc[2] = fma(y, y, acc[2]);
+}
+
+// y = g - g_prev (+ lambda s) ; s'y, s's, y'y   (:915-923 + the dots of :892 and of :676,:686-687)
+struct PairYDiffOp {
+	const double* g;
+	const double* g_prev;
+	const double* s;
+	double lambda;
+	double* y_out;
+	template <int W> struct In { Pack<W> g, gp, s; };
+	__device__ void prologue(double*) {}
+	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
+	{
+		return In<W>{ld<W, false>(g, i), ld<W, false>(g_prev, i), ld<W, false>(s, i)};
+	}
+	template <int W> __device__ __forceinline__ void apply(uint32_t i, const In<W>& v, double (&acc)[3]) const
+	{
+		Pack<W> y;
+		#pragma unroll
+		for (int k = 0; k < W; k++) {
+			double d = v.g.v[k] - v.gp.v[k];
+			if (lambda > 0) d = fma(lambda, v.s.v[k], d);
+			y.v[k] = d;
+			three_dots(v.s.v[k], d, acc);
+		}
+		st<W>(y_out, i, y);
+	}
+};
+
+// y = hess_vec ; x_avg_prev <- x_avg ; x_sum <- 0 ; dots   (:1139-1140, :962-966)
+struct PairYHvOp {
+	const double* hv;
+	const double* s;
+	double* y_out;
+	double* x_sum;        // nullable
+	double* x_avg_prev;
+	template <int W> struct In { Pack<W> hv, s, xs; };
+	__device__ void prologue(double*) {}
+	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
+	{
+		In<W> v;
+		v.hv = ld<W, false>(hv, i);
+		v.s = ld<W, false>(s, i);
+		if (x_sum) v.xs = ld<W, false>(x_sum, i);
+		return v;
+	}
+	template <int W> __device__ __forceinline__ void apply(uint32_t i, const In<W>& v, double (&acc)[3]) const
+	{
+		#pragma unroll
+		for (int k = 0; k < W; k++) three_dots(v.s.v[k], v.hv.v[k], acc);
+		st<W>(y_out, i, v.hv);
+		if (x_sum) {
+			Pack<W> z;
+			#pragma unroll
+			for (int k = 0; k < W; k++) z.v[k] = 0.0;
+			st<W>(x_avg_prev, i, v.xs);
+			st<W>(x_sum, i, z);
+		}
+	}
+};
+
+struct Dots3Op {
+	const double* s;
+	const double* y;
+	template <int W> struct In { Pack<W> s, y; };
+	__device__ void prologue(double*) {}
+	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
+	{
+		return In<W>{ld<W, false>(s, i), ld<W, false>(y, i)};
+	}
+	template <int W> __device__ __forceinline__ void apply(uint32_t, const In<W>& v, double (&acc)[3]) const
+	{
+		#pragma unroll
+		for (int k = 0; k < W; k++) three_dots(v.s.v[k], v.y.v[k], acc);
+	}
+};
+
+struct ScaleOp {
+	double* x;
+	double a;
+	template <int W> struct In { Pack<W> x; };
+	__device__ void prologue(double*) {}
+	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const { return In<W>{ld<W, false>(x, i)}; }
+	template <int W> __device__ __forceinline__ void apply(uint32_t i, const In<W>& v, double (&)[1]) const
+	{
+		Pack<W> o;
+		#pragma unroll
+		for (int k = 0; k < W; k++) o.v[k] = v.x.v[k] * a;
+		st<W>(x, i, o);
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
+// empirical Fisher product (reference src/stochqn.c:946-949): t = F s ; y = F' t / fu
+// ------------------------------------------------------------------------------------------------
+// pass 1: blockIdx.y selects a group of kFisherRows rows; each lane keeps one accumulator per row
+// of the group while it strides over its columns, so F is read exactly once and s once per group.
+template <int W, bool NT>
+__global__ void __launch_bounds__(kBlock) k_fisher_t(const double* F, size_t ld_, uint32_t n, uint32_t fu,
+                                                     const double* s, double* parts)
+{
+	__shared__ double sh[kWaves];
+	const uint32_t row0 = blockIdx.y * kFisherRows;
+	const uint32_t nrows = (fu - row0 < (uint32_t) kFisherRows) ? fu - row0 : (uint32_t) kFisherRows;
+	double acc[kFisherRows];
+	#pragma unroll
+	for (int k = 0; k < kFisherRows; k++) acc[k] = 0;
+	const uint32_t packs = n / W;
+	const uint32_t stride = gridDim.x * kBlock;
+	const double* Fg = F + (size_t) row0 * ld_;
+	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
+		const Pack<W> sv = ld<W, false>(s, p * W);
+		Pack<W> f[kFisherRows];
+		#pragma unroll
+		for (int k = 0; k < kFisherRows; k++)
+			if ((uint32_t) k < nrows) f[k] = ld<W, NT>(Fg + (size_t) k * ld_, p * W);
+		#pragma unroll
+		for (int k = 0; k < kFisherRows; k++)
+			if ((uint32_t) k < nrows) {
+				#pragma unroll
+				for (int j = 0; j < W; j++) acc[k] = fma(f[k].v[j], sv.v[j], acc[k]);
+			}
+	}
+	if (W > 1) {
+		const uint32_t i = packs * W + threadIdx.x;
+		if (blockIdx.x == gridDim.x - 1 && i < n)
+			for (uint32_t k = 0; k < nrows; k++) acc[k] = fma(Fg[(size_t) k * ld_ + i], s[i], acc[k]);
+	}
+	#pragma unroll
+	for (int k = 0; k < kFisherRows; k++) {
+		const double t = block_sum(acc[k], sh);
+		if (threadIdx.x == 0 && (uint32_t) k < nrows) parts[(size_t) (row0 + k) * kMaxGrid + blockIdx.x] = t;
+	}
+}
+
+// pass 2: y_j = (1/fu) * sum_k t_k F[k][j], rows accumulated in index order; fused with the
+// curvature dots of the new pair.
+template <int W, bool NT>
+__global__ void __launch_bounds__(kBlock) k_fisher_y(const double* F, size_t ld_, uint32_t n, uint32_t fu,
+                                                     const double* t, double inv_fu, const double* s, double* y,
+                                                     double* parts_out)
+{
+	extern __shared__ double t_sh[];   // fu doubles
+	__shared__ double sh[kWaves];
+	for (uint32_t k = threadIdx.x; k < fu; k += kBlock) t_sh[k] = t[k];
+	__syncthreads();
+	double acc[3] = {0, 0, 0};
+	const uint32_t packs = n / W;
+	const uint32_t stride = gridDim.x * kBlock;
+	constexpr int R = 8;
+	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
+		Pack<W> a;
+		#pragma unroll
+		for (int j = 0; j < W; j++) a.v[j] = 0;
+		const Pack<W> sv = ld<W, false>(s, p * W);
+		uint32_t k = 0;
+		for (; k + R <= fu; k += R) {
+			Pack<W> f[R];
+			#pragma unroll
+			for (int u = 0; u < R; u++) f[u] = ld<W, NT>(F + (size_t) (k + u) * ld_, p * W);
+			#pragma unroll
+			for (int u = 0; u < R; u++) {
+				#pragma unroll
+				for (int j = 0; j < W; j++) a.v[j] = fma(f[u].v[j], t_sh[k + u], a.v[j]);
+			}
+		}
+		for (; k < fu; k++) {
+			const Pack<W> f = ld<W, NT>(F + (size_t) k * ld_, p * W);
+			#pragma unroll
+			for (int j = 0; j < W; j++) a.v[j] = fma(f.v[j], t_sh[k], a.v[j]);
+		}
+		#pragma unroll
+		for (int j = 0; j < W; j++) { a.v[j] = inv_fu * a.v[j]; three_dots(sv.v[j], a.v[j], acc); }
+		st<W>(y, p * W, a);
+	}
+	if (W > 1) {
+		const uint32_t i = packs * W + threadIdx.x;
+		if (blockIdx.x == gridDim.x - 1 && i < n) {
+			double a = 0;
+			for (uint32_t k = 0; k < fu; k++) a = fma(F[(size_t) k * ld_ + i], t_sh[k], a);
+			a = inv_fu * a;
+			three_dots(s[i], a, acc);
+			y[i] = a;
+		}
+	}
+	#pragma unroll
+	for (int j = 0; j < 3; j++) {
+		const double v = block_sum(acc[j], sh);
+		if (threadIdx.x == 0) parts_out[j * kMaxGrid + blockIdx.x] = v;
+	}
+}
+
+// out[j] = sum of partial array j (one workgroup per quantity)
+__global__ void __launch_bounds__(kBlock) k_fin(const double* parts, int count, int stride, double* out)
+{
+	__shared__ double sh[kWaves];
+	const double t = total_of(parts + (size_t) blockIdx.x * stride, count, sh);
+	if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+
+// sy_dst = sum of partial array 0 (s'y), yy_dst = sum of partial array 2 (y'y)
+__global__ void __launch_bounds__(kBlock) k_commit(const double* parts, int count, int stride, double* sy_dst, double* yy_dst)
+{
+	__shared__ double sh[kWaves];
+	const double a = total_of(parts, count, sh);
+	const double b = total_of(parts + 2 * (size_t) stride, count, sh);
+	if (threadIdx.x == 0) { *sy_dst = a; *yy_dst = b; }
+}
+
+__global__ void k_set2(double* a, double va, double* b, double vb)
+{
+	if (a) *a = va;
+	if (b) *b = vb;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+inline bool aligned16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <class... P> inline bool all_aligned(P... ps) { return (aligned16(ps) && ...); }
+
+struct ProfScope {
+	const Scratch& sc;
+	ProfScope(const Scratch& s, int id) : sc(s) { if (sc.prof) sc.prof->begin(id, sc.stream); }
+	~ProfScope() { if (sc.prof) sc.prof->end(sc.stream); }
+};
+
+template <int NP, class Op>
+void run_sweep(const Scratch& sc, int id, size_t n, bool vec, const Op& op, double* parts_out, int grid)
+{
+	ProfScope ps(sc, id);
+	if (vec) hipLaunchKernelGGL((k_sweep<2, NP, Op>), dim3(grid), dim3(kBlock), 0, sc.stream, op, (uint32_t) n, parts_out);
+	else     hipLaunchKernelGGL((k_sweep<1, NP, Op>), dim3(grid), dim3(kBlock), 0, sc.stream, op, (uint32_t) n, parts_out);
+}
+
+// What the consumer of buffer `buf` has to read: the raw partials, or (multi-GPU) the summed scalars.
+Partials finish(const Scratch& sc, int buf, int nsums, int grid)
+{
+	Partials raw{sc.part[buf], grid, kMaxGrid};
+	if (!sc.allreduce) return raw;
+	launch_fin(sc, raw, nsums, sc.red[buf]);
+	sc.allreduce(sc.user, sc.red[buf], nsums, sc.stream);
+	return Partials{sc.red[buf], 1, 1};
+}
+
+}  // namespace
+
+const char* kernel_name(int id)
+{
+	static const char* names[K_COUNT] = {
+		"first", "bwd", "mid", "fwd", "fwd_last", "apply", "pair_s", "pair_y_diff", "pair_y_hv",
+		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy"};
+	return (id >= 0 && id < K_COUNT) ? names[id] : "?";
+}
+
+int sweep_grid(const Scratch& sc, size_t n)
+{
+	// one pack pair per lane and unroll step; never more workgroups than the partial stride
+	size_t per_block = (size_t) kBlock * 2 * kUnroll;
+	size_t g = (n + per_block - 1) / per_block;
+	if (g < 1) g = 1;
+	if (g > (size_t) sc.grid_cap) g = sc.grid_cap;
+	return (int) g;
+}
+
+Partials launch_first(const Scratch& sc, int buf, size_t n, const FirstArgs& a)
+{
+	const int grid = sweep_grid(sc, n);
+	const bool vec = all_aligned(a.q, a.s_newest, a.gprev_out, a.frow_out, a.G, a.H0_out);
+	const bool rms = a.rmsprop_weight > 0 && a.rmsprop_weight < 1;
+	if (sc.nontemporal) run_sweep<2>(sc, K_FIRST, n, vec, FirstOp<true>{a, rms, a.rmsprop_weight, 1 - a.rmsprop_weight}, sc.part[buf], grid);
+	else                run_sweep<2>(sc, K_FIRST, n, vec, FirstOp<false>{a, rms, a.rmsprop_weight, 1 - a.rmsprop_weight}, sc.part[buf], grid);
+	return finish(sc, buf, a.s_newest ? 1 : 2, grid);
+}
+
+Partials launch_bwd(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, int i,
+                    const double* y_i, double* q, const double* s_prev)
+{
+	const int grid = sweep_grid(sc, n);
+	const bool vec = all_aligned(y_i, q, s_prev);
+	if (sc.nontemporal) run_sweep<1>(sc, K_BWD, n, vec, BwdOp<true>{in, sy_row, sc.alpha + i, sc.rho + i, y_i, q, s_prev, 0}, sc.part[buf], grid);
+	else                run_sweep<1>(sc, K_BWD, n, vec, BwdOp<false>{in, sy_row, sc.alpha + i, sc.rho + i, y_i, q, s_prev, 0}, sc.part[buf], grid);
+	return finish(sc, buf, 1, grid);
+}
+
+Partials launch_mid(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, const double* y_0,
+                    double* q, const MidScale& ms)
+{
+	const int grid = sweep_grid(sc, n);
+	const bool vec = all_aligned(y_0, q, ms.H0);
+	if (sc.nontemporal) run_sweep<1>(sc, K_MID, n, vec, MidOp<true>{in, sy_row, sc.alpha, sc.rho, y_0, q, ms, 0, 0}, sc.part[buf], grid);
+	else                run_sweep<1>(sc, K_MID, n, vec, MidOp<false>{in, sy_row, sc.alpha, sc.rho, y_0, q, ms, 0, 0}, sc.part[buf], grid);
+	return finish(sc, buf, 1, grid);
+}
+
+Partials launch_fwd(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, int i,
+                    const double* s_i, double* r, const double* y_next)
+{
+	const int grid = sweep_grid(sc, n);
+	const bool vec = all_aligned(s_i, r, y_next);
+	ApplyArgs none{};
+	if (sc.nontemporal) run_sweep<2>(sc, K_FWD, n, vec, FwdOp<true, false, false>{in, sy_row, sc.alpha + i, s_i, r, y_next, none, 0}, sc.part[buf], grid);
+	else                run_sweep<2>(sc, K_FWD, n, vec, FwdOp<false, false, false>{in, sy_row, sc.alpha + i, s_i, r, y_next, none, 0}, sc.part[buf], grid);
+	return finish(sc, buf, 1, grid);
+}
+
+Partials launch_fwd_last(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, int i,
+                         const double* s_i, double* r, const ApplyArgs* fuse)
+{
+	const int grid = sweep_grid(sc, n);
+	if (fuse) {
+		const bool vec = all_aligned(s_i, r, fuse->x, fuse->x_sum, fuse->s_slot);
+		if (sc.nontemporal) run_sweep<2>(sc, K_FWD_LAST, n, vec, FwdOp<true, true, true>{in, sy_row, sc.alpha + i, s_i, r, nullptr, *fuse, 0}, sc.part[buf], grid);
+		else                run_sweep<2>(sc, K_FWD_LAST, n, vec, FwdOp<false, true, true>{in, sy_row, sc.alpha + i, s_i, r, nullptr, *fuse, 0}, sc.part[buf], grid);
+		return Partials{nullptr, 0, 0};
+	}
+	const bool vec = all_aligned(s_i, r);
+	ApplyArgs none{};
+	if (sc.nontemporal) run_sweep<2>(sc, K_FWD_LAST, n, vec, FwdOp<true, true, false>{in, sy_row, sc.alpha + i, s_i, r, nullptr, none, 0}, sc.part[buf], grid);
+	else                run_sweep<2>(sc, K_FWD_LAST, n, vec, FwdOp<false, true, false>{in, sy_row, sc.alpha + i, s_i, r, nullptr, none, 0}, sc.part[buf], grid);
+	return finish(sc, buf, 2, grid);
+}
+
+void launch_apply(const Scratch& sc, size_t n, double n_global, Partials guard, const double* r_in, double* grad_out,
+                  const ApplyArgs& a, bool guarded)
+{
+	const int grid = sweep_grid(sc, n);
+	const bool vec = all_aligned(r_in, grad_out, a.x, a.x_sum, a.s_slot);
+	run_sweep<0>(sc, K_APPLY, n, vec, ApplyOp{guard, guarded, n_global, r_in, grad_out, a, sc.report, false}, nullptr, grid);
+}
+
+void launch_pair_s(const Scratch& sc, size_t n, double* x_sum, double inv_L, bool scale, const double* x_avg_prev,
+                   double* s_out)
+{
+	const int grid = sweep_grid(sc, n);
+	const bool vec = all_aligned(x_sum, x_avg_prev, s_out);
+	run_sweep<0>(sc, K_PAIR_S, n, vec, PairSOp{x_sum, inv_L, scale, x_avg_prev, s_out}, nullptr, grid);
+}
+
+Partials launch_pair_y_diff(const Scratch& sc, int buf, size_t n, const double* g, const double* g_prev,
+                            const double* s, double lambda, double* y_out)
+{
+	const int grid = sweep_grid(sc, n);
+	const bool vec = all_aligned(g, g_prev, s, y_out);
+	run_sweep<3>(sc, K_PAIR_Y_DIFF, n, vec, PairYDiffOp{g, g_prev, s, lambda, y_out}, sc.part[buf], grid);
+	return finish(sc, buf, 3, grid);
+}
+
+Partials launch_pair_y_hv(const Scratch& sc, int buf, size_t n, const double* hv, const double* s, double* y_out,
+                          double* x_sum, double* x_avg_prev)
+{
+	const int grid = sweep_grid(sc, n);
+	const bool vec = all_aligned(hv, s, y_out, x_sum, x_avg_prev);
+	run_sweep<3>(sc, K_PAIR_Y_HV, n, vec, PairYHvOp{hv, s, y_out, x_sum, x_avg_prev}, sc.part[buf], grid);
+	return finish(sc, buf, 3, grid);
+}
+
+Partials launch_dots3(const Scratch& sc, int buf, size_t n, const double* s, const double* y)
+{
+	const int grid = sweep_grid(sc, n);
+	const bool vec = all_aligned(s, y);
+	run_sweep<3>(sc, K_DOTS3, n, vec, Dots3Op{s, y}, sc.part[buf], grid);
+	return finish(sc, buf, 3, grid);
+}
+
+Partials launch_fisher(const Scratch& sc, int buf, size_t n, const double* F, size_t fu, const double* s,
+                       double* t_dev, double* y_out)
+{
+	const int grid = sweep_grid(sc, n);
+	const bool vec = all_aligned(F, s, y_out) && (n % 2 == 0);
+	const dim3 g1(grid, (unsigned) ((fu + kFisherRows - 1) / kFisherRows));
+	{
+		ProfScope ps(sc, K_FISHER_T);
+		if (vec) hipLaunchKernelGGL((k_fisher_t<2, true>), g1, dim3(kBlock), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part);
+		else     hipLaunchKernelGGL((k_fisher_t<1, true>), g1, dim3(kBlock), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part);
+	}
+	launch_fin(sc, Partials{sc.fisher_part, grid, kMaxGrid}, (int) fu, t_dev);
+	if (sc.allreduce) sc.allreduce(sc.user, t_dev, (int) fu, sc.stream);
+	{
+		ProfScope ps(sc, K_FISHER_Y);
+		const size_t shmem = fu * sizeof(double);
+		const double inv = 1.0 / (double) fu;
+		if (vec) hipLaunchKernelGGL((k_fisher_y<2, true>), dim3(grid), dim3(kBlock), shmem, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, t_dev, inv, s, y_out, sc.part[buf]);
+		else     hipLaunchKernelGGL((k_fisher_y<1, true>), dim3(grid), dim3(kBlock), shmem, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, t_dev, inv, s, y_out, sc.part[buf]);
+	}
+	return finish(sc, buf, 3, grid);
+}
+
+void launch_fin(const Scratch& sc, Partials in, int nsums, double* out)
+{
+	ProfScope ps(sc, K_FIN);
+	hipLaunchKernelGGL(k_fin, dim3(nsums), dim3(kBlock), 0, sc.stream, in.parts, in.count, in.stride, out);
+}
+
+void launch_commit(const Scratch& sc, Partials in, double* sy_dst, double* yy_dst)
+{
+	ProfScope ps(sc, K_SMALL);
+	hipLaunchKernelGGL(k_commit, dim3(1), dim3(kBlock), 0, sc.stream, in.parts, in.count, in.stride, sy_dst, yy_dst);
+}
+
+void launch_set2(const Scratch& sc, double* a, double va, double* b, double vb)
+{
+	ProfScope ps(sc, K_SMALL);
+	hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, sc.stream, a, va, b, vb);
+}
+
+void launch_scale(const Scratch& sc, size_t n, double* x, double a)
+{
+	const int grid = sweep_grid(sc, n);
+	run_sweep<0>(sc, K_SMALL, n, aligned16(x), ScaleOp{x, a}, nullptr, grid);
+}
+
+}  // namespace sqn

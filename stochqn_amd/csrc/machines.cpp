@@ -1,0 +1,868 @@
+// machines.cpp -- the free-mode C ABI (include/stochqn.h) on top of the HIP sweeps.
+//
+// Host side of the hot path: the three reverse-communication state machines (reference
+// src/stochqn.c:978-1315), take_step (:802-840), correction-pair construction (:861-966) and the
+// ring bookkeeping (:554-610), written against the transition tables of SURVEY.md section 8a.
+// Every vector operation is a kernel from kernels.hip on the context's stream; the host only
+// moves counters, and reads back at most a handful of scalars per call.
+//
+// Residency rules (DESIGN.md "boundary"):
+//   * struct arrays that are device pointers are used in place; host arrays are mirrored in HBM
+//     (context keyed by bfgs_mem.s_mem) and only x, grad, *req, *req_vec are kept in step;
+//   * x / grad / hess_vec are classified per call; host ones are staged over PCIe.
+#include "runtime.hpp"
+#include "stochqn_hip.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+using namespace sqn;
+
+static_assert(sizeof(bfgs_mem) == 96 && sizeof(fisher_mem) == 40, "ABI layout (reference include/stochqn.h:86-107)");
+static_assert(sizeof(workspace_oLBFGS) == 48 && sizeof(workspace_SQN) == 64 && sizeof(workspace_adaQN) == 120,
+              "ABI layout (reference include/stochqn.h:109-151)");
+
+namespace {
+
+// ---- one run_* invocation -----------------------------------------------------------------------
+struct Call {
+	DevCtx* c = nullptr;
+	bool host_caller = false;       // x lives in host memory: *req / *req_vec must be host-readable
+	double* x_caller = nullptr;
+	double* g_caller = nullptr;
+	double* x = nullptr;            // device views
+	double* g = nullptr;
+	bool g_host = false;
+};
+
+inline size_t N(const DevCtx* c) { return (size_t) c->n; }
+inline double* row(View& v, size_t r, const DevCtx* c) { return v.dev + r * N(c); }
+
+void d2d(DevCtx* c, double* dst, const double* src, size_t count)
+{
+	if (c->sc.prof) c->sc.prof->begin(K_COPY, c->sc.stream);
+	SQN_HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, c->sc.stream));
+	if (c->sc.prof) c->sc.prof->end(c->sc.stream);
+}
+
+void zero(DevCtx* c, double* dst, size_t count)
+{
+	if (c->sc.prof) c->sc.prof->begin(K_COPY, c->sc.stream);
+	SQN_HIP_OK(hipMemsetAsync(dst, 0, count * sizeof(double), c->sc.stream));
+	if (c->sc.prof) c->sc.prof->end(c->sc.stream);
+}
+
+void to_host(DevCtx* c, void* dst, const double* src, size_t count)
+{
+	SQN_HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
+}
+
+bool bind_bfgs(DevCtx* c, bfgs_mem* b, bool import_rows)
+{
+	const size_t n = N(c), m = b->mem_size;
+	const size_t bak = b->min_curvature > 0 ? n : 0;
+	return bind(c, c->S, b->s_mem, m * n, import_rows) && bind(c, c->Y, b->y_mem, m * n, import_rows) &&
+	       bind(c, c->sbak, b->s_bak, bak, true) && bind(c, c->ybak, b->y_bak, bak, true);
+}
+
+// Start a call: find the context, bind every struct array, classify and stage x / grad.
+bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resumed, double* x, double* grad)
+{
+	if (!b || !b->s_mem || !b->y_mem || n <= 0 || b->mem_size == 0) return false;
+	bool fresh = false;
+	DevCtx* c = acquire(b->s_mem, kind, n, b->mem_size, fsize, &fresh);
+	if (!c) return false;
+	io.c = c;
+	if (!bind_bfgs(c, b, fresh && resumed)) return false;
+	if (fresh) {
+		comm_attach(c);
+		c->rho_ok.assign(c->m, 0);
+	}
+	io.x_caller = x;
+	io.g_caller = grad;
+	io.host_caller = !is_device_pointer(x);
+	io.g_host = !is_device_pointer(grad);
+	return true;
+}
+
+void stage_xg(Call& io, bool need_x, bool need_g)
+{
+	DevCtx* c = io.c;
+	if (need_x) io.x = stage_in(c, 0, io.x_caller, N(c), io.host_caller);
+	if (need_g) io.g = stage_in(c, 1, io.g_caller, N(c), io.g_host);
+}
+
+// Make a workspace array readable where the caller expects to read `*req` from.
+double* publish(Call& io, View& v, size_t offset, int slot)
+{
+	DevCtx* c = io.c;
+	double* dev = v.dev + offset;
+	if (!io.host_caller) return dev;
+	if (v.mirror) {                       // caller's own host array: refresh it, hand it back
+		double* host = (double*) const_cast<void*>(v.caller) + offset;
+		to_host(c, host, dev, N(c));
+		return host;
+	}
+	if (!c->host_stage[slot]) SQN_HIP_OK(hipHostMalloc((void**) &c->host_stage[slot], N(c) * sizeof(double), hipHostMallocDefault));
+	to_host(c, c->host_stage[slot], dev, N(c));
+	return c->host_stage[slot];
+}
+
+// End of a call that touched x / grad: bring host copies up to date, then synchronise.
+void close_call(Call& io, bool x_changed, bool g_changed)
+{
+	DevCtx* c = io.c;
+	if (x_changed && io.host_caller && io.x) to_host(c, io.x_caller, io.x, N(c));
+	if (g_changed && io.g_host && io.g && options().strict_grad) to_host(c, io.g_caller, io.g, N(c));
+	sync(c);
+}
+
+// ---- ring bookkeeping (reference src/stochqn.c:554-579) ----------------------------------------
+void ring_reset(bfgs_mem* b) { b->mem_used = 0; b->mem_st_ix = 0; }
+void ring_advance(bfgs_mem* b)
+{
+	b->mem_st_ix = (b->mem_st_ix + 1) % b->mem_size;
+	b->mem_used = (b->mem_used + 1 >= b->mem_size) ? b->mem_size : b->mem_used + 1;
+}
+void fisher_reset(fisher_mem* f) { if (f) { f->mem_used = 0; f->mem_st_ix = 0; } }
+void fisher_advance(fisher_mem* f)
+{
+	f->mem_st_ix = (f->mem_st_ix + 1) % f->mem_size;
+	f->mem_used = (f->mem_used + 1 >= f->mem_size) ? f->mem_size : f->mem_used + 1;
+}
+
+// ---- two-loop recursion (reference src/stochqn.c:663-708) as a chain of fused sweeps -----------
+// Logical pair i lives in physical row (st + i) % m, st = row of the oldest pair.
+void ensure_rho(DevCtx* c, size_t st, size_t used)
+{
+	for (size_t i = 0; i < used; i++) {
+		const size_t r = (st + i) % c->m;
+		if (c->rho_ok[r]) continue;
+		Partials p = launch_dots3(c->sc, c->next_buf(), N(c), row(c->S, r, c), row(c->Y, r, c));
+		launch_commit(c->sc, p, c->sc.sy + r, c->sc.yy + r);
+		c->rho_ok[r] = 1;
+	}
+}
+
+struct StepIn {
+	double step = 0;
+	double* x = nullptr;
+	double* g = nullptr;
+	size_t used = 0, st_ix = 0;      // ring counters as the caller's struct has them
+	double h0 = 0;                   // oLBFGS hess_init
+	double* H0 = nullptr;            // adaQN diagonal target
+	double* G = nullptr;             // adaQN grad_sum_sq (NULL = no rescaling)
+	double w = 0, eps = 0;
+	double* gprev_out = nullptr;     // oLBFGS
+	double* frow_out = nullptr;      // adaQN Fisher row
+	double* x_sum = nullptr;         // SQN / adaQN
+	double* s_slot = nullptr;        // oLBFGS
+	int check_nan = 0;
+};
+
+// Returns the last-forward / guard partials; after this the direction is in `g`.
+Partials enqueue_two_loop(DevCtx* c, double* g, size_t used, size_t st, const FirstArgs& fa_in, double h0,
+                          double* H0, const ApplyArgs* fuse)
+{
+	const Scratch& sc = c->sc;
+	const size_t n = N(c), m = c->m, k = used;
+	auto r_of = [&](size_t i) { return (st + i) % m; };
+	ensure_rho(c, st, k);
+
+	FirstArgs fa = fa_in;
+	fa.q = g;
+	fa.s_newest = row(c->S, r_of(k - 1), c);
+	Partials p = launch_first(sc, c->next_buf(), n, fa);
+	for (size_t i = k - 1; i >= 1; i--)
+		p = launch_bwd(sc, c->next_buf(), n, p, sc.sy + r_of(i), (int) i, row(c->Y, r_of(i), c), g, row(c->S, r_of(i - 1), c));
+
+	MidScale ms{};
+	if (H0 != nullptr) ms.H0 = H0;                                   // :695
+	else if (h0 > 0) ms.h0 = h0;                                     // :698
+	else { ms.sy_newest = sc.sy + r_of(k - 1); ms.yy_newest = sc.yy + r_of(k - 1); }   // :683-689
+	p = launch_mid(sc, c->next_buf(), n, p, sc.sy + r_of(0), row(c->Y, r_of(0), c), g, ms);
+
+	for (size_t i = 0; i + 1 < k; i++)
+		p = launch_fwd(sc, c->next_buf(), n, p, sc.sy + r_of(i), (int) i, row(c->S, r_of(i), c), g, row(c->Y, r_of(i + 1), c));
+	return launch_fwd_last(sc, c->next_buf(), n, p, sc.sy + r_of(k - 1), (int) (k - 1), row(c->S, r_of(k - 1), c), g, fuse);
+}
+
+// take_step (reference src/stochqn.c:802-840) + the caller's follow-up that only depends on the
+// guard (x_sum += x, oLBFGS s-slot).  Enqueues everything and the read-back of the report block.
+void enqueue_step(Call& io, const StepIn& in)
+{
+	DevCtx* c = io.c;
+	const Scratch& sc = c->sc;
+	const size_t n = N(c);
+	ApplyArgs ap{in.x, in.x_sum, in.s_slot, in.step};
+	FirstArgs fa{};
+	fa.q = in.g;
+	fa.gprev_out = in.gprev_out;
+	fa.frow_out = in.frow_out;
+	fa.G = in.G;
+	fa.rmsprop_weight = in.w;
+	fa.scal_reg = in.eps;
+
+	if (in.used == 0) {
+		fa.H0_out = nullptr;                                          // rescale in place (:811)
+		const bool need_first = in.check_nan || fa.gprev_out || fa.frow_out || fa.G;
+		Partials guard{nullptr, 0, 0};
+		if (need_first) guard = launch_first(sc, c->next_buf(), n, fa);
+		launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
+	} else {
+		fa.H0_out = in.H0;                                            // :818
+		const size_t st = (in.st_ix == in.used) ? 0 : in.st_ix;      // :820
+		Partials guard = enqueue_two_loop(c, in.g, in.used, st, fa, in.h0, in.G ? in.H0 : nullptr,
+		                                  in.check_nan ? nullptr : &ap);
+		if (in.check_nan) launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, true);
+		to_host(c, c->pin + 8, sc.rho, c->m);                         // buffer_rho | buffer_alpha
+		to_host(c, c->pin + 8 + c->m, sc.alpha, c->m);
+	}
+	if (in.check_nan || in.used == 0) to_host(c, c->pin, sc.report, 4);
+	else { c->pin[0] = 0; }
+}
+
+// after sync(): was the step rejected?  Also hands buffer_rho / buffer_alpha back to the caller.
+bool step_was_bad(Call& io, bfgs_mem* b, size_t used_before)
+{
+	DevCtx* c = io.c;
+	if (used_before > 0) {
+		double* dst[2] = {b->buffer_rho, b->buffer_alpha};
+		for (int j = 0; j < 2; j++) {
+			if (!dst[j]) continue;
+			if (is_device_pointer(dst[j]))
+				SQN_HIP_OK(hipMemcpy(dst[j], c->pin + 8 + j * c->m, used_before * sizeof(double), hipMemcpyHostToDevice));
+			else
+				std::memcpy(dst[j], c->pin + 8 + j * c->m, used_before * sizeof(double));
+		}
+	}
+	return c->pin[0] != 0.0;
+}
+
+// ---- correction pairs ----------------------------------------------------------------------------
+// reference "backup" = bak -> slot (src/stochqn.c:589-595).  The s half is dead (the slot's s is
+// rewritten right after in every caller), the y half is observable.
+void backup_pair(DevCtx* c, bfgs_mem* b)
+{
+	if (!(b->min_curvature > 0)) return;
+	d2d(c, row(c->Y, b->mem_st_ix, c), c->ybak.dev, N(c));
+	c->rho_ok[b->mem_st_ix] = 0;
+}
+
+// update_s_vector (reference src/stochqn.c:861-870)
+void make_s(DevCtx* c, bfgs_mem* b, bool needs_div)
+{
+	backup_pair(c, b);
+	const bool scale = needs_div && b->upd_freq > 1;                  // :286-291
+	launch_pair_s(c->sc, N(c), c->xsum.dev, 1 / (double) b->upd_freq, scale, c->xprev.dev, row(c->S, b->mem_st_ix, c));
+	c->rho_ok[b->mem_st_ix] = 0;
+}
+
+// check_min_curvature (reference src/stochqn.c:883-900) given the (s'y, s's, y'y) partials of the
+// pair in the slot.  Synchronises (the decision is taken on the host).
+void accept_or_reject(DevCtx* c, bfgs_mem* b, Partials p, info_enum* info)
+{
+	const size_t st = b->mem_st_ix;
+	const double* src = p.parts;
+	if (p.count != 1) { launch_fin(c->sc, p, 3, c->sc.red[0]); src = c->sc.red[0]; }
+	to_host(c, c->pin + 4, src, 3);
+	sync(c);
+	const double sy = c->pin[4], ss = c->pin[5], yy = c->pin[6];
+	if (b->min_curvature > 0) {
+		const double curv = sy / ss;
+		if (curv <= b->min_curvature) {                                // NaN curvature is accepted
+			d2d(c, row(c->S, st, c), c->sbak.dev, N(c));                // "rollback" = bak -> slot (:597-604)
+			d2d(c, row(c->Y, st, c), c->ybak.dev, N(c));
+			c->rho_ok[st] = 0;
+			*info = curvature_too_small;
+			return;
+		}
+	}
+	launch_set2(c->sc, c->sc.sy + st, sy, c->sc.yy + st, yy);
+	c->rho_ok[st] = 1;
+	ring_advance(b);
+}
+
+void average_sum(DevCtx* c, size_t L)                                   // average_from_sum (:286-291)
+{
+	if (L > 1) launch_scale(c->sc, N(c), c->xsum.dev, 1 / (double) L);
+}
+
+void archive_average(DevCtx* c)                                          // archive_x_avg (:606-610)
+{
+	d2d(c, c->xprev.dev, c->xsum.dev, N(c));
+	zero(c, c->xsum.dev, N(c));
+}
+
+int invalid(task_enum* task, const char* who)
+{
+	*task = invalid_input;
+	std::fprintf(stderr, "%s got an invalid workspace as input.\n", who);
+	return -1000;
+}
+
+int no_device(task_enum* task, const char* who)
+{
+	*task = invalid_input;
+	std::fprintf(stderr, "%s: no usable HIP device (this build of libstochqn has no CPU path).\n", who);
+	return -1000;
+}
+
+void* dev_alloc(size_t count, bool zero_fill)
+{
+	void* p = nullptr;
+	if (hipMalloc(&p, count * sizeof(double)) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+	if (zero_fill) SQN_HIP_OK(hipMemset(p, 0, count * sizeof(double)));
+	return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+// =================================================================================================
+// oLBFGS (reference src/stochqn.c:978-1036)
+// =================================================================================================
+int run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_enum* task,
+               workspace_oLBFGS* w, info_enum* iter_info)
+{
+	*iter_info = no_problems_encountered;
+	if (!w || !w->bfgs_memory || w->section < 0 || w->section > 2) return invalid(task, "oLBFGS");
+	if (!device_ready()) return no_device(task, "oLBFGS");
+	bfgs_mem* b = w->bfgs_memory;
+	*req = x;
+
+	if (w->section == 0) {                     // first call: ask for a gradient
+		*task = calc_grad;
+		w->section = 1;
+		return 0;
+	}
+
+	Call io;
+	if (!open_call(io, KIND_OLBFGS, w->n, b, 0, w->niter > 0 || b->mem_used > 0, x, grad)) return invalid(task, "oLBFGS");
+	DevCtx* c = io.c;
+	if (!bind(c, c->gprev, w->grad_prev, N(c), true)) return invalid(task, "oLBFGS");
+
+	if (w->section == 1) {                     // step; s-slot; ask for the gradient on the same batch
+		stage_xg(io, true, true);
+		const size_t used = b->mem_used;
+		StepIn in;
+		in.step = step_size; in.x = io.x; in.g = io.g;
+		in.used = used; in.st_ix = b->mem_st_ix;
+		in.h0 = w->hess_init;
+		in.gprev_out = c->gprev.dev;                                  // :996
+		in.s_slot = row(c->S, b->mem_st_ix, c);                       // :1006-1007, predicated on the guard
+		in.check_nan = w->check_nan;
+		enqueue_step(io, in);
+		w->niter++;
+		close_call(io, true, true);
+		if (step_was_bad(io, b, used)) {
+			ring_reset(b);                                            // :831, :1015
+			*iter_info = search_direction_was_nan;
+			*task = calc_grad;
+			w->section = 1;
+			return 0;
+		}
+		c->rho_ok[b->mem_st_ix] = 0;
+		if (b->min_curvature > 0) { backup_pair(c, b); sync(c); }     // :1005 (y half)
+		*task = calc_grad_same_batch;
+		w->section = 2;
+		return 1;
+	}
+
+	// section 2: y-slot from the gradient difference, accept / reject, ask for a new gradient
+	stage_xg(io, false, true);
+	const size_t st = b->mem_st_ix;
+	Partials p = launch_pair_y_diff(c->sc, c->next_buf(), N(c), io.g, c->gprev.dev, row(c->S, st, c), b->y_reg, row(c->Y, st, c));
+	accept_or_reject(c, b, p, iter_info);
+	sync(c);
+	*task = calc_grad;
+	w->section = 1;
+	return 0;
+}
+
+// =================================================================================================
+// SQN (reference src/stochqn.c:1038-1153)
+// =================================================================================================
+int run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real_t** req, real_t** req_vec,
+            task_enum* task, workspace_SQN* w, info_enum* iter_info)
+{
+	*iter_info = no_problems_encountered;
+	if (!w || !w->bfgs_memory || w->section < 0 || w->section > 4) return invalid(task, "SQN");
+	if (!device_ready()) return no_device(task, "SQN");
+	bfgs_mem* b = w->bfgs_memory;
+	int ret = 0;
+
+	if (w->section != 0) {
+		Call io;
+		if (!open_call(io, KIND_SQN, w->n, b, 0, w->niter > 0 || b->mem_used > 0, x, grad)) return invalid(task, "SQN");
+		DevCtx* c = io.c;
+		const size_t n = N(c);
+		if (!bind(c, c->gprev, w->grad_prev, w->use_grad_diff ? n : 0, true) ||
+		    !bind(c, c->xsum, w->x_sum, n, true) || !bind(c, c->xprev, w->x_avg_prev, n, true))
+			return invalid(task, "SQN");
+
+		switch (w->section) {
+		case 1: {
+			stage_xg(io, true, true);
+			const size_t used = b->mem_used;
+			StepIn in;
+			in.step = step_size; in.x = io.x; in.g = io.g;
+			in.used = used; in.st_ix = b->mem_st_ix;
+			in.x_sum = c->xsum.dev;                                   // :1067, fused into the update
+			in.check_nan = w->check_nan;
+			enqueue_step(io, in);
+			w->niter++;
+			close_call(io, true, true);
+			if (step_was_bad(io, b, used)) { ring_reset(b); *iter_info = search_direction_was_nan; ret = 0; }
+			else ret = 1;
+
+			if (w->niter % b->upd_freq != 0) break;
+			if (w->niter == b->upd_freq) {                            // :1078-1094: first average only
+				average_sum(c, b->upd_freq);
+				archive_average(c);
+				if (!w->use_grad_diff) { sync(c); break; }
+				*task = calc_grad_big_batch;
+				*req = publish(io, c->xprev, 0, 0);
+				sync(c);
+				w->section = 2;
+				return ret;
+			}
+			make_s(c, b, true);                                       // :1097
+			*req = publish(io, c->xsum, 0, 0);
+			if (w->use_grad_diff) { *task = calc_grad_big_batch; w->section = 3; }
+			else {
+				*task = calc_hess_vec;
+				w->section = 4;
+				*req_vec = publish(io, c->S, b->mem_st_ix * n, 1);
+			}
+			sync(c);
+			return ret;
+		}
+		case 2:                                                       // :1118-1122
+			stage_xg(io, false, true);
+			d2d(c, c->gprev.dev, io.g, n);
+			sync(c);
+			break;
+		case 3: {                                                     // :1125-1134
+			stage_xg(io, false, true);
+			const size_t st = b->mem_st_ix;
+			Partials p = launch_pair_y_diff(c->sc, c->next_buf(), n, io.g, c->gprev.dev, row(c->S, st, c), b->y_reg, row(c->Y, st, c));
+			accept_or_reject(c, b, p, iter_info);
+			if (*iter_info == no_problems_encountered) {
+				d2d(c, c->gprev.dev, io.g, n);
+				d2d(c, c->xprev.dev, c->xsum.dev, n);
+			}
+			zero(c, c->xsum.dev, n);
+			sync(c);
+			break;
+		}
+		case 4: {                                                     // :1137-1142
+			const bool hv_host = !is_device_pointer(hess_vec);
+			double* hv = stage_in(c, 2, hess_vec, n, hv_host);
+			const size_t st = b->mem_st_ix;
+			Partials p = launch_pair_y_hv(c->sc, c->next_buf(), n, hv, row(c->S, st, c), row(c->Y, st, c), c->xsum.dev, c->xprev.dev);
+			accept_or_reject(c, b, p, iter_info);
+			sync(c);
+			break;
+		}
+		}
+	}
+	w->section = 1;                                                   // resume_main_loop (:1148-1152)
+	*task = calc_grad;
+	*req = x;
+	return ret;
+}
+
+// =================================================================================================
+// adaQN (reference src/stochqn.c:1155-1315)
+// =================================================================================================
+int run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** req, task_enum* task,
+              workspace_adaQN* w, info_enum* iter_info)
+{
+	*iter_info = no_problems_encountered;
+	if (!w || !w->bfgs_memory || w->section < 0 || w->section > 5) return invalid(task, "adaQN");
+	if (!device_ready()) return no_device(task, "adaQN");
+	bfgs_mem* b = w->bfgs_memory;
+	fisher_mem* fm = w->use_grad_diff ? nullptr : w->fisher_memory;
+	int ret = 0;
+	bool build_y = false;
+
+	if (w->section == 3) {                                             // :1258-1262, scalar only
+		w->f_prev = f;
+	} else if (w->section != 0) {
+		Call io;
+		const size_t fsize = fm ? fm->mem_size : 0;
+		const bool resumed = w->niter > 0 || b->mem_used > 0;
+		if (!open_call(io, KIND_ADAQN, w->n, b, fsize, resumed, x, grad)) return invalid(task, "adaQN");
+		DevCtx* c = io.c;
+		const size_t n = N(c);
+		if (!bind(c, c->gprev, w->grad_prev, w->use_grad_diff ? n : 0, true) ||
+		    !bind(c, c->xsum, w->x_sum, n, true) || !bind(c, c->xprev, w->x_avg_prev, n, true) ||
+		    !bind(c, c->H0, w->H0, n, false) || !bind(c, c->G, w->grad_sum_sq, n, true) ||
+		    !bind(c, c->F, fm ? fm->F : nullptr, fsize * n, resumed && fm && fm->mem_used > 0))
+			return invalid(task, "adaQN");
+
+		switch (w->section) {
+		case 1: {
+			stage_xg(io, true, true);
+			const size_t used = b->mem_used;
+			StepIn in;
+			in.step = step_size; in.x = io.x; in.g = io.g;
+			in.used = used; in.st_ix = b->mem_st_ix;
+			in.H0 = c->H0.dev; in.G = c->G.dev;
+			in.w = w->rmsprop_weight; in.eps = w->scal_reg;
+			if (fm) { in.frow_out = row(c->F, fm->mem_st_ix, c); fisher_advance(fm); }   // :1174
+			in.x_sum = c->xsum.dev;                                   // :1191
+			in.check_nan = w->check_nan;
+			enqueue_step(io, in);
+			close_call(io, true, true);
+			if (step_was_bad(io, b, used)) { ring_reset(b); *iter_info = search_direction_was_nan; ret = 0; }
+			else ret = 1;
+			w->niter++;
+
+			if (w->niter % b->upd_freq != 0) break;
+			if (w->niter == b->upd_freq) {                            // :1206-1224
+				average_sum(c, b->upd_freq);
+				archive_average(c);
+				if (w->use_grad_diff || w->max_incr > 0) {
+					*task = w->use_grad_diff ? calc_grad_big_batch : calc_fun_val_batch;
+					*req = publish(io, c->xprev, 0, 0);
+					sync(c);
+					w->section = w->use_grad_diff ? 2 : 3;
+					return ret;
+				}
+				sync(c);
+				break;
+			}
+			if (w->max_incr > 0) {                                    // :1227-1234
+				average_sum(c, b->upd_freq);
+				*task = calc_fun_val_batch;
+				*req = publish(io, c->xsum, 0, 0);
+				sync(c);
+				w->section = 5;
+				return ret;
+			}
+			make_s(c, b, true);                                       // :1237
+			build_y = true;
+			break;
+		}
+		case 2:                                                       // :1242-1255
+			stage_xg(io, false, true);
+			d2d(c, c->gprev.dev, io.g, n);
+			if (w->max_incr) {
+				*task = calc_fun_val_batch;
+				*req = publish(io, c->xprev, 0, 0);
+				sync(c);
+				w->section = 3;
+				return 0;
+			}
+			sync(c);
+			break;
+		case 4: {                                                     // :1265-1270
+			stage_xg(io, false, true);
+			const size_t st = b->mem_st_ix;
+			Partials p = launch_pair_y_diff(c->sc, c->next_buf(), n, io.g, c->gprev.dev, row(c->S, st, c), b->y_reg, row(c->Y, st, c));
+			accept_or_reject(c, b, p, iter_info);
+			if (*iter_info == no_problems_encountered) d2d(c, c->gprev.dev, io.g, n);
+			zero(c, c->xsum.dev, n);
+			sync(c);
+			break;
+		}
+		case 5:                                                       // :1273-1291
+			if (f > w->max_incr * w->f_prev || std::isinf(f) || std::isnan(f)) {
+				ring_reset(b);
+				fisher_reset(fm);
+				stage_xg(io, true, false);
+				d2d(c, io.x, c->xprev.dev, n);                        // x <- x_avg_prev
+				*iter_info = func_increased;
+				ret = 1;
+				close_call(io, true, false);
+				break;
+			}
+			w->f_prev = f;
+			make_s(c, b, false);
+			build_y = true;
+			break;
+		}
+
+		if (build_y) {                                                // update_y (:1297-1308)
+			if (!w->use_grad_diff && !fm) return invalid(task, "adaQN");
+			if (w->use_grad_diff) {
+				*req = publish(io, c->xsum, 0, 0);
+				*task = calc_grad_big_batch;
+				sync(c);
+				w->section = 4;
+				return ret;
+			}
+			const size_t st = b->mem_st_ix;
+			Partials p = launch_fisher(c->sc, c->next_buf(), n, c->F.dev, fm->mem_used, row(c->S, st, c), c->fisher_t, row(c->Y, st, c));
+			if (fm->buffer_y) to_host(c, c->pin + 8 + 2 * c->m, c->fisher_t, fm->mem_used);
+			accept_or_reject(c, b, p, iter_info);
+			if (fm->buffer_y) {
+				if (is_device_pointer(fm->buffer_y))
+					SQN_HIP_OK(hipMemcpy(fm->buffer_y, c->pin + 8 + 2 * c->m, fm->mem_used * sizeof(double), hipMemcpyHostToDevice));
+				else
+					std::memcpy(fm->buffer_y, c->pin + 8 + 2 * c->m, fm->mem_used * sizeof(double));
+			}
+			if (*iter_info == no_problems_encountered) d2d(c, c->xprev.dev, c->xsum.dev, n);
+			zero(c, c->xsum.dev, n);
+			sync(c);
+		}
+	}
+	w->section = 1;                                                   // resume_main_loop (:1310-1314)
+	*task = calc_grad;
+	*req = x;
+	return ret;
+}
+
+// =================================================================================================
+// library-owned workspaces (reference src/stochqn.c:300-547): structs and the small host-readable
+// buffers in host memory, every n-sized array in HBM.
+// =================================================================================================
+bfgs_mem* initialize_bfgs_mem(const size_t mem_size, const int n, const real_t min_curvature, const real_t y_reg,
+                              const size_t upd_freq)
+{
+	if (!device_ready() || n <= 0 || mem_size == 0) return nullptr;
+	bfgs_mem* b = (bfgs_mem*) std::calloc(1, sizeof(bfgs_mem));
+	if (!b) return nullptr;
+	b->s_mem = (real_t*) dev_alloc((size_t) n * mem_size, false);
+	b->y_mem = (real_t*) dev_alloc((size_t) n * mem_size, false);
+	b->buffer_rho = (real_t*) std::calloc(mem_size, sizeof(real_t));
+	b->buffer_alpha = (real_t*) std::calloc(mem_size, sizeof(real_t));
+	if (min_curvature > 0) {                     // zero-filled: deterministic superset of the reference's malloc
+		b->s_bak = (real_t*) dev_alloc((size_t) n, true);
+		b->y_bak = (real_t*) dev_alloc((size_t) n, true);
+	}
+	b->mem_size = mem_size;
+	b->upd_freq = upd_freq;
+	b->y_reg = y_reg;
+	b->min_curvature = min_curvature;
+	if (!b->s_mem || !b->y_mem || !b->buffer_rho || !b->buffer_alpha || (min_curvature > 0 && (!b->s_bak || !b->y_bak))) {
+		std::fprintf(stderr, "Error: Could not allocate memory for BFGS storage.\n");
+		dealloc_bfgs_mem(b);
+		return nullptr;
+	}
+	return b;
+}
+
+void dealloc_bfgs_mem(bfgs_mem* b)
+{
+	if (!b) return;
+	release(b->s_mem);
+	if (b->s_mem) (void) hipFree(b->s_mem);
+	if (b->y_mem) (void) hipFree(b->y_mem);
+	if (b->s_bak) (void) hipFree(b->s_bak);
+	if (b->y_bak) (void) hipFree(b->y_bak);
+	std::free(b->buffer_rho);
+	std::free(b->buffer_alpha);
+	std::free(b);
+}
+
+fisher_mem* initialize_fisher_mem(const size_t mem_size, const int n)
+{
+	if (!device_ready() || n <= 0 || mem_size == 0) return nullptr;
+	fisher_mem* f = (fisher_mem*) std::calloc(1, sizeof(fisher_mem));
+	if (!f) return nullptr;
+	f->F = (real_t*) dev_alloc((size_t) n * mem_size, false);
+	f->buffer_y = (real_t*) std::calloc(mem_size, sizeof(real_t));
+	f->mem_size = mem_size;
+	if (!f->F || !f->buffer_y) {
+		std::fprintf(stderr, "Error: Could not allocate memory for Fisher storage.\n");
+		dealloc_fisher_mem(f);
+		return nullptr;
+	}
+	return f;
+}
+
+void dealloc_fisher_mem(fisher_mem* f)
+{
+	if (!f) return;
+	if (f->F) (void) hipFree(f->F);
+	std::free(f->buffer_y);
+	std::free(f);
+}
+
+static bool gpu_or_complain(const char* who)
+{
+	if (device_ready()) return true;
+	std::fprintf(stderr, "Error: %s: no usable HIP device (this build of libstochqn has no CPU path).\n", who);
+	return false;
+}
+
+workspace_oLBFGS* initialize_oLBFGS(const int n, const size_t mem_size, const real_t hess_init, const real_t y_reg,
+                                    const real_t min_curvature, const int check_nan, const int nthreads)
+{
+	if (!gpu_or_complain("initialize_oLBFGS")) return nullptr;
+	workspace_oLBFGS* w = (workspace_oLBFGS*) std::calloc(1, sizeof(*w));
+	if (!w) return nullptr;
+	w->bfgs_memory = initialize_bfgs_mem(mem_size, n, min_curvature, y_reg, 1);
+	w->grad_prev = (real_t*) dev_alloc((size_t) (n > 0 ? n : 1), false);
+	w->hess_init = hess_init;
+	w->check_nan = check_nan;
+	w->nthreads = nthreads;
+	w->n = n;
+	if (!w->bfgs_memory || !w->grad_prev) {
+		std::fprintf(stderr, "Error: Could not allocate memory for oLBFGS.\n");
+		dealloc_oLBFGS(w);
+		return nullptr;
+	}
+	return w;
+}
+
+void dealloc_oLBFGS(workspace_oLBFGS* w)
+{
+	if (!w) return;
+	dealloc_bfgs_mem(w->bfgs_memory);
+	if (w->grad_prev) (void) hipFree(w->grad_prev);
+	std::free(w);
+}
+
+workspace_SQN* initialize_SQN(const int n, const size_t mem_size, const size_t bfgs_upd_freq, const real_t min_curvature,
+                              const int use_grad_diff, const real_t y_reg, const int check_nan, const int nthreads)
+{
+	if (!gpu_or_complain("initialize_SQN")) return nullptr;
+	workspace_SQN* w = (workspace_SQN*) std::calloc(1, sizeof(*w));
+	if (!w) return nullptr;
+	const size_t nn = (size_t) (n > 0 ? n : 1);
+	w->bfgs_memory = initialize_bfgs_mem(mem_size, n, min_curvature, y_reg, bfgs_upd_freq);
+	w->grad_prev = use_grad_diff ? (real_t*) dev_alloc(nn, false) : nullptr;
+	w->x_sum = (real_t*) dev_alloc(nn, true);
+	w->x_avg_prev = (real_t*) dev_alloc(nn, false);
+	w->use_grad_diff = use_grad_diff;
+	w->check_nan = check_nan;
+	w->nthreads = nthreads;
+	w->n = n;
+	if (!w->bfgs_memory || !w->x_sum || !w->x_avg_prev || (use_grad_diff && !w->grad_prev)) {
+		std::fprintf(stderr, "Error: Could not allocate memory for SQN.\n");
+		dealloc_SQN(w);
+		return nullptr;
+	}
+	return w;
+}
+
+void dealloc_SQN(workspace_SQN* w)
+{
+	if (!w) return;
+	dealloc_bfgs_mem(w->bfgs_memory);
+	if (w->grad_prev) (void) hipFree(w->grad_prev);
+	if (w->x_sum) (void) hipFree(w->x_sum);
+	if (w->x_avg_prev) (void) hipFree(w->x_avg_prev);
+	std::free(w);
+}
+
+workspace_adaQN* initialize_adaQN(const int n, const size_t mem_size, const size_t fisher_size, const size_t bfgs_upd_freq,
+                                  const real_t max_incr, const real_t min_curvature, const real_t scal_reg,
+                                  const real_t rmsprop_weight, const int use_grad_diff, const real_t y_reg,
+                                  const int check_nan, const int nthreads)
+{
+	if (!gpu_or_complain("initialize_adaQN")) return nullptr;
+	workspace_adaQN* w = (workspace_adaQN*) std::calloc(1, sizeof(*w));
+	if (!w) return nullptr;
+	const size_t nn = (size_t) (n > 0 ? n : 1);
+	w->bfgs_memory = initialize_bfgs_mem(mem_size, n, min_curvature, y_reg, bfgs_upd_freq);
+	if (use_grad_diff) w->grad_prev = (real_t*) dev_alloc(nn, false);
+	else               w->fisher_memory = initialize_fisher_mem(fisher_size, n);
+	w->H0 = (real_t*) dev_alloc(nn, false);
+	w->x_sum = (real_t*) dev_alloc(nn, true);
+	w->x_avg_prev = (real_t*) dev_alloc(nn, false);
+	w->grad_sum_sq = (real_t*) dev_alloc(nn, true);
+	w->max_incr = max_incr;
+	w->scal_reg = scal_reg;
+	w->rmsprop_weight = rmsprop_weight;
+	w->use_grad_diff = use_grad_diff;
+	w->check_nan = check_nan;
+	w->nthreads = nthreads;
+	w->n = n;
+	if (!w->bfgs_memory || !w->H0 || !w->x_sum || !w->x_avg_prev || !w->grad_sum_sq ||
+	    (use_grad_diff ? !w->grad_prev : !w->fisher_memory)) {
+		std::fprintf(stderr, "Error: Could not allocate memory for adaQN.\n");
+		dealloc_adaQN(w);
+		return nullptr;
+	}
+	return w;
+}
+
+void dealloc_adaQN(workspace_adaQN* w)
+{
+	if (!w) return;
+	dealloc_bfgs_mem(w->bfgs_memory);
+	dealloc_fisher_mem(w->fisher_memory);
+	if (w->H0) (void) hipFree(w->H0);
+	if (w->grad_prev) (void) hipFree(w->grad_prev);
+	if (w->x_sum) (void) hipFree(w->x_sum);
+	if (w->x_avg_prev) (void) hipFree(w->x_avg_prev);
+	if (w->grad_sum_sq) (void) hipFree(w->grad_sum_sq);
+	std::free(w);
+}
+
+// =================================================================================================
+// isolated kernels of stochqn_hip.h
+// =================================================================================================
+int stochqn_hip_two_loop(double grad[], int n, double H0[], double h0, double y_mem[], double s_mem[],
+                         size_t mem_size, size_t mem_used, size_t mem_st_ix, double buffer_rho[], double buffer_alpha[])
+{
+	if (!device_ready() || !grad || !y_mem || !s_mem || n <= 0 || mem_size == 0 || mem_used == 0 || mem_used > mem_size)
+		return -1000;
+	bool fresh = false;
+	DevCtx* c = acquire(s_mem, KIND_RAW, n, mem_size, 0, &fresh);
+	if (!c) return -1000;
+	const size_t nn = (size_t) n;
+	if (!bind(c, c->S, s_mem, mem_size * nn, true) || !bind(c, c->Y, y_mem, mem_size * nn, true) ||
+	    !bind(c, c->H0, H0, H0 ? nn : 0, true))
+		return -1000;
+	// host arrays may have changed since the last call: refresh the mirrors, drop the cached dots
+	if (c->H0.mirror) SQN_HIP_OK(hipMemcpyAsync(c->H0.dev, H0, nn * sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
+	if (c->S.mirror && !fresh) SQN_HIP_OK(hipMemcpyAsync(c->S.dev, s_mem, mem_size * nn * sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
+	if (c->Y.mirror && !fresh) SQN_HIP_OK(hipMemcpyAsync(c->Y.dev, y_mem, mem_size * nn * sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
+	if (c->S.mirror || c->Y.mirror) c->rho_ok.assign(c->m, 0);
+	if (fresh) comm_attach(c);
+	const bool g_host = !is_device_pointer(grad);
+	double* g = stage_in(c, 1, grad, nn, g_host);
+	FirstArgs fa{};
+	Partials guard = enqueue_two_loop(c, g, mem_used, mem_st_ix % mem_size, fa, h0, H0 ? c->H0.dev : nullptr, nullptr);
+	(void) guard;
+	to_host(c, c->pin + 8, c->sc.rho, c->m);
+	to_host(c, c->pin + 8 + c->m, c->sc.alpha, c->m);
+	if (g_host) to_host(c, grad, g, nn);
+	sync(c);
+	double* dst[2] = {buffer_rho, buffer_alpha};
+	for (int j = 0; j < 2; j++) {
+		if (!dst[j]) continue;
+		if (is_device_pointer(dst[j])) SQN_HIP_OK(hipMemcpy(dst[j], c->pin + 8 + j * c->m, mem_used * sizeof(double), hipMemcpyHostToDevice));
+		else std::memcpy(dst[j], c->pin + 8 + j * c->m, mem_used * sizeof(double));
+	}
+	return 0;
+}
+
+int stochqn_hip_fisher_product(double F[], size_t fu, int n, double s[], double buffer_y[], double y[])
+{
+	if (!device_ready() || !F || !s || !y || n <= 0 || fu == 0) return -1000;
+	bool fresh = false;
+	DevCtx* c = acquire(F, KIND_RAW, n, 1, fu, &fresh);
+	if (!c) return -1000;
+	const size_t nn = (size_t) n;
+	if (fresh) comm_attach(c);
+	// F: used in place when on the device, else mirrored (re-uploaded every call: contents may have changed)
+	if (!bind(c, c->F, F, fu * nn, false)) return -1000;
+	if (c->F.mirror) SQN_HIP_OK(hipMemcpyAsync(c->F.dev, F, fu * nn * sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
+	const bool s_host = !is_device_pointer(s), y_host = !is_device_pointer(y);
+	double* sd = stage_in(c, 0, s, nn, s_host);
+	double* yd = y;
+	if (y_host) {
+		if (!c->stage[1]) SQN_HIP_OK(hipMalloc((void**) &c->stage[1], nn * sizeof(double)));
+		yd = c->stage[1];
+	}
+	launch_fisher(c->sc, c->next_buf(), nn, c->F.dev, fu, sd, c->fisher_t, yd);
+	to_host(c, c->pin + 8 + 2 * c->m, c->fisher_t, fu);
+	if (y_host) to_host(c, y, yd, nn);
+	sync(c);
+	if (buffer_y) {
+		if (is_device_pointer(buffer_y)) SQN_HIP_OK(hipMemcpy(buffer_y, c->pin + 8 + 2 * c->m, fu * sizeof(double), hipMemcpyHostToDevice));
+		else std::memcpy(buffer_y, c->pin + 8 + 2 * c->m, fu * sizeof(double));
+	}
+	return 0;
+}
+
+}  // extern "C"

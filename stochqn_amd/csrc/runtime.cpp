@@ -1,0 +1,361 @@
+// runtime.cpp -- context registry, pointer residency, mirrors, RCCL hook, options, profiler API.
+#include "runtime.hpp"
+#include "stochqn_hip.h"
+
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+
+namespace sqn {
+
+namespace {
+
+std::mutex g_mu;
+std::unordered_map<const void*, DevCtx*> g_ctx;
+Options g_opt;
+bool g_profile = false;
+double g_retired_ms[K_COUNT] = {0};
+long long g_retired_launches[K_COUNT] = {0};
+bool g_atexit = false;
+
+// ---- RCCL, loaded on demand -------------------------------------------------------------------
+struct Comm {
+	void* dl = nullptr;
+	ncclComm_t comm = nullptr;
+	int rank = 0, nranks = 1;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+	ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	const char* (*GetErrorString)(ncclResult_t) = nullptr;
+} g_comm;
+
+bool load_rccl()
+{
+	if (g_comm.dl) return true;
+	const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+	for (const char* nm : names) {
+		g_comm.dl = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+		if (g_comm.dl) break;
+	}
+	if (!g_comm.dl) { std::fprintf(stderr, "stochqn: cannot dlopen RCCL: %s\n", dlerror()); return false; }
+	g_comm.GetUniqueId = (decltype(g_comm.GetUniqueId)) dlsym(g_comm.dl, "ncclGetUniqueId");
+	g_comm.CommInitRank = (decltype(g_comm.CommInitRank)) dlsym(g_comm.dl, "ncclCommInitRank");
+	g_comm.AllReduce = (decltype(g_comm.AllReduce)) dlsym(g_comm.dl, "ncclAllReduce");
+	g_comm.CommDestroy = (decltype(g_comm.CommDestroy)) dlsym(g_comm.dl, "ncclCommDestroy");
+	g_comm.GetErrorString = (decltype(g_comm.GetErrorString)) dlsym(g_comm.dl, "ncclGetErrorString");
+	if (!g_comm.GetUniqueId || !g_comm.CommInitRank || !g_comm.AllReduce || !g_comm.CommDestroy) {
+		std::fprintf(stderr, "stochqn: RCCL library lacks the expected symbols\n");
+		return false;
+	}
+	return true;
+}
+
+void allreduce_hook(void*, double* buf, int count, hipStream_t stream)
+{
+	ncclResult_t r = g_comm.AllReduce(buf, buf, (size_t) count, ncclDouble, ncclSum, g_comm.comm, stream);
+	if (r != ncclSuccess)
+		std::fprintf(stderr, "stochqn: ncclAllReduce failed: %s\n", g_comm.GetErrorString ? g_comm.GetErrorString(r) : "?");
+}
+
+void free_view(View& v)
+{
+	if (v.mirror && v.dev) SQN_HIP_OK(hipFree(v.dev));
+	v = View{};
+}
+
+void destroy(DevCtx* c)
+{
+	if (c->sc.stream) SQN_HIP_OK(hipStreamSynchronize(c->sc.stream));
+	c->prof.collect();
+	for (int i = 0; i < K_COUNT; i++) { g_retired_ms[i] += c->prof.total_ms[i]; g_retired_launches[i] += c->prof.launches[i]; }
+	for (auto& p : c->prof.pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
+	for (auto e : c->prof.pool) (void) hipEventDestroy(e);
+	View* vs[] = {&c->S, &c->Y, &c->sbak, &c->ybak, &c->gprev, &c->xsum, &c->xprev, &c->H0, &c->G, &c->F};
+	for (View* v : vs) free_view(*v);
+	if (c->pool) SQN_HIP_OK(hipFree(c->pool));
+	if (c->sc.fisher_part) SQN_HIP_OK(hipFree(c->sc.fisher_part));
+	if (c->fisher_t) SQN_HIP_OK(hipFree(c->fisher_t));
+	for (double* p : c->stage) if (p) SQN_HIP_OK(hipFree(p));
+	for (double* p : c->host_stage) if (p) SQN_HIP_OK(hipHostFree(p));
+	if (c->pin) SQN_HIP_OK(hipHostFree(c->pin));
+	if (c->sc.stream) SQN_HIP_OK(hipStreamDestroy(c->sc.stream));
+	delete c;
+}
+
+void at_exit() { /* device memory dies with the process; destroying streams here can race with the
+                    HIP runtime's own teardown, so contexts are simply abandoned */ }
+
+}  // namespace
+
+Options& options() { return g_opt; }
+
+bool device_ready()
+{
+	static int state = -1;
+	if (state < 0) {
+		int count = 0;
+		hipError_t e = hipGetDeviceCount(&count);
+		state = (e == hipSuccess && count > 0) ? 1 : 0;
+		if (!state) (void) hipGetLastError();
+	}
+	return state == 1;
+}
+
+bool is_device_pointer(const void* p)
+{
+	if (!p) return false;
+	hipPointerAttribute_t a;
+	hipError_t e = hipPointerGetAttributes(&a, p);
+	if (e != hipSuccess) { (void) hipGetLastError(); return false; }   // ordinary malloc / R / numpy memory
+	return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+DevCtx* lookup(const void* key)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	auto it = g_ctx.find(key);
+	return it == g_ctx.end() ? nullptr : it->second;
+}
+
+DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* fresh)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	*fresh = false;
+	auto it = g_ctx.find(key);
+	if (it != g_ctx.end()) {
+		DevCtx* c = it->second;
+		if (c->kind == kind && c->n == n && c->m == m && c->fsize == fsize) {
+			c->sc.nontemporal = g_opt.nontemporal;
+			c->sc.grid_cap = g_opt.grid_cap;
+			c->sc.prof = g_profile ? &c->prof : nullptr;
+			return c;
+		}
+		destroy(c);              // same address, different problem: the old owner is gone
+		g_ctx.erase(it);
+	}
+	DevCtx* c = new DevCtx();
+	c->key = key; c->kind = kind; c->n = n; c->m = m; c->fsize = fsize;
+	c->n_global = (double) n;
+	SQN_HIP_OK(hipStreamCreate(&c->sc.stream));   // blocking flavour: ordered after the null stream
+	// pool layout: part0 | part1 | red0 | red1 | sy | yy | alpha | rho | report
+	const size_t part = (size_t) kMaxSums * kMaxGrid;
+	const size_t total = 2 * part + 2 * 256 + 4 * m + 8;
+	if (hipMalloc((void**) &c->pool, total * sizeof(double)) != hipSuccess) {
+		std::fprintf(stderr, "stochqn: could not allocate device scratch\n");
+		(void) hipStreamDestroy(c->sc.stream);
+		delete c;
+		return nullptr;
+	}
+	SQN_HIP_OK(hipMemset(c->pool, 0, total * sizeof(double)));
+	double* p = c->pool;
+	c->sc.part[0] = p; p += part;
+	c->sc.part[1] = p; p += part;
+	c->sc.red[0] = p; p += 256;
+	c->sc.red[1] = p; p += 256;
+	c->sc.sy = p; p += m;
+	c->sc.yy = p; p += m;
+	c->sc.alpha = p; p += m;
+	c->sc.rho = p; p += m;
+	c->sc.report = p;
+	c->pin_count = 16 + 2 * m + fsize;
+	SQN_HIP_OK(hipHostMalloc((void**) &c->pin, c->pin_count * sizeof(double), hipHostMallocDefault));
+	if (fsize > 0) {
+		SQN_HIP_OK(hipMalloc((void**) &c->sc.fisher_part, fsize * kMaxGrid * sizeof(double)));
+		SQN_HIP_OK(hipMalloc((void**) &c->fisher_t, fsize * sizeof(double)));
+	}
+	c->rho_ok.assign(m, 0);
+	c->sc.nontemporal = g_opt.nontemporal;
+	c->sc.grid_cap = g_opt.grid_cap;
+	c->sc.prof = g_profile ? &c->prof : nullptr;
+	c->sc.allreduce = nullptr;
+	c->sc.user = c;
+	g_ctx[key] = c;
+	if (!g_atexit) { g_atexit = true; std::atexit(at_exit); }
+	*fresh = true;
+	return c;
+}
+
+void release(const void* key)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	auto it = g_ctx.find(key);
+	if (it == g_ctx.end()) return;
+	destroy(it->second);
+	g_ctx.erase(it);
+}
+
+void release_all()
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	for (auto& kv : g_ctx) destroy(kv.second);
+	g_ctx.clear();
+}
+
+bool bind(DevCtx* c, View& v, double* caller, size_t count, bool import)
+{
+	(void) c;
+	if (caller == v.caller && count == v.count && (v.dev || count == 0)) return true;
+	free_view(v);
+	v.caller = caller;
+	v.count = count;
+	if (!caller || count == 0) return true;
+	if (is_device_pointer(caller)) { v.dev = caller; v.mirror = false; return true; }
+	if (hipMalloc((void**) &v.dev, count * sizeof(double)) != hipSuccess) {
+		std::fprintf(stderr, "stochqn: could not allocate a %zu-double device mirror\n", count);
+		v = View{};
+		return false;
+	}
+	v.mirror = true;
+	// without `import` the mirror starts with indeterminate contents, like the reference's malloc
+	if (import) SQN_HIP_OK(hipMemcpy(v.dev, caller, count * sizeof(double), hipMemcpyHostToDevice));
+	return true;
+}
+
+void export_view(DevCtx* c, View& v)
+{
+	if (v.mirror && v.dev && v.caller)
+		SQN_HIP_OK(hipMemcpyAsync(const_cast<void*>(v.caller), v.dev, v.count * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
+}
+
+double* stage_in(DevCtx* c, int which, double* caller, size_t count, bool host)
+{
+	if (!host) return caller;
+	if (!c->stage[which]) SQN_HIP_OK(hipMalloc((void**) &c->stage[which], (size_t) c->n * sizeof(double)));
+	SQN_HIP_OK(hipMemcpyAsync(c->stage[which], caller, count * sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
+	return c->stage[which];
+}
+
+void sync(DevCtx* c)
+{
+	SQN_HIP_OK(hipStreamSynchronize(c->sc.stream));
+	if (c->sc.prof) c->prof.collect();
+}
+
+int comm_nranks() { return g_comm.comm ? g_comm.nranks : 1; }
+
+void comm_attach(DevCtx* c)
+{
+	if (!g_comm.comm) { c->sc.allreduce = nullptr; c->n_global = (double) c->n; return; }
+	c->sc.allreduce = allreduce_hook;
+	// global problem size for the ||dir|| > 1e3*n guard (reference src/stochqn.c:829)
+	double nn = (double) c->n;
+	SQN_HIP_OK(hipMemcpyAsync(c->sc.red[0], &nn, sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
+	allreduce_hook(nullptr, c->sc.red[0], 1, c->sc.stream);
+	SQN_HIP_OK(hipMemcpyAsync(&nn, c->sc.red[0], sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
+	SQN_HIP_OK(hipStreamSynchronize(c->sc.stream));
+	c->n_global = nn;
+}
+
+}  // namespace sqn
+
+// ------------------------------------------------------------------------------------------------
+// C entry points of stochqn_hip.h that do not involve the optimiser arithmetic
+// ------------------------------------------------------------------------------------------------
+using namespace sqn;
+
+extern "C" {
+
+int stochqn_hip_available(void) { return device_ready() ? 1 : 0; }
+
+void stochqn_hip_invalidate(const void* s_mem)
+{
+	if (DevCtx* c = lookup(s_mem)) c->rho_ok.assign(c->m, 0);
+}
+
+void stochqn_hip_release(const void* s_mem) { release(s_mem); }
+void stochqn_hip_release_all(void) { release_all(); }
+
+int stochqn_hip_export(const void* s_mem)
+{
+	DevCtx* c = lookup(s_mem);
+	if (!c) return -1000;
+	View* vs[] = {&c->S, &c->Y, &c->sbak, &c->ybak, &c->gprev, &c->xsum, &c->xprev, &c->H0, &c->G, &c->F};
+	for (View* v : vs) export_view(c, *v);
+	sync(c);
+	return 0;
+}
+
+int stochqn_hip_set_option(const char* name, double value)
+{
+	if (!name) return -1;
+	if (!std::strcmp(name, "nontemporal")) g_opt.nontemporal = value != 0;
+	else if (!std::strcmp(name, "grid_cap")) {
+		int g = (int) value;
+		if (g < 1) g = 1;
+		if (g > kMaxGrid) g = kMaxGrid;
+		g_opt.grid_cap = g;
+	}
+	else if (!std::strcmp(name, "strict_grad")) g_opt.strict_grad = value != 0;
+	else return -1;
+	return 0;
+}
+
+void stochqn_hip_profile_enable(int on)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	g_profile = on != 0;
+	for (auto& kv : g_ctx) kv.second->sc.prof = g_profile ? &kv.second->prof : nullptr;
+}
+
+void stochqn_hip_profile_reset(void)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	for (auto& kv : g_ctx) kv.second->prof.reset();
+	for (int i = 0; i < K_COUNT; i++) { g_retired_ms[i] = 0; g_retired_launches[i] = 0; }
+}
+
+int stochqn_hip_profile_kernels(void) { return K_COUNT; }
+const char* stochqn_hip_profile_name(int id) { return kernel_name(id); }
+
+int stochqn_hip_profile_get(int id, long long* launches, double* total_ms)
+{
+	if (id < 0 || id >= K_COUNT) return -1;
+	std::lock_guard<std::mutex> lk(g_mu);
+	long long l = g_retired_launches[id];
+	double ms = g_retired_ms[id];
+	for (auto& kv : g_ctx) { l += kv.second->prof.launches[id]; ms += kv.second->prof.total_ms[id]; }
+	if (launches) *launches = l;
+	if (total_ms) *total_ms = ms;
+	return 0;
+}
+
+int stochqn_hip_comm_unique_id(void* out128)
+{
+	if (!load_rccl()) return -1;
+	ncclUniqueId id;
+	if (g_comm.GetUniqueId(&id) != ncclSuccess) return -1;
+	std::memcpy(out128, &id, sizeof(id));
+	return 0;
+}
+
+int stochqn_hip_comm_init(int rank, int nranks, const void* unique_id128)
+{
+	if (!device_ready() || !load_rccl()) return -1;
+	if (g_comm.comm) return 0;
+	ncclUniqueId id;
+	std::memcpy(&id, unique_id128, sizeof(id));
+	ncclResult_t r = g_comm.CommInitRank(&g_comm.comm, nranks, id, rank);
+	if (r != ncclSuccess) {
+		std::fprintf(stderr, "stochqn: ncclCommInitRank failed: %s\n", g_comm.GetErrorString ? g_comm.GetErrorString(r) : "?");
+		g_comm.comm = nullptr;
+		return -1;
+	}
+	g_comm.rank = rank;
+	g_comm.nranks = nranks;
+	return 0;
+}
+
+int stochqn_hip_comm_nranks(void) { return comm_nranks(); }
+
+void stochqn_hip_comm_finalize(void)
+{
+	release_all();
+	if (g_comm.comm) { g_comm.CommDestroy(g_comm.comm); g_comm.comm = nullptr; g_comm.nranks = 1; g_comm.rank = 0; }
+}
+
+}  // extern "C"

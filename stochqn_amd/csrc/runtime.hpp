@@ -1,0 +1,82 @@
+// runtime.hpp -- device contexts behind the C ABI: where each caller array lives, the mirrors of
+// host arrays in HBM, scratch for the sweep chain, the RCCL hook and the global options.
+#pragma once
+#include "sqn_device.hpp"
+#include "stochqn.h"
+
+#include <cstdio>
+#include <vector>
+
+namespace sqn {
+
+enum Kind { KIND_OLBFGS = 1, KIND_SQN = 2, KIND_ADAQN = 3, KIND_RAW = 4 };
+
+// One caller array as the kernels see it.  `caller` is the pointer found in the caller's struct;
+// when that is device memory `dev == caller`, otherwise `dev` is a mirror owned by the context.
+struct View {
+	const void* caller = nullptr;
+	double* dev = nullptr;
+	size_t count = 0;
+	bool mirror = false;
+};
+
+struct Options {
+	bool nontemporal = true;
+	int grid_cap = kMaxGrid;
+	bool strict_grad = true;
+};
+Options& options();
+
+struct DevCtx {
+	const void* key = nullptr;
+	int kind = 0;
+	int n = 0;
+	size_t m = 0;
+	size_t fsize = 0;
+	double n_global = 0;
+
+	View S, Y, sbak, ybak, gprev, xsum, xprev, H0, G, F;
+	Scratch sc{};
+	Profiler prof;
+	int buf = 0;                       // ping-pong index of the next partial buffer
+	double* pool = nullptr;            // one allocation behind sc.part/red/sy/yy/alpha/rho/report
+	double* fisher_t = nullptr;        // [fsize] F*s on device
+	double* stage[3] = {nullptr, nullptr, nullptr};   // device staging for host x / grad / hess_vec
+	double* host_stage[2] = {nullptr, nullptr};       // pinned host landing zones for *req / *req_vec
+	double* pin = nullptr;             // pinned host read-back block
+	size_t pin_count = 0;
+	std::vector<char> rho_ok;          // per physical row: sc.sy / sc.yy hold this row's dots
+
+	int next_buf() { int b = buf; buf ^= 1; return b; }
+};
+
+bool device_ready();                                   // a HIP device exists and is usable
+bool is_device_pointer(const void* p);
+
+// Find or create the context of a workspace.  `fresh` tells the caller whether it was created now.
+DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* fresh);
+DevCtx* lookup(const void* key);
+void release(const void* key);
+void release_all();
+
+// (Re)bind a view to the caller's pointer.  Host pointers get a device mirror of `count` doubles;
+// with `import` the host contents are uploaded into a newly created mirror.
+bool bind(DevCtx* c, View& v, double* caller, size_t count, bool import);
+void export_view(DevCtx* c, View& v);                  // mirror -> caller's host array
+
+double* stage_in(DevCtx* c, int which, double* caller, size_t count, bool host);   // H2D if host
+void sync(DevCtx* c);                                  // stream sync + profiler collection
+
+// multi-GPU
+int comm_nranks();
+void comm_attach(DevCtx* c);                           // install the all-reduce hook, compute n_global
+
+#define SQN_HIP_OK(expr)                                                                             \
+	do {                                                                                             \
+		hipError_t e_ = (expr);                                                                      \
+		if (e_ != hipSuccess)                                                                        \
+			std::fprintf(stderr, "stochqn: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_),  \
+			             __FILE__, __LINE__);                                                        \
+	} while (0)
+
+}  // namespace sqn

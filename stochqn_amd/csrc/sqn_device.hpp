@@ -1,0 +1,162 @@
+// sqn_device.hpp -- interface between the host state machines (machines.cpp) and the HIP
+// kernels (kernels.hip).  Everything here takes DEVICE pointers and enqueues work on a stream;
+// nothing synchronises.  Names follow the reference's domain: correction pairs (s, y), the
+// two-loop recursion, the Fisher ring, the diagonal rescale.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace sqn {
+
+constexpr int kBlock = 256;       // threads per workgroup (4 wave64)
+constexpr int kMaxGrid = 2048;    // 256 CUs x 8 resident workgroups; also the partial-sum stride
+constexpr int kMaxSums = 3;       // sums one sweep can produce (s'y, s's, y'y)
+constexpr int kFisherRows = 8;    // Fisher rows one workgroup accumulates per pass-1 sweep
+
+// Kernel ids for the built-in HIP-event profiler (stochqn_hip_profile_*).
+enum KernelId {
+	K_FIRST = 0, K_BWD, K_MID, K_FWD, K_FWD_LAST, K_APPLY, K_PAIR_S, K_PAIR_Y_DIFF, K_PAIR_Y_HV,
+	K_DOTS3, K_FISHER_T, K_FISHER_Y, K_FIN, K_SMALL, K_COPY, K_COUNT
+};
+const char* kernel_name(int id);
+
+// HIP-event stopwatch around every kernel launch (one event pair per launch, resolved after the
+// stream has been synchronised).  Durations are accumulated per KernelId.
+struct Profiler {
+	struct Pending { int id; hipEvent_t a, b; };
+	std::vector<Pending> pending;
+	std::vector<hipEvent_t> pool;
+	double total_ms[K_COUNT] = {0};
+	long long launches[K_COUNT] = {0};
+
+	hipEvent_t get()
+	{
+		if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+		hipEvent_t e;
+		(void) hipEventCreate(&e);
+		return e;
+	}
+	void begin(int id, hipStream_t st)
+	{
+		Pending p{id, get(), get()};
+		(void) hipEventRecord(p.a, st);
+		pending.push_back(p);
+	}
+	void end(hipStream_t st) { (void) hipEventRecord(pending.back().b, st); }
+	void collect()  // call only after the stream has been synchronised
+	{
+		for (auto& p : pending) {
+			float ms = 0;
+			if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { total_ms[p.id] += ms; launches[p.id]++; }
+			pool.push_back(p.a);
+			pool.push_back(p.b);
+		}
+		pending.clear();
+	}
+	void reset()
+	{
+		for (int i = 0; i < K_COUNT; i++) { total_ms[i] = 0; launches[i] = 0; }
+	}
+};
+
+// A reduction result as the NEXT kernel sees it: `count` partial sums per quantity, quantity j
+// starting at parts[j * stride].  Single GPU: the producer's per-workgroup partials (count =
+// producer grid).  Multi GPU: the all-reduced scalars (count = 1, stride = 1).
+struct Partials {
+	const double* parts;
+	int count;
+	int stride;
+};
+
+// Per-context device scratch (owned by DevCtx in machines.cpp).
+struct Scratch {
+	hipStream_t stream;
+	double* part[2];      // two ping-pong partial buffers, each kMaxSums * kMaxGrid doubles
+	double* fisher_part;  // [fisher_size][kMaxGrid] partials of pass 1 (lazily sized)
+	double* red[2];       // all-reduce landing zones, 256 doubles each
+	double* sy;           // [m] s'y of each physical row (rho = 1/sy)
+	double* yy;           // [m] y'y of each physical row (gamma = sy/yy)
+	double* alpha;        // [m] alpha by logical index
+	double* rho;          // [m] rho by logical index (for buffer_rho write-back)
+	double* report;       // [4]: bad flag, sum r^2, nonfinite count, spare
+	int grid_cap;         // max workgroups per sweep (<= kMaxGrid)
+	bool nontemporal;     // stream S/Y/F rows with nt loads
+	Profiler* prof;       // NULL unless stochqn_hip_profile_enable(1)
+	// multi-GPU: in-place sum of `count` doubles at `buf` across all ranks, enqueued on `stream`.
+	// NULL on a single GPU.
+	void (*allreduce)(void* user, double* buf, int count, hipStream_t stream);
+	void* user;
+};
+
+int sweep_grid(const Scratch& sc, size_t n);
+
+// ---- two-loop chain ---------------------------------------------------------------------------
+// first sweep: optional side effects on the raw gradient, then either the newest pair's s'q
+// (s_newest != NULL) or the guard sums (sum dir^2, nonfinite) of the plain / rescaled gradient.
+struct FirstArgs {
+	double* q;               // gradient, n
+	const double* s_newest;  // NULL when the ring is empty
+	double* gprev_out;       // oLBFGS: grad_prev <- g            (nullable)
+	double* frow_out;        // adaQN : Fisher row  <- g           (nullable)
+	double* G;               // adaQN : grad_sum_sq in/out         (nullable)
+	double* H0_out;          // adaQN : g/sqrt(G+eps) goes here; NULL -> into q itself
+	double rmsprop_weight, scal_reg;
+};
+Partials launch_first(const Scratch& sc, int buf, size_t n, const FirstArgs& a);
+
+// backward sweep i: alpha_i = rho_i * <in>; q -= alpha_i*y_i; out = s_prev'q
+Partials launch_bwd(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, int logical_i,
+                    const double* y_i, double* q, const double* s_prev);
+
+// middle sweep: alpha_0; q -= alpha_0*y_0; r = H0-scaling(q); out = y_0'r
+struct MidScale {
+	const double* sy_newest;  // gamma = *sy_newest / *yy_newest when both non-NULL
+	const double* yy_newest;
+	double h0;                // else scalar h0 when H0 == NULL
+	const double* H0;         // else element-wise
+};
+Partials launch_mid(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row,
+                    const double* y_0, double* q, const MidScale& ms);
+
+// forward sweep i: beta = rho_i*<in>; r += (alpha_i-beta)*s_i; out = y_next'r
+Partials launch_fwd(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, int logical_i,
+                    const double* s_i, double* r, const double* y_next);
+
+// last forward sweep; out = (sum r^2, nonfinite).  With `fuse` non-NULL (check_nan == 0) the
+// position update is applied in the same pass and nothing is produced.
+struct ApplyArgs {
+	double* x;            // n
+	double* x_sum;        // nullable (SQN / adaQN)
+	double* s_slot;       // nullable (oLBFGS: s <- -step*r, grad <- -step*r)
+	double step;
+};
+Partials launch_fwd_last(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, int logical_i,
+                         const double* s_i, double* r, const ApplyArgs* fuse);
+
+// guarded position update: bad = nonfinite>0 || sqrt(sum r^2) > 1e3*n_global; writes report[0..2]
+void launch_apply(const Scratch& sc, size_t n, double n_global, Partials guard, const double* r_in, double* grad_out,
+                  const ApplyArgs& a, bool guarded);
+
+// ---- correction pairs ---------------------------------------------------------------------------
+void launch_pair_s(const Scratch& sc, size_t n, double* x_sum, double inv_L, bool scale, const double* x_avg_prev,
+                   double* s_out);
+Partials launch_pair_y_diff(const Scratch& sc, int buf, size_t n, const double* g, const double* g_prev,
+                            const double* s, double lambda, double* y_out);
+Partials launch_pair_y_hv(const Scratch& sc, int buf, size_t n, const double* hv, const double* s, double* y_out,
+                          double* x_sum, double* x_avg_prev);
+Partials launch_dots3(const Scratch& sc, int buf, size_t n, const double* s, const double* y);
+// Fisher product y = F'(F s)/fu; returns the (s'y, s's, y'y) partials; t_out[fu] receives F s.
+Partials launch_fisher(const Scratch& sc, int buf, size_t n, const double* F, size_t fu, const double* s,
+                       double* t_dev, double* y_out);
+
+// reduce `nsums` partial arrays to scalars: out[j] = sum_b parts[j*stride+b]
+void launch_fin(const Scratch& sc, Partials in, int nsums, double* out);
+// sy_dst <- total of quantity 0, yy_dst <- total of quantity 2 (device-side commit of a pair's dots)
+void launch_commit(const Scratch& sc, Partials in, double* sy_dst, double* yy_dst);
+// tiny helpers
+void launch_set2(const Scratch& sc, double* a, double va, double* b, double vb);
+void launch_scale(const Scratch& sc, size_t n, double* x, double a);
+
+}  // namespace sqn

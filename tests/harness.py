@@ -1,0 +1,199 @@
+"""Shared drivers for the parity tests: scripted optimisation problems run call by call through a
+free-mode object, recording everything observable through the C ABI after every call."""
+import numpy as np
+
+from stochqn_amd.free import oLBFGS_free, SQN_free, adaQN_free
+
+
+def to_np(a):
+    if isinstance(a, np.ndarray):
+        return a.copy()
+    return a.detach().cpu().numpy().copy()
+
+
+# ------------------------------------------------------------------------------------------------
+# problems
+# ------------------------------------------------------------------------------------------------
+class Rosenbrock2D:
+    """fr / grr / Hvr of reference R/optimizers_free.R:56-66,181-195."""
+    n = 2
+
+    @staticmethod
+    def x0():
+        return np.array([0.0, 2.0])
+
+    @staticmethod
+    def f(x):
+        return 100 * (x[1] - x[0] * x[0]) ** 2 + (1 - x[0]) ** 2
+
+    @staticmethod
+    def grad(x, call):
+        return np.array([-400 * x[0] * (x[1] - x[0] * x[0]) - 2 * (1 - x[0]), 200 * (x[1] - x[0] * x[0])])
+
+    @staticmethod
+    def hess_vec(x, v):
+        H = np.array([[1200 * x[0] ** 2 - 400 * x[1] + 2, -400 * x[0]], [-400 * x[0], 200.0]])
+        return H @ v
+
+
+class RosenbrockND:
+    """rosen / rosen_der / rosen_hess_prod of reference example/c_rosen.c:13-60."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def f(self, x):
+        return float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1.0 - x[:-1]) ** 2))
+
+    def grad(self, x, call=0):
+        n = self.n
+        out = np.zeros(n)
+        out[0] = -400.0 * x[0] * (x[1] - x[0] * x[0]) - 2.0 * (1.0 - x[0])
+        out[n - 1] = 200.0 * (x[n - 1] - x[n - 2] * x[n - 2])
+        for i in range(1, n - 1):
+            d1 = 200.0 * (x[i] - x[i - 1] * x[i - 1])
+            d2 = 400.0 * (x[i + 1] - x[i] * x[i]) * x[i]
+            d3 = 2.0 * (1.0 - x[i])
+            out[i] = d1 - d2 - d3
+        return out
+
+    def hess_vec(self, x, p):
+        n = self.n
+        out = np.zeros(n)
+        out[0] = (1200 * x[0] * x[0] - 400 * x[1] + 2.0) * p[0] - 400 * x[0] * p[0]
+        out[n - 1] = -400.0 * x[n - 2] * p[n - 2] + 200.0 * p[n - 1]
+        for i in range(1, n - 1):
+            d1 = -400.0 * x[i - 1] * p[i - 1]
+            d2 = (202 + 1200 * x[i] * x[i] - 400 * x[i + 1]) * p[i]
+            d3 = 400.0 * x[i] * p[i + 1]
+            out[i] = d1 + d2 - d3
+        return out
+
+
+class NoisyQuadratic:
+    """f(x) = 1/2 sum d_i x_i^2 with multiplicative gradient noise that depends only on
+    (seed, call index), so two backends see identical 'stochastic' gradients."""
+
+    def __init__(self, n, seed=0, noise=0.01, nan_calls=(), f_spike_calls=()):
+        rng = np.random.default_rng(seed)
+        self.n = n
+        self.d = 0.5 + rng.random(n)
+        self._x0 = 1.0 + rng.random(n)
+        self.seed = seed
+        self.noise = noise
+        self.nan_calls = set(nan_calls)
+        self.f_spike_calls = set(f_spike_calls)
+
+    def x0(self):
+        return self._x0.copy()
+
+    def f(self, x, call=0):
+        v = 0.5 * float(np.sum(self.d * x * x))
+        return v * 10.0 if call in self.f_spike_calls else v
+
+    def grad(self, x, call):
+        u = np.random.default_rng([self.seed, call]).random(self.n)
+        g = self.d * x * (1.0 + self.noise * (2.0 * u - 1.0))
+        if call in self.nan_calls:
+            g = g.copy()
+            g[self.n // 2] = np.nan
+        return g
+
+    def hess_vec(self, x, v):
+        return self.d * v
+
+
+# ------------------------------------------------------------------------------------------------
+# trace driver
+# ------------------------------------------------------------------------------------------------
+def _req_id(opt, x, req):
+    """Which caller array does the request alias?"""
+    cands = {"x": x}
+    for name in ("x_sum", "x_avg_prev"):
+        if hasattr(opt, name):
+            cands[name] = getattr(opt, name)
+    sp = opt._sp
+    p = sp.ptr(req)
+    for name, arr in cands.items():
+        if p == sp.ptr(arr):
+            return name
+    return "other"
+
+
+def run_trace(opt, problem, x, step, ncalls, step_fn=None):
+    """Drive `opt` for `ncalls` run_optimizer calls.  Returns a list of per-call records."""
+    trace = []
+    last_grad_x = None
+    for call in range(ncalls):
+        st = step_fn(call) if step_fn else step
+        r = opt.run_optimizer(x, st)
+        task = r["task"]
+        req = r["requested_on"]
+        rec = {
+            "task": task,
+            "info": r["info"]["iteration_info"],
+            "changed": r["info"]["x_changed_in_run"],
+            "niter": r["info"]["iteration_number"],
+            "section": opt.section,
+            "mem_used": opt.BFGS_mem.mem_used,
+            "mem_st_ix": opt.BFGS_mem.mem_st_ix,
+            "x": to_np(x),
+        }
+        if hasattr(opt, "Fisher_mem"):
+            rec["f_used"] = opt.Fisher_mem.mem_used
+            rec["f_st"] = opt.Fisher_mem.mem_st_ix
+            rec["f_prev"] = opt.f_prev
+        if task == "calc_hess_vec":
+            rx, rv = req
+            rec["req_id"] = _req_id(opt, x, rx)
+            rec["req"] = to_np(rx)
+            rec["req_vec"] = to_np(rv)
+            opt.update_hess_vec(problem.hess_vec(to_np(rx), to_np(rv)))
+        else:
+            rec["req_id"] = _req_id(opt, x, req)
+            rec["req"] = to_np(req)
+            if task in ("calc_grad", "calc_grad_same_batch", "calc_grad_big_batch"):
+                # same-batch gradients reuse the noise of the previous calc_grad call
+                if task == "calc_grad":
+                    last_grad_x = call
+                noise_call = last_grad_x if task == "calc_grad_same_batch" else call
+                opt.update_gradient(problem.grad(to_np(req), noise_call))
+            elif task == "calc_fun_val_batch":
+                opt.update_function(problem.f(to_np(req), call) if isinstance(problem, NoisyQuadratic)
+                                    else problem.f(to_np(req)))
+        trace.append(rec)
+    return trace
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if not np.all(np.isfinite(b)):
+        return 0.0 if np.array_equal(np.isnan(a), np.isnan(b)) and np.allclose(
+            a[np.isfinite(b)], b[np.isfinite(b)], rtol=1e-10, atol=0) else np.inf
+    nb = np.linalg.norm(b)
+    if nb == 0:
+        return float(np.linalg.norm(a))
+    return float(np.linalg.norm(a - b) / nb)
+
+
+INT_KEYS = ("task", "info", "changed", "niter", "section", "mem_used", "mem_st_ix", "req_id", "f_used", "f_st")
+VEC_KEYS = ("x", "req", "req_vec")
+
+
+def compare_traces(got, want, tol=1e-10):
+    """Integer-exact on everything discrete, norm-wise relative `tol` on every vector (fp64)."""
+    assert len(got) == len(want)
+    for i, (g, w) in enumerate(zip(got, want)):
+        for k in INT_KEYS:
+            if k in w:
+                assert g[k] == w[k], "call %d: %s differs: %r vs %r" % (i, k, g[k], w[k])
+        for k in VEC_KEYS:
+            if k in w:
+                e = rel_err(g[k], w[k])
+                assert e <= tol, "call %d: %s rel err %.3e > %.1e" % (i, k, e, tol)
+        if "f_prev" in w:
+            assert abs(g["f_prev"] - w["f_prev"]) <= tol * max(1.0, abs(w["f_prev"]))
+
+
+OPTIMIZERS = {"oLBFGS": oLBFGS_free, "SQN": SQN_free, "adaQN": adaQN_free}

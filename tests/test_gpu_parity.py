@@ -1,0 +1,250 @@
+"""GPU parity tests proper: the HIP library through its C ABI against the CPU oracle and against
+the reference's own known answers.  Tolerance: 1e-10 relative (fp64), the figure BASELINE.json's
+north_star states; everything discrete (task / info / section / counters / which array *req
+aliases) must match exactly."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from harness import OPTIMIZERS, NoisyQuadratic, compare_traces, rel_err, run_trace
+from test_oracle_known_answers import GOLD, check_known_answer, run_c_rosen, host_view
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+# ---------------------------------------------------------------------------------------------
+# reference known answers through the product
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("space", ["host", "device"])
+@pytest.mark.parametrize("case", ["oLBFGS_rosen2d", "SQN_rosen2d", "adaQN_rosen2d"])
+def test_known_answers(case, space, hip_backend):
+    # chaotic Rosenbrock trajectories amplify last-bit differences; 1e3 x the oracle's own pin
+    check_known_answer(case, hip_backend, space=space, tol_scale=1e3)
+
+
+def test_c_rosen_protocol_host_caller(hip_backend):
+    """Library-owned workspace (arrays in HBM) driven by a host caller exactly like c_rosen.c."""
+    k = GOLD["c_rosen"]
+    out = run_c_rosen(hip_backend, np.array(k["x0"]), host_view)
+    for key in ("f_initial", "f_it10", "f_it200", "f_final"):
+        assert out[key].strip() == k[key], (key, out[key])
+    assert out["x_final"] == k["x_final"]
+
+
+# ---------------------------------------------------------------------------------------------
+# per-call trace parity on noisy quadratics
+# ---------------------------------------------------------------------------------------------
+CONFIGS = [
+    # name, optimizer, kwargs, step, calls, problem kwargs
+    ("olbfgs_default", "oLBFGS", dict(mem_size=4), 0.1, 60, {}),
+    ("olbfgs_nocurv_hess_init", "oLBFGS", dict(mem_size=3, min_curvature=None, hess_init=0.5, y_reg=1e-3), 0.05, 50, {}),
+    ("olbfgs_nonan_check", "oLBFGS", dict(mem_size=5, check_nan=False, min_curvature=None), 0.1, 50, {}),
+    ("olbfgs_nan_grad", "oLBFGS", dict(mem_size=4), 0.1, 60, dict(nan_calls=(21, 22))),
+    ("olbfgs_reject_all", "oLBFGS", dict(mem_size=2, min_curvature=10.0), 0.1, 30, {}),
+    ("sqn_hessvec", "SQN", dict(mem_size=3, bfgs_upd_freq=4), 0.1, 80, {}),
+    ("sqn_hessvec_L1", "SQN", dict(mem_size=3, bfgs_upd_freq=1, min_curvature=None), 0.1, 30, {}),
+    ("sqn_graddiff", "SQN", dict(mem_size=3, bfgs_upd_freq=5, use_grad_diff=True, y_reg=1e-2), 0.1, 90, {}),
+    ("sqn_reject", "SQN", dict(mem_size=2, bfgs_upd_freq=3, min_curvature=5.0), 0.1, 60, {}),
+    ("sqn_nan", "SQN", dict(mem_size=3, bfgs_upd_freq=4), 0.1, 60, dict(nan_calls=(30,))),
+    ("sqn_nonan_check", "SQN", dict(mem_size=3, bfgs_upd_freq=4, check_nan=False), 0.1, 60, {}),
+    ("adaqn_fisher_rms", "adaQN", dict(mem_size=3, fisher_size=7, bfgs_upd_freq=4, rmsprop_weight=0.9), 0.05, 90, {}),
+    ("adaqn_fisher_adagrad_nomaxincr", "adaQN", dict(mem_size=3, fisher_size=5, bfgs_upd_freq=3, max_incr=None), 0.05, 70, {}),
+    ("adaqn_graddiff", "adaQN", dict(mem_size=3, bfgs_upd_freq=4, use_grad_diff=True, rmsprop_weight=0.5), 0.05, 90, {}),
+    ("adaqn_graddiff_nomaxincr", "adaQN", dict(mem_size=2, bfgs_upd_freq=3, use_grad_diff=True, max_incr=None), 0.05, 60, {}),
+    ("adaqn_func_increased", "adaQN", dict(mem_size=3, fisher_size=6, bfgs_upd_freq=4), 0.05, 90, dict(f_spike_calls=range(40, 60))),
+    ("adaqn_nan", "adaQN", dict(mem_size=3, fisher_size=6, bfgs_upd_freq=4), 0.05, 70, dict(nan_calls=(33,))),
+    ("adaqn_nonan_check", "adaQN", dict(mem_size=3, fisher_size=6, bfgs_upd_freq=4, check_nan=False), 0.05, 70, {}),
+]
+
+
+def both_traces(cfg, n, space, hip_backend, oracle_backend):
+    name, optname, kw, step, calls, pkw = cfg
+    P = NoisyQuadratic(n, seed=7, **pkw)
+    ref_opt = OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw)
+    want = run_trace(ref_opt, P, P.x0(), step, calls)
+    opt = OPTIMIZERS[optname](backend=hip_backend, space=space, **kw)
+    x = P.x0()
+    if space == "device":
+        x = torch_cuda().as_tensor(x, device="cuda")
+    got = run_trace(opt, P, x, step, calls)
+    return got, want
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 1000, 4097])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_trace_parity_device_arrays(cfg, n, hip_backend, oracle_backend):
+    got, want = both_traces(cfg, n, "device", hip_backend, oracle_backend)
+    compare_traces(got, want, TOL)
+
+
+@pytest.mark.parametrize("n", [2, 65, 1000])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_trace_parity_host_arrays(cfg, n, hip_backend, oracle_backend):
+    """Profile B of SURVEY.md 8b: every array in host memory, structs rebuilt per call."""
+    got, want = both_traces(cfg, n, "host", hip_backend, oracle_backend)
+    compare_traces(got, want, TOL)
+
+
+def test_golden_traces(hip_backend):
+    """Committed regression vectors (tests/golden/traces.json, made by tests/golden/make_traces.py)."""
+    path = os.path.join(os.path.dirname(__file__), "golden", "traces.json")
+    gold = json.load(open(path))
+    by_name = {c[0]: c for c in CONFIGS}
+    for name, entry in gold["traces"].items():
+        cfg = by_name[name]
+        P = NoisyQuadratic(entry["n"], seed=7, **cfg[5])
+        opt = OPTIMIZERS[cfg[1]](backend=hip_backend, space="device", **cfg[2])
+        x = torch_cuda().as_tensor(P.x0(), device="cuda")
+        got = run_trace(opt, P, x, cfg[3], cfg[4])
+        compare_traces(got, entry["trace"], TOL)
+
+
+# ---------------------------------------------------------------------------------------------
+# isolated two-loop recursion (reference src/stochqn.c:663-708)
+# ---------------------------------------------------------------------------------------------
+def make_pairs(rng, n, m):
+    d = 0.5 + rng.random(n)
+    S = 1e-3 * (rng.random((m, n)) - 0.5)
+    Y = S * d
+    return S.reshape(-1).copy(), Y.reshape(-1).copy()
+
+
+def hip_two_loop(lib, g, H0, h0, Y, S, n, m, used, st):
+    rho = np.zeros(m)
+    alpha = np.zeros(m)
+    lib.stochqn_hip_two_loop.restype = C.c_int
+    lib.stochqn_hip_two_loop.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+    rc = lib.stochqn_hip_two_loop(g.data_ptr(), n, None if H0 is None else H0.data_ptr(), h0, Y.data_ptr(),
+                                  S.data_ptr(), m, used, st, rho.ctypes.data, alpha.ctypes.data)
+    assert rc == 0
+    return rho, alpha
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4096, 1000003])
+@pytest.mark.parametrize("m,used,st", [(1, 1, 0), (5, 5, 3), (5, 2, 0), (5, 3, 4), (20, 20, 7), (20, 1, 19)])
+@pytest.mark.parametrize("mode", ["gamma", "h0", "H0"])
+def test_two_loop_matches_oracle(n, m, used, st, mode, hip_backend):
+    import stochqn_amd
+    from oracle import oracle
+    torch = torch_cuda()
+    rng = np.random.default_rng(n * 131 + m * 7 + used)
+    S, Y = make_pairs(rng, n, m)
+    g = rng.random(n) - 0.5
+    H0 = (0.5 + rng.random(n)) if mode == "H0" else None
+    h0 = 0.37 if mode == "h0" else 0.0
+
+    want = g.copy()
+    rho_w, alpha_w = oracle.two_loop(want, H0, h0, Y, S, m, used, st)
+
+    dS, dY, dg = (torch.as_tensor(a, device="cuda") for a in (S, Y, g))
+    dH0 = None if H0 is None else torch.as_tensor(H0, device="cuda")
+    rho, alpha = hip_two_loop(stochqn_amd.cdll(), dg, dH0, h0, dY, dS, n, m, used, st)
+    stochqn_amd.cdll().stochqn_hip_release(C.c_void_p(dS.data_ptr()))
+
+    assert rel_err(dg.cpu().numpy(), want) <= TOL
+    assert np.allclose(rho[:used], rho_w[:used], rtol=TOL, atol=0)
+    assert np.allclose(alpha[:used], alpha_w[:used], rtol=1e-9, atol=1e-14 * np.abs(alpha_w[:used]).max())
+
+
+def test_two_loop_host_pointers(hip_backend):
+    """Same entry point fed with plain numpy memory (staged over PCIe behind the ABI)."""
+    import stochqn_amd
+    from oracle import oracle
+    lib = stochqn_amd.cdll()
+    n, m, used, st = 1001, 4, 4, 2
+    rng = np.random.default_rng(5)
+    S, Y = make_pairs(rng, n, m)
+    g = rng.random(n) - 0.5
+    want = g.copy()
+    oracle.two_loop(want, None, 0.0, Y, S, m, used, st)
+    rho = np.zeros(m)
+    alpha = np.zeros(m)
+    lib.stochqn_hip_two_loop.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+    assert lib.stochqn_hip_two_loop(g.ctypes.data, n, None, 0.0, Y.ctypes.data, S.ctypes.data, m, used, st,
+                                    rho.ctypes.data, alpha.ctypes.data) == 0
+    lib.stochqn_hip_release(C.c_void_p(S.ctypes.data))
+    assert rel_err(g, want) <= TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# empirical Fisher product (reference src/stochqn.c:936-952)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 65, 4096, 100001])
+@pytest.mark.parametrize("fu", [1, 7, 8, 9, 32, 100])
+def test_fisher_product_matches_oracle(n, fu, hip_backend):
+    import stochqn_amd
+    from oracle import oracle
+    torch = torch_cuda()
+    lib = stochqn_amd.cdll()
+    rng = np.random.default_rng(n + fu)
+    F = rng.standard_normal(fu * n)
+    s = rng.standard_normal(n)
+    t_w, y_w = oracle.fisher_product(F, fu, s)
+    dF, ds = torch.as_tensor(F, device="cuda"), torch.as_tensor(s, device="cuda")
+    dy = torch.zeros(n, dtype=torch.float64, device="cuda")
+    t = np.zeros(fu)
+    lib.stochqn_hip_fisher_product.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.stochqn_hip_fisher_product(dF.data_ptr(), fu, n, ds.data_ptr(), t.ctypes.data, dy.data_ptr()) == 0
+    lib.stochqn_hip_release(C.c_void_p(dF.data_ptr()))
+    assert rel_err(t, t_w) <= TOL
+    assert rel_err(dy.cpu().numpy(), y_w) <= TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE sizes (the oracle is too slow / too big there)
+# ---------------------------------------------------------------------------------------------
+def device_pairs(torch, n, m, seed):
+    """d_i, S, Y = d*S generated on the device (SURVEY.md 8d synthetic inputs, torch RNG)."""
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    d = 0.5 + torch.rand(n, dtype=torch.float64, device="cuda", generator=gen)
+    S = torch.empty(m * n, dtype=torch.float64, device="cuda")
+    Y = torch.empty(m * n, dtype=torch.float64, device="cuda")
+    for k in range(m):
+        s = 1e-3 * (torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) - 0.5)
+        S[k * n:(k + 1) * n] = s
+        Y[k * n:(k + 1) * n] = d * s
+    return d, S, Y, gen
+
+
+@pytest.mark.parametrize("n,m", [(10_000_000, 10), (100_000_000, 20)])
+def test_two_loop_properties_at_baseline_size(n, m, hip_backend):
+    """(i) secant equation: the L-BFGS inverse maps the newest y onto the newest s exactly;
+    (ii) linearity in the gradient; (iii) bit-reproducibility of a repeated call."""
+    import stochqn_amd
+    torch = torch_cuda()
+    lib = stochqn_amd.cdll()
+    d, S, Y, gen = device_pairs(torch, n, m, 20240611)
+    st = 3 % m
+    newest = (st + m - 1) % m
+    q = Y[newest * n:(newest + 1) * n].clone()
+    hip_two_loop(lib, q, None, 0.0, Y, S, n, m, m, st)
+    s_new = S[newest * n:(newest + 1) * n]
+    assert float(torch.linalg.norm(q - s_new) / torch.linalg.norm(s_new)) <= TOL
+
+    g1 = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) - 0.5
+    g2 = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) - 0.5
+    a, b = 0.75, -1.25
+    mix = a * g1 + b * g2
+    r1, r2 = g1.clone(), g2.clone()
+    hip_two_loop(lib, r1, None, 0.0, Y, S, n, m, m, st)
+    hip_two_loop(lib, r2, None, 0.0, Y, S, n, m, m, st)
+    hip_two_loop(lib, mix, None, 0.0, Y, S, n, m, m, st)
+    lin = a * r1 + b * r2
+    assert float(torch.linalg.norm(mix - lin) / torch.linalg.norm(lin)) <= TOL
+
+    again = g1.clone()
+    hip_two_loop(lib, again, None, 0.0, Y, S, n, m, m, st)
+    assert torch.equal(again, r1)
+    lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))

@@ -1,0 +1,84 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden/known_answers.json)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from harness import OPTIMIZERS, Rosenbrock2D, RosenbrockND, run_trace
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "known_answers.json")))
+
+
+def check_known_answer(case, backend, space="host", tol_scale=1.0):
+    k = GOLD[case]
+    opt = OPTIMIZERS[k["optimizer"]](backend=backend, space=space, **k["kwargs"])
+    P = Rosenbrock2D()
+    x = P.x0()
+    if space == "device":
+        import torch
+        x = torch.as_tensor(x, device="cuda")
+    tr = run_trace(opt, P, x, k["step"], k["calls"])
+    xf = tr[-1]["x"]
+    rtol = k["rtol"] * tol_scale
+    assert np.allclose(xf, k["x"], rtol=rtol, atol=0), (xf, k["x"])
+    assert abs(P.f(xf) - k["f"]) <= 50 * rtol * abs(k["f"])
+    assert tr[-1]["niter"] == k["niter"]
+    assert tr[-1]["mem_used"] == k["mem_used"]
+    if "mem_st_ix" in k:
+        assert tr[-1]["mem_st_ix"] == k["mem_st_ix"]
+    if "all_info" in k:
+        assert all(r["info"] == k["all_info"] for r in tr)
+    if "n_hess_vec" in k:
+        assert sum(r["task"] == "calc_hess_vec" for r in tr) == k["n_hess_vec"]
+    if "n_fun_val" in k:
+        assert sum(r["task"] == "calc_fun_val_batch" for r in tr) == k["n_fun_val"]
+    if "fisher_used" in k:
+        assert tr[-1]["f_used"] == k["fisher_used"]
+
+
+def run_c_rosen(be, x, make_host_view):
+    """The call protocol of reference example/c_rosen.c:69-128 on library-owned workspaces."""
+    k = GOLD["c_rosen"]
+    n = k["n"]
+    P = RosenbrockND(n)
+    g = np.zeros(n)
+    hv = np.zeros(n)
+    out = {"f_initial": "%6.4f" % P.f(x)}
+    w = be.initialize_SQN(n, k["mem_size"], k["bfgs_upd_freq"], k["min_curvature"], k["use_grad_diff"],
+                          k["y_reg"], k["check_nan"], 1)
+    assert bool(w), "initialize_SQN returned NULL"
+    req, rv, task, info = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
+    args = lambda: (k["step"], x.ctypes.data, g.ctypes.data, hv.ctypes.data, C.byref(req), C.byref(rv),
+                    C.byref(task), w, C.byref(info))
+    be.run_SQN(*args())
+    while w.contents.niter < k["niter_stop"]:
+        if task.value == 101:
+            g[:] = P.grad(make_host_view(req.value, n))
+        elif task.value == 104:
+            hv[:] = P.hess_vec(make_host_view(req.value, n), make_host_view(rv.value, n))
+        changed = be.run_SQN(*args())
+        if changed and (w.contents.niter + 1) % 10 == 0:
+            out["f_it%d" % (w.contents.niter + 1)] = "%6.4f" % P.f(x)
+    out["f_final"] = "%6.4f" % P.f(x)
+    out["x_final"] = ["%f" % v for v in x]
+    be.dealloc_SQN(w)
+    return out
+
+
+def host_view(ptr, n):
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), (n,))
+
+
+@pytest.mark.parametrize("case", ["oLBFGS_rosen2d", "SQN_rosen2d", "adaQN_rosen2d"])
+def test_oracle_reproduces_reference_trajectories(case, oracle_backend):
+    check_known_answer(case, oracle_backend)
+
+
+def test_oracle_reproduces_c_rosen_output(oracle_backend):
+    k = GOLD["c_rosen"]
+    out = run_c_rosen(oracle_backend, np.array(k["x0"]), host_view)
+    for key in ("f_initial", "f_it10", "f_it200", "f_final"):
+        assert out[key].strip() == k[key], (key, out[key])
+    assert out["x_final"] == k["x_final"]
