@@ -3,7 +3,7 @@
 The structure layouts mirror reference include/stochqn.h:86-151 (sizes 96/40/48/64/120 bytes on
 x86-64 LP64) and the enum values of reference include/stochqn.h:268-291.  `bind()` attaches the
 prototypes of the 9 public entry points (reference include/stochqn.h:227-238,381-383) to a loaded
-shared library; `prefix` lets the test-suite bind the CPU oracle (`oracle_*` symbols) with the very
+shared library; `prefix` lets the test-suite bind a differently-prefixed checker library with the very
 same declarations.
 """
 import ctypes as C

@@ -265,7 +265,7 @@ void accept_or_reject(DevCtx* c, bfgs_mem* b, Partials p, info_enum* info)
 {
 	const size_t st = b->mem_st_ix;
 	const double* src = p.parts;
-	if (p.count != 1) { launch_fin(c->sc, p, 3, c->sc.red[0]); src = c->sc.red[0]; }
+	if (p.stride != 1) { launch_fin(c->sc, p, 3, c->sc.red[0]); src = c->sc.red[0]; }   // raw per-workgroup partials
 	to_host(c, c->pin + 4, src, 3);
 	sync(c);
 	const double sy = c->pin[4], ss = c->pin[5], yy = c->pin[6];

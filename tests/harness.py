@@ -197,3 +197,99 @@ def compare_traces(got, want, tol=1e-10):
 
 
 OPTIMIZERS = {"oLBFGS": oLBFGS_free, "SQN": SQN_free, "adaQN": adaQN_free}
+
+
+# ------------------------------------------------------------------------------------------------
+# lock-step driver: identical inputs into both libraries on EVERY call
+# ------------------------------------------------------------------------------------------------
+STATE_ARRAYS = ("gradient", "grad_prev", "x_sum", "x_avg_prev", "H0", "grad_sum_sq", "hess_vec")
+MEM_ARRAYS = (("BFGS_mem", "s_mem"), ("BFGS_mem", "y_mem"), ("BFGS_mem", "s_bak"), ("BFGS_mem", "y_bak"),
+              ("Fisher_mem", "F"))
+
+
+def _arrays(opt):
+    out = {}
+    for name in STATE_ARRAYS:
+        if hasattr(opt, name):
+            out[name] = getattr(opt, name)
+    for holder, name in MEM_ARRAYS:
+        if hasattr(opt, holder):
+            out[holder + "." + name] = getattr(getattr(opt, holder), name)
+    return out
+
+
+def run_lockstep(ref, opt, problem, x_ref, x_dev, step, ncalls, tol, on_sync=None):
+    """Drive the oracle-backed `ref` and the library under test `opt` with the SAME inputs on every
+    call: after each call all outputs and the complete optimiser state are compared (integers
+    exactly, vectors norm-wise to `tol`), then the state of `opt` is overwritten with the oracle's,
+    so rounding differences cannot be amplified by the (possibly ill-conditioned) trajectory."""
+    last_grad_call = None
+    for call in range(ncalls):
+        rr = ref.run_optimizer(x_ref, step)
+        ro = opt.run_optimizer(x_dev, step)
+        where = "call %d (%s)" % (call, rr["task"])
+        assert ro["task"] == rr["task"], where
+        assert ro["info"] == rr["info"], where
+        for k in ("niter", "section"):
+            assert getattr(opt, k) == getattr(ref, k), (where, k)
+        for k in ("mem_used", "mem_st_ix"):
+            assert getattr(opt.BFGS_mem, k) == getattr(ref.BFGS_mem, k), (where, k)
+            if hasattr(ref, "Fisher_mem"):
+                assert getattr(opt.Fisher_mem, k) == getattr(ref.Fisher_mem, k), (where, "fisher " + k)
+        if hasattr(ref, "f_prev"):
+            assert opt.f_prev == ref.f_prev, where
+        e = rel_err(to_np(x_dev), x_ref)
+        assert e <= tol, "%s: x rel err %.3e" % (where, e)
+
+        # what is requested, and where
+        task = rr["task"]
+        req_r, req_o = rr["requested_on"], ro["requested_on"]
+        if task == "calc_hess_vec":
+            assert _req_id(opt, x_dev, req_o[0]) == _req_id(ref, x_ref, req_r[0]), where
+            for a, b_ in zip(req_o, req_r):
+                e = rel_err(to_np(a), b_)
+                assert e <= tol, "%s: request rel err %.3e" % (where, e)
+        else:
+            assert _req_id(opt, x_dev, req_o) == _req_id(ref, x_ref, req_r), where
+            e = rel_err(to_np(req_o), req_r)
+            assert e <= tol, "%s: request rel err %.3e" % (where, e)
+
+        # complete state, array by array (pair / Fisher memories row by row)
+        A_r, A_o = _arrays(ref), _arrays(opt)
+        n = ref._n
+        for name, a_r in A_r.items():
+            a_o = to_np(A_o[name])
+            a_r = np.asarray(a_r)
+            if a_r.shape[0] > n and a_r.shape[0] % n == 0:
+                for row in range(a_r.shape[0] // n):
+                    e = rel_err(a_o[row * n:(row + 1) * n], a_r[row * n:(row + 1) * n])
+                    assert e <= tol, "%s: %s row %d rel err %.3e" % (where, name, row, e)
+            else:
+                e = rel_err(a_o, a_r)
+                assert e <= tol, "%s: %s rel err %.3e" % (where, name, e)
+        for name in ("buffer_rho", "buffer_alpha"):
+            k = ref.BFGS_mem.mem_used
+            a_r, a_o = getattr(ref.BFGS_mem, name)[:k], getattr(opt.BFGS_mem, name)[:k]
+            if np.all(np.isfinite(a_r)) and rr["info"] == "no_problems_encountered":
+                assert np.allclose(a_o, a_r, rtol=1e3 * tol, atol=1e-300), (where, name, a_o, a_r)
+
+        # overwrite the state under test with the oracle's, then hand identical inputs to both
+        opt._sp.assign(x_dev, x_ref)
+        for name, a_r in A_r.items():
+            opt._sp.assign(A_o[name], a_r)
+        if on_sync:
+            on_sync(opt)
+        if task in ("calc_grad", "calc_grad_same_batch", "calc_grad_big_batch"):
+            if task == "calc_grad":
+                last_grad_call = call
+            g = problem.grad(np.asarray(req_r).copy(), last_grad_call if task == "calc_grad_same_batch" else call)
+            ref.update_gradient(g)
+            opt.update_gradient(g)
+        elif task == "calc_hess_vec":
+            hv = problem.hess_vec(np.asarray(req_r[0]).copy(), np.asarray(req_r[1]).copy())
+            ref.update_hess_vec(hv)
+            opt.update_hess_vec(hv)
+        elif task == "calc_fun_val_batch":
+            f = problem.f(np.asarray(req_r).copy(), call)
+            ref.update_function(f)
+            opt.update_function(f)

@@ -1,0 +1,120 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every symbol that
+include/*.h declares, the struct layouts are the reference's, and -- with no GPU -- every entry
+point fails loudly instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import stochqn_amd
+from stochqn_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+
+def declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = src.split("#ifdef __cplusplus\n#include <new>")[0]          # C part only
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", src)
+    return sorted(set(n for n in names if not n.startswith("defined")))
+
+
+def test_struct_layouts_match_reference():
+    # sizes/offsets of reference include/stochqn.h:86-151 on x86-64 LP64
+    for st, size in _abi.EXPECTED_SIZES.items():
+        assert C.sizeof(st) == size, st
+    assert _abi.bfgs_mem.mem_size.offset == 48 and _abi.bfgs_mem.min_curvature.offset == 88
+    assert _abi.fisher_mem.mem_st_ix.offset == 32
+    assert _abi.workspace_oLBFGS.niter.offset == 24 and _abi.workspace_oLBFGS.n.offset == 44
+    assert _abi.workspace_SQN.niter.offset == 40 and _abi.workspace_SQN.n.offset == 60
+    assert _abi.workspace_adaQN.f_prev.offset == 56 and _abi.workspace_adaQN.niter.offset == 96
+    assert _abi.workspace_adaQN.n.offset == 116
+
+
+def test_library_exports_every_declared_symbol():
+    lib = stochqn_amd.cdll()
+    for header in ("stochqn.h", "stochqn_hip.h"):
+        names = declared_functions(header)
+        assert len(names) >= 9
+        for name in names:
+            assert hasattr(lib, name), "%s declared in %s but not exported" % (name, header)
+    for name in _abi.PUBLIC_SYMBOLS:
+        assert hasattr(lib, name)
+
+
+def test_header_compiles_as_c_and_cxx(tmp_path):
+    inc = os.path.join(ROOT, "include")
+    c_src = tmp_path / "t.c"
+    c_src.write_text('#include "stochqn.h"\n#include "stochqn_hip.h"\n'
+                     '_Static_assert(sizeof(bfgs_mem)==96 && sizeof(fisher_mem)==40 && sizeof(workspace_oLBFGS)==48 &&'
+                     ' sizeof(workspace_SQN)==64 && sizeof(workspace_adaQN)==120, "layout");\n'
+                     '_Static_assert(calc_grad==101 && invalid_input==100 && calc_fun_val_batch==105 &&'
+                     ' func_increased==201 && search_direction_was_nan==203 && received_invalid_input==-1000, "enums");\n'
+                     'int main(void){return 0;}\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, "-c", str(c_src), "-o", str(tmp_path / "t.o")])
+    cxx = tmp_path / "t.cpp"
+    cxx.write_text('#include "stochqn.h"\n'
+                   'int use(oLBFGS& a, SQN& b, adaQN& c, double* x, double* g){\n'
+                   '  a.run(0.1, x, g); b.run(0.1, x, g, g); c.run(0.1, x, 0.0, g);\n'
+                   '  return (int) (a.get_n_iter() + b.get_n_iter() + c.get_n_iter()) + (b.get_req_vec() != 0)\n'
+                   '         + (int) a.get_task() + (int) c.get_iter_info() + (a.get_req() != 0) + (int) b.workspace->niter;\n}\n')
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-c", str(cxx), "-o", str(tmp_path / "t2.o")])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_reference_examples_link_against_the_new_library(tmp_path):
+    """Link-level drop-in proof: the reference's own C and C++ callers, unmodified, against this
+    repository's header and libstochqn.so (they cannot RUN here: no GPU)."""
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(stochqn_amd.LIB_PATH)
+    hip = ["-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+    subprocess.check_call(["gcc", "-std=c99", "-I", inc, os.path.join(REF, "example", "c_rosen.c"),
+                           "-L", libdir, "-lstochqn", *hip, "-o", str(tmp_path / "c_rosen")])
+    subprocess.check_call(["g++", "-I", inc, os.path.join(REF, "example", "cpp_rosen.cpp"),
+                           "-L", libdir, "-lstochqn", *hip, "-o", str(tmp_path / "cpp_rosen")])
+    out = subprocess.check_output(["nm", "-u", str(tmp_path / "c_rosen")]).decode()
+    assert "initialize_SQN" in out and "run_SQN" in out and "dealloc_SQN" in out
+
+
+def test_no_gpu_means_loud_failure_not_fallback(capfd):
+    lib = stochqn_amd.cdll()
+    if lib.stochqn_hip_available() == 1:
+        pytest.skip("a GPU is visible: the loud-failure path cannot be exercised")
+    be = stochqn_amd.lib()
+    assert not be.initialize_oLBFGS(4, 3, 0.0, 0.0, 0.0, 1, 1)
+    assert not be.initialize_SQN(4, 3, 2, 0.0, 0, 0.0, 1, 1)
+    assert not be.initialize_adaQN(4, 3, 5, 2, 1.01, 1e-4, 1e-4, 0.9, 0, 0.0, 1, 1)
+    err = capfd.readouterr().err
+    assert "no usable HIP device" in err
+    # caller-owned state (profile B): section 1 needs arithmetic -> must refuse
+    opt = stochqn_amd.oLBFGS_free(mem_size=3)
+    x = np.array([0.0, 2.0])
+    with pytest.raises(ValueError):
+        opt.run_optimizer(x, 0.1)
+    assert "no usable HIP device" in capfd.readouterr().err
+    lib.stochqn_hip_two_loop.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+    g = np.zeros(4)
+    assert lib.stochqn_hip_two_loop(g.ctypes.data, 4, None, 0.0, g.ctypes.data, g.ctypes.data, 1, 1, 0, None, None) == -1000
+
+
+def test_product_package_never_touches_the_oracle():
+    """The product path must not import, link or dlopen anything under oracle/."""
+    pkg = os.path.join(ROOT, "stochqn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".hpp", ".h", "Makefile", ".map")):
+                text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "liboracle" not in text and "oracle_" not in text, os.path.join(dirpath, fn)
+                for line in text.splitlines():
+                    if re.match(r"\s*(from|import)\s+oracle", line):
+                        raise AssertionError("%s imports the oracle" % fn)
+    if shutil.which("ldd"):
+        out = subprocess.check_output(["ldd", stochqn_amd.LIB_PATH]).decode()
+        assert "oracle" not in out

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from harness import OPTIMIZERS, NoisyQuadratic, compare_traces, rel_err, run_trace
+from harness import OPTIMIZERS, NoisyQuadratic, compare_traces, rel_err, run_lockstep, run_trace
 from test_oracle_known_answers import GOLD, check_known_answer, run_c_rosen, host_view
 
 pytestmark = pytest.mark.gpu
@@ -67,6 +67,12 @@ CONFIGS = [
 ]
 
 
+# Free-running trajectories whose two-loop is ill-conditioned (rank-deficient Fisher pairs) amplify
+# last-bit differences by up to 10x per call (measured: 1e-16 per call -> 7e-9 after 45 calls); the
+# per-call bar of 1e-10 is enforced for them by the lock-step test below.
+FREE_RUN_TOL = {"adaqn_fisher_adagrad_nomaxincr": 1e-7}
+
+
 def both_traces(cfg, n, space, hip_backend, oracle_backend):
     name, optname, kw, step, calls, pkw = cfg
     P = NoisyQuadratic(n, seed=7, **pkw)
@@ -84,7 +90,24 @@ def both_traces(cfg, n, space, hip_backend, oracle_backend):
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_trace_parity_device_arrays(cfg, n, hip_backend, oracle_backend):
     got, want = both_traces(cfg, n, "device", hip_backend, oracle_backend)
-    compare_traces(got, want, TOL)
+    compare_traces(got, want, FREE_RUN_TOL.get(cfg[0], TOL))
+
+
+@pytest.mark.parametrize("n", [3, 64, 1000, 4097, 70001])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_lockstep_parity(cfg, n, hip_backend, oracle_backend):
+    """Identical state and inputs into the oracle and the HIP library on every call; every output
+    array, every state array and every scalar compared after every call."""
+    import stochqn_amd
+    name, optname, kw, step, calls, pkw = cfg
+    P = NoisyQuadratic(n, seed=11, **pkw)
+    ref = OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw)
+    opt = OPTIMIZERS[optname](backend=hip_backend, space="device", **kw)
+    x_ref = P.x0()
+    x_dev = torch_cuda().as_tensor(P.x0(), device="cuda")
+    lib = stochqn_amd.cdll()
+    inval = lambda o: lib.stochqn_hip_invalidate(C.c_void_p(o._sp.ptr(o.BFGS_mem.s_mem)))
+    run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 60), TOL, on_sync=inval)
 
 
 @pytest.mark.parametrize("n", [2, 65, 1000])
@@ -92,7 +115,7 @@ def test_trace_parity_device_arrays(cfg, n, hip_backend, oracle_backend):
 def test_trace_parity_host_arrays(cfg, n, hip_backend, oracle_backend):
     """Profile B of SURVEY.md 8b: every array in host memory, structs rebuilt per call."""
     got, want = both_traces(cfg, n, "host", hip_backend, oracle_backend)
-    compare_traces(got, want, TOL)
+    compare_traces(got, want, FREE_RUN_TOL.get(cfg[0], TOL))
 
 
 def test_golden_traces(hip_backend):

@@ -1,0 +1,96 @@
+"""world_size-2 (gloo, CPU) check of the sharding scheme the multi-GPU path uses: every rank owns
+a contiguous slice of all n-vectors and of every pair row; each dot product of the recursion is a
+local partial plus one all-reduce(sum) of 1-3 scalars; the guard uses the GLOBAL n and the global
+sum of squares.  The per-rank arithmetic here is numpy (a model of the sweeps in kernels.hip, in
+the same fused order); the unsharded oracle is the reference result."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def allsum(vals):
+    t = torch.tensor(vals, dtype=torch.float64)
+    dist.all_reduce(t)
+    return t.tolist()
+
+
+def sharded_two_loop(q, S, Y, m, used, st, sy, yy):
+    """The sweep chain of kernels.hip on one shard; S, Y are [m][n_local]."""
+    row = lambda i: (st + i) % m
+    k = used
+    alpha = [0.0] * k
+    (p,) = allsum([float(S[row(k - 1)] @ q)])                        # first
+    for i in range(k - 1, 0, -1):                                    # bwd
+        alpha[i] = (1.0 / sy[row(i)]) * p
+        q -= alpha[i] * Y[row(i)]
+        (p,) = allsum([float(S[row(i - 1)] @ q)])
+    alpha[0] = (1.0 / sy[row(0)]) * p                                # mid
+    q -= alpha[0] * Y[row(0)]
+    q *= sy[row(k - 1)] / yy[row(k - 1)]
+    (p,) = allsum([float(Y[row(0)] @ q)])
+    for i in range(k - 1):                                           # fwd
+        beta = (1.0 / sy[row(i)]) * p
+        q += (alpha[i] - beta) * S[row(i)]
+        (p,) = allsum([float(Y[row(i + 1)] @ q)])
+    beta = (1.0 / sy[row(k - 1)]) * p                                # fwd_last
+    q += (alpha[k - 1] - beta) * S[row(k - 1)]
+    ss, nonfinite = allsum([float(q @ q), float(np.sum(~np.isfinite(q)))])
+    return ss, nonfinite
+
+
+def worker(rank, world, port, n, m, st, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(123)                                 # same global data on every rank
+    d = 0.5 + rng.random(n)
+    S = 1e-3 * (rng.random((m, n)) - 0.5)
+    Y = S * d
+    g = rng.random(n) - 0.5
+    x = 1.0 + rng.random(n)
+    lo, hi = n * rank // world, n * (rank + 1) // world              # contiguous slice, bench.py's partition
+    Sl, Yl, ql, xl = S[:, lo:hi].copy(), Y[:, lo:hi].copy(), g[lo:hi].copy(), x[lo:hi].copy()
+    # pair statistics are all-reduced when a pair is accepted (accept_or_reject in machines.cpp)
+    sy = [allsum([float(Sl[r] @ Yl[r])])[0] for r in range(m)]
+    yy = [allsum([float(Yl[r] @ Yl[r])])[0] for r in range(m)]
+    (n_global,) = allsum([float(hi - lo)])                           # comm_attach()
+    ss, nonfinite = sharded_two_loop(ql, Sl, Yl, m, m, st, sy, yy)
+    bad = nonfinite > 0 or not (np.sqrt(ss) <= 1e3 * n_global)       # identical decision on every rank
+    if not bad:
+        xl -= 0.1 * ql
+    np.save(os.path.join(out_dir, "r%d.npy" % rank), np.concatenate([ql, xl]))
+    np.save(os.path.join(out_dir, "meta%d.npy" % rank), np.array([n_global, ss, float(bad)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,m,st", [(1001, 5, 3), (4096, 3, 0)])
+def test_sharded_recursion_equals_unsharded_oracle(tmp_path, n, m, st):
+    from oracle import oracle
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(worker, args=(world, port, n, m, st, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(123)
+    d = 0.5 + rng.random(n)
+    S = 1e-3 * (rng.random((m, n)) - 0.5)
+    Y = S * d
+    g = rng.random(n) - 0.5
+    x = 1.0 + rng.random(n)
+    want = g.copy()
+    oracle.two_loop(want, None, 0.0, Y.reshape(-1).copy(), S.reshape(-1).copy(), m, m, st)
+    parts = [np.load(tmp_path / ("r%d.npy" % r)) for r in range(world)]
+    q = np.concatenate([p[:len(p) // 2] for p in parts])
+    xs = np.concatenate([p[len(p) // 2:] for p in parts])
+    metas = [np.load(tmp_path / ("meta%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(metas[0], metas[1])                        # bit-identical scalars on all ranks
+    assert metas[0][0] == n and metas[0][2] == 0.0
+    assert np.linalg.norm(q - want) / np.linalg.norm(want) < 1e-12
+    assert np.linalg.norm(xs - (x - 0.1 * want)) / np.linalg.norm(x) < 1e-12
