@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=10_000_000)
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="stochqn_hip_set_option before the run (grid_cap, reverse, nontemporal)")
     return ap.parse_args()
 
 
@@ -66,6 +68,10 @@ def main():
     lib = stochqn_amd.cdll()
     be = stochqn_amd.lib()
     assert lib.stochqn_hip_available() == 1
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    for kv in args.opt:
+        name, val = kv.split("=")
+        assert lib.stochqn_hip_set_option(name.encode(), float(val)) == 0, kv
 
     dist = None
     if world > 1:
@@ -232,6 +238,7 @@ def main():
                        "parallelism": "n sharded over %d GPU(s); one RCCL all-reduce per dot product" % world,
                        "calls": counters["calls"], "hess_vec_requests": counters["hv"],
                        "rejected_steps": counters["bad"], "rejected_pairs": counters["rejected"],
+                       "options": args.opt,
                        "f_start": f0, "f_end": f1},
             "roofline": roof,
             "two_loop": two_loop,

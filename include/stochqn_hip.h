@@ -45,7 +45,8 @@ int stochqn_hip_export(const void *s_mem);
 
 /* ---- options -------------------------------------------------------------------------------------
  * "nontemporal" (default 1)  stream pair / Fisher rows with non-temporal loads
- * "grid_cap"    (default 2048) maximum workgroups per sweep
+ * "grid_cap"    (default 0 = one workgroup per compute unit) maximum workgroups per sweep
+ * "reverse"     (default 1)  alternate the traversal direction of consecutive sweeps
  * "strict_grad" (default 1)  host callers: copy the search direction back into `grad`
  * Returns 0, or -1 for an unknown name. Applies to contexts created afterwards and existing ones. */
 int stochqn_hip_set_option(const char *name, double value);

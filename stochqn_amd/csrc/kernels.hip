@@ -96,22 +96,26 @@ __device__ __forceinline__ double total_of(const double* parts, int count, doubl
 // The sweep skeleton.  Op supplies `In<W> load<W>(i)` (loads only) and `apply<W>(i, in, acc)`
 // (arithmetic + stores) so that all loads of an unrolled group are issued before its first store.
 template <int W, int NP, class Op>
-__device__ __forceinline__ void sweep(uint32_t n, const Op& op, double (&acc)[NP > 0 ? NP : 1])
+__device__ __forceinline__ void sweep(uint32_t n, bool rev, const Op& op, double (&acc)[NP > 0 ? NP : 1])
 {
 	const uint32_t packs = n / W;
 	const uint32_t stride = gridDim.x * kBlock;
+	const uint32_t last = packs - 1;
 	uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+	// `rev` walks the packs from the far end: the previous sweep finished there, so the part of
+	// q / r it wrote last is the part still sitting in the 256 MiB Infinity Cache.
 	// packs <= 2^31 and stride*(kUnroll) <= 2^21, so the sums below stay inside 32 bits
 	for (; p + (kUnroll - 1) * stride < packs; p += kUnroll * stride) {
 		typename Op::template In<W> in[kUnroll];
 		#pragma unroll
-		for (int u = 0; u < kUnroll; u++) in[u] = op.template load<W>((p + u * stride) * W);
+		for (int u = 0; u < kUnroll; u++) { const uint32_t i = p + u * stride; in[u] = op.template load<W>((rev ? last - i : i) * W); }
 		#pragma unroll
-		for (int u = 0; u < kUnroll; u++) op.template apply<W>((p + u * stride) * W, in[u], acc);
+		for (int u = 0; u < kUnroll; u++) { const uint32_t i = p + u * stride; op.template apply<W>((rev ? last - i : i) * W, in[u], acc); }
 	}
 	for (; p < packs; p += stride) {
-		typename Op::template In<W> in = op.template load<W>(p * W);
-		op.template apply<W>(p * W, in, acc);
+		const uint32_t i = rev ? last - p : p;
+		typename Op::template In<W> in = op.template load<W>(i * W);
+		op.template apply<W>(i * W, in, acc);
 	}
 	if constexpr (W > 1) {  // odd tail (n not a multiple of W): the last workgroup's first lanes
 		const uint32_t i = packs * W + threadIdx.x;
@@ -123,12 +127,12 @@ __device__ __forceinline__ void sweep(uint32_t n, const Op& op, double (&acc)[NP
 }
 
 template <int W, int NP, class Op>
-__global__ void __launch_bounds__(kBlock) k_sweep(Op op, uint32_t n, double* parts_out)
+__global__ void __launch_bounds__(kBlock) k_sweep(Op op, uint32_t n, int rev, double* parts_out)
 {
 	__shared__ double sh[kWaves];
 	op.prologue(sh);
 	double acc[NP > 0 ? NP : 1] = {0};
-	sweep<W, NP>(n, op, acc);
+	sweep<W, NP>(n, rev != 0, op, acc);
 	#pragma unroll
 	for (int j = 0; j < NP; j++) {
 		double t = block_sum(acc[j], sh);
@@ -648,8 +652,9 @@ template <int NP, class Op>
 void run_sweep(const Scratch& sc, int id, size_t n, bool vec, const Op& op, double* parts_out, int grid)
 {
 	ProfScope ps(sc, id);
-	if (vec) hipLaunchKernelGGL((k_sweep<2, NP, Op>), dim3(grid), dim3(kBlock), 0, sc.stream, op, (uint32_t) n, parts_out);
-	else     hipLaunchKernelGGL((k_sweep<1, NP, Op>), dim3(grid), dim3(kBlock), 0, sc.stream, op, (uint32_t) n, parts_out);
+	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
+	if (vec) hipLaunchKernelGGL((k_sweep<2, NP, Op>), dim3(grid), dim3(kBlock), 0, sc.stream, op, (uint32_t) n, rev, parts_out);
+	else     hipLaunchKernelGGL((k_sweep<1, NP, Op>), dim3(grid), dim3(kBlock), 0, sc.stream, op, (uint32_t) n, rev, parts_out);
 }
 
 // What the consumer of buffer `buf` has to read: the raw partials, or (multi-GPU) the summed scalars.

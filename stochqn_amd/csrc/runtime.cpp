@@ -94,6 +94,29 @@ void at_exit() { /* device memory dies with the process; destroying streams here
 
 Options& options() { return g_opt; }
 
+int default_grid_cap()
+{
+	static int cus = 0;
+	if (!cus) {
+		int dev = 0, n = 0;
+		if (hipGetDevice(&dev) == hipSuccess &&
+		    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+		else cus = 256;
+		if (cus > kMaxGrid) cus = kMaxGrid;
+	}
+	return cus;
+}
+
+void begin_call(DevCtx* c)
+{
+	c->sc.nontemporal = g_opt.nontemporal;
+	c->sc.grid_cap = g_opt.grid_cap > 0 ? g_opt.grid_cap : default_grid_cap();
+	c->sc.reverse = g_opt.reverse;
+	c->sc.prof = g_profile ? &c->prof : nullptr;
+	c->sc.phase = &c->phase;
+	c->phase = 1;
+}
+
 bool device_ready()
 {
 	static int state = -1;
@@ -130,9 +153,7 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	if (it != g_ctx.end()) {
 		DevCtx* c = it->second;
 		if (c->kind == kind && c->n == n && c->m == m && c->fsize == fsize) {
-			c->sc.nontemporal = g_opt.nontemporal;
-			c->sc.grid_cap = g_opt.grid_cap;
-			c->sc.prof = g_profile ? &c->prof : nullptr;
+			begin_call(c);
 			return c;
 		}
 		destroy(c);              // same address, different problem: the old owner is gone
@@ -169,9 +190,7 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 		SQN_HIP_OK(hipMalloc((void**) &c->fisher_t, fsize * sizeof(double)));
 	}
 	c->rho_ok.assign(m, 0);
-	c->sc.nontemporal = g_opt.nontemporal;
-	c->sc.grid_cap = g_opt.grid_cap;
-	c->sc.prof = g_profile ? &c->prof : nullptr;
+	begin_call(c);
 	c->sc.allreduce = nullptr;
 	c->sc.user = c;
 	g_ctx[key] = c;
@@ -286,10 +305,11 @@ int stochqn_hip_set_option(const char* name, double value)
 	if (!std::strcmp(name, "nontemporal")) g_opt.nontemporal = value != 0;
 	else if (!std::strcmp(name, "grid_cap")) {
 		int g = (int) value;
-		if (g < 1) g = 1;
+		if (g < 0) g = 0;
 		if (g > kMaxGrid) g = kMaxGrid;
 		g_opt.grid_cap = g;
 	}
+	else if (!std::strcmp(name, "reverse")) g_opt.reverse = value != 0;
 	else if (!std::strcmp(name, "strict_grad")) g_opt.strict_grad = value != 0;
 	else return -1;
 	return 0;

@@ -22,9 +22,11 @@ struct View {
 
 struct Options {
 	bool nontemporal = true;
-	int grid_cap = kMaxGrid;
+	int grid_cap = 0;            // 0 = one workgroup per compute unit (measured optimum)
+	bool reverse = true;
 	bool strict_grad = true;
 };
+int default_grid_cap();
 Options& options();
 
 struct DevCtx {
@@ -39,6 +41,7 @@ struct DevCtx {
 	Scratch sc{};
 	Profiler prof;
 	int buf = 0;                       // ping-pong index of the next partial buffer
+	int phase = 1;                     // sweep parity inside the current API call (reset by begin_call)
 	double* pool = nullptr;            // one allocation behind sc.part/red/sy/yy/alpha/rho/report
 	double* fisher_t = nullptr;        // [fsize] F*s on device
 	double* stage[3] = {nullptr, nullptr, nullptr};   // device staging for host x / grad / hess_vec
@@ -65,6 +68,7 @@ bool bind(DevCtx* c, View& v, double* caller, size_t count, bool import);
 void export_view(DevCtx* c, View& v);                  // mirror -> caller's host array
 
 double* stage_in(DevCtx* c, int which, double* caller, size_t count, bool host);   // H2D if host
+void begin_call(DevCtx* c);                            // refresh options, restart the sweep parity
 void sync(DevCtx* c);                                  // stream sync + profiler collection
 
 // multi-GPU

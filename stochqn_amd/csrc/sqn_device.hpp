@@ -81,8 +81,10 @@ struct Scratch {
 	double* alpha;        // [m] alpha by logical index
 	double* rho;          // [m] rho by logical index (for buffer_rho write-back)
 	double* report;       // [4]: bad flag, sum r^2, nonfinite count, spare
-	int grid_cap;         // max workgroups per sweep (<= kMaxGrid)
+	int grid_cap;         // max workgroups per sweep (<= kMaxGrid); default = one per CU
 	bool nontemporal;     // stream S/Y/F rows with nt loads
+	bool reverse;         // alternate the traversal direction from sweep to sweep (Infinity-Cache reuse of q / r)
+	int* phase;           // sweep counter of the current API call (parity = direction)
 	Profiler* prof;       // NULL unless stochqn_hip_profile_enable(1)
 	// multi-GPU: in-place sum of `count` doubles at `buf` across all ranks, enqueued on `stream`.
 	// NULL on a single GPU.
