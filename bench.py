@@ -205,9 +205,11 @@ def main():
     if "bwd" in kern:
         cnt, ms = kern["bwd"]
         ach = 4 * n * 8 / (ms / cnt * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(n)
         roof = {"bound": "hbm", "kernel": "bwd (fused backward sweep: read y_i,q,s_{i-1}; write q)",
                 "achieved": round(ach, 1), "peak": PEAK, "unit": "GB/s", "frac": round(ach / PEAK, 4),
-                "traffic": None, "alg_bytes_per_launch": 4 * n * 8, "avg_launch_ms": round(ms / cnt, 4)}
+                "traffic": traffic, "traffic_source": traffic_src,
+                "alg_bytes_per_launch": 4 * n * 8, "avg_launch_ms": round(ms / cnt, 4)}
     two_loop_ms = sum(kern[k][1] for k in ("first", "bwd", "mid", "fwd", "fwd_last") if k in kern) / max(args.steps, 1)
     two_loop = None
     if two_loop_ms > 0:
@@ -249,6 +251,21 @@ def main():
     if dist is not None:
         lib.stochqn_hip_comm_finalize()
         dist.destroy_process_group()
+
+
+def pmc_traffic(n):
+    """HBM bytes per launch of the backward sweep from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; profiles/summarise.py).  The counters
+    were taken at n = 1e8; the kernel is a pure stream, so bytes scale with n."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    for k, v in d.items():
+        if "BwdOp" in k:
+            return int(round(v["hbm_bytes_per_launch"] * n / 1e8)), os.path.relpath(files[-1], ROOT) + " (measured at n=1e8)"
+    return None, None
 
 
 def cpu_baseline(args, m, L):

@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the headline bench.py line): the other BASELINE.json configurations
+and the PCIe-inclusive host-caller rate, all through the free-mode objects of stochqn_amd.
+
+    python tools/bench_configs.py [c2] [c3host] [c4] [rccl1]
+
+Prints one JSON line per configuration.
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import stochqn_amd
+from stochqn_amd import oLBFGS_free, SQN_free, adaQN_free
+
+dev = torch.device("cuda", 0)
+lib = stochqn_amd.cdll()
+lib.stochqn_hip_profile_name.restype = C.c_char_p
+
+
+def kernels():
+    out = {}
+    for i in range(lib.stochqn_hip_profile_kernels()):
+        cnt, ms = C.c_longlong(), C.c_double()
+        lib.stochqn_hip_profile_get(i, C.byref(cnt), C.byref(ms))
+        if cnt.value:
+            out[lib.stochqn_hip_profile_name(i).decode()] = {"launches": cnt.value, "avg_ms": round(ms.value / cnt.value, 4)}
+    return out
+
+
+class DeviceQuadratic:
+    def __init__(self, n, seed=20240611):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        self.n = n
+        self.d = 0.5 + torch.rand(n, dtype=torch.float64, device=dev, generator=g)
+        self.dn = [self.d * (1 + 0.01 * (2 * torch.rand(n, dtype=torch.float64, device=dev, generator=g) - 1)) for _ in range(2)]
+        self.x0 = 1 + torch.rand(n, dtype=torch.float64, device=dev, generator=g)
+
+    def f(self, x):
+        return float(0.5 * torch.sum(self.d * x * x))
+
+
+def drive(opt, P, x, step, steps, warmup, host=False):
+    """Run until `steps` iterations after `warmup`; returns seconds and calls."""
+    t = 0
+    calls = 0
+    last_k = 0
+
+    def advance(k):
+        nonlocal t, calls, last_k
+        target = opt.niter + k if opt.initialized else k
+        while (opt.niter if opt.initialized else 0) < target:
+            r = opt.run_optimizer(x, step)
+            calls += 1
+            task, req = r["task"], r["requested_on"]
+            if task == "calc_grad":
+                last_k = t % 2
+                t += 1
+            if task in ("calc_grad", "calc_grad_same_batch", "calc_grad_big_batch"):
+                if host:
+                    opt.gradient[:] = (P.dn_h[last_k] * req)
+                else:
+                    torch.mul(P.dn[last_k], req, out=opt.gradient)
+            elif task == "calc_hess_vec":
+                rx, rv = req
+                if host:
+                    opt.hess_vec[:] = P.d_h * rv
+                else:
+                    torch.mul(P.d, rv, out=opt.hess_vec)
+            elif task == "calc_fun_val_batch":
+                opt.update_function(0.5 * float(np.sum(P.d_h * req * req)) if host else P.f(req))
+
+    advance(warmup)
+    torch.cuda.synchronize()
+    lib.stochqn_hip_profile_enable(1)
+    lib.stochqn_hip_profile_reset()
+    c0 = calls
+    t0 = time.perf_counter()
+    advance(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lib.stochqn_hip_profile_enable(0)
+    return dt, calls - c0
+
+
+def report(name, workload, n, m, dt, steps, calls, extra=None):
+    k = kernels()
+    tl = sum(k[x]["avg_ms"] * k[x]["launches"] for x in ("first", "bwd", "mid", "fwd", "fwd_last") if x in k) / steps
+    out = {"config": name, "workload": workload, "steps_per_s": round(steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3),
+           "calls": calls, "two_loop_ms": round(tl, 4),
+           "two_loop_alg_GBps": round(64.0 * m * n / (tl * 1e-3) / 1e9, 1) if tl > 0 else None, "kernels": k}
+    if extra:
+        out.update(extra)
+    print(json.dumps(out), flush=True)
+    lib.stochqn_hip_release_all()
+
+
+def c2():
+    n, m = 10_000_000, 10
+    P = DeviceQuadratic(n)
+    x = P.x0.clone()
+    opt = oLBFGS_free(mem_size=m, min_curvature=None, check_nan=True, space="device")
+    dt, calls = drive(opt, P, x, 0.1, 200, 30)
+    report("C2", "oLBFGS n=1e7 m=10 fp64 check_nan=1, device-resident", n, m, dt, 200, calls, {"f_end": P.f(x), "mem_used": opt.BFGS_mem.mem_used})
+
+
+def c3host():
+    """SQN, every array in host memory (profile B): PCIe-inclusive rate."""
+    n, m = 10_000_000, 20
+    P = DeviceQuadratic(n)
+    P.d_h = P.d.cpu().numpy()
+    P.dn_h = [a.cpu().numpy() for a in P.dn]
+    x = P.x0.cpu().numpy().copy()
+    opt = SQN_free(mem_size=m, bfgs_upd_freq=2, min_curvature=None, space="host")
+    dt, calls = drive(opt, P, x, 0.05, 30, 45, host=True)
+    report("C3-host", "SQN n=1e7 m=20 L=2, ALL arrays in host memory (PCIe inclusive, numpy gradient included)", n, m, dt, 30, calls,
+           {"mem_used": opt.BFGS_mem.mem_used})
+
+
+def c4():
+    """adaQN, empirical-Fisher pairs + RMSProp H0.  adaQN's H0 is the rescaled GRADIENT (reference
+    src/stochqn.c:781,695), so its direction is only sane while x keeps its sign: small steps, L=20,
+    and the ring is filled by running the optimiser itself (400 untimed steps).  The timed window is
+    iterations 400..440, while the ring holds 19-20 pairs: shortly after that adaQN itself blows up on
+    this synthetic quadratic (the CPU oracle does the same at n >= 2e5: the Fisher pairs built from
+    nearly parallel gradients are degenerate), which flushes the ring and would understate the cost."""
+    n, m, f = 100_000_000, 20, 128
+    P = DeviceQuadratic(n)
+    for max_incr in (None, 1.01):
+        x = P.x0.clone()
+        opt = adaQN_free(mem_size=m, fisher_size=f, bfgs_upd_freq=20, max_incr=max_incr, min_curvature=1e-4,
+                         scal_reg=1e-4, rmsprop_weight=0.9, space="device")
+        dt, calls = drive(opt, P, x, 1e-3, 40, 400)
+        report("C4", "adaQN n=1e8 m=20 fisher_size=128 L=20 rmsprop=0.9 max_incr=%s, device-resident" % max_incr, n, m, dt, 40, calls,
+               {"mem_used": opt.BFGS_mem.mem_used, "fisher_used": opt.Fisher_mem.mem_used, "f_end": P.f(x), "f_start": P.f(P.x0)})
+
+
+def rccl1():
+    """Exercise the all-reduce code path with a 1-rank RCCL communicator."""
+    buf = (C.c_ubyte * 128)()
+    assert lib.stochqn_hip_comm_unique_id(buf) == 0
+    assert lib.stochqn_hip_comm_init(0, 1, bytes(buf)) == 0
+    n, m = 100_000_000, 20
+    P = DeviceQuadratic(n)
+    x = P.x0.clone()
+    opt = SQN_free(mem_size=m, bfgs_upd_freq=1, min_curvature=None, space="device")
+    drive(opt, P, x, 0.05, 1, 25)
+    opt.BFGS_mem.upd_freq = 10
+    opt.bfgs_upd_freq = 10
+    opt.niter = 10 * ((opt.niter + 9) // 10)
+    dt, calls = drive(opt, P, x, 0.05, 30, 2)
+    report("RCCL-1rank", "SQN n=1e8 m=20 L=10 with a 1-rank RCCL communicator (k_fin + ncclAllReduce per sweep)", n, m, dt, 30, calls,
+           {"nranks": lib.stochqn_hip_comm_nranks(), "mem_used": opt.BFGS_mem.mem_used})
+    lib.stochqn_hip_comm_finalize()
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2", "c3host", "c4"]
+    for w in which:
+        globals()[w]()
