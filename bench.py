@@ -193,8 +193,13 @@ def main():
         if cnt.value:
             kern[lib.stochqn_hip_profile_name(i).decode()] = (cnt.value, ms.value)
     PEAK = 8000.0  # GB/s, MI355X HBM3E (MI355X_MICROARCH.md)
-    words = {"first": 2, "bwd": 4, "mid": 3, "fwd": 4, "fwd_last": 3, "apply": 5}  # algorithmic n-words per launch
-    roof = None
+    # algorithmic n-words per launch
+    words = {"first": 2, "bwd": 4, "mid": 3, "fwd": 4, "fwd_last": 3, "apply": 5,
+             "rows_dot": 2 * m + 1, "rows_dot3": 2 * m + 3, "combine": 2 * m + 2}
+    what = {"bwd": "fused backward sweep: read y_i, q, s_{i-1}; write q",
+            "fwd": "fused forward sweep: read s_i, r, y_{i+1}; write r",
+            "combine": "two-pass form, pass B: read g and the %d rows of S and Y; write r" % (2 * m),
+            "rows_dot": "two-pass form, pass A: read g and the %d rows of S and Y" % (2 * m)}
     detail = {}
     for name, (cnt, ms) in kern.items():
         avg = ms / cnt
@@ -202,20 +207,29 @@ def main():
         if name in words:
             e["alg_GBps"] = round(words[name] * n * 8 / (avg * 1e-3) / 1e9, 1)
         detail[name] = e
-    if "bwd" in kern:
-        cnt, ms = kern["bwd"]
-        ach = 4 * n * 8 / (ms / cnt * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(n)
-        roof = {"bound": "hbm", "kernel": "bwd (fused backward sweep: read y_i,q,s_{i-1}; write q)",
+    roof = None
+    cands = [k for k in what if k in kern]
+    if cands:
+        dom = max(cands, key=lambda k: kern[k][1])               # largest share of device time
+        cnt, ms = kern[dom]
+        alg = words[dom] * n * 8
+        ach = alg / (ms / cnt * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dom, n, m)
+        roof = {"bound": "hbm", "kernel": "%s (%s)" % (dom, what[dom]),
                 "achieved": round(ach, 1), "peak": PEAK, "unit": "GB/s", "frac": round(ach / PEAK, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "alg_bytes_per_launch": 4 * n * 8, "avg_launch_ms": round(ms / cnt, 4)}
-    two_loop_ms = sum(kern[k][1] for k in ("first", "bwd", "mid", "fwd", "fwd_last") if k in kern) / max(args.steps, 1)
+                "alg_bytes_per_launch": alg, "avg_launch_ms": round(ms / cnt, 4)}
+    chain = ("first", "bwd", "mid", "fwd", "fwd_last", "rows_dot", "rows_dot3", "coef", "combine")
+    two_loop_ms = sum(kern[k][1] for k in chain if k in kern) / max(args.steps, 1)
     two_loop = None
     if two_loop_ms > 0:
-        gbps = 64.0 * m * n / (two_loop_ms * 1e-3) / 1e9
-        two_loop = {"ms": round(two_loop_ms, 3), "alg_bytes": 64 * m * n, "alg_GBps": round(gbps, 1),
-                    "frac_of_8TBps": round(gbps / PEAK, 4)}
+        form = "two-pass" if "combine" in kern else "sweeps"
+        own = (4 * m + 3) if form == "two-pass" else 8 * m           # n-words this form has to move
+        two_loop = {"form": form, "ms": round(two_loop_ms, 3),
+                    "bytes_moved": own * n * 8, "GBps_on_bytes_moved": round(own * n * 8 / (two_loop_ms * 1e-3) / 1e9, 1),
+                    "frac_of_8TBps_on_bytes_moved": round(own * n * 8 / (two_loop_ms * 1e-3) / 1e9 / PEAK, 4),
+                    "reference_form_bytes": 64 * m * n,
+                    "effective_GBps_vs_reference_form": round(64.0 * m * n / (two_loop_ms * 1e-3) / 1e9, 1)}
 
     steps_per_s = args.steps / elapsed
     n_total = n * world
@@ -253,18 +267,22 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(n):
-    """HBM bytes per launch of the backward sweep from the committed rocprofv3 PMC passes
-    (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; profiles/summarise.py).  The counters
-    were taken at n = 1e8; the kernel is a pure stream, so bytes scale with n."""
+def pmc_traffic(kernel, n, m):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
+    gfx950 + WRITE_SIZE, separate passes; profiles/summarise.py).  The counters were taken at
+    n = 1e8, m = 20; the kernels are pure streams, so bytes scale with n."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None, None
-    d = json.load(open(files[-1]))
-    for k, v in d.items():
-        if "BwdOp" in k:
-            return int(round(v["hbm_bytes_per_launch"] * n / 1e8)), os.path.relpath(files[-1], ROOT) + " (measured at n=1e8)"
+    key = {"bwd": "BwdOp", "fwd": "FwdOp<true, false, false>", "combine": "k_combine<2", "rows_dot": "k_rows_dot_all<2, 5"}[kernel]
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+        d = json.load(open(f))
+        for k, v in d.items():
+            if key in k and (m == 20 or kernel in ("bwd", "fwd")):
+                raw = v["raw"]
+                # rows_dot: the same kernel also runs Gram maintenance with the probe among the rows
+                # (one stream fewer); pass A is the largest dispatch
+                stat = "max_KiB" if kernel == "rows_dot" else "median_KiB"
+                b = raw.get("FETCH_SIZE", {}).get(stat, 0.0) * 1024 * 2 + raw.get("WRITE_SIZE", {}).get(stat, 0.0) * 1024
+                return int(round(b * n / 1e8)), os.path.relpath(f, ROOT) + " (measured at n=1e8, m=20)"
     return None, None
 
 

@@ -47,6 +47,10 @@ int stochqn_hip_export(const void *s_mem);
  * "nontemporal" (default 1)  stream pair / Fisher rows with non-temporal loads
  * "grid_cap"    (default 0 = one workgroup per compute unit) maximum workgroups per sweep
  * "reverse"     (default 1)  alternate the traversal direction of consecutive sweeps
+ * "twopass"     (default 1)  scalar-H0 two-loop (oLBFGS, SQN) in the two-pass form: inner products
+ *                            of g with all stored pairs, O(m^2) scalar recursion over cached Gram
+ *                            blocks, one combine pass -- (4m+3)n words instead of 8mn; 0 = the
+ *                            chain of 2m+1 dependent sweeps (always used by adaQN and for m > 24)
  * "strict_grad" (default 1)  host callers: copy the search direction back into `grad`
  * Returns 0, or -1 for an unknown name. Applies to contexts created afterwards and existing ones. */
 int stochqn_hip_set_option(const char *name, double value);

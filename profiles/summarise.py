@@ -29,6 +29,9 @@ def short(name):
     m = re.search(r"k_sweep<(\d), (\d), (\w+)(<[^>]*>)?", name)
     if m:
         return "k_sweep<W=%s,NP=%s,%s%s>" % (m.group(1), m.group(2), m.group(3), m.group(4) or "")
+    m = re.search(r"(k_rows_dot_all|k_rows_dot|k_combine|k_fisher_t|k_fisher_y)<([^>]*)>", name)
+    if m:
+        return "%s<%s>" % (m.group(1), m.group(2))
     return re.sub(r"\(.*", "", name)[:80]
 
 
@@ -55,6 +58,7 @@ for k, d in pmc.items():
     wr = d.get("WRITE_SIZE", {}).get("median_KiB", 0.0) * 1024
     summary[k] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr, "raw": d}
 json.dump(summary, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+shutil.copy(os.path.join(ROOT, "gpurun_out", "prof_stats.json"), os.path.join(out, tag + "_bench_under_rocprofv3.json"))
 for k in sorted(summary, key=lambda k: -summary[k]["hbm_bytes_per_launch"])[:12]:
     s = summary[k]
     print("%-60s read %.3e  write %.3e  total %.3e" % (k, s["read_bytes_per_launch"], s["write_bytes_per_launch"], s["hbm_bytes_per_launch"]))

@@ -93,6 +93,16 @@ __device__ __forceinline__ double total_of(const double* parts, int count, doubl
 	return block_sum(a, sh);
 }
 
+// Total of one partial array computed by ONE wave (lane-strided adds, then the shuffle tree); lets
+// the 1-workgroup scalar kernels reduce kWaves quantities at a time without workgroup barriers.
+__device__ __forceinline__ double wave_total_of(const double* parts, int count)
+{
+	double a = 0;
+	for (int i = threadIdx.x & 63; i < count; i += 64) a += parts[i];
+	a = wave_sum(a);
+	return __shfl(a, 0, 64);
+}
+
 // The sweep skeleton.  Op supplies `In<W> load<W>(i)` (loads only) and `apply<W>(i, in, acc)`
 // (arithmetic + stores) so that all loads of an unrolled group are issued before its first store.
 template <int W, int NP, class Op>
@@ -612,6 +622,246 @@ __global__ void __launch_bounds__(kBlock) k_fisher_y(const double* F, size_t ld_
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// two-pass form: rows-dot (pass A, Gram maintenance), coefficient recursion, combine (pass B)
+// ------------------------------------------------------------------------------------------------
+// partial[j][workgroup] = sum over this workgroup's packs of rows[j] . probe.  NG groups of 8 rows,
+// one accumulator per row and lane; the probe pack is loaded once and reused for every row.
+// NPR probes: quantity (pr * rows + j) = rows[j] . probe[pr].  With NPR = 3 the pass that computes
+// [S;Y]g for the recursion also produces the new pair's row of the Gram blocks (probes y_r, s_r).
+struct Probes { const double* p[3]; };
+
+// Single-probe pass A: one accumulator per row and lane, NG groups of 8 rows; the compiler hoists
+// the row loads of a pack ahead of the arithmetic (one wave per SIMD, up to 512 registers per lane),
+// which measured faster than the row-split form below for a single probe (5.1 vs 5.8 ms, n=1e8, 40 rows).
+template <int W, int NG, bool NT>
+__global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, const double* probe, double* copy_out, uint32_t n, int rev,
+                                                         double* parts)
+{
+	__shared__ double sh[kWaves];
+	double acc[NG * 8];
+	#pragma unroll
+	for (int j = 0; j < NG * 8; j++) acc[j] = 0;
+	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
+	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
+		const uint32_t i = (rev ? last - p : p) * W;
+		const Pack<W> pv = ld<W, false>(probe, i);
+		if (copy_out) st<W>(copy_out, i, pv);
+		#pragma unroll
+		for (int g = 0; g < NG; g++) {
+			Pack<W> f[8];
+			#pragma unroll
+			for (int u = 0; u < 8; u++)
+				if (g * 8 + u < rs.count) f[u] = ld<W, NT>(rs.row[g * 8 + u], i);
+			#pragma unroll
+			for (int u = 0; u < 8; u++)
+				if (g * 8 + u < rs.count) {
+					#pragma unroll
+					for (int k = 0; k < W; k++) acc[g * 8 + u] = fma(f[u].v[k], pv.v[k], acc[g * 8 + u]);
+				}
+		}
+	}
+	if (W > 1) {
+		const uint32_t i = packs * W + threadIdx.x;
+		if (blockIdx.x == gridDim.x - 1 && i < n) {
+			const double pv = probe[i];
+			if (copy_out) copy_out[i] = pv;
+			#pragma unroll
+			for (int j = 0; j < NG * 8; j++)
+				if (j < rs.count) acc[j] = fma(rs.row[j][i], pv, acc[j]);
+		}
+	}
+	#pragma unroll
+	for (int j = 0; j < NG * 8; j++) {
+		if (j < rs.count) {           // uniform
+			const double t = block_sum(acc[j], sh);
+			if (threadIdx.x == 0) parts[(size_t) j * kMaxGrid + blockIdx.x] = t;
+		}
+	}
+}
+
+// Work split: the 4 waves of a workgroup share the same columns and divide the ROWS among them
+// (wave w owns rows [w*RPW, (w+1)*RPW)), so a lane carries only RPW*NPR accumulators and the loads
+// of a whole pack fit in registers (all issued before the first use).  The probe packs are read
+// by every wave with default-policy loads: one HBM fetch, three L2/L1 hits.
+template <int W, int RPW, int NPR, bool NT>
+__global__ void __launch_bounds__(kBlock) k_rows_dot(RowSet rs, Probes pr, double* copy_out, uint32_t n, int rev, double* parts)
+{
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int row0 = wave * RPW;
+	double acc[NPR][RPW];
+	#pragma unroll
+	for (int q = 0; q < NPR; q++)
+		#pragma unroll
+		for (int j = 0; j < RPW; j++) acc[q][j] = 0;
+	const uint32_t packs = n / W, stride = gridDim.x * 64, last = packs - 1;
+	for (uint32_t p = blockIdx.x * 64 + lane; p < packs; p += stride) {
+		const uint32_t i = (rev ? last - p : p) * W;
+		Pack<W> pv[NPR], f[RPW];
+		#pragma unroll
+		for (int q = 0; q < NPR; q++) pv[q] = ld<W, false>(pr.p[q], i);
+		#pragma unroll
+		for (int j = 0; j < RPW; j++)
+			if (row0 + j < rs.count) f[j] = ld<W, NT>(rs.row[row0 + j], i);
+		if (copy_out && wave == 0) st<W>(copy_out, i, pv[0]);
+		#pragma unroll
+		for (int j = 0; j < RPW; j++)
+			if (row0 + j < rs.count) {
+				#pragma unroll
+				for (int q = 0; q < NPR; q++)
+					#pragma unroll
+					for (int k = 0; k < W; k++) acc[q][j] = fma(f[j].v[k], pv[q].v[k], acc[q][j]);
+			}
+	}
+	if (W > 1) {
+		const uint32_t i = packs * W;
+		if (blockIdx.x == gridDim.x - 1 && lane == 0 && i < n) {       // odd tail element
+			if (copy_out && wave == 0) copy_out[i] = pr.p[0][i];
+			#pragma unroll
+			for (int q = 0; q < NPR; q++) {
+				const double pv = pr.p[q][i];
+				#pragma unroll
+				for (int j = 0; j < RPW; j++)
+					if (row0 + j < rs.count) acc[q][j] = fma(rs.row[row0 + j][i], pv, acc[q][j]);
+			}
+		}
+	}
+	#pragma unroll
+	for (int q = 0; q < NPR; q++)
+		#pragma unroll
+		for (int j = 0; j < RPW; j++) {
+			const double t = wave_sum(acc[q][j]);
+			if (lane == 0 && row0 + j < rs.count) parts[(size_t) (q * rs.count + row0 + j) * kMaxGrid + blockIdx.x] = t;
+		}
+}
+
+// Fused Gram maintenance: pass A ran over the k pairs in use (rows 0..k-1 = S, k..2k-1 = Y, logical
+// order) with probes (g, y_r, s_r); quantities 2k.. are the dots with y_r, 4k.. the dots with s_r.
+__global__ void __launch_bounds__(kBlock) k_gram_store_fused(const double* parts, int count, int stride, CoefArgs a, int r,
+                                                             double* gsy, double* gyy)
+{
+	const int k = a.k, m = a.m, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	for (int i = wave; i < k; i += kWaves) {
+		const int j = a.rows[i];
+		const double sjyr = wave_total_of(parts + (size_t) (2 * k + i) * stride, count);       // s_j'y_r
+		const double yjyr = wave_total_of(parts + (size_t) (2 * k + k + i) * stride, count);   // y_j'y_r
+		const double yjsr = wave_total_of(parts + (size_t) (4 * k + k + i) * stride, count);   // y_j's_r
+		if (lane == 0) {
+			gsy[(size_t) j * m + r] = sjyr;
+			gsy[(size_t) r * m + j] = yjsr;
+			gyy[(size_t) j * m + r] = yjyr;
+			gyy[(size_t) r * m + j] = yjyr;
+		}
+	}
+}
+
+// Gram maintenance for ring row r: a[j] = s_j'y_r (j < m), a[m+j] = y_j'y_r, b[j] = y_j's_r
+__global__ void __launch_bounds__(kBlock) k_gram_store(const double* a, int a_count, int a_stride, const double* b, int b_count,
+                                                       int b_stride, int m, int r, double* gsy, double* gyy)
+{
+	__shared__ double sh[kWaves];
+	for (int j = 0; j < m; j++) {
+		const double sjyr = total_of(a + (size_t) j * a_stride, a_count, sh);
+		const double yjyr = total_of(a + (size_t) (m + j) * a_stride, a_count, sh);
+		const double yjsr = total_of(b + (size_t) j * b_stride, b_count, sh);
+		if (threadIdx.x == 0) {
+			gsy[(size_t) j * m + r] = sjyr;
+			gsy[(size_t) r * m + j] = yjsr;
+			gyy[(size_t) j * m + r] = yjyr;
+			gyy[(size_t) r * m + j] = yjyr;
+		}
+	}
+}
+
+// The scalar part of the recursion (reference src/stochqn.c:671-707 with every inner product
+// expanded over the cached Gram blocks).  One workgroup; lane 0 runs the O(k^2) recursion from LDS.
+__global__ void __launch_bounds__(kBlock) k_coef(const double* bparts, int count, int stride, CoefArgs a, const double* gsy,
+                                                 const double* gyy, double* alpha_out, double* rho_out, double* coef)
+{
+	__shared__ double SY[kPairsMax * kPairsMax], YY[kPairsMax * kPairsMax], bS[kPairsMax], bY[kPairsMax];
+	__shared__ double al[kPairsMax], rho[kPairsMax], c[kPairsMax];
+	const int k = a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	for (int e = threadIdx.x; e < k * k; e += kBlock) {      // logical-order copies of the Gram blocks
+		const int i = e / k, j = e % k;
+		SY[e] = gsy[(size_t) a.rows[i] * a.m + a.rows[j]];
+		YY[e] = gyy[(size_t) a.rows[i] * a.m + a.rows[j]];
+	}
+	for (int q = wave; q < 2 * k; q += kWaves) {             // b = [S;Y]g, one wave per quantity
+		const double t = wave_total_of(bparts + (size_t) q * stride, count);
+		if (lane == 0) { if (q < k) bS[q] = t; else bY[q - k] = t; }
+	}
+	__syncthreads();
+	if (threadIdx.x != 0) return;
+	for (int i = k - 1; i >= 0; i--) {                       // backward loop: alpha_i = rho_i s_i'q_{i+1}
+		double sq = bS[i];
+		for (int j = k - 1; j > i; j--) sq = fma(-al[j], SY[i * k + j], sq);
+		rho[i] = 1.0 / SY[i * k + i];
+		al[i] = rho[i] * sq;
+		alpha_out[i] = al[i];
+		rho_out[i] = rho[i];
+	}
+	const double gamma = (a.h0 > 0) ? a.h0 : SY[(k - 1) * k + (k - 1)] / YY[(k - 1) * k + (k - 1)];
+	coef[0] = gamma;
+	for (int i = 0; i < k; i++) {                            // forward loop: beta_i = rho_i y_i'r_i
+		double yq = bY[i];
+		for (int j = k - 1; j >= 0; j--) yq = fma(-al[j], YY[i * k + j], yq);     // y_i'q_0
+		double yr = gamma * yq;
+		for (int j = 0; j < i; j++) yr = fma(c[j], SY[j * k + i], yr);            // + sum_{j<i} c_j s_j'y_i
+		c[i] = al[i] - rho[i] * yr;
+		coef[1 + i] = -(gamma * al[i]);                      // coefficient of y_i
+		coef[1 + k + i] = c[i];                              // coefficient of s_i
+	}
+}
+
+// pass B: r = gamma g + sum_i cy_i y_i + sum_i cs_i s_i  (pairs visited oldest to newest)
+template <int W, bool NT>
+__global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const double* coef, double* g, uint32_t n, int rev,
+                                                    double* parts)
+{
+	__shared__ double sh[kWaves];
+	__shared__ double cf[1 + 2 * kPairsMax];
+	const int k = ys.count;
+	for (int e = threadIdx.x; e < 1 + 2 * k; e += kBlock) cf[e] = coef[e];
+	__syncthreads();
+	double acc0 = 0, acc1 = 0;
+	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
+	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
+		const uint32_t i = (rev ? last - p : p) * W;
+		Pack<W> r = ld<W, false>(g, i);
+		#pragma unroll
+		for (int e = 0; e < W; e++) r.v[e] = cf[0] * r.v[e];
+		for (int j0 = 0; j0 < k; j0 += 4) {
+			Pack<W> fy[4], fs[4];
+			#pragma unroll
+			for (int u = 0; u < 4; u++)
+				if (j0 + u < k) { fy[u] = ld<W, NT>(ys.row[j0 + u], i); fs[u] = ld<W, NT>(ss.row[j0 + u], i); }
+			#pragma unroll
+			for (int u = 0; u < 4; u++)
+				if (j0 + u < k) {
+					#pragma unroll
+					for (int e = 0; e < W; e++) {
+						r.v[e] = fma(cf[1 + j0 + u], fy[u].v[e], r.v[e]);
+						r.v[e] = fma(cf[1 + k + j0 + u], fs[u].v[e], r.v[e]);
+					}
+				}
+		}
+		#pragma unroll
+		for (int e = 0; e < W; e++) { acc0 = fma(r.v[e], r.v[e], acc0); acc1 += (isfinite(r.v[e]) ? 0.0 : 1.0); }
+		st<W>(g, i, r);
+	}
+	if (W > 1) {
+		const uint32_t i = packs * W + threadIdx.x;
+		if (blockIdx.x == gridDim.x - 1 && i < n) {
+			double r = cf[0] * g[i];
+			for (int j = 0; j < k; j++) { r = fma(cf[1 + j], ys.row[j][i], r); r = fma(cf[1 + k + j], ss.row[j][i], r); }
+			acc0 = fma(r, r, acc0); acc1 += (isfinite(r) ? 0.0 : 1.0);
+			g[i] = r;
+		}
+	}
+	const double t0 = block_sum(acc0, sh), t1 = block_sum(acc1, sh);
+	if (threadIdx.x == 0) { parts[blockIdx.x] = t0; parts[kMaxGrid + blockIdx.x] = t1; }
+}
+
 // out[j] = sum of partial array j (one workgroup per quantity)
 __global__ void __launch_bounds__(kBlock) k_fin(const double* parts, int count, int stride, double* out)
 {
@@ -673,17 +923,21 @@ const char* kernel_name(int id)
 {
 	static const char* names[K_COUNT] = {
 		"first", "bwd", "mid", "fwd", "fwd_last", "apply", "pair_s", "pair_y_diff", "pair_y_hv",
-		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy"};
+		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy", "rows_dot", "coef", "combine", "gram", "rows_dot3"};
 	return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
-int sweep_grid(const Scratch& sc, size_t n)
+int sweep_grid(const Scratch& sc, size_t n, int per_cu)
 {
-	// one pack pair per lane and unroll step; never more workgroups than the partial stride
+	// one pack pair per lane and unroll step; never more workgroups than the partial stride.
+	// `per_cu`: kernels with a large share of stores (apply) or a long per-pack dependency chain
+	// (combine) measured best with two workgroups per CU, the 3-read/1-write sweeps with one.
 	size_t per_block = (size_t) kBlock * 2 * kUnroll;
 	size_t g = (n + per_block - 1) / per_block;
+	size_t cap = (size_t) sc.grid_cap * per_cu;
+	if (cap > (size_t) kMaxGrid) cap = kMaxGrid;
 	if (g < 1) g = 1;
-	if (g > (size_t) sc.grid_cap) g = sc.grid_cap;
+	if (g > cap) g = cap;
 	return (int) g;
 }
 
@@ -748,7 +1002,7 @@ Partials launch_fwd_last(const Scratch& sc, int buf, size_t n, Partials in, cons
 void launch_apply(const Scratch& sc, size_t n, double n_global, Partials guard, const double* r_in, double* grad_out,
                   const ApplyArgs& a, bool guarded)
 {
-	const int grid = sweep_grid(sc, n);
+	const int grid = sweep_grid(sc, n, 2);
 	const bool vec = all_aligned(r_in, grad_out, a.x, a.x_sum, a.s_slot);
 	run_sweep<0>(sc, K_APPLY, n, vec, ApplyOp{guard, guarded, n_global, r_in, grad_out, a, sc.report, false}, nullptr, grid);
 }
@@ -808,6 +1062,142 @@ Partials launch_fisher(const Scratch& sc, int buf, size_t n, const double* F, si
 		else     hipLaunchKernelGGL((k_fisher_y<1, true>), dim3(grid), dim3(kBlock), shmem, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, t_dev, inv, s, y_out, sc.part[buf]);
 	}
 	return finish(sc, buf, 3, grid);
+}
+
+static bool rows_aligned(const RowSet& r)
+{
+	for (int j = 0; j < r.count; j++) if (!aligned16(r.row[j])) return false;
+	return true;
+}
+
+// Workgroups of the row-split kernel that are resident per CU (register-limited: 3 at 10 rows per
+// wave and 3 probes).  The grid is a whole number of such rounds: 1024 workgroups at 3 per CU ran
+// 40 % slower than 768 (a second, quarter-full round).
+template <class K> static int resident_per_cu(K kernel)
+{
+	int blocks = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, kBlock, 0) != hipSuccess || blocks < 1) blocks = 1;
+	return blocks > 8 ? 8 : blocks;
+}
+
+template <int W, int NPR>
+static int rows_dot_dispatch(const Scratch& sc, int slot, size_t max_grid, int rpw, const RowSet& rows, const Probes& pr,
+                             double* copy_out, uint32_t n, int rev)
+{
+	int grid = 1;
+	#define SQN_RD(RPW)                                                                                                  \
+		{                                                                                                                \
+			static const int per_cu = resident_per_cu(k_rows_dot<W, RPW, NPR, true>);                                      \
+			size_t g = sc.rows_grid > 0 ? (size_t) sc.rows_grid : (size_t) sc.grid_cap * per_cu;                          \
+			if (g > max_grid) g = max_grid;                                                                              \
+			if (g > (size_t) kMaxGrid) g = kMaxGrid;                                                                     \
+			grid = (int) g;                                                                                              \
+			hipLaunchKernelGGL((k_rows_dot<W, RPW, NPR, true>), dim3(grid), dim3(kBlock), 0, sc.stream, rows, pr, copy_out, n, rev, sc.rows_part[slot]); \
+		}
+	if (rpw <= 2) SQN_RD(2)
+	else if (rpw <= 4) SQN_RD(4)
+	else if (rpw <= 6) SQN_RD(6)
+	else if (rpw <= 8) SQN_RD(8)
+	else if (rpw <= 10) SQN_RD(10)
+	else SQN_RD(12)
+	#undef SQN_RD
+	return grid;
+}
+
+template <int W>
+static void rows_dot_all_dispatch(const Scratch& sc, int slot, int grid, int ng, const RowSet& rows, const double* probe,
+                                  double* copy_out, uint32_t n, int rev)
+{
+	#define SQN_RA(NG) hipLaunchKernelGGL((k_rows_dot_all<W, NG, true>), dim3(grid), dim3(kBlock), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[slot])
+	switch (ng) {
+	case 1: SQN_RA(1); break;
+	case 2: SQN_RA(2); break;
+	case 3: SQN_RA(3); break;
+	case 4: SQN_RA(4); break;
+	case 5: SQN_RA(5); break;
+	default: SQN_RA(6); break;
+	}
+	#undef SQN_RA
+}
+
+Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& rows, const double* probe, double* copy_out,
+                         int kernel_id, const double* probe_y, const double* probe_s)
+{
+	if (!probe_y && !sc.rows_split) {      // single probe: every lane keeps all rows
+		const int grid = sweep_grid(sc, n);
+		const bool vec = rows_aligned(rows) && all_aligned(probe, copy_out);
+		const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
+		{
+			ProfScope ps(sc, kernel_id);
+			if (vec) rows_dot_all_dispatch<2>(sc, slot, grid, (rows.count + 7) / 8, rows, probe, copy_out, (uint32_t) n, rev);
+			else     rows_dot_all_dispatch<1>(sc, slot, grid, (rows.count + 7) / 8, rows, probe, copy_out, (uint32_t) n, rev);
+		}
+		Partials raw{sc.rows_part[slot], grid, kMaxGrid};
+		if (!sc.allreduce) return raw;
+		launch_fin(sc, raw, rows.count, sc.red[slot]);
+		sc.allreduce(sc.user, sc.red[slot], rows.count, sc.stream);
+		return Partials{sc.red[slot], 1, 1};
+	}
+
+	// a workgroup covers 64 packs per step here (its 4 waves split the rows), so it takes 4x the
+	// workgroups of a sweep to keep the same number of lanes on the columns
+	const bool vec = rows_aligned(rows) && all_aligned(probe, copy_out, probe_y, probe_s);
+	size_t max_grid = (n / (vec ? 2 : 1) + 63) / 64;         // a workgroup covers 64 packs per step here
+	if (max_grid < 1) max_grid = 1;
+	int grid = 1;
+	const int ng = (rows.count + kWaves - 1) / kWaves;     // rows per wave
+	const int npr = probe_y ? 3 : 1;
+	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
+	const Probes pr{{probe, probe_y, probe_s}};
+	{
+		ProfScope ps(sc, kernel_id);
+		if (npr == 3) {
+			if (vec) grid = rows_dot_dispatch<2, 3>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
+			else     grid = rows_dot_dispatch<1, 3>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
+		} else {
+			if (vec) grid = rows_dot_dispatch<2, 1>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
+			else     grid = rows_dot_dispatch<1, 1>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
+		}
+	}
+	const int nq = npr * rows.count;
+	Partials raw{sc.rows_part[slot], grid, kMaxGrid};
+	if (!sc.allreduce) return raw;
+	launch_fin(sc, raw, nq, sc.red[slot]);
+	sc.allreduce(sc.user, sc.red[slot], nq, sc.stream);
+	return Partials{sc.red[slot], 1, 1};
+}
+
+void launch_gram_store_fused(const Scratch& sc, Partials p, const CoefArgs& a, int r)
+{
+	ProfScope ps(sc, K_SMALL);
+	hipLaunchKernelGGL(k_gram_store_fused, dim3(1), dim3(kBlock), 0, sc.stream, p.parts, p.count, p.stride, a, r, sc.gsy, sc.gyy);
+}
+
+void launch_gram_store(const Scratch& sc, Partials a, Partials b, int m, int r)
+{
+	ProfScope ps(sc, K_SMALL);
+	hipLaunchKernelGGL(k_gram_store, dim3(1), dim3(kBlock), 0, sc.stream, a.parts, a.count, a.stride, b.parts, b.count, b.stride,
+	                   m, r, sc.gsy, sc.gyy);
+}
+
+void launch_coef(const Scratch& sc, Partials b, const CoefArgs& a)
+{
+	ProfScope ps(sc, K_COEF);
+	hipLaunchKernelGGL(k_coef, dim3(1), dim3(kBlock), 0, sc.stream, b.parts, b.count, b.stride, a, sc.gsy, sc.gyy, sc.alpha, sc.rho,
+	                   sc.coef);
+}
+
+Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, const RowSet& ss, double* g)
+{
+	const int grid = sweep_grid(sc, n, 2);
+	const bool vec = rows_aligned(ys) && rows_aligned(ss) && aligned16(g);
+	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
+	{
+		ProfScope ps(sc, K_COMBINE);
+		if (vec) hipLaunchKernelGGL((k_combine<2, true>), dim3(grid), dim3(kBlock), 0, sc.stream, ys, ss, sc.coef, g, (uint32_t) n, rev, sc.part[buf]);
+		else     hipLaunchKernelGGL((k_combine<1, true>), dim3(grid), dim3(kBlock), 0, sc.stream, ys, ss, sc.coef, g, (uint32_t) n, rev, sc.part[buf]);
+	}
+	return finish(sc, buf, 2, grid);
 }
 
 void launch_fin(const Scratch& sc, Partials in, int nsums, double* out)

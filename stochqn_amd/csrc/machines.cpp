@@ -78,6 +78,7 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 	if (fresh) {
 		comm_attach(c);
 		c->rho_ok.assign(c->m, 0);
+		c->gram_ok.assign(c->m, 0);
 	}
 	io.x_caller = x;
 	io.g_caller = grad;
@@ -188,6 +189,68 @@ Partials enqueue_two_loop(DevCtx* c, double* g, size_t used, size_t st, const Fi
 	return launch_fwd_last(sc, c->next_buf(), n, p, sc.sy + r_of(k - 1), (int) (k - 1), row(c->S, r_of(k - 1), c), g, fuse);
 }
 
+// ---- two-pass form (scalar H0): Gram maintenance + rows-dot / coef / combine ----------------------
+bool twopass_ok(const DevCtx* c, size_t used, const double* H0_vec)
+{
+	return options().twopass && H0_vec == nullptr && used >= 1 && c->m <= (size_t) kPairsMax;
+}
+
+// Refresh row r and column r of the Gram blocks: s_j'y_r, y_j'y_r, y_j's_r for every ring row j.
+void ensure_gram(DevCtx* c, size_t st, size_t used)
+{
+	const size_t m = c->m;
+	for (size_t i = 0; i < used; i++) {
+		const size_t r = (st + i) % m;
+		if (c->gram_ok[r]) continue;
+		RowSet all{}, ys{};
+		for (size_t j = 0; j < m; j++) {
+			all.row[j] = row(c->S, j, c);
+			all.row[m + j] = row(c->Y, j, c);
+			ys.row[j] = row(c->Y, j, c);
+		}
+		all.count = (int) (2 * m);
+		ys.count = (int) m;
+		Partials a = launch_rows_dot(c->sc, 0, N(c), all, row(c->Y, r, c), nullptr, K_GRAM);
+		Partials b = launch_rows_dot(c->sc, 1, N(c), ys, row(c->S, r, c), nullptr, K_GRAM);
+		launch_gram_store(c->sc, a, b, (int) m, (int) r);
+		c->gram_ok[r] = 1;
+	}
+}
+
+// Returns the guard partials (sum r^2, nonfinite); the direction replaces g.
+Partials enqueue_two_pass(DevCtx* c, double* g, size_t used, size_t st, double h0, double* gprev_out)
+{
+	const size_t m = c->m, k = used;
+	RowSet rows{}, ys{}, ss{};
+	CoefArgs a{};
+	a.k = (int) k;
+	a.m = (int) m;
+	a.h0 = h0;
+	int stale = 0, stale_row = -1;
+	for (size_t i = 0; i < k; i++) {
+		const size_t r = (st + i) % m;
+		a.rows[i] = (int) r;
+		rows.row[i] = ss.row[i] = row(c->S, r, c);
+		rows.row[k + i] = ys.row[i] = row(c->Y, r, c);
+		if (!c->gram_ok[r]) { stale++; stale_row = (int) r; }
+	}
+	rows.count = (int) (2 * k);
+	ys.count = ss.count = (int) k;
+	Partials b;
+	if (stale == 1) {
+		// the usual case -- exactly one pair entered the ring since the last step: its Gram row comes
+		// out of the same pass over S and Y that computes [S;Y]g (2 extra probe vectors, no extra pass)
+		b = launch_rows_dot(c->sc, 0, N(c), rows, g, gprev_out, K_ROWS_DOT3, row(c->Y, stale_row, c), row(c->S, stale_row, c));
+		launch_gram_store_fused(c->sc, b, a, stale_row);
+		c->gram_ok[stale_row] = 1;
+	} else {
+		ensure_gram(c, st, k);
+		b = launch_rows_dot(c->sc, 0, N(c), rows, g, gprev_out);
+	}
+	launch_coef(c->sc, b, a);
+	return launch_combine(c->sc, c->next_buf(), N(c), ys, ss, g);
+}
+
 // take_step (reference src/stochqn.c:802-840) + the caller's follow-up that only depends on the
 // guard (x_sum += x, oLBFGS s-slot).  Enqueues everything and the read-back of the report block.
 void enqueue_step(Call& io, const StepIn& in)
@@ -213,14 +276,19 @@ void enqueue_step(Call& io, const StepIn& in)
 	} else {
 		fa.H0_out = in.H0;                                            // :818
 		const size_t st = (in.st_ix == in.used) ? 0 : in.st_ix;      // :820
-		Partials guard = enqueue_two_loop(c, in.g, in.used, st, fa, in.h0, in.G ? in.H0 : nullptr,
-		                                  in.check_nan ? nullptr : &ap);
-		if (in.check_nan) launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, true);
+		if (twopass_ok(c, in.used, in.G ? in.H0 : nullptr)) {
+			Partials guard = enqueue_two_pass(c, in.g, in.used, st, in.h0, in.gprev_out);
+			launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
+		} else {
+			Partials guard = enqueue_two_loop(c, in.g, in.used, st, fa, in.h0, in.G ? in.H0 : nullptr,
+			                                  in.check_nan ? nullptr : &ap);
+			if (in.check_nan) launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, true);
+		}
 		to_host(c, c->pin + 8, sc.rho, c->m);                         // buffer_rho | buffer_alpha
 		to_host(c, c->pin + 8 + c->m, sc.alpha, c->m);
 	}
-	if (in.check_nan || in.used == 0) to_host(c, c->pin, sc.report, 4);
-	else { c->pin[0] = 0; }
+	if (in.check_nan) to_host(c, c->pin, sc.report, 4);   // bad flag, sum r^2, #nonfinite from the apply kernel
+	else c->pin[0] = 0;                                   // unguarded: the step is always taken
 }
 
 // after sync(): was the step rejected?  Also hands buffer_rho / buffer_alpha back to the caller.
@@ -247,7 +315,7 @@ void backup_pair(DevCtx* c, bfgs_mem* b)
 {
 	if (!(b->min_curvature > 0)) return;
 	d2d(c, row(c->Y, b->mem_st_ix, c), c->ybak.dev, N(c));
-	c->rho_ok[b->mem_st_ix] = 0;
+	c->touch_row(b->mem_st_ix);
 }
 
 // update_s_vector (reference src/stochqn.c:861-870)
@@ -256,7 +324,7 @@ void make_s(DevCtx* c, bfgs_mem* b, bool needs_div)
 	backup_pair(c, b);
 	const bool scale = needs_div && b->upd_freq > 1;                  // :286-291
 	launch_pair_s(c->sc, N(c), c->xsum.dev, 1 / (double) b->upd_freq, scale, c->xprev.dev, row(c->S, b->mem_st_ix, c));
-	c->rho_ok[b->mem_st_ix] = 0;
+	c->touch_row(b->mem_st_ix);
 }
 
 // check_min_curvature (reference src/stochqn.c:883-900) given the (s'y, s's, y'y) partials of the
@@ -274,13 +342,14 @@ void accept_or_reject(DevCtx* c, bfgs_mem* b, Partials p, info_enum* info)
 		if (curv <= b->min_curvature) {                                // NaN curvature is accepted
 			d2d(c, row(c->S, st, c), c->sbak.dev, N(c));                // "rollback" = bak -> slot (:597-604)
 			d2d(c, row(c->Y, st, c), c->ybak.dev, N(c));
-			c->rho_ok[st] = 0;
+			c->touch_row(st);
 			*info = curvature_too_small;
 			return;
 		}
 	}
 	launch_set2(c->sc, c->sc.sy + st, sy, c->sc.yy + st, yy);
 	c->rho_ok[st] = 1;
+	c->gram_ok[st] = 0;            // cross products with the other rows: refreshed lazily by ensure_gram
 	ring_advance(b);
 }
 
@@ -364,7 +433,7 @@ int run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_e
 			w->section = 1;
 			return 0;
 		}
-		c->rho_ok[b->mem_st_ix] = 0;
+		c->touch_row(b->mem_st_ix);
 		if (b->min_curvature > 0) { backup_pair(c, b); sync(c); }     // :1005 (y half)
 		*task = calc_grad_same_batch;
 		w->section = 2;
@@ -816,13 +885,18 @@ int stochqn_hip_two_loop(double grad[], int n, double H0[], double h0, double y_
 	if (c->H0.mirror) SQN_HIP_OK(hipMemcpyAsync(c->H0.dev, H0, nn * sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
 	if (c->S.mirror && !fresh) SQN_HIP_OK(hipMemcpyAsync(c->S.dev, s_mem, mem_size * nn * sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
 	if (c->Y.mirror && !fresh) SQN_HIP_OK(hipMemcpyAsync(c->Y.dev, y_mem, mem_size * nn * sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
-	if (c->S.mirror || c->Y.mirror) c->rho_ok.assign(c->m, 0);
+	if (c->S.mirror || c->Y.mirror) { c->rho_ok.assign(c->m, 0); c->gram_ok.assign(c->m, 0); }
 	if (fresh) comm_attach(c);
 	const bool g_host = !is_device_pointer(grad);
 	double* g = stage_in(c, 1, grad, nn, g_host);
-	FirstArgs fa{};
-	Partials guard = enqueue_two_loop(c, g, mem_used, mem_st_ix % mem_size, fa, h0, H0 ? c->H0.dev : nullptr, nullptr);
-	(void) guard;
+	if (twopass_ok(c, mem_used, H0 ? c->H0.dev : nullptr)) {
+		(void) enqueue_two_pass(c, g, mem_used, mem_st_ix % mem_size, h0, nullptr);
+	} else {
+		FirstArgs fa{};
+		ApplyArgs none{};
+		(void) none;
+		(void) enqueue_two_loop(c, g, mem_used, mem_st_ix % mem_size, fa, h0, H0 ? c->H0.dev : nullptr, nullptr);
+	}
 	to_host(c, c->pin + 8, c->sc.rho, c->m);
 	to_host(c, c->pin + 8 + c->m, c->sc.alpha, c->m);
 	if (g_host) to_host(c, grad, g, nn);

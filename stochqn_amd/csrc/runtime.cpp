@@ -111,7 +111,9 @@ void begin_call(DevCtx* c)
 {
 	c->sc.nontemporal = g_opt.nontemporal;
 	c->sc.grid_cap = g_opt.grid_cap > 0 ? g_opt.grid_cap : default_grid_cap();
+	c->sc.rows_grid = g_opt.rows_grid;
 	c->sc.reverse = g_opt.reverse;
+	c->sc.rows_split = g_opt.rows_split;
 	c->sc.prof = g_profile ? &c->prof : nullptr;
 	c->sc.phase = &c->phase;
 	c->phase = 1;
@@ -163,9 +165,10 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	c->key = key; c->kind = kind; c->n = n; c->m = m; c->fsize = fsize;
 	c->n_global = (double) n;
 	SQN_HIP_OK(hipStreamCreate(&c->sc.stream));   // blocking flavour: ordered after the null stream
-	// pool layout: part0 | part1 | red0 | red1 | sy | yy | alpha | rho | report
+	// pool layout: part0 | part1 | red0 | red1 | sy | yy | alpha | rho | report | rows_part x2 | gsy | gyy | coef
 	const size_t part = (size_t) kMaxSums * kMaxGrid;
-	const size_t total = 2 * part + 2 * 256 + 4 * m + 8;
+	const size_t rows_part = (size_t) 3 * kRowsMax * kMaxGrid;
+	const size_t total = 2 * part + 2 * 256 + 4 * m + 8 + 2 * rows_part + 2 * m * m + (2 + 2 * kPairsMax);
 	if (hipMalloc((void**) &c->pool, total * sizeof(double)) != hipSuccess) {
 		std::fprintf(stderr, "stochqn: could not allocate device scratch\n");
 		(void) hipStreamDestroy(c->sc.stream);
@@ -182,7 +185,12 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	c->sc.yy = p; p += m;
 	c->sc.alpha = p; p += m;
 	c->sc.rho = p; p += m;
-	c->sc.report = p;
+	c->sc.report = p; p += 8;
+	c->sc.rows_part[0] = p; p += rows_part;
+	c->sc.rows_part[1] = p; p += rows_part;
+	c->sc.gsy = p; p += m * m;
+	c->sc.gyy = p; p += m * m;
+	c->sc.coef = p;
 	c->pin_count = 16 + 2 * m + fsize;
 	SQN_HIP_OK(hipHostMalloc((void**) &c->pin, c->pin_count * sizeof(double), hipHostMallocDefault));
 	if (fsize > 0) {
@@ -190,6 +198,7 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 		SQN_HIP_OK(hipMalloc((void**) &c->fisher_t, fsize * sizeof(double)));
 	}
 	c->rho_ok.assign(m, 0);
+	c->gram_ok.assign(m, 0);
 	begin_call(c);
 	c->sc.allreduce = nullptr;
 	c->sc.user = c;
@@ -283,7 +292,7 @@ int stochqn_hip_available(void) { return device_ready() ? 1 : 0; }
 
 void stochqn_hip_invalidate(const void* s_mem)
 {
-	if (DevCtx* c = lookup(s_mem)) c->rho_ok.assign(c->m, 0);
+	if (DevCtx* c = lookup(s_mem)) { c->rho_ok.assign(c->m, 0); c->gram_ok.assign(c->m, 0); }
 }
 
 void stochqn_hip_release(const void* s_mem) { release(s_mem); }
@@ -309,7 +318,15 @@ int stochqn_hip_set_option(const char* name, double value)
 		if (g > kMaxGrid) g = kMaxGrid;
 		g_opt.grid_cap = g;
 	}
+	else if (!std::strcmp(name, "rows_grid")) {
+		int g = (int) value;
+		if (g < 0) g = 0;
+		if (g > kMaxGrid) g = kMaxGrid;
+		g_opt.rows_grid = g;
+	}
+	else if (!std::strcmp(name, "rows_split")) g_opt.rows_split = value != 0;
 	else if (!std::strcmp(name, "reverse")) g_opt.reverse = value != 0;
+	else if (!std::strcmp(name, "twopass")) g_opt.twopass = value != 0;
 	else if (!std::strcmp(name, "strict_grad")) g_opt.strict_grad = value != 0;
 	else return -1;
 	return 0;

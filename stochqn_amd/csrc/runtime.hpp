@@ -23,7 +23,10 @@ struct View {
 struct Options {
 	bool nontemporal = true;
 	int grid_cap = 0;            // 0 = one workgroup per compute unit (measured optimum)
+	int rows_grid = 0;           // 0 = four workgroups per compute unit for the row-split rows-dot pass
+	bool rows_split = false;     // single-probe passes keep all rows per lane unless set
 	bool reverse = true;
+	bool twopass = true;         // scalar-H0 two-loop in the two-pass (Gram) form when the ring has <= kPairsMax pairs
 	bool strict_grad = true;
 };
 int default_grid_cap();
@@ -49,6 +52,8 @@ struct DevCtx {
 	double* pin = nullptr;             // pinned host read-back block
 	size_t pin_count = 0;
 	std::vector<char> rho_ok;          // per physical row: sc.sy / sc.yy hold this row's dots
+	std::vector<char> gram_ok;         // per physical row: its row and column of sc.gsy / sc.gyy are current
+	void touch_row(size_t r) { rho_ok[r] = 0; gram_ok[r] = 0; }   // row r of S or Y was rewritten
 
 	int next_buf() { int b = buf; buf ^= 1; return b; }
 };

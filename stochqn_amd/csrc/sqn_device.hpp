@@ -14,11 +14,13 @@ constexpr int kBlock = 256;       // threads per workgroup (4 wave64)
 constexpr int kMaxGrid = 2048;    // 256 CUs x 8 resident workgroups; also the partial-sum stride
 constexpr int kMaxSums = 3;       // sums one sweep can produce (s'y, s's, y'y)
 constexpr int kFisherRows = 8;    // Fisher rows one workgroup accumulates per pass-1 sweep
+constexpr int kRowsMax = 48;      // rows one rows-dot launch can take (one accumulator per row and lane)
+constexpr int kPairsMax = 24;     // largest ring the two-pass form handles (2*kPairsMax rows per launch)
 
 // Kernel ids for the built-in HIP-event profiler (stochqn_hip_profile_*).
 enum KernelId {
 	K_FIRST = 0, K_BWD, K_MID, K_FWD, K_FWD_LAST, K_APPLY, K_PAIR_S, K_PAIR_Y_DIFF, K_PAIR_Y_HV,
-	K_DOTS3, K_FISHER_T, K_FISHER_Y, K_FIN, K_SMALL, K_COPY, K_COUNT
+	K_DOTS3, K_FISHER_T, K_FISHER_Y, K_FIN, K_SMALL, K_COPY, K_ROWS_DOT, K_COEF, K_COMBINE, K_GRAM, K_ROWS_DOT3, K_COUNT
 };
 const char* kernel_name(int id);
 
@@ -81,7 +83,13 @@ struct Scratch {
 	double* alpha;        // [m] alpha by logical index
 	double* rho;          // [m] rho by logical index (for buffer_rho write-back)
 	double* report;       // [4]: bad flag, sum r^2, nonfinite count, spare
+	double* rows_part[2]; // two [3*kRowsMax][kMaxGrid] partial buffers of rows-dot launches (up to 3 probes)
+	double* gsy;          // [m][m] Gram block  gsy[i*m+j] = s_i'y_j   (physical rows)
+	double* gyy;          // [m][m] Gram block  gyy[i*m+j] = y_i'y_j
+	double* coef;         // [1 + 2*kPairsMax]: gamma, then the y- and s-coefficients of the combine pass
 	int grid_cap;         // max workgroups per sweep (<= kMaxGrid); default = one per CU
+	int rows_grid;        // workgroups of a row-split rows-dot pass; 0 = CUs x resident workgroups per CU
+	bool rows_split;      // use the row-split rows-dot kernel for single-probe passes too
 	bool nontemporal;     // stream S/Y/F rows with nt loads
 	bool reverse;         // alternate the traversal direction from sweep to sweep (Infinity-Cache reuse of q / r)
 	int* phase;           // sweep counter of the current API call (parity = direction)
@@ -92,7 +100,7 @@ struct Scratch {
 	void* user;
 };
 
-int sweep_grid(const Scratch& sc, size_t n);
+int sweep_grid(const Scratch& sc, size_t n, int per_cu = 1);
 
 // ---- two-loop chain ---------------------------------------------------------------------------
 // first sweep: optional side effects on the raw gradient, then either the newest pair's s'q
@@ -152,6 +160,36 @@ Partials launch_dots3(const Scratch& sc, int buf, size_t n, const double* s, con
 // Fisher product y = F'(F s)/fu; returns the (s'y, s's, y'y) partials; t_out[fu] receives F s.
 Partials launch_fisher(const Scratch& sc, int buf, size_t n, const double* F, size_t fu, const double* s,
                        double* t_dev, double* y_out);
+
+// ---- two-pass ("Gram") form of the two-loop recursion for scalar H0 -------------------------------
+// The recursion only needs the inner products of g with every stored s_i, y_i and the inner
+// products among the stored vectors; the latter are cached when a pair enters the ring.  So:
+//   pass A  b = [S;Y] g                      (reads every row once + g)            launch_rows_dot
+//   coef    alpha_i, beta_i from b and the Gram blocks, O(k^2) scalars, one wave   launch_coef
+//   pass B  r = gamma g - gamma sum alpha_j y_j + sum (alpha_j - beta_j) s_j       launch_combine
+// = (4k+3) n words instead of 8k n.  Same quantities as reference src/stochqn.c:663-708, other
+// association of the floating-point sums (measured difference ~1e-15 relative).
+struct RowSet {
+	const double* row[kRowsMax];
+	int count;
+};
+// out partials: quantity j = rows.row[j]' probe.  Optional copy of the probe (oLBFGS grad_prev).
+// With probe_y / probe_s (the pair just accepted into ring row r) the same pass also yields
+// rows[j]'probe_y (quantities count..2count-1) and rows[j]'probe_s (2count..3count-1).
+Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& rows, const double* probe, double* copy_out,
+                         int kernel_id = K_ROWS_DOT, const double* probe_y = nullptr, const double* probe_s = nullptr);
+// scatter the dots of one ring row against all rows into the Gram blocks
+void launch_gram_store(const Scratch& sc, Partials sy_yy /*2m: s_j'y_r then y_j'y_r*/, Partials ys /*m: y_j's_r*/, int m, int r);
+struct CoefArgs {
+	int k;                    // pairs in use
+	int m;                    // ring size (Gram leading dimension)
+	int rows[kPairsMax];      // physical row of logical pair i (oldest first)
+	double h0;                // > 0: scalar H0, else gamma from the newest pair
+};
+void launch_gram_store_fused(const Scratch& sc, Partials p /*3 x 2k quantities of a 3-probe pass A*/, const CoefArgs& a, int r);
+void launch_coef(const Scratch& sc, Partials b /*2k: s_i'g then y_i'g, logical order*/, const CoefArgs& a);
+// r (in place of g) and the guard sums (sum r^2, nonfinite)
+Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& y_rows, const RowSet& s_rows, double* g);
 
 // reduce `nsums` partial arrays to scalars: out[j] = sum_b parts[j*stride+b]
 void launch_fin(const Scratch& sc, Partials in, int nsums, double* out);

@@ -16,6 +16,18 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
+@pytest.fixture(params=["twopass", "sweeps"])
+def form(request, hip_backend):
+    """Run a test once per implementation of the scalar-H0 two-loop: the two-pass (Gram) form that
+    is the default, and the chain of dependent sweeps (adaQN always uses the latter)."""
+    import stochqn_amd
+    lib = stochqn_amd.cdll()
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    assert lib.stochqn_hip_set_option(b"twopass", 1.0 if request.param == "twopass" else 0.0) == 0
+    yield request.param
+    lib.stochqn_hip_set_option(b"twopass", 1.0)
+
+
 def torch_cuda():
     import torch
     assert torch.cuda.is_available()
@@ -27,12 +39,12 @@ def torch_cuda():
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("space", ["host", "device"])
 @pytest.mark.parametrize("case", ["oLBFGS_rosen2d", "SQN_rosen2d", "adaQN_rosen2d"])
-def test_known_answers(case, space, hip_backend):
+def test_known_answers(case, space, form, hip_backend):
     # chaotic Rosenbrock trajectories amplify last-bit differences; 1e3 x the oracle's own pin
     check_known_answer(case, hip_backend, space=space, tol_scale=1e3)
 
 
-def test_c_rosen_protocol_host_caller(hip_backend):
+def test_c_rosen_protocol_host_caller(form, hip_backend):
     """Library-owned workspace (arrays in HBM) driven by a host caller exactly like c_rosen.c."""
     k = GOLD["c_rosen"]
     out = run_c_rosen(hip_backend, np.array(k["x0"]), host_view)
@@ -88,14 +100,14 @@ def both_traces(cfg, n, space, hip_backend, oracle_backend):
 
 @pytest.mark.parametrize("n", [1, 2, 7, 64, 1000, 4097])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
-def test_trace_parity_device_arrays(cfg, n, hip_backend, oracle_backend):
+def test_trace_parity_device_arrays(cfg, n, form, hip_backend, oracle_backend):
     got, want = both_traces(cfg, n, "device", hip_backend, oracle_backend)
     compare_traces(got, want, FREE_RUN_TOL.get(cfg[0], TOL))
 
 
 @pytest.mark.parametrize("n", [3, 64, 1000, 4097, 70001])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
-def test_lockstep_parity(cfg, n, hip_backend, oracle_backend):
+def test_lockstep_parity(cfg, n, form, hip_backend, oracle_backend):
     """Identical state and inputs into the oracle and the HIP library on every call; every output
     array, every state array and every scalar compared after every call."""
     import stochqn_amd
@@ -112,13 +124,13 @@ def test_lockstep_parity(cfg, n, hip_backend, oracle_backend):
 
 @pytest.mark.parametrize("n", [2, 65, 1000])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
-def test_trace_parity_host_arrays(cfg, n, hip_backend, oracle_backend):
+def test_trace_parity_host_arrays(cfg, n, form, hip_backend, oracle_backend):
     """Profile B of SURVEY.md 8b: every array in host memory, structs rebuilt per call."""
     got, want = both_traces(cfg, n, "host", hip_backend, oracle_backend)
     compare_traces(got, want, FREE_RUN_TOL.get(cfg[0], TOL))
 
 
-def test_golden_traces(hip_backend):
+def test_golden_traces(form, hip_backend):
     """Committed regression vectors (tests/golden/traces.json, made by tests/golden/make_traces.py)."""
     path = os.path.join(os.path.dirname(__file__), "golden", "traces.json")
     gold = json.load(open(path))
@@ -157,7 +169,7 @@ def hip_two_loop(lib, g, H0, h0, Y, S, n, m, used, st):
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 4096, 1000003])
 @pytest.mark.parametrize("m,used,st", [(1, 1, 0), (5, 5, 3), (5, 2, 0), (5, 3, 4), (20, 20, 7), (20, 1, 19)])
 @pytest.mark.parametrize("mode", ["gamma", "h0", "H0"])
-def test_two_loop_matches_oracle(n, m, used, st, mode, hip_backend):
+def test_two_loop_matches_oracle(n, m, used, st, mode, form, hip_backend):
     import stochqn_amd
     from oracle import oracle
     torch = torch_cuda()
@@ -242,7 +254,7 @@ def device_pairs(torch, n, m, seed):
 
 
 @pytest.mark.parametrize("n,m", [(10_000_000, 10), (100_000_000, 20)])
-def test_two_loop_properties_at_baseline_size(n, m, hip_backend):
+def test_two_loop_properties_at_baseline_size(n, m, form, hip_backend):
     """(i) secant equation: the L-BFGS inverse maps the newest y onto the newest s exactly;
     (ii) linearity in the gradient; (iii) bit-reproducibility of a repeated call."""
     import stochqn_amd
