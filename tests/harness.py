@@ -123,7 +123,7 @@ def _req_id(opt, x, req):
 def run_trace(opt, problem, x, step, ncalls, step_fn=None):
     """Drive `opt` for `ncalls` run_optimizer calls.  Returns a list of per-call records."""
     trace = []
-    last_grad_x = None
+    last_grad_x = 999983        # a resumed run may start with a same-batch request
     for call in range(ncalls):
         st = step_fn(call) if step_fn else step
         r = opt.run_optimizer(x, st)
@@ -223,7 +223,7 @@ def run_lockstep(ref, opt, problem, x_ref, x_dev, step, ncalls, tol, on_sync=Non
     call: after each call all outputs and the complete optimiser state are compared (integers
     exactly, vectors norm-wise to `tol`), then the state of `opt` is overwritten with the oracle's,
     so rounding differences cannot be amplified by the (possibly ill-conditioned) trajectory."""
-    last_grad_call = None
+    last_grad_call = 999983     # a resumed run may start with a same-batch request
     for call in range(ncalls):
         rr = ref.run_optimizer(x_ref, step)
         ro = opt.run_optimizer(x_dev, step)

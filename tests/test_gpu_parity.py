@@ -283,3 +283,133 @@ def test_two_loop_properties_at_baseline_size(n, m, form, hip_backend):
     hip_two_loop(lib, again, None, 0.0, Y, S, n, m, m, st)
     assert torch.equal(again, r1)
     lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))
+
+
+# ---------------------------------------------------------------------------------------------
+# state that lives behind the ABI: export / resume, the bak->slot quirk with a full ring, options
+# ---------------------------------------------------------------------------------------------
+def _lib():
+    import stochqn_amd
+    lib = stochqn_amd.cdll()
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    lib.stochqn_hip_export.argtypes = [C.c_void_p]
+    lib.stochqn_hip_release.argtypes = [C.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("optname,kw", [
+    ("SQN", dict(mem_size=3, bfgs_upd_freq=4)),
+    ("oLBFGS", dict(mem_size=4)),
+    ("adaQN", dict(mem_size=3, fisher_size=6, bfgs_upd_freq=4, rmsprop_weight=0.9)),
+])
+def test_export_and_resume_host_state(optname, kw, form, hip_backend, oracle_backend):
+    """Host caller (profile B): export refreshes every host array from its device mirror, so that
+    the object can be pickled; dropping the context (= new process) and calling on re-imports it."""
+    lib = _lib()
+    n = 777
+    P = NoisyQuadratic(n, seed=5)
+    ref = OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw)
+    opt = OPTIMIZERS[optname](backend=hip_backend, space="host", **kw)
+    x_ref, x = P.x0(), P.x0()
+    want = run_trace(ref, P, x_ref, 0.05, 41)
+    got = run_trace(opt, P, x, 0.05, 41)
+    compare_traces(got, want, TOL)
+    key = C.c_void_p(opt.BFGS_mem.s_mem.ctypes.data)
+    assert lib.stochqn_hip_export(key) == 0
+    used = opt.BFGS_mem.mem_used
+    assert used > 0
+    for name in ("s_mem", "y_mem"):
+        a, b = getattr(opt.BFGS_mem, name), getattr(ref.BFGS_mem, name)
+        assert rel_err(a, b) <= TOL, name
+    for name in ("x_sum", "x_avg_prev", "grad_sum_sq", "grad_prev"):
+        if hasattr(ref, name) and getattr(ref, name).shape[0] == n:
+            assert rel_err(getattr(opt, name), getattr(ref, name)) <= TOL, name
+    if hasattr(ref, "Fisher_mem"):
+        assert rel_err(opt.Fisher_mem.F, ref.Fisher_mem.F) <= TOL
+    lib.stochqn_hip_release(key)                       # "new process": the device context is gone
+    # both continue from their host state; call indices keep counting so the noise stays in step
+    P2 = NoisyQuadratic(n, seed=6)
+    want2 = run_trace(ref, P2, x_ref, 0.05, 40)
+    got2 = run_trace(opt, P2, x, 0.05, 40)
+    compare_traces(got2, want2, TOL)
+
+
+def test_rejected_pair_with_full_ring_reproduces_bak_quirk(form, hip_backend, oracle_backend):
+    """once the ring is full, a rejected pair leaves the bak buffers' contents in
+    the slot of the oldest (still counted) pair; with zero bak buffers the next direction is NaN and
+    the ring is flushed.  min_curvature is raised mid-run (a field callers may change at any time)."""
+    import stochqn_amd
+    n = 500
+    P = NoisyQuadratic(n, seed=9)
+    kw = dict(mem_size=3, min_curvature=1e-6)
+    ref = OPTIMIZERS["oLBFGS"](backend=oracle_backend, space="host", **kw)
+    opt = OPTIMIZERS["oLBFGS"](backend=hip_backend, space="device", **kw)
+    x_ref = P.x0()
+    x_dev = torch_cuda().as_tensor(P.x0(), device="cuda")
+    lib = stochqn_amd.cdll()
+    inval = lambda o: lib.stochqn_hip_invalidate(C.c_void_p(o._sp.ptr(o.BFGS_mem.s_mem)))
+    run_lockstep(ref, opt, P, x_ref, x_dev, 0.1, 13, TOL, on_sync=inval)       # ring full (3 pairs)
+    assert ref.BFGS_mem.mem_used == 3
+    ref.BFGS_mem.min_curvature = opt.BFGS_mem.min_curvature = 1e6              # reject everything from now on
+    infos = []
+
+    class Spy:
+        def __init__(self, o): self.o = o
+        def __getattr__(self, k): return getattr(self.o, k)
+        def run_optimizer(self, x, s):
+            r = self.o.run_optimizer(x, s)
+            infos.append(r["info"]["iteration_info"])
+            return r
+    run_lockstep(Spy(ref), opt, P, x_ref, x_dev, 0.1, 12, TOL, on_sync=inval)
+    assert "curvature_too_small" in infos and "search_direction_was_nan" in infos
+
+
+def test_strict_grad_option_host_caller(hip_backend, oracle_backend):
+    """strict_grad=0: a host caller's `grad` array is left alone (no PCIe copy of the direction);
+    x and the requests are unaffected."""
+    lib = _lib()
+    n = 300
+    P = NoisyQuadratic(n, seed=2)
+    kw = dict(mem_size=3, bfgs_upd_freq=3)
+    want = run_trace(OPTIMIZERS["SQN"](backend=oracle_backend, space="host", **kw), P, P.x0(), 0.1, 30)
+    try:
+        assert lib.stochqn_hip_set_option(b"strict_grad", 0.0) == 0
+        opt = OPTIMIZERS["SQN"](backend=hip_backend, space="host", **kw)
+        x = P.x0()
+        last = None
+        got = []
+        for call in range(30):
+            r = opt.run_optimizer(x, 0.1)
+            if last is not None:
+                assert np.array_equal(opt.gradient, last)          # untouched by the library
+            rec = {"task": r["task"], "info": r["info"]["iteration_info"], "x": x.copy(), "niter": opt.niter}
+            got.append(rec)
+            if r["task"] == "calc_hess_vec":
+                rx, rv = r["requested_on"]
+                opt.update_hess_vec(P.hess_vec(rx.copy(), rv.copy()))
+            else:
+                opt.update_gradient(P.grad(np.asarray(r["requested_on"]).copy(), call))
+            last = opt.gradient.copy()
+        for g, w in zip(got, want):
+            assert g["task"] == w["task"] and g["info"] == w["info"] and g["niter"] == w["niter"]
+            assert rel_err(g["x"], w["x"]) <= TOL
+    finally:
+        lib.stochqn_hip_set_option(b"strict_grad", 1.0)
+
+
+def test_single_rank_rccl_path_matches(form, hip_backend, oracle_backend):
+    """With a communicator attached every reduction goes k_fin -> ncclAllReduce -> consumer; with
+    one rank the numbers must not change."""
+    import stochqn_amd
+    lib = stochqn_amd.cdll()
+    buf = (C.c_ubyte * 128)()
+    if lib.stochqn_hip_comm_unique_id(buf) != 0:
+        pytest.fail("RCCL could not be loaded")
+    assert lib.stochqn_hip_comm_init(0, 1, bytes(buf)) == 0
+    try:
+        assert lib.stochqn_hip_comm_nranks() == 1
+        for cfg in [c for c in CONFIGS if c[0] in ("sqn_hessvec", "olbfgs_default", "adaqn_fisher_rms", "sqn_graddiff")]:
+            got, want = both_traces(cfg, 1000, "device", hip_backend, oracle_backend)
+            compare_traces(got, want, FREE_RUN_TOL.get(cfg[0], TOL))
+    finally:
+        lib.stochqn_hip_comm_finalize()
