@@ -51,7 +51,7 @@ if __name__ == "__main__":
     if kind == "sqn":
         opt.BFGS_mem.upd_freq = opt.bfgs_upd_freq = 10
         opt.niter = 10 * ((opt.niter + 9) // 10)
-    base = {"grid_cap": 0, "rows_grid": 0, "rows_split": 0, "reverse": 1, "twopass": 1, "nontemporal": 1}
+    base = {"grid_cap": 0, "rows_grid": 0, "rows_split": 0, "reverse": 1, "twopass": 1, "nontemporal": 1, "combine_batch": 8}
     for rep in range(2):
         for v in variants:
             o = dict(base); o.update(v)

@@ -78,6 +78,52 @@ __global__ void __launch_bounds__(BLOCK) k_rows(const double* S, const double* Y
 	}
 }
 
+// combine with deferred stores: each lane computes T packs (strided by the grid) and stores them together
+template <int BLOCK, int G, int T>
+__global__ void __launch_bounds__(BLOCK) k_combine_batched(const double* S, const double* Y, size_t ld_, const double* coef, double* g, uint32_t n, double* parts)
+{
+	__shared__ double cf[1 + 2 * K];
+	__shared__ double sh[BLOCK / 64];
+	for (int e = threadIdx.x; e < 1 + 2 * K; e += BLOCK) cf[e] = coef[e];
+	__syncthreads();
+	const uint32_t packs = n / 2, stride = gridDim.x * BLOCK;
+	double acc = 0;
+	for (uint32_t p0 = blockIdx.x * BLOCK + threadIdx.x; p0 < packs; p0 += T * stride) {
+		d2 out[T];
+		#pragma unroll
+		for (int t = 0; t < T; t++) {
+			const uint32_t p = p0 + t * stride;
+			if (p < packs) {
+				const size_t i = (size_t) p * 2;
+				d2 r = ld<false>(g, i);
+				r.x *= cf[0]; r.y *= cf[0];
+				#pragma unroll
+				for (int j0 = 0; j0 < K; j0 += G) {
+					d2 fy[G], fs[G];
+					#pragma unroll
+					for (int u = 0; u < G; u++) { fy[u] = ld<true>(Y + (size_t) (j0 + u) * ld_, i); fs[u] = ld<true>(S + (size_t) (j0 + u) * ld_, i); }
+					#pragma unroll
+					for (int u = 0; u < G; u++) {
+						r.x = fma(cf[1 + j0 + u], fy[u].x, r.x); r.y = fma(cf[1 + j0 + u], fy[u].y, r.y);
+						r.x = fma(cf[1 + K + j0 + u], fs[u].x, r.x); r.y = fma(cf[1 + K + j0 + u], fs[u].y, r.y);
+					}
+				}
+				acc = fma(r.x, r.x, acc); acc = fma(r.y, r.y, acc);
+				out[t] = r;
+			}
+		}
+		#pragma unroll
+		for (int t = 0; t < T; t++) {
+			const uint32_t p = p0 + t * stride;
+			if (p < packs) st(g, (size_t) p * 2, out[t]);
+		}
+	}
+	acc = wave_sum(acc);
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < BLOCK / 64; w++) t += sh[w]; parts[blockIdx.x] = t; }
+}
+
 static double median(std::vector<float>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 template <class F> double time_ms(F&& launch, int reps = 7)
 {
@@ -105,9 +151,11 @@ int main(int argc, char** argv)
 #define RUNR(BLOCK, G, NT, GRID, REV) { double ms = time_ms([&](int i) { hipLaunchKernelGGL((k_rows<BLOCK, G, NT>), dim3(GRID), dim3(BLOCK), 0, 0, S, Y, (size_t) n, g, n, (REV) ? (i & 1) : 0, parts); }); \
 	printf("rows    B%-4d G%-2d nt%d grid %-5d rev %d : %.3f ms  %.0f GB/s\n", BLOCK, G, NT, GRID, REV, ms, (2.0 * K + 1) * 8.0 * n / ms / 1e6); }
 	double* out; CK(hipMalloc(&out, (size_t) n * 8));
-	for (int grid : {256, 512, 2048}) {
-		RUNC(256, 4, true, grid, 0, 0); RUNC(256, 4, true, grid, 0, 1); RUNC(256, 4, true, grid, 0, 2); RUNC(256, 4, true, grid, 0, 3);
-		RUNC(256, 4, true, grid, 1, 0); RUNC(256, 20, true, grid, 0, 1);
+#define RUNB(BLOCK, G, T, GRID) { double ms = time_ms([&](int i) { hipLaunchKernelGGL((k_combine_batched<BLOCK, G, T>), dim3(GRID), dim3(BLOCK), 0, 0, S, Y, (size_t) n, coef, g, n, parts); }); \
+	printf("combine-batched B%-4d G%-2d T%-2d grid %-5d : %.3f ms  %.0f GB/s\n", BLOCK, G, T, GRID, ms, (2.0 * K + 2) * 8.0 * n / ms / 1e6); }
+	for (int grid : {512, 2048}) {
+		RUNC(256, 4, true, grid, 0, 0); RUNC(256, 4, true, grid, 0, 1);
+		RUNB(256, 4, 2, grid); RUNB(256, 4, 4, grid); RUNB(256, 4, 8, grid); RUNB(256, 4, 16, grid); RUNB(256, 4, 32, grid);
 	}
 	return 0;
 }

@@ -813,8 +813,10 @@ __global__ void __launch_bounds__(kBlock) k_coef(const double* bparts, int count
 	}
 }
 
-// pass B: r = gamma g + sum_i cy_i y_i + sum_i cs_i s_i  (pairs visited oldest to newest)
-template <int W, bool NT>
+// pass B: r = gamma g + sum_i cy_i y_i + sum_i cs_i s_i  (pairs visited oldest to newest).
+// A lane finishes T packs before it stores any of them: the single store stream (1 of 2k+2) costs
+// disproportionately when it trickles out between the loads, less when it leaves in groups.
+template <int W, bool NT, int T>
 __global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const double* coef, double* g, uint32_t n, int rev,
                                                     double* parts)
 {
@@ -825,29 +827,41 @@ __global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const 
 	__syncthreads();
 	double acc0 = 0, acc1 = 0;
 	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
-	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
-		const uint32_t i = (rev ? last - p : p) * W;
-		Pack<W> r = ld<W, false>(g, i);
+	for (uint32_t p0 = blockIdx.x * kBlock + threadIdx.x; p0 < packs; p0 += T * stride) {
+		Pack<W> out[T];
 		#pragma unroll
-		for (int e = 0; e < W; e++) r.v[e] = cf[0] * r.v[e];
-		for (int j0 = 0; j0 < k; j0 += 4) {
-			Pack<W> fy[4], fs[4];
-			#pragma unroll
-			for (int u = 0; u < 4; u++)
-				if (j0 + u < k) { fy[u] = ld<W, NT>(ys.row[j0 + u], i); fs[u] = ld<W, NT>(ss.row[j0 + u], i); }
-			#pragma unroll
-			for (int u = 0; u < 4; u++)
-				if (j0 + u < k) {
+		for (int t = 0; t < T; t++) {
+			const uint32_t p = p0 + t * stride;
+			if (p < packs) {
+				const uint32_t i = (rev ? last - p : p) * W;
+				Pack<W> r = ld<W, false>(g, i);
+				#pragma unroll
+				for (int e = 0; e < W; e++) r.v[e] = cf[0] * r.v[e];
+				for (int j0 = 0; j0 < k; j0 += 4) {
+					Pack<W> fy[4], fs[4];
 					#pragma unroll
-					for (int e = 0; e < W; e++) {
-						r.v[e] = fma(cf[1 + j0 + u], fy[u].v[e], r.v[e]);
-						r.v[e] = fma(cf[1 + k + j0 + u], fs[u].v[e], r.v[e]);
-					}
+					for (int u = 0; u < 4; u++)
+						if (j0 + u < k) { fy[u] = ld<W, NT>(ys.row[j0 + u], i); fs[u] = ld<W, NT>(ss.row[j0 + u], i); }
+					#pragma unroll
+					for (int u = 0; u < 4; u++)
+						if (j0 + u < k) {
+							#pragma unroll
+							for (int e = 0; e < W; e++) {
+								r.v[e] = fma(cf[1 + j0 + u], fy[u].v[e], r.v[e]);
+								r.v[e] = fma(cf[1 + k + j0 + u], fs[u].v[e], r.v[e]);
+							}
+						}
 				}
+				#pragma unroll
+				for (int e = 0; e < W; e++) { acc0 = fma(r.v[e], r.v[e], acc0); acc1 += (isfinite(r.v[e]) ? 0.0 : 1.0); }
+				out[t] = r;
+			}
 		}
 		#pragma unroll
-		for (int e = 0; e < W; e++) { acc0 = fma(r.v[e], r.v[e], acc0); acc1 += (isfinite(r.v[e]) ? 0.0 : 1.0); }
-		st<W>(g, i, r);
+		for (int t = 0; t < T; t++) {
+			const uint32_t p = p0 + t * stride;
+			if (p < packs) st<W>(g, (rev ? last - p : p) * W, out[t]);
+		}
 	}
 	if (W > 1) {
 		const uint32_t i = packs * W + threadIdx.x;
@@ -1194,8 +1208,11 @@ Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, 
 	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
 	{
 		ProfScope ps(sc, K_COMBINE);
-		if (vec) hipLaunchKernelGGL((k_combine<2, true>), dim3(grid), dim3(kBlock), 0, sc.stream, ys, ss, sc.coef, g, (uint32_t) n, rev, sc.part[buf]);
-		else     hipLaunchKernelGGL((k_combine<1, true>), dim3(grid), dim3(kBlock), 0, sc.stream, ys, ss, sc.coef, g, (uint32_t) n, rev, sc.part[buf]);
+		#define SQN_CB(W, T) hipLaunchKernelGGL((k_combine<W, true, T>), dim3(grid), dim3(kBlock), 0, sc.stream, ys, ss, sc.coef, g, (uint32_t) n, rev, sc.part[buf])
+		const int T = sc.combine_batch;
+		if (vec) { if (T >= 8) SQN_CB(2, 8); else if (T >= 4) SQN_CB(2, 4); else if (T >= 2) SQN_CB(2, 2); else SQN_CB(2, 1); }
+		else     { if (T >= 8) SQN_CB(1, 8); else if (T >= 4) SQN_CB(1, 4); else if (T >= 2) SQN_CB(1, 2); else SQN_CB(1, 1); }
+		#undef SQN_CB
 	}
 	return finish(sc, buf, 2, grid);
 }

@@ -114,6 +114,7 @@ void begin_call(DevCtx* c)
 	c->sc.rows_grid = g_opt.rows_grid;
 	c->sc.reverse = g_opt.reverse;
 	c->sc.rows_split = g_opt.rows_split;
+	c->sc.combine_batch = g_opt.combine_batch;
 	c->sc.prof = g_profile ? &c->prof : nullptr;
 	c->sc.phase = &c->phase;
 	c->phase = 1;
@@ -325,6 +326,7 @@ int stochqn_hip_set_option(const char* name, double value)
 		g_opt.rows_grid = g;
 	}
 	else if (!std::strcmp(name, "rows_split")) g_opt.rows_split = value != 0;
+	else if (!std::strcmp(name, "combine_batch")) g_opt.combine_batch = (int) value;
 	else if (!std::strcmp(name, "reverse")) g_opt.reverse = value != 0;
 	else if (!std::strcmp(name, "twopass")) g_opt.twopass = value != 0;
 	else if (!std::strcmp(name, "strict_grad")) g_opt.strict_grad = value != 0;

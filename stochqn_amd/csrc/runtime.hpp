@@ -25,6 +25,7 @@ struct Options {
 	int grid_cap = 0;            // 0 = one workgroup per compute unit (measured optimum)
 	int rows_grid = 0;           // 0 = four workgroups per compute unit for the row-split rows-dot pass
 	bool rows_split = false;     // single-probe passes keep all rows per lane unless set
+	int combine_batch = 8;       // packs a lane finishes in pass B before it stores them
 	bool reverse = true;
 	bool twopass = true;         // scalar-H0 two-loop in the two-pass (Gram) form when the ring has <= kPairsMax pairs
 	bool strict_grad = true;
