@@ -118,3 +118,35 @@ def test_product_package_never_touches_the_oracle():
     if shutil.which("ldd"):
         out = subprocess.check_output(["ldd", stochqn_amd.LIB_PATH]).decode()
         assert "oracle" not in out
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_reference_cython_shim_builds_against_the_new_library(tmp_path):
+    """Link-level drop-in proof for the Python binding: the reference's own
+    stochqn/wrapper_double.pyx + pywrapper.pxi, read where they lie and cythonized OUT of tree,
+    compile against this repository's header and link against libstochqn.so; the extension imports
+    and exposes the three py_run_* entry points.  (It cannot compute here: no GPU.)"""
+    cython = shutil.which("cython")
+    if cython is None:
+        pytest.skip("cython not installed")
+    (tmp_path / "stochqn").mkdir()
+    (tmp_path / "include").mkdir()
+    shutil.copy(os.path.join(ROOT, "include", "stochqn.h"), tmp_path / "include" / "stochqn.h")   # OUR header
+    c_file = tmp_path / "stochqn" / "wrapper_double.c"
+    subprocess.check_call([cython, "-3", os.path.join(REF, "stochqn", "wrapper_double.pyx"), "-o", str(c_file)],
+                          cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    import sysconfig
+    so = tmp_path / "stochqn" / ("wrapper_double" + sysconfig.get_config_var("EXT_SUFFIX"))
+    libdir = os.path.dirname(stochqn_amd.LIB_PATH)
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-w", "-I", np.get_include(), "-I", sysconfig.get_paths()["include"],
+                           str(c_file), "-L", libdir, "-lstochqn", "-Wl,-rpath," + libdir,
+                           "-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(so)])
+    undefined = subprocess.check_output(["nm", "-D", "-u", str(so)]).decode()
+    for sym in ("run_oLBFGS", "run_SQN", "run_adaQN"):
+        assert sym in undefined                   # resolved by libstochqn.so at load time
+    code = ("import sys; sys.path.insert(0, %r); import wrapper_double as w; "
+            "assert all(hasattr(w, f) for f in ('py_run_oLBFGS', 'py_run_SQN', 'py_run_adaQN')); print('ok')"
+            % str(tmp_path / "stochqn"))
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.check_output([os.sys.executable, "-c", code], env=env).decode()
+    assert out.strip() == "ok"
