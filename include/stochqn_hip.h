@@ -76,6 +76,16 @@ int stochqn_hip_comm_init(int rank, int nranks, const void *unique_id128);
 int stochqn_hip_comm_nranks(void);
 void stochqn_hip_comm_finalize(void);
 
+/* ---- loop-back reducer (rehearsal of the sharded path on ONE GPU) -----------------------------------
+ * P host threads each drive one shard (its own arrays, its own context) on the same device; the
+ * all-reduce becomes a host-side rendezvous of those threads that sums in rank order.  Protocol:
+ * loopback_init(P) once; every worker thread calls loopback_join(rank) before its first run_*;
+ * all workers must issue the same sequence of calls; loopback_finalize() when they are done.
+ * Not for production: it exists so that the sharding logic is testable without a second GPU. */
+int stochqn_hip_loopback_init(int nranks);
+int stochqn_hip_loopback_join(int rank);
+void stochqn_hip_loopback_finalize(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,8 +7,10 @@
 #include <dlfcn.h>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 namespace sqn {
 
@@ -60,6 +62,48 @@ void allreduce_hook(void*, double* buf, int count, hipStream_t stream)
 	ncclResult_t r = g_comm.AllReduce(buf, buf, (size_t) count, ncclDouble, ncclSum, g_comm.comm, stream);
 	if (r != ncclSuccess)
 		std::fprintf(stderr, "stochqn: ncclAllReduce failed: %s\n", g_comm.GetErrorString ? g_comm.GetErrorString(r) : "?");
+}
+
+// ---- loop-back reducer: P shards of one problem driven by P host threads on ONE GPU ------------
+// Rehearses the sharded path where only one device is available (tests): the all-reduce is a
+// host-side rendezvous of the calling threads, summed in rank order.
+struct Loopback {
+	int nranks = 0;
+	std::mutex mu;
+	std::condition_variable cv;
+	int arrived = 0;
+	long generation = 0;
+	std::vector<double> slots;      // [nranks][256]
+} g_loop;
+thread_local int t_loop_rank = -1;
+
+void loop_barrier()
+{
+	std::unique_lock<std::mutex> lk(g_loop.mu);
+	const long gen = g_loop.generation;
+	if (++g_loop.arrived == g_loop.nranks) {
+		g_loop.arrived = 0;
+		g_loop.generation++;
+		g_loop.cv.notify_all();
+	} else {
+		g_loop.cv.wait(lk, [&] { return g_loop.generation != gen; });
+	}
+}
+
+void loopback_hook(void*, double* buf, int count, hipStream_t stream)
+{
+	double tmp[256];
+	SQN_HIP_OK(hipStreamSynchronize(stream));
+	SQN_HIP_OK(hipMemcpy(tmp, buf, (size_t) count * sizeof(double), hipMemcpyDeviceToHost));
+	std::memcpy(&g_loop.slots[(size_t) t_loop_rank * 256], tmp, (size_t) count * sizeof(double));
+	loop_barrier();
+	for (int j = 0; j < count; j++) {
+		double s = 0;
+		for (int r = 0; r < g_loop.nranks; r++) s += g_loop.slots[(size_t) r * 256 + j];
+		tmp[j] = s;
+	}
+	loop_barrier();                 // nobody overwrites a slot before everybody has read it
+	SQN_HIP_OK(hipMemcpy(buf, tmp, (size_t) count * sizeof(double), hipMemcpyHostToDevice));
 }
 
 void free_view(View& v)
@@ -265,16 +309,17 @@ void sync(DevCtx* c)
 	if (c->sc.prof) c->prof.collect();
 }
 
-int comm_nranks() { return g_comm.comm ? g_comm.nranks : 1; }
+int comm_nranks() { return g_comm.comm ? g_comm.nranks : (g_loop.nranks > 1 && t_loop_rank >= 0 ? g_loop.nranks : 1); }
 
 void comm_attach(DevCtx* c)
 {
-	if (!g_comm.comm) { c->sc.allreduce = nullptr; c->n_global = (double) c->n; return; }
-	c->sc.allreduce = allreduce_hook;
+	const bool loop = g_loop.nranks > 1 && t_loop_rank >= 0;
+	if (!g_comm.comm && !loop) { c->sc.allreduce = nullptr; c->n_global = (double) c->n; return; }
+	c->sc.allreduce = loop ? loopback_hook : allreduce_hook;
 	// global problem size for the ||dir|| > 1e3*n guard (reference src/stochqn.c:829)
 	double nn = (double) c->n;
 	SQN_HIP_OK(hipMemcpyAsync(c->sc.red[0], &nn, sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
-	allreduce_hook(nullptr, c->sc.red[0], 1, c->sc.stream);
+	c->sc.allreduce(nullptr, c->sc.red[0], 1, c->sc.stream);
 	SQN_HIP_OK(hipMemcpyAsync(&nn, c->sc.red[0], sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
 	SQN_HIP_OK(hipStreamSynchronize(c->sc.stream));
 	c->n_global = nn;
@@ -390,6 +435,30 @@ int stochqn_hip_comm_init(int rank, int nranks, const void* unique_id128)
 }
 
 int stochqn_hip_comm_nranks(void) { return comm_nranks(); }
+
+int stochqn_hip_loopback_init(int nranks)
+{
+	if (nranks < 1 || g_comm.comm) return -1;
+	std::lock_guard<std::mutex> lk(g_loop.mu);
+	g_loop.nranks = nranks;
+	g_loop.arrived = 0;
+	g_loop.slots.assign((size_t) nranks * 256, 0.0);
+	return 0;
+}
+
+int stochqn_hip_loopback_join(int rank)
+{
+	if (rank < 0 || rank >= g_loop.nranks) return -1;
+	t_loop_rank = rank;
+	return 0;
+}
+
+void stochqn_hip_loopback_finalize(void)
+{
+	release_all();
+	g_loop.nranks = 0;
+	t_loop_rank = -1;
+}
 
 void stochqn_hip_comm_finalize(void)
 {

@@ -413,3 +413,90 @@ def test_single_rank_rccl_path_matches(form, hip_backend, oracle_backend):
             compare_traces(got, want, FREE_RUN_TOL.get(cfg[0], TOL))
     finally:
         lib.stochqn_hip_comm_finalize()
+
+
+# ---------------------------------------------------------------------------------------------
+# sharded path of the LIBRARY ITSELF on one GPU: P shards, P host threads, loop-back all-reduce
+# ---------------------------------------------------------------------------------------------
+def _sharded_run(optname, kw, P_full, nshards, step, calls, hip_backend):
+    import threading
+    import stochqn_amd
+    lib = stochqn_amd.cdll()
+    n = P_full.n
+    bounds = [(n * r // nshards, n * (r + 1) // nshards) for r in range(nshards)]
+    bounds[0] = (0, bounds[0][1] + 1) if nshards > 1 and bounds[0][1] + 1 < bounds[1][1] else bounds[0]   # uneven on purpose
+    if nshards > 1:
+        bounds[1] = (bounds[0][1], bounds[1][1])
+    traces = [None] * nshards
+    errors = []
+    fparts = [0.0] * nshards
+    rendezvous = threading.Barrier(nshards)
+    assert lib.stochqn_hip_loopback_init(nshards) == 0
+
+    def worker(r):
+        try:
+            assert lib.stochqn_hip_loopback_join(r) == 0
+            lo, hi = bounds[r]
+            opt = OPTIMIZERS[optname](backend=hip_backend, space="host", **kw)
+            x = P_full.x0()[lo:hi].copy()
+            tr = []
+            last = 999983
+            for call in range(calls):
+                res = opt.run_optimizer(x, step)
+                task, req = res["task"], res["requested_on"]
+                tr.append({"task": task, "info": res["info"]["iteration_info"], "niter": opt.niter, "section": opt.section,
+                           "mem_used": opt.BFGS_mem.mem_used, "mem_st_ix": opt.BFGS_mem.mem_st_ix, "x": x.copy()})
+                if task in ("calc_grad", "calc_grad_same_batch", "calc_grad_big_batch"):
+                    if task == "calc_grad":
+                        last = call
+                    c = last if task == "calc_grad_same_batch" else call
+                    full = np.zeros(n)
+                    full[lo:hi] = req
+                    opt.update_gradient(P_full.grad(full, c)[lo:hi])          # diagonal problem: g_i depends on x_i only
+                elif task == "calc_hess_vec":
+                    opt.update_hess_vec(P_full.d[lo:hi] * req[1])
+                elif task == "calc_fun_val_batch":
+                    fparts[r] = 0.5 * float(np.sum(P_full.d[lo:hi] * req * req))
+                    rendezvous.wait()
+                    f = sum(fparts) * (10.0 if call in P_full.f_spike_calls else 1.0)
+                    rendezvous.wait()
+                    opt.update_function(f)
+            traces[r] = tr
+        except Exception as e:                                   # pragma: no cover
+            errors.append((r, repr(e)))
+            try:
+                rendezvous.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(nshards)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    alive = [t.is_alive() for t in threads]
+    lib.stochqn_hip_loopback_finalize()
+    assert not any(alive), "a shard thread hung"
+    assert not errors, errors
+    return traces, bounds
+
+
+@pytest.mark.parametrize("nshards", [2, 3])
+@pytest.mark.parametrize("name", ["sqn_hessvec", "olbfgs_default", "sqn_graddiff", "adaqn_fisher_rms", "sqn_nan", "olbfgs_reject_all"])
+def test_sharded_library_equals_unsharded_oracle(name, nshards, form, hip_backend, oracle_backend):
+    """Every shard runs the real kernels on its slice; every reduction goes k_fin -> all-reduce
+    (loop-back) -> consumer, exactly as with RCCL.  All shards must take the same decisions as the
+    unsharded oracle and their slices must concatenate to its x."""
+    cfg = [c for c in CONFIGS if c[0] == name][0]
+    _, optname, kw, step, calls, pkw = cfg
+    n = 3001
+    P = NoisyQuadratic(n, seed=7, **pkw)
+    want = run_trace(OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw), P, P.x0(), step, calls)
+    traces, bounds = _sharded_run(optname, kw, P, nshards, step, calls, hip_backend)
+    for i, w in enumerate(want):
+        for r in range(nshards):
+            g = traces[r][i]
+            for k in ("task", "info", "niter", "section", "mem_used", "mem_st_ix"):
+                assert g[k] == w[k], (i, r, k, g[k], w[k])
+        x = np.concatenate([traces[r][i]["x"] for r in range(nshards)])
+        assert rel_err(x, w["x"]) <= FREE_RUN_TOL.get(name, TOL), (i, rel_err(x, w["x"]))
