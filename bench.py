@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=10_000_000)
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-reference-form", action="store_true",
+                    help="skip the extra untimed steps in the reference's sweep form")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="stochqn_hip_set_option before the run (grid_cap, reverse, nontemporal)")
     return ap.parse_args()
@@ -235,6 +237,45 @@ def main():
     n_total = n * world
     value = steps_per_s * n_total / 1e8
 
+    # ---- outside the timed region: the same workload in the reference's own dependency structure
+    # (2m+1 dependent fused sweeps, 64*m*n algorithmic bytes) for the roofline the north star names --
+    ref_form = None
+    if "combine" in kern and not args.no_profile and not args.no_reference_form:
+        lib.stochqn_hip_set_option(b"twopass", 0.0)
+        for t in range(2):
+            one_step(args.warmup + args.steps + t)
+        lib.stochqn_hip_profile_enable(1)
+        lib.stochqn_hip_profile_reset()
+        barrier()
+        t1 = time.perf_counter()
+        extra = 10
+        for t in range(extra):
+            one_step(args.warmup + args.steps + 2 + t)
+        barrier()
+        el2 = time.perf_counter() - t1
+        lib.stochqn_hip_profile_enable(0)
+        lib.stochqn_hip_set_option(b"twopass", 1.0)
+        k2 = {}
+        for i in range(nk):
+            cnt, ms = C.c_longlong(), C.c_double()
+            lib.stochqn_hip_profile_get(i, C.byref(cnt), C.byref(ms))
+            if cnt.value:
+                k2[lib.stochqn_hip_profile_name(i).decode()] = (cnt.value, ms.value)
+        if "bwd" in k2:
+            cnt, ms = k2["bwd"]
+            ach = 4 * n * 8 / (ms / cnt * 1e-3) / 1e9
+            tl = sum(k2[k][1] for k in ("first", "bwd", "mid", "fwd", "fwd_last") if k in k2) / extra
+            tr, src = pmc_traffic("bwd", n, m)
+            ref_form = {"note": "same workload with --opt twopass=0, %d steps after the timed region" % extra,
+                        "steps_per_s": round(extra / el2 * n_total / 1e8, 3),
+                        "two_loop_ms": round(tl, 3), "two_loop_alg_bytes": 64 * m * n,
+                        "two_loop_alg_GBps": round(64.0 * m * n / (tl * 1e-3) / 1e9, 1),
+                        "two_loop_frac_of_8TBps": round(64.0 * m * n / (tl * 1e-3) / 1e9 / PEAK, 4),
+                        "roofline": {"bound": "hbm", "kernel": "bwd (%s)" % what["bwd"], "achieved": round(ach, 1),
+                                     "peak": PEAK, "unit": "GB/s", "frac": round(ach / PEAK, 4), "traffic": tr,
+                                     "traffic_source": src, "alg_bytes_per_launch": 4 * n * 8,
+                                     "avg_launch_ms": round(ms / cnt, 4)}}
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample ---------------------------------
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -258,6 +299,7 @@ def main():
                        "f_start": f0, "f_end": f1},
             "roofline": roof,
             "two_loop": two_loop,
+            "reference_form": ref_form,
             "kernels": detail,
             "cpu_baseline": cpu,
         }

@@ -816,9 +816,9 @@ __global__ void __launch_bounds__(kBlock) k_coef(const double* bparts, int count
 // pass B: r = gamma g + sum_i cy_i y_i + sum_i cs_i s_i  (pairs visited oldest to newest).
 // A lane finishes T packs before it stores any of them: the single store stream (1 of 2k+2) costs
 // disproportionately when it trickles out between the loads, less when it leaves in groups.
-template <int W, bool NT, int T>
-__global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const double* coef, double* g, uint32_t n, int rev,
-                                                    double* parts)
+template <int W, bool NT, int T, bool H0V>
+__global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const double* coef, double* g, const double* H0,
+                                                    uint32_t n, int rev, double* parts)
 {
 	__shared__ double sh[kWaves];
 	__shared__ double cf[1 + 2 * kPairsMax];
@@ -835,22 +835,53 @@ __global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const 
 			if (p < packs) {
 				const uint32_t i = (rev ? last - p : p) * W;
 				Pack<W> r = ld<W, false>(g, i);
-				#pragma unroll
-				for (int e = 0; e < W; e++) r.v[e] = cf[0] * r.v[e];
-				for (int j0 = 0; j0 < k; j0 += 4) {
-					Pack<W> fy[4], fs[4];
-					#pragma unroll
-					for (int u = 0; u < 4; u++)
-						if (j0 + u < k) { fy[u] = ld<W, NT>(ys.row[j0 + u], i); fs[u] = ld<W, NT>(ss.row[j0 + u], i); }
-					#pragma unroll
-					for (int u = 0; u < 4; u++)
-						if (j0 + u < k) {
-							#pragma unroll
-							for (int e = 0; e < W; e++) {
-								r.v[e] = fma(cf[1 + j0 + u], fy[u].v[e], r.v[e]);
-								r.v[e] = fma(cf[1 + k + j0 + u], fs[u].v[e], r.v[e]);
+				if constexpr (H0V) {
+					// q_0 = g - sum alpha_j y_j (newest pair first), r_0 = q_0 .* H0, then the s terms
+					const Pack<W> h = ld<W, false>(H0, i);
+					for (int j0 = k; j0 > 0; j0 -= 4) {
+						Pack<W> fy[4];
+						#pragma unroll
+						for (int u = 0; u < 4; u++)
+							if (j0 - 1 - u >= 0) fy[u] = ld<W, NT>(ys.row[j0 - 1 - u], i);
+						#pragma unroll
+						for (int u = 0; u < 4; u++)
+							if (j0 - 1 - u >= 0) {
+								#pragma unroll
+								for (int e = 0; e < W; e++) r.v[e] = fma(cf[1 + j0 - 1 - u], fy[u].v[e], r.v[e]);
 							}
-						}
+					}
+					#pragma unroll
+					for (int e = 0; e < W; e++) r.v[e] = r.v[e] * h.v[e];
+					for (int j0 = 0; j0 < k; j0 += 4) {
+						Pack<W> fs[4];
+						#pragma unroll
+						for (int u = 0; u < 4; u++)
+							if (j0 + u < k) fs[u] = ld<W, NT>(ss.row[j0 + u], i);
+						#pragma unroll
+						for (int u = 0; u < 4; u++)
+							if (j0 + u < k) {
+								#pragma unroll
+								for (int e = 0; e < W; e++) r.v[e] = fma(cf[1 + k + j0 + u], fs[u].v[e], r.v[e]);
+							}
+					}
+				} else {
+					#pragma unroll
+					for (int e = 0; e < W; e++) r.v[e] = cf[0] * r.v[e];
+					for (int j0 = 0; j0 < k; j0 += 4) {
+						Pack<W> fy[4], fs[4];
+						#pragma unroll
+						for (int u = 0; u < 4; u++)
+							if (j0 + u < k) { fy[u] = ld<W, NT>(ys.row[j0 + u], i); fs[u] = ld<W, NT>(ss.row[j0 + u], i); }
+						#pragma unroll
+						for (int u = 0; u < 4; u++)
+							if (j0 + u < k) {
+								#pragma unroll
+								for (int e = 0; e < W; e++) {
+									r.v[e] = fma(cf[1 + j0 + u], fy[u].v[e], r.v[e]);
+									r.v[e] = fma(cf[1 + k + j0 + u], fs[u].v[e], r.v[e]);
+								}
+							}
+					}
 				}
 				#pragma unroll
 				for (int e = 0; e < W; e++) { acc0 = fma(r.v[e], r.v[e], acc0); acc1 += (isfinite(r.v[e]) ? 0.0 : 1.0); }
@@ -866,14 +897,203 @@ __global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const 
 	if (W > 1) {
 		const uint32_t i = packs * W + threadIdx.x;
 		if (blockIdx.x == gridDim.x - 1 && i < n) {
-			double r = cf[0] * g[i];
-			for (int j = 0; j < k; j++) { r = fma(cf[1 + j], ys.row[j][i], r); r = fma(cf[1 + k + j], ss.row[j][i], r); }
+			double r;
+			if constexpr (H0V) {
+				r = g[i];
+				for (int j = k - 1; j >= 0; j--) r = fma(cf[1 + j], ys.row[j][i], r);
+				r = r * H0[i];
+				for (int j = 0; j < k; j++) r = fma(cf[1 + k + j], ss.row[j][i], r);
+			} else {
+				r = cf[0] * g[i];
+				for (int j = 0; j < k; j++) { r = fma(cf[1 + j], ys.row[j][i], r); r = fma(cf[1 + k + j], ss.row[j][i], r); }
+			}
 			acc0 = fma(r, r, acc0); acc1 += (isfinite(r) ? 0.0 : 1.0);
 			g[i] = r;
 		}
 	}
 	const double t0 = block_sum(acc0, sh), t1 = block_sum(acc1, sh);
 	if (threadIdx.x == 0) { parts[blockIdx.x] = t0; parts[kMaxGrid + blockIdx.x] = t1; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass A with adaQN's diagonal H0: all inner products of one step in one pass over S and Y.
+// A workgroup stages a tile of kTile columns of every row in LDS (one 1 KiB wave-load per row tile,
+// rows dealt round-robin to the 4 waves), wave 0 applies the side effects on the raw gradient and
+// publishes h = g/sqrt(G+eps), the waves write z_i = y_i .* h next to their y_i, and then every
+// THREAD owns one or two of the Q = 3k + k(k+1)/2 quantities and walks the tile:
+// quantity(rowA, rowB) += sum_e L[rowA][e] L[rowB][e].  No cross-lane reduction at all; the
+// per-workgroup partial of a quantity is that thread's accumulator.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTile = 128;
+constexpr int kTileLd = kTile + 1;     // odd LDS row stride: threads of a wave read different rows at the same column
+
+// two neighbouring columns of a row: one 16-B access when every row is 16-B aligned (VEC), else two
+// 8-B accesses; columns at or beyond n read as `fill` and are never written
+template <bool VEC, bool NT> __device__ __forceinline__ d2 ld_cols(const double* p, uint32_t i, uint32_t n, double fill)
+{
+	d2 v = {fill, fill};
+	if constexpr (VEC) {
+		if (i + 1 < n) v = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2*>(p + i)) : *reinterpret_cast<const d2*>(p + i);
+	} else {
+		if (i < n) v.x = NT ? __builtin_nontemporal_load(p + i) : p[i];
+		if (i + 1 < n) v.y = NT ? __builtin_nontemporal_load(p + i + 1) : p[i + 1];
+	}
+	return v;
+}
+template <bool VEC> __device__ __forceinline__ void st_cols(double* p, uint32_t i, uint32_t n, d2 v)
+{
+	if constexpr (VEC) { if (i + 1 < n) *reinterpret_cast<d2*>(p + i) = v; }
+	else { if (i < n) p[i] = v.x; if (i + 1 < n) p[i + 1] = v.y; }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(kBlock) k_gram_h0(GramH0Args a, bool rms, double w_old, double w_new, uint32_t n, double* parts)
+{
+	extern __shared__ double L[];      // (3k+2) rows x kTileLd: S | Y | Z | g | h
+	const int k = a.s_rows.count;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int rowG = 3 * k, rowH = 3 * k + 1;
+	const int Q = 3 * k + k * (k + 1) / 2;
+	// which (rowA, rowB) this thread accumulates
+	int qa[2], qb[2], nq = 0;
+	for (int q = threadIdx.x; q < Q; q += kBlock) {
+		int ra, rb;
+		if (q < k) { ra = q; rb = rowG; }                          // s_i'g
+		else if (q < 2 * k) { ra = q; rb = rowG; }                 // y_i'g   (row k+i)
+		else if (q < 3 * k) { ra = q; rb = rowG; }                 // u_i = z_i'g (row 2k+i)
+		else {                                                     // W_ij, i <= j, rows enumerated i-major
+			int t = q - 3 * k, i = 0;
+			while (t >= k - i) { t -= k - i; i++; }
+			ra = 2 * k + i;                                        // z_i
+			rb = k + i + t;                                        // y_j, j = i + t
+		}
+		qa[nq] = ra; qb[nq] = rb; nq++;
+	}
+	double acc[2] = {0, 0}, acc_odd[2] = {0, 0};      // two chains per quantity: even / odd columns
+	const uint32_t tiles = (n + kTile - 1) / kTile;
+	constexpr int kShare = (kPairsMax + kWaves - 1) / kWaves;
+	d2 sv[kShare], yv[kShare], gv = {0, 0}, Gv = {1, 1};
+	// software pipeline: the row tiles of the NEXT tile are fetched into registers while this one
+	// is being accumulated out of LDS, so that the HBM latency is paid under the LDS phase
+	auto fetch = [&](uint32_t tile) {
+		const uint32_t i = tile * kTile + 2 * lane;
+		const uint32_t lim = tile < tiles ? n : 0;                 // past the last tile: everything reads as fill
+		#pragma unroll
+		for (int u = 0; u < kShare; u++) {
+			const int r = wave + u * kWaves;
+			sv[u] = (r < k) ? ld_cols<VEC, true>(a.s_rows.row[r], i, lim, 0.0) : d2{0, 0};
+			yv[u] = (r < k) ? ld_cols<VEC, true>(a.y_rows.row[r], i, lim, 0.0) : d2{0, 0};
+		}
+		if (wave == 0) {
+			gv = ld_cols<VEC, false>(a.g, i, lim, 0.0);
+			Gv = ld_cols<VEC, false>(a.G, i, lim, 1.0);
+		}
+	};
+	fetch(blockIdx.x);
+	for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+		const uint32_t i = tile * kTile + 2 * lane;                // this lane's two columns
+		// -- stage the fetched registers into LDS
+		d2 yk[kShare];
+		#pragma unroll
+		for (int u = 0; u < kShare; u++) {
+			const int r = wave + u * kWaves;
+			yk[u] = yv[u];
+			if (r < k) {
+				L[r * kTileLd + 2 * lane] = sv[u].x; L[r * kTileLd + 2 * lane + 1] = sv[u].y;
+				L[(k + r) * kTileLd + 2 * lane] = yv[u].x; L[(k + r) * kTileLd + 2 * lane + 1] = yv[u].y;
+			}
+		}
+		if (wave == 0) {
+			d2 Gn, h;
+			Gn.x = rms ? (w_old * Gv.x + w_new * (gv.x * gv.x)) : (Gv.x + gv.x * gv.x);      // reference :738 / :745
+			Gn.y = rms ? (w_old * Gv.y + w_new * (gv.y * gv.y)) : (Gv.y + gv.y * gv.y);
+			h.x = gv.x / sqrt(Gn.x + a.scal_reg);                                                // :781
+			h.y = gv.y / sqrt(Gn.y + a.scal_reg);
+			st_cols<VEC>(a.G, i, n, Gn);
+			st_cols<VEC>(a.H0_out, i, n, h);
+			if (a.frow_out) st_cols<VEC>(a.frow_out, i, n, gv);
+			if (i >= n) h.x = 0;                                   // columns beyond n must not contribute
+			if (i + 1 >= n) h.y = 0;
+			L[rowG * kTileLd + 2 * lane] = gv.x; L[rowG * kTileLd + 2 * lane + 1] = gv.y;
+			L[rowH * kTileLd + 2 * lane] = h.x;  L[rowH * kTileLd + 2 * lane + 1] = h.y;
+		}
+		fetch(tile + gridDim.x);                                   // next tile's loads are now in flight
+		__syncthreads();
+		const double hx = L[rowH * kTileLd + 2 * lane], hy = L[rowH * kTileLd + 2 * lane + 1];
+		#pragma unroll
+		for (int u = 0; u < kShare; u++) {
+			const int r = wave + u * kWaves;
+			if (r < k) { L[(2 * k + r) * kTileLd + 2 * lane] = yk[u].x * hx; L[(2 * k + r) * kTileLd + 2 * lane + 1] = yk[u].y * hy; }
+		}
+		__syncthreads();
+		// -- accumulate: one or two quantities per thread over the tile's columns
+		if (nq > 0) {
+			const double* A0 = L + qa[0] * kTileLd;
+			const double* B0 = L + qb[0] * kTileLd;
+			if (nq == 1) {
+				#pragma unroll 8
+				for (int e = 0; e < kTile; e += 2) { acc[0] = fma(A0[e], B0[e], acc[0]); acc_odd[0] = fma(A0[e + 1], B0[e + 1], acc_odd[0]); }
+			} else {
+				const double* A1 = L + qa[1] * kTileLd;
+				const double* B1 = L + qb[1] * kTileLd;
+				#pragma unroll 4
+				for (int e = 0; e < kTile; e += 2) {
+					acc[0] = fma(A0[e], B0[e], acc[0]); acc_odd[0] = fma(A0[e + 1], B0[e + 1], acc_odd[0]);
+					acc[1] = fma(A1[e], B1[e], acc[1]); acc_odd[1] = fma(A1[e + 1], B1[e + 1], acc_odd[1]);
+				}
+			}
+		}
+		__syncthreads();
+	}
+	acc[0] += acc_odd[0];
+	acc[1] += acc_odd[1];
+	int j = 0;
+	for (int q = threadIdx.x; q < Q; q += kBlock) parts[(size_t) q * kMaxGrid + blockIdx.x] = acc[j++];
+}
+
+// Scalar recursion for the diagonal-H0 form.  Backward loop as in k_coef; forward loop with
+// y_i'r_0 = u_i - sum_j alpha_j W_ij.  coef: [1+j] = -alpha_j (inside the H0 bracket), [1+k+j] = c_j.
+__global__ void __launch_bounds__(kBlock) k_coef_h0(const double* bparts, int count, int stride, CoefArgs a, const double* gsy,
+                                                    double* alpha_out, double* rho_out, double* coef)
+{
+	__shared__ double SY[kPairsMax * kPairsMax], Wm[kPairsMax * kPairsMax], bS[kPairsMax], U[kPairsMax];
+	__shared__ double al[kPairsMax], rho[kPairsMax], c[kPairsMax];
+	const int k = a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int Q = 3 * k + k * (k + 1) / 2;
+	for (int e = threadIdx.x; e < k * k; e += kBlock) SY[e] = gsy[(size_t) a.rows[e / k] * a.m + a.rows[e % k]];
+	for (int q = wave; q < Q; q += kWaves) {
+		const double t = wave_total_of(bparts + (size_t) q * stride, count);
+		if (lane == 0) {
+			if (q < k) bS[q] = t;
+			else if (q < 2 * k) { /* y_i'g: not needed by this form */ }
+			else if (q < 3 * k) U[q - 2 * k] = t;
+			else {
+				int r = q - 3 * k, i = 0;
+				while (r >= k - i) { r -= k - i; i++; }
+				Wm[i * k + i + r] = t;
+				Wm[(i + r) * k + i] = t;
+			}
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x != 0) return;
+	for (int i = k - 1; i >= 0; i--) {
+		double sq = bS[i];
+		for (int j = k - 1; j > i; j--) sq = fma(-al[j], SY[i * k + j], sq);
+		rho[i] = 1.0 / SY[i * k + i];
+		al[i] = rho[i] * sq;
+		alpha_out[i] = al[i];
+		rho_out[i] = rho[i];
+	}
+	coef[0] = 1.0;
+	for (int i = 0; i < k; i++) {
+		double yr = U[i];
+		for (int j = k - 1; j >= 0; j--) yr = fma(-al[j], Wm[i * k + j], yr);     // y_i'(H0 .* q_0)
+		for (int j = 0; j < i; j++) yr = fma(c[j], SY[j * k + i], yr);
+		c[i] = al[i] - rho[i] * yr;
+		coef[1 + i] = -al[i];
+		coef[1 + k + i] = c[i];
+	}
 }
 
 // out[j] = sum of partial array j (one workgroup per quantity)
@@ -937,7 +1157,7 @@ const char* kernel_name(int id)
 {
 	static const char* names[K_COUNT] = {
 		"first", "bwd", "mid", "fwd", "fwd_last", "apply", "pair_s", "pair_y_diff", "pair_y_hv",
-		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy", "rows_dot", "coef", "combine", "gram", "rows_dot3"};
+		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy", "rows_dot", "coef", "combine", "gram", "rows_dot3", "gram_h0"};
 	return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
@@ -1201,20 +1421,63 @@ void launch_coef(const Scratch& sc, Partials b, const CoefArgs& a)
 	                   sc.coef);
 }
 
-Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, const RowSet& ss, double* g)
+Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, const RowSet& ss, double* g, const double* H0)
 {
 	const int grid = sweep_grid(sc, n, 2);
-	const bool vec = rows_aligned(ys) && rows_aligned(ss) && aligned16(g);
+	const bool vec = rows_aligned(ys) && rows_aligned(ss) && all_aligned(g, H0);
 	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
 	{
 		ProfScope ps(sc, K_COMBINE);
-		#define SQN_CB(W, T) hipLaunchKernelGGL((k_combine<W, true, T>), dim3(grid), dim3(kBlock), 0, sc.stream, ys, ss, sc.coef, g, (uint32_t) n, rev, sc.part[buf])
+		#define SQN_CB(W, T, HV) hipLaunchKernelGGL((k_combine<W, true, T, HV>), dim3(grid), dim3(kBlock), 0, sc.stream, ys, ss, sc.coef, g, H0, (uint32_t) n, rev, sc.part[buf])
 		const int T = sc.combine_batch;
-		if (vec) { if (T >= 8) SQN_CB(2, 8); else if (T >= 4) SQN_CB(2, 4); else if (T >= 2) SQN_CB(2, 2); else SQN_CB(2, 1); }
-		else     { if (T >= 8) SQN_CB(1, 8); else if (T >= 4) SQN_CB(1, 4); else if (T >= 2) SQN_CB(1, 2); else SQN_CB(1, 1); }
+		if (H0) {
+			if (vec) { if (T >= 4) SQN_CB(2, 4, true); else SQN_CB(2, 1, true); }
+			else     { if (T >= 4) SQN_CB(1, 4, true); else SQN_CB(1, 1, true); }
+		} else {
+			if (vec) { if (T >= 8) SQN_CB(2, 8, false); else if (T >= 4) SQN_CB(2, 4, false); else if (T >= 2) SQN_CB(2, 2, false); else SQN_CB(2, 1, false); }
+			else     { if (T >= 8) SQN_CB(1, 8, false); else if (T >= 4) SQN_CB(1, 4, false); else if (T >= 2) SQN_CB(1, 2, false); else SQN_CB(1, 1, false); }
+		}
 		#undef SQN_CB
 	}
 	return finish(sc, buf, 2, grid);
+}
+
+Partials launch_gram_h0(const Scratch& sc, size_t n, const GramH0Args& a)
+{
+	const int k = a.s_rows.count;
+	const int Q = 3 * k + k * (k + 1) / 2;
+	const size_t shmem = (size_t) (3 * k + 2) * kTileLd * sizeof(double);
+	size_t tiles = (n + kTile - 1) / kTile;
+	size_t g = (size_t) sc.grid_cap * 2;              // LDS allows two resident workgroups per CU: one loads while one accumulates
+	if (g > tiles) g = tiles;
+	if (g > (size_t) kMaxGrid) g = kMaxGrid;
+	if (g < 1) g = 1;
+	const int grid = (int) g;
+	const bool rms = a.rmsprop_weight > 0 && a.rmsprop_weight < 1;
+	const bool vec = rows_aligned(a.s_rows) && rows_aligned(a.y_rows) && all_aligned(a.g, a.G, a.H0_out, a.frow_out) && n % 2 == 0;
+	static bool lds_opt_in = false;
+	if (!lds_opt_in) {     // up to (3*24+2) x 129 doubles = 76 KiB of dynamic LDS
+		const int bytes = (int) ((3 * kPairsMax + 2) * kTileLd * sizeof(double));
+		(void) hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_h0<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+		(void) hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_h0<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+		lds_opt_in = true;
+	}
+	{
+		ProfScope ps(sc, K_GRAM_H0);
+		if (vec) hipLaunchKernelGGL(k_gram_h0<true>, dim3(grid), dim3(kBlock), shmem, sc.stream, a, rms, a.rmsprop_weight, 1 - a.rmsprop_weight, (uint32_t) n, sc.rows_part[0]);
+		else     hipLaunchKernelGGL(k_gram_h0<false>, dim3(grid), dim3(kBlock), shmem, sc.stream, a, rms, a.rmsprop_weight, 1 - a.rmsprop_weight, (uint32_t) n, sc.rows_part[0]);
+	}
+	Partials raw{sc.rows_part[0], grid, kMaxGrid};
+	if (!sc.allreduce) return raw;
+	launch_fin(sc, raw, Q, sc.red[0]);
+	sc.allreduce(sc.user, sc.red[0], Q, sc.stream);
+	return Partials{sc.red[0], 1, 1};
+}
+
+void launch_coef_h0(const Scratch& sc, Partials b, const CoefArgs& a)
+{
+	ProfScope ps(sc, K_COEF);
+	hipLaunchKernelGGL(k_coef_h0, dim3(1), dim3(kBlock), 0, sc.stream, b.parts, b.count, b.stride, a, sc.gsy, sc.alpha, sc.rho, sc.coef);
 }
 
 void launch_fin(const Scratch& sc, Partials in, int nsums, double* out)

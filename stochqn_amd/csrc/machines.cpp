@@ -67,12 +67,21 @@ bool bind_bfgs(DevCtx* c, bfgs_mem* b, bool import_rows)
 }
 
 // Start a call: find the context, bind every struct array, classify and stage x / grad.
-bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resumed, double* x, double* grad)
+bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resumed, double* x, double* grad,
+               size_t niter, int section)
 {
 	if (!b || !b->s_mem || !b->y_mem || n <= 0 || b->mem_size == 0) return false;
 	bool fresh = false;
 	DevCtx* c = acquire(b->s_mem, kind, n, b->mem_size, fsize, &fresh);
 	if (!c) return false;
+	if (!fresh && c->has_last && (c->last_niter != niter || c->last_section != section)) {
+		// Same address, same shape, but not the state this context last handed back: the arrays
+		// belong to another optimiser object now (R / Python never call dealloc_*).  Start over
+		// from what the caller passes (host arrays are re-imported, caches dropped).
+		release(b->s_mem);
+		c = acquire(b->s_mem, kind, n, b->mem_size, fsize, &fresh);
+		if (!c) return false;
+	}
 	io.c = c;
 	if (!bind_bfgs(c, b, fresh && resumed)) return false;
 	if (fresh) {
@@ -251,6 +260,42 @@ Partials enqueue_two_pass(DevCtx* c, double* g, size_t used, size_t st, double h
 	return launch_combine(c->sc, c->next_buf(), N(c), ys, ss, g);
 }
 
+// adaQN (diagonal H0) in two passes: all inner products incl. the H0-weighted ones + the side effects
+// on the raw gradient in one pass over S and Y, the scalar recursion, the combine pass.
+bool twopass_h0_ok(const DevCtx* c, size_t used, const StepIn& in)
+{
+	// like twopass_ok: only quantities that are identical on every rank of a sharded run may select
+	// the algorithm (local n, alignment ... merely select kernel variants with the same reductions)
+	return options().twopass && options().twopass_h0 && in.G != nullptr && in.H0 != nullptr && used >= 1 &&
+	       c->m <= (size_t) kPairsMax;
+}
+
+Partials enqueue_two_pass_h0(DevCtx* c, const StepIn& in, size_t st)
+{
+	const size_t m = c->m, k = in.used;
+	ensure_gram(c, st, k);
+	GramH0Args ga{};
+	CoefArgs a{};
+	a.k = (int) k;
+	a.m = (int) m;
+	for (size_t i = 0; i < k; i++) {
+		const size_t r = (st + i) % m;
+		a.rows[i] = (int) r;
+		ga.s_rows.row[i] = row(c->S, r, c);
+		ga.y_rows.row[i] = row(c->Y, r, c);
+	}
+	ga.s_rows.count = ga.y_rows.count = (int) k;
+	ga.g = in.g;
+	ga.G = in.G;
+	ga.H0_out = in.H0;
+	ga.frow_out = in.frow_out;
+	ga.rmsprop_weight = in.w;
+	ga.scal_reg = in.eps;
+	Partials b = launch_gram_h0(c->sc, N(c), ga);
+	launch_coef_h0(c->sc, b, a);
+	return launch_combine(c->sc, c->next_buf(), N(c), ga.y_rows, ga.s_rows, in.g, in.H0);
+}
+
 // take_step (reference src/stochqn.c:802-840) + the caller's follow-up that only depends on the
 // guard (x_sum += x, oLBFGS s-slot).  Enqueues everything and the read-back of the report block.
 void enqueue_step(Call& io, const StepIn& in)
@@ -279,20 +324,21 @@ void enqueue_step(Call& io, const StepIn& in)
 		if (twopass_ok(c, in.used, in.G ? in.H0 : nullptr)) {
 			Partials guard = enqueue_two_pass(c, in.g, in.used, st, in.h0, in.gprev_out);
 			launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
+		} else if (twopass_h0_ok(c, in.used, in)) {
+			Partials guard = enqueue_two_pass_h0(c, in, st);
+			launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
 		} else {
 			Partials guard = enqueue_two_loop(c, in.g, in.used, st, fa, in.h0, in.G ? in.H0 : nullptr,
 			                                  in.check_nan ? nullptr : &ap);
 			if (in.check_nan) launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, true);
 		}
-		to_host(c, c->pin + 8, sc.rho, c->m);                         // buffer_rho | buffer_alpha
-		to_host(c, c->pin + 8 + c->m, sc.alpha, c->m);
 	}
-	if (in.check_nan) to_host(c, c->pin, sc.report, 4);   // bad flag, sum r^2, #nonfinite from the apply kernel
-	else c->pin[0] = 0;                                   // unguarded: the step is always taken
+	// one read-back per step: report (bad flag, sum r^2, #nonfinite) | rho | alpha, contiguous in the pool
+	if (in.check_nan || in.used > 0) to_host(c, c->pin, sc.report, 8 + 2 * c->m);
 }
 
 // after sync(): was the step rejected?  Also hands buffer_rho / buffer_alpha back to the caller.
-bool step_was_bad(Call& io, bfgs_mem* b, size_t used_before)
+bool step_was_bad(Call& io, bfgs_mem* b, size_t used_before, int check_nan)
 {
 	DevCtx* c = io.c;
 	if (used_before > 0) {
@@ -305,7 +351,7 @@ bool step_was_bad(Call& io, bfgs_mem* b, size_t used_before)
 				std::memcpy(dst[j], c->pin + 8 + j * c->m, used_before * sizeof(double));
 		}
 	}
-	return c->pin[0] != 0.0;
+	return check_nan && c->pin[0] != 0.0;       // unguarded: the step is always taken
 }
 
 // ---- correction pairs ----------------------------------------------------------------------------
@@ -386,6 +432,18 @@ void* dev_alloc(size_t count, bool zero_fill)
 	return p;
 }
 
+// Section 0 is only ever seen on a brand-new optimiser object: whatever context still hangs on this
+// address belongs to a dead one.  On return the caller-visible state is noted so that the next call
+// can be recognised as its continuation (open_call).
+template <class W> void before_call(W* w)
+{
+	if (w && w->bfgs_memory && w->section == 0) release(w->bfgs_memory->s_mem);
+}
+template <class W> void after_call(W* w)
+{
+	if (w && w->bfgs_memory) note_state(w->bfgs_memory->s_mem, w->niter, w->section);
+}
+
 }  // namespace
 
 extern "C" {
@@ -393,8 +451,8 @@ extern "C" {
 // =================================================================================================
 // oLBFGS (reference src/stochqn.c:978-1036)
 // =================================================================================================
-int run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_enum* task,
-               workspace_oLBFGS* w, info_enum* iter_info)
+static int run_oLBFGS_impl(real_t step_size, real_t x[], real_t grad[], real_t** req, task_enum* task,
+                           workspace_oLBFGS* w, info_enum* iter_info)
 {
 	*iter_info = no_problems_encountered;
 	if (!w || !w->bfgs_memory || w->section < 0 || w->section > 2) return invalid(task, "oLBFGS");
@@ -409,7 +467,7 @@ int run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_e
 	}
 
 	Call io;
-	if (!open_call(io, KIND_OLBFGS, w->n, b, 0, w->niter > 0 || b->mem_used > 0, x, grad)) return invalid(task, "oLBFGS");
+	if (!open_call(io, KIND_OLBFGS, w->n, b, 0, w->niter > 0 || b->mem_used > 0, x, grad, w->niter, w->section)) return invalid(task, "oLBFGS");
 	DevCtx* c = io.c;
 	if (!bind(c, c->gprev, w->grad_prev, N(c), true)) return invalid(task, "oLBFGS");
 
@@ -426,7 +484,7 @@ int run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_e
 		enqueue_step(io, in);
 		w->niter++;
 		close_call(io, true, true);
-		if (step_was_bad(io, b, used)) {
+		if (step_was_bad(io, b, used, w->check_nan)) {
 			ring_reset(b);                                            // :831, :1015
 			*iter_info = search_direction_was_nan;
 			*task = calc_grad;
@@ -454,8 +512,8 @@ int run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_e
 // =================================================================================================
 // SQN (reference src/stochqn.c:1038-1153)
 // =================================================================================================
-int run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real_t** req, real_t** req_vec,
-            task_enum* task, workspace_SQN* w, info_enum* iter_info)
+static int run_SQN_impl(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real_t** req, real_t** req_vec,
+                        task_enum* task, workspace_SQN* w, info_enum* iter_info)
 {
 	*iter_info = no_problems_encountered;
 	if (!w || !w->bfgs_memory || w->section < 0 || w->section > 4) return invalid(task, "SQN");
@@ -465,7 +523,7 @@ int run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real
 
 	if (w->section != 0) {
 		Call io;
-		if (!open_call(io, KIND_SQN, w->n, b, 0, w->niter > 0 || b->mem_used > 0, x, grad)) return invalid(task, "SQN");
+		if (!open_call(io, KIND_SQN, w->n, b, 0, w->niter > 0 || b->mem_used > 0, x, grad, w->niter, w->section)) return invalid(task, "SQN");
 		DevCtx* c = io.c;
 		const size_t n = N(c);
 		if (!bind(c, c->gprev, w->grad_prev, w->use_grad_diff ? n : 0, true) ||
@@ -484,7 +542,7 @@ int run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real
 			enqueue_step(io, in);
 			w->niter++;
 			close_call(io, true, true);
-			if (step_was_bad(io, b, used)) { ring_reset(b); *iter_info = search_direction_was_nan; ret = 0; }
+			if (step_was_bad(io, b, used, w->check_nan)) { ring_reset(b); *iter_info = search_direction_was_nan; ret = 0; }
 			else ret = 1;
 
 			if (w->niter % b->upd_freq != 0) break;
@@ -547,8 +605,8 @@ int run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real
 // =================================================================================================
 // adaQN (reference src/stochqn.c:1155-1315)
 // =================================================================================================
-int run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** req, task_enum* task,
-              workspace_adaQN* w, info_enum* iter_info)
+static int run_adaQN_impl(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** req, task_enum* task,
+                          workspace_adaQN* w, info_enum* iter_info)
 {
 	*iter_info = no_problems_encountered;
 	if (!w || !w->bfgs_memory || w->section < 0 || w->section > 5) return invalid(task, "adaQN");
@@ -564,7 +622,7 @@ int run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** re
 		Call io;
 		const size_t fsize = fm ? fm->mem_size : 0;
 		const bool resumed = w->niter > 0 || b->mem_used > 0;
-		if (!open_call(io, KIND_ADAQN, w->n, b, fsize, resumed, x, grad)) return invalid(task, "adaQN");
+		if (!open_call(io, KIND_ADAQN, w->n, b, fsize, resumed, x, grad, w->niter, w->section)) return invalid(task, "adaQN");
 		DevCtx* c = io.c;
 		const size_t n = N(c);
 		if (!bind(c, c->gprev, w->grad_prev, w->use_grad_diff ? n : 0, true) ||
@@ -587,7 +645,7 @@ int run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** re
 			in.check_nan = w->check_nan;
 			enqueue_step(io, in);
 			close_call(io, true, true);
-			if (step_was_bad(io, b, used)) { ring_reset(b); *iter_info = search_direction_was_nan; ret = 0; }
+			if (step_was_bad(io, b, used, w->check_nan)) { ring_reset(b); *iter_info = search_direction_was_nan; ret = 0; }
 			else ret = 1;
 			w->niter++;
 
@@ -684,6 +742,34 @@ int run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** re
 	*task = calc_grad;
 	*req = x;
 	return ret;
+}
+
+// The exported entry points.
+int run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_enum* task, workspace_oLBFGS* w,
+               info_enum* iter_info)
+{
+	before_call(w);
+	const int rc = run_oLBFGS_impl(step_size, x, grad, req, task, w, iter_info);
+	after_call(w);
+	return rc;
+}
+
+int run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real_t** req, real_t** req_vec, task_enum* task,
+            workspace_SQN* w, info_enum* iter_info)
+{
+	before_call(w);
+	const int rc = run_SQN_impl(step_size, x, grad, hess_vec, req, req_vec, task, w, iter_info);
+	after_call(w);
+	return rc;
+}
+
+int run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** req, task_enum* task, workspace_adaQN* w,
+              info_enum* iter_info)
+{
+	before_call(w);
+	const int rc = run_adaQN_impl(step_size, x, f, grad, req, task, w, iter_info);
+	after_call(w);
+	return rc;
 }
 
 // =================================================================================================
@@ -897,8 +983,7 @@ int stochqn_hip_two_loop(double grad[], int n, double H0[], double h0, double y_
 		(void) none;
 		(void) enqueue_two_loop(c, g, mem_used, mem_st_ix % mem_size, fa, h0, H0 ? c->H0.dev : nullptr, nullptr);
 	}
-	to_host(c, c->pin + 8, c->sc.rho, c->m);
-	to_host(c, c->pin + 8 + c->m, c->sc.alpha, c->m);
+	to_host(c, c->pin, c->sc.report, 8 + 2 * c->m);
 	if (g_host) to_host(c, grad, g, nn);
 	sync(c);
 	double* dst[2] = {buffer_rho, buffer_alpha};

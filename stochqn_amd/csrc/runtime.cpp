@@ -73,7 +73,7 @@ struct Loopback {
 	std::condition_variable cv;
 	int arrived = 0;
 	long generation = 0;
-	std::vector<double> slots;      // [nranks][256]
+	std::vector<double> slots;      // [nranks][kRedMax]
 } g_loop;
 thread_local int t_loop_rank = -1;
 
@@ -92,14 +92,14 @@ void loop_barrier()
 
 void loopback_hook(void*, double* buf, int count, hipStream_t stream)
 {
-	double tmp[256];
+	double tmp[kRedMax];
 	SQN_HIP_OK(hipStreamSynchronize(stream));
 	SQN_HIP_OK(hipMemcpy(tmp, buf, (size_t) count * sizeof(double), hipMemcpyDeviceToHost));
-	std::memcpy(&g_loop.slots[(size_t) t_loop_rank * 256], tmp, (size_t) count * sizeof(double));
+	std::memcpy(&g_loop.slots[(size_t) t_loop_rank * kRedMax], tmp, (size_t) count * sizeof(double));
 	loop_barrier();
 	for (int j = 0; j < count; j++) {
 		double s = 0;
-		for (int r = 0; r < g_loop.nranks; r++) s += g_loop.slots[(size_t) r * 256 + j];
+		for (int r = 0; r < g_loop.nranks; r++) s += g_loop.slots[(size_t) r * kRedMax + j];
 		tmp[j] = s;
 	}
 	loop_barrier();                 // nobody overwrites a slot before everybody has read it
@@ -210,10 +210,10 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	c->key = key; c->kind = kind; c->n = n; c->m = m; c->fsize = fsize;
 	c->n_global = (double) n;
 	SQN_HIP_OK(hipStreamCreate(&c->sc.stream));   // blocking flavour: ordered after the null stream
-	// pool layout: part0 | part1 | red0 | red1 | sy | yy | alpha | rho | report | rows_part x2 | gsy | gyy | coef
+	// pool layout: part0 | part1 | red0 | red1 | sy | yy | report | rho | alpha | rows_part x2 | gsy | gyy | coef
 	const size_t part = (size_t) kMaxSums * kMaxGrid;
-	const size_t rows_part = (size_t) 3 * kRowsMax * kMaxGrid;
-	const size_t total = 2 * part + 2 * 256 + 4 * m + 8 + 2 * rows_part + 2 * m * m + (2 + 2 * kPairsMax);
+	const size_t rows_part = (size_t) kRedMax * kMaxGrid;
+	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + 2 * m * m + (2 + 2 * kPairsMax);
 	if (hipMalloc((void**) &c->pool, total * sizeof(double)) != hipSuccess) {
 		std::fprintf(stderr, "stochqn: could not allocate device scratch\n");
 		(void) hipStreamDestroy(c->sc.stream);
@@ -224,13 +224,13 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	double* p = c->pool;
 	c->sc.part[0] = p; p += part;
 	c->sc.part[1] = p; p += part;
-	c->sc.red[0] = p; p += 256;
-	c->sc.red[1] = p; p += 256;
+	c->sc.red[0] = p; p += kRedMax;
+	c->sc.red[1] = p; p += kRedMax;
 	c->sc.sy = p; p += m;
 	c->sc.yy = p; p += m;
-	c->sc.alpha = p; p += m;
+	c->sc.report = p; p += 8;        // report | rho | alpha are contiguous: one D2H per step
 	c->sc.rho = p; p += m;
-	c->sc.report = p; p += 8;
+	c->sc.alpha = p; p += m;
 	c->sc.rows_part[0] = p; p += rows_part;
 	c->sc.rows_part[1] = p; p += rows_part;
 	c->sc.gsy = p; p += m * m;
@@ -251,6 +251,16 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	if (!g_atexit) { g_atexit = true; std::atexit(at_exit); }
 	*fresh = true;
 	return c;
+}
+
+void note_state(const void* key, size_t niter, int section)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	auto it = g_ctx.find(key);
+	if (it == g_ctx.end()) return;
+	it->second->has_last = true;
+	it->second->last_niter = niter;
+	it->second->last_section = section;
 }
 
 void release(const void* key)
@@ -374,6 +384,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "combine_batch")) g_opt.combine_batch = (int) value;
 	else if (!std::strcmp(name, "reverse")) g_opt.reverse = value != 0;
 	else if (!std::strcmp(name, "twopass")) g_opt.twopass = value != 0;
+	else if (!std::strcmp(name, "twopass_h0")) g_opt.twopass_h0 = value != 0;
 	else if (!std::strcmp(name, "strict_grad")) g_opt.strict_grad = value != 0;
 	else return -1;
 	return 0;
@@ -442,7 +453,7 @@ int stochqn_hip_loopback_init(int nranks)
 	std::lock_guard<std::mutex> lk(g_loop.mu);
 	g_loop.nranks = nranks;
 	g_loop.arrived = 0;
-	g_loop.slots.assign((size_t) nranks * 256, 0.0);
+	g_loop.slots.assign((size_t) nranks * kRedMax, 0.0);
 	return 0;
 }
 

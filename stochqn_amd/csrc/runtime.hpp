@@ -28,6 +28,7 @@ struct Options {
 	int combine_batch = 8;       // packs a lane finishes in pass B before it stores them
 	bool reverse = true;
 	bool twopass = true;         // scalar-H0 two-loop in the two-pass (Gram) form when the ring has <= kPairsMax pairs
+	bool twopass_h0 = false;     // adaQN (diagonal H0) in the two-pass form as well
 	bool strict_grad = true;
 };
 int default_grid_cap();
@@ -52,6 +53,11 @@ struct DevCtx {
 	double* host_stage[2] = {nullptr, nullptr};       // pinned host landing zones for *req / *req_vec
 	double* pin = nullptr;             // pinned host read-back block
 	size_t pin_count = 0;
+	// what the caller's struct looked like when the last call on this context returned; a call that
+	// does not continue from there belongs to a different optimiser object at the same address
+	bool has_last = false;
+	size_t last_niter = 0;
+	int last_section = 0;
 	std::vector<char> rho_ok;          // per physical row: sc.sy / sc.yy hold this row's dots
 	std::vector<char> gram_ok;         // per physical row: its row and column of sc.gsy / sc.gyy are current
 	void touch_row(size_t r) { rho_ok[r] = 0; gram_ok[r] = 0; }   // row r of S or Y was rewritten
@@ -65,6 +71,7 @@ bool is_device_pointer(const void* p);
 // Find or create the context of a workspace.  `fresh` tells the caller whether it was created now.
 DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* fresh);
 DevCtx* lookup(const void* key);
+void note_state(const void* key, size_t niter, int section);   // remember the caller-visible state on return
 void release(const void* key);
 void release_all();
 

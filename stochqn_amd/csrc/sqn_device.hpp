@@ -16,11 +16,13 @@ constexpr int kMaxSums = 3;       // sums one sweep can produce (s'y, s's, y'y)
 constexpr int kFisherRows = 8;    // Fisher rows one workgroup accumulates per pass-1 sweep
 constexpr int kRowsMax = 48;      // rows one rows-dot launch can take (one accumulator per row and lane)
 constexpr int kPairsMax = 24;     // largest ring the two-pass form handles (2*kPairsMax rows per launch)
+constexpr int kQuantMax = 3 * kPairsMax + kPairsMax * (kPairsMax + 1) / 2;   // 372: quantities of the diagonal-H0 pass A
+constexpr int kRedMax = 384;      // doubles per all-reduce landing zone (>= kQuantMax, >= 3*kRowsMax)
 
 // Kernel ids for the built-in HIP-event profiler (stochqn_hip_profile_*).
 enum KernelId {
 	K_FIRST = 0, K_BWD, K_MID, K_FWD, K_FWD_LAST, K_APPLY, K_PAIR_S, K_PAIR_Y_DIFF, K_PAIR_Y_HV,
-	K_DOTS3, K_FISHER_T, K_FISHER_Y, K_FIN, K_SMALL, K_COPY, K_ROWS_DOT, K_COEF, K_COMBINE, K_GRAM, K_ROWS_DOT3, K_COUNT
+	K_DOTS3, K_FISHER_T, K_FISHER_Y, K_FIN, K_SMALL, K_COPY, K_ROWS_DOT, K_COEF, K_COMBINE, K_GRAM, K_ROWS_DOT3, K_GRAM_H0, K_COUNT
 };
 const char* kernel_name(int id);
 
@@ -77,13 +79,13 @@ struct Scratch {
 	hipStream_t stream;
 	double* part[2];      // two ping-pong partial buffers, each kMaxSums * kMaxGrid doubles
 	double* fisher_part;  // [fisher_size][kMaxGrid] partials of pass 1 (lazily sized)
-	double* red[2];       // all-reduce landing zones, 256 doubles each
+	double* red[2];       // all-reduce landing zones, kRedMax doubles each
 	double* sy;           // [m] s'y of each physical row (rho = 1/sy)
 	double* yy;           // [m] y'y of each physical row (gamma = sy/yy)
 	double* alpha;        // [m] alpha by logical index
 	double* rho;          // [m] rho by logical index (for buffer_rho write-back)
 	double* report;       // [4]: bad flag, sum r^2, nonfinite count, spare
-	double* rows_part[2]; // two [3*kRowsMax][kMaxGrid] partial buffers of rows-dot launches (up to 3 probes)
+	double* rows_part[2]; // two [kRedMax][kMaxGrid] partial buffers of rows-dot / Gram passes
 	double* gsy;          // [m][m] Gram block  gsy[i*m+j] = s_i'y_j   (physical rows)
 	double* gyy;          // [m][m] Gram block  gyy[i*m+j] = y_i'y_j
 	double* coef;         // [1 + 2*kPairsMax]: gamma, then the y- and s-coefficients of the combine pass
@@ -189,8 +191,27 @@ struct CoefArgs {
 };
 void launch_gram_store_fused(const Scratch& sc, Partials p /*3 x 2k quantities of a 3-probe pass A*/, const CoefArgs& a, int r);
 void launch_coef(const Scratch& sc, Partials b /*2k: s_i'g then y_i'g, logical order*/, const CoefArgs& a);
-// r (in place of g) and the guard sums (sum r^2, nonfinite)
-Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& y_rows, const RowSet& s_rows, double* g);
+// r (in place of g) and the guard sums (sum r^2, nonfinite).  With H0 != NULL (adaQN):
+// r = H0 .* (g + sum cy_j y_j) + sum cs_j s_j, else r = coef[0] g + sum cy_j y_j + sum cs_j s_j.
+Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& y_rows, const RowSet& s_rows, double* g,
+                        const double* H0 = nullptr);
+
+// ---- two-pass form with the diagonal H0 of adaQN -----------------------------------------------------
+// r_0 = H0 .* q_0 makes the forward loop need H0-weighted inner products: u_i = sum y_i H0 g and
+// W_ij = sum y_i H0 y_j.  H0 changes every step, so they are recomputed every step -- in the same pass
+// over S and Y that yields [S;Y]g and applies adaQN's side effects on the raw gradient
+// (G <- update, H0 <- g/sqrt(G+eps), Fisher row <- g; reference src/stochqn.c:738-781,1174).
+struct GramH0Args {
+	RowSet s_rows, y_rows;     // the k pairs in use, logical order
+	const double* g;
+	double* G;
+	double* H0_out;
+	double* frow_out;          // nullable
+	double rmsprop_weight, scal_reg;
+};
+// quantities: [0,k) s_i'g, [k,2k) y_i'g, [2k,3k) u_i, then W_ij for i <= j row by row
+Partials launch_gram_h0(const Scratch& sc, size_t n, const GramH0Args& a);
+void launch_coef_h0(const Scratch& sc, Partials b, const CoefArgs& a);
 
 // reduce `nsums` partial arrays to scalars: out[j] = sum_b parts[j*stride+b]
 void launch_fin(const Scratch& sc, Partials in, int nsums, double* out);

@@ -151,6 +151,19 @@ class _StochQN_free:
         """Hand over the gradient that the last request asked for."""
         self._sp.assign(self.gradient, gradient)
 
+    def release(self):
+        """Free the device context that mirrors this object's arrays (the reference's Python
+        objects have no such call; the library also recognises a recycled address by itself)."""
+        if getattr(self, "initialized", False) and hasattr(self._be.lib, "stochqn_hip_release"):
+            import ctypes
+            self._be.lib.stochqn_hip_release(ctypes.c_void_p(self._sp.ptr(self.BFGS_mem.s_mem)))
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
     # -- helpers -----------------------------------------------------------------------------
     def _check_x(self, x):
         if not self._sp.is_array(x):

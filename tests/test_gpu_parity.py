@@ -18,14 +18,17 @@ TOL = 1e-10
 
 @pytest.fixture(params=["twopass", "sweeps"])
 def form(request, hip_backend):
-    """Run a test once per implementation of the scalar-H0 two-loop: the two-pass (Gram) form that
-    is the default, and the chain of dependent sweeps (adaQN always uses the latter)."""
+    """Run a test once per implementation of the two-loop: the two-pass (Gram) form -- for the
+    scalar H0 of oLBFGS / SQN and for adaQN's diagonal H0 -- and the chain of dependent sweeps."""
     import stochqn_amd
     lib = stochqn_amd.cdll()
     lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
-    assert lib.stochqn_hip_set_option(b"twopass", 1.0 if request.param == "twopass" else 0.0) == 0
+    on = 1.0 if request.param == "twopass" else 0.0
+    assert lib.stochqn_hip_set_option(b"twopass", on) == 0
+    assert lib.stochqn_hip_set_option(b"twopass_h0", on) == 0
     yield request.param
     lib.stochqn_hip_set_option(b"twopass", 1.0)
+    lib.stochqn_hip_set_option(b"twopass_h0", 0.0)
 
 
 def torch_cuda():
