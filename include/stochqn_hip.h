@@ -50,7 +50,11 @@ int stochqn_hip_export(const void *s_mem);
  * "twopass"     (default 1)  scalar-H0 two-loop (oLBFGS, SQN) in the two-pass form: inner products
  *                            of g with all stored pairs, O(m^2) scalar recursion over cached Gram
  *                            blocks, one combine pass -- (4m+3)n words instead of 8mn; 0 = the
- *                            chain of 2m+1 dependent sweeps (always used by adaQN and for m > 24)
+ *                            chain of 2m+1 dependent sweeps (always used for m > 24)
+ * "twopass_h0"  (default 1)  the same for adaQN's diagonal H0: the H0-weighted inner products are
+ *                            recomputed every step in the pass that also applies adaQN's side
+ *                            effects on the raw gradient (needs "twopass" = 1 as well)
+ * "rows_grid", "rows_split", "combine_batch", "h0_per_cu": kernel-shape knobs, see DESIGN.md 3.2
  * "strict_grad" (default 1)  host callers: copy the search direction back into `grad`
  * Returns 0, or -1 for an unknown name. Applies to contexts created afterwards and existing ones. */
 int stochqn_hip_set_option(const char *name, double value);

@@ -3,7 +3,7 @@ import ctypes as C, json, sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import stochqn_amd
-from stochqn_amd import SQN_free, oLBFGS_free
+from stochqn_amd import SQN_free, oLBFGS_free, adaQN_free
 lib = stochqn_amd.cdll()
 lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
 lib.stochqn_hip_profile_name.restype = C.c_char_p
@@ -24,14 +24,19 @@ def setup(kind, n, m, L):
     x = 1 + torch.rand(n, dtype=torch.float64, device=dev, generator=g)
     if kind == "sqn":
         opt = SQN_free(mem_size=m, bfgs_upd_freq=1, min_curvature=None, space="device")
+    elif kind == "adaqn":
+        opt = adaQN_free(mem_size=m, fisher_size=16, bfgs_upd_freq=2, max_incr=None, min_curvature=None, scal_reg=1e-4,
+                         rmsprop_weight=0.9, space="device")
     else:
         opt = oLBFGS_free(mem_size=m, min_curvature=None, space="device")
     return opt, d, dn, x
 
+INFOS = {}
 def advance(opt, d, dn, x, step, k):
     target = (opt.niter if opt.initialized else 0) + k
     while (opt.niter if opt.initialized else 0) < target:
         r = opt.run_optimizer(x, step)
+        INFOS[r["info"]["iteration_info"]] = INFOS.get(r["info"]["iteration_info"], 0) + 1
         if r["task"] in ("calc_grad", "calc_grad_same_batch"): torch.mul(dn, r["requested_on"], out=opt.gradient)
         elif r["task"] == "calc_hess_vec": torch.mul(d, r["requested_on"][1], out=opt.hess_vec)
 
@@ -47,13 +52,16 @@ if __name__ == "__main__":
     kind, n, m = sys.argv[1], int(float(sys.argv[2])), int(sys.argv[3])
     variants = [json.loads(a) for a in sys.argv[4:]] or [{}]
     opt, d, dn, x = setup(kind, n, m, 1)
-    advance(opt, d, dn, x, 0.01, m + 3)          # fill the ring (L=1)
+    advance(opt, d, dn, x, 1e-4 if kind == "adaqn" else 0.01, (2 * m + 6) if kind == "adaqn" else (m + 3))   # fill the ring
+    print("after fill: niter", opt.niter, "mem_used", opt.BFGS_mem.mem_used, INFOS, flush=True)
+    if kind == "adaqn":
+        opt.BFGS_mem.upd_freq = opt.bfgs_upd_freq = 1000000      # no more pair updates: time the step path only
     if kind == "sqn":
         opt.BFGS_mem.upd_freq = opt.bfgs_upd_freq = 10
         opt.niter = 10 * ((opt.niter + 9) // 10)
-    base = {"grid_cap": 0, "rows_grid": 0, "rows_split": 0, "reverse": 1, "twopass": 1, "nontemporal": 1, "combine_batch": 8}
+    base = {"grid_cap": 0, "rows_grid": 0, "rows_split": 0, "reverse": 1, "twopass": 1, "nontemporal": 1, "combine_batch": 8, "twopass_h0": 0, "h0_per_cu": 0}
     for rep in range(2):
         for v in variants:
             o = dict(base); o.update(v)
-            ms, k = measure(opt, d, dn, x, 0.01, 20, o)
+            ms, k = measure(opt, d, dn, x, 1e-4 if kind == "adaqn" else 0.01, 20, o)
             print(json.dumps({"variant": v, "ms_per_step": ms, "kernels": k}), flush=True)

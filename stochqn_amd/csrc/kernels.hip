@@ -924,8 +924,8 @@ __global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const 
 // quantity(rowA, rowB) += sum_e L[rowA][e] L[rowB][e].  No cross-lane reduction at all; the
 // per-workgroup partial of a quantity is that thread's accumulator.
 // ------------------------------------------------------------------------------------------------
-constexpr int kTile = 128;
-constexpr int kTileLd = kTile + 1;     // odd LDS row stride: threads of a wave read different rows at the same column
+constexpr int kTile = 128;             // columns per tile: lane l stages columns 2l, 2l+1 and accumulates l, l+64
+constexpr int kTileLd = kTile + 2;     // LDS row stride in doubles (even: 16-B aligned pairs)
 
 // two neighbouring columns of a row: one 16-B access when every row is 16-B aligned (VEC), else two
 // 8-B accesses; columns at or beyond n read as `fill` and are never written
@@ -946,109 +946,120 @@ template <bool VEC> __device__ __forceinline__ void st_cols(double* p, uint32_t 
 	else { if (i < n) p[i] = v.x; if (i + 1 < n) p[i + 1] = v.y; }
 }
 
-template <bool VEC>
-__global__ void __launch_bounds__(kBlock) k_gram_h0(GramH0Args a, bool rms, double w_old, double w_new, uint32_t n, double* parts)
+// The body of k_gram_h0 for wave WAVE of the workgroup.  KT = ring size rounded up (compile time), so
+// that every accumulator has a compile-time register: this wave owns the pairs whose older index is
+// i = WAVE, WAVE+4, ...: u_i, y_i'g, s_i'g and W_ij for j >= i -- per lane, per column, summed over
+// the lane's two columns of every tile; one shuffle reduction per quantity at the very end.
+template <int KT, int WAVE, bool VEC>
+__device__ __forceinline__ void gram_h0_wave(const GramH0Args& a, bool rms, double w_old, double w_new, uint32_t n, double* parts,
+                                             double* L)
 {
-	extern __shared__ double L[];      // (3k+2) rows x kTileLd: S | Y | Z | g | h
+	constexpr int kMine = (KT - WAVE + kWaves - 1) / kWaves;      // rows i = WAVE + 4*ii owned by this wave
 	const int k = a.s_rows.count;
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int rowG = 3 * k, rowH = 3 * k + 1;
-	const int Q = 3 * k + k * (k + 1) / 2;
-	// which (rowA, rowB) this thread accumulates
-	int qa[2], qb[2], nq = 0;
-	for (int q = threadIdx.x; q < Q; q += kBlock) {
-		int ra, rb;
-		if (q < k) { ra = q; rb = rowG; }                          // s_i'g
-		else if (q < 2 * k) { ra = q; rb = rowG; }                 // y_i'g   (row k+i)
-		else if (q < 3 * k) { ra = q; rb = rowG; }                 // u_i = z_i'g (row 2k+i)
-		else {                                                     // W_ij, i <= j, rows enumerated i-major
-			int t = q - 3 * k, i = 0;
-			while (t >= k - i) { t -= k - i; i++; }
-			ra = 2 * k + i;                                        // z_i
-			rb = k + i + t;                                        // y_j, j = i + t
-		}
-		qa[nq] = ra; qb[nq] = rb; nq++;
+	const int lane = threadIdx.x & 63;
+	const int rowG = 2 * k, rowH = 2 * k + 1;
+	double aS[kMine], aY[kMine], aU[kMine], aW[kMine][KT];         // aW[ii][j] used for j >= i only (rest folds away)
+	#pragma unroll
+	for (int ii = 0; ii < kMine; ii++) {
+		aS[ii] = aY[ii] = aU[ii] = 0;
+		#pragma unroll
+		for (int j = 0; j < KT; j++) aW[ii][j] = 0;
 	}
-	double acc[2] = {0, 0}, acc_odd[2] = {0, 0};      // two chains per quantity: even / odd columns
 	const uint32_t tiles = (n + kTile - 1) / kTile;
-	constexpr int kShare = (kPairsMax + kWaves - 1) / kWaves;
-	d2 sv[kShare], yv[kShare], gv = {0, 0}, Gv = {1, 1};
-	// software pipeline: the row tiles of the NEXT tile are fetched into registers while this one
-	// is being accumulated out of LDS, so that the HBM latency is paid under the LDS phase
-	auto fetch = [&](uint32_t tile) {
-		const uint32_t i = tile * kTile + 2 * lane;
-		const uint32_t lim = tile < tiles ? n : 0;                 // past the last tile: everything reads as fill
-		#pragma unroll
-		for (int u = 0; u < kShare; u++) {
-			const int r = wave + u * kWaves;
-			sv[u] = (r < k) ? ld_cols<VEC, true>(a.s_rows.row[r], i, lim, 0.0) : d2{0, 0};
-			yv[u] = (r < k) ? ld_cols<VEC, true>(a.y_rows.row[r], i, lim, 0.0) : d2{0, 0};
-		}
-		if (wave == 0) {
-			gv = ld_cols<VEC, false>(a.g, i, lim, 0.0);
-			Gv = ld_cols<VEC, false>(a.G, i, lim, 1.0);
-		}
-	};
-	fetch(blockIdx.x);
 	for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-		const uint32_t i = tile * kTile + 2 * lane;                // this lane's two columns
-		// -- stage the fetched registers into LDS
-		d2 yk[kShare];
+		const uint32_t i0 = tile * kTile + 2 * lane;               // the two columns this lane stages
+		// -- stage: rows r = WAVE + 4u of S and Y (all loads first), wave 0 also g, G and the side effects
+		d2 sv[kMine], yv[kMine];
 		#pragma unroll
-		for (int u = 0; u < kShare; u++) {
-			const int r = wave + u * kWaves;
-			yk[u] = yv[u];
-			if (r < k) {
-				L[r * kTileLd + 2 * lane] = sv[u].x; L[r * kTileLd + 2 * lane + 1] = sv[u].y;
-				L[(k + r) * kTileLd + 2 * lane] = yv[u].x; L[(k + r) * kTileLd + 2 * lane + 1] = yv[u].y;
-			}
+		for (int u = 0; u < kMine; u++) {
+			const int r = WAVE + u * kWaves;
+			sv[u] = (r < k) ? ld_cols<VEC, true>(a.s_rows.row[r], i0, n, 0.0) : d2{0, 0};
+			yv[u] = (r < k) ? ld_cols<VEC, true>(a.y_rows.row[r], i0, n, 0.0) : d2{0, 0};
 		}
-		if (wave == 0) {
+		if constexpr (WAVE == 0) {
+			const d2 gv = ld_cols<VEC, false>(a.g, i0, n, 0.0);
+			const d2 Gv = ld_cols<VEC, false>(a.G, i0, n, 1.0);
 			d2 Gn, h;
 			Gn.x = rms ? (w_old * Gv.x + w_new * (gv.x * gv.x)) : (Gv.x + gv.x * gv.x);      // reference :738 / :745
 			Gn.y = rms ? (w_old * Gv.y + w_new * (gv.y * gv.y)) : (Gv.y + gv.y * gv.y);
 			h.x = gv.x / sqrt(Gn.x + a.scal_reg);                                                // :781
 			h.y = gv.y / sqrt(Gn.y + a.scal_reg);
-			st_cols<VEC>(a.G, i, n, Gn);
-			st_cols<VEC>(a.H0_out, i, n, h);
-			if (a.frow_out) st_cols<VEC>(a.frow_out, i, n, gv);
-			if (i >= n) h.x = 0;                                   // columns beyond n must not contribute
-			if (i + 1 >= n) h.y = 0;
-			L[rowG * kTileLd + 2 * lane] = gv.x; L[rowG * kTileLd + 2 * lane + 1] = gv.y;
-			L[rowH * kTileLd + 2 * lane] = h.x;  L[rowH * kTileLd + 2 * lane + 1] = h.y;
+			st_cols<VEC>(a.G, i0, n, Gn);
+			st_cols<VEC>(a.H0_out, i0, n, h);
+			if (a.frow_out) st_cols<VEC>(a.frow_out, i0, n, gv);
+			if (i0 >= n) h.x = 0;                                  // columns beyond n must not contribute
+			if (i0 + 1 >= n) h.y = 0;
+			*reinterpret_cast<d2*>(L + rowG * kTileLd + 2 * lane) = gv;
+			*reinterpret_cast<d2*>(L + rowH * kTileLd + 2 * lane) = h;
 		}
-		fetch(tile + gridDim.x);                                   // next tile's loads are now in flight
-		__syncthreads();
-		const double hx = L[rowH * kTileLd + 2 * lane], hy = L[rowH * kTileLd + 2 * lane + 1];
 		#pragma unroll
-		for (int u = 0; u < kShare; u++) {
-			const int r = wave + u * kWaves;
-			if (r < k) { L[(2 * k + r) * kTileLd + 2 * lane] = yk[u].x * hx; L[(2 * k + r) * kTileLd + 2 * lane + 1] = yk[u].y * hy; }
+		for (int u = 0; u < kMine; u++) {
+			const int r = WAVE + u * kWaves;
+			if (r < k) {
+				*reinterpret_cast<d2*>(L + r * kTileLd + 2 * lane) = sv[u];
+				*reinterpret_cast<d2*>(L + (k + r) * kTileLd + 2 * lane) = yv[u];
+			}
 		}
 		__syncthreads();
-		// -- accumulate: one or two quantities per thread over the tile's columns
-		if (nq > 0) {
-			const double* A0 = L + qa[0] * kTileLd;
-			const double* B0 = L + qb[0] * kTileLd;
-			if (nq == 1) {
-				#pragma unroll 8
-				for (int e = 0; e < kTile; e += 2) { acc[0] = fma(A0[e], B0[e], acc[0]); acc_odd[0] = fma(A0[e + 1], B0[e + 1], acc_odd[0]); }
-			} else {
-				const double* A1 = L + qa[1] * kTileLd;
-				const double* B1 = L + qb[1] * kTileLd;
-				#pragma unroll 4
-				for (int e = 0; e < kTile; e += 2) {
-					acc[0] = fma(A0[e], B0[e], acc[0]); acc_odd[0] = fma(A0[e + 1], B0[e + 1], acc_odd[0]);
-					acc[1] = fma(A1[e], B1[e], acc[1]); acc_odd[1] = fma(A1[e + 1], B1[e + 1], acc_odd[1]);
+		// -- accumulate: columns lane and lane + 64 of the tile, all of this wave's quantities in registers
+		#pragma unroll
+		for (int half = 0; half < 2; half++) {
+			const int c = lane + 64 * half;
+			const double gc = L[rowG * kTileLd + c], hc = L[rowH * kTileLd + c];
+			double y[KT];
+			#pragma unroll
+			for (int j = 0; j < KT; j++) y[j] = (j < k) ? L[(k + j) * kTileLd + c] : 0.0;
+			#pragma unroll
+			for (int ii = 0; ii < kMine; ii++) {
+				constexpr int dummy = 0; (void) dummy;
+				const int i = WAVE + ii * kWaves;
+				if (i < k) {
+					const double sc_ = L[i * kTileLd + c];
+					const double z = y[i] * hc;
+					aS[ii] = fma(sc_, gc, aS[ii]);
+					aY[ii] = fma(y[i], gc, aY[ii]);
+					aU[ii] = fma(z, gc, aU[ii]);
+					#pragma unroll
+					for (int j = 0; j < KT; j++)
+						if (j >= i) aW[ii][j] = fma(z, y[j], aW[ii][j]);   // j >= k adds z*0
 				}
 			}
 		}
 		__syncthreads();
 	}
-	acc[0] += acc_odd[0];
-	acc[1] += acc_odd[1];
-	int j = 0;
-	for (int q = threadIdx.x; q < Q; q += kBlock) parts[(size_t) q * kMaxGrid + blockIdx.x] = acc[j++];
+	// -- one partial per quantity and workgroup
+	#pragma unroll
+	for (int ii = 0; ii < kMine; ii++) {
+		const int i = WAVE + ii * kWaves;
+		if (i < k) {
+			const double tS = wave_sum(aS[ii]), tY = wave_sum(aY[ii]), tU = wave_sum(aU[ii]);
+			if (lane == 0) {
+				parts[(size_t) i * kMaxGrid + blockIdx.x] = tS;
+				parts[(size_t) (k + i) * kMaxGrid + blockIdx.x] = tY;
+				parts[(size_t) (2 * k + i) * kMaxGrid + blockIdx.x] = tU;
+			}
+			const int base = 3 * k + i * k - (i * (i - 1)) / 2;        // first W_ij of row i (i-major, j >= i)
+			#pragma unroll
+			for (int j = 0; j < KT; j++) {
+				if (j >= i && j < k) {
+					const double t = wave_sum(aW[ii][j]);
+					if (lane == 0) parts[(size_t) (base + j - i) * kMaxGrid + blockIdx.x] = t;
+				}
+			}
+		}
+	}
+}
+
+template <int KT, bool VEC>
+__global__ void __launch_bounds__(kBlock) k_gram_h0(GramH0Args a, bool rms, double w_old, double w_new, uint32_t n, double* parts)
+{
+	extern __shared__ __attribute__((aligned(16))) double L[];       // (2k+2) rows x kTileLd: S | Y | g | h
+	switch (threadIdx.x >> 6) {
+	case 0: gram_h0_wave<KT, 0, VEC>(a, rms, w_old, w_new, n, parts, L); break;
+	case 1: gram_h0_wave<KT, 1, VEC>(a, rms, w_old, w_new, n, parts, L); break;
+	case 2: gram_h0_wave<KT, 2, VEC>(a, rms, w_old, w_new, n, parts, L); break;
+	default: gram_h0_wave<KT, 3, VEC>(a, rms, w_old, w_new, n, parts, L); break;
+	}
 }
 
 // Scalar recursion for the diagonal-H0 form.  Backward loop as in k_coef; forward loop with
@@ -1442,30 +1453,38 @@ Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, 
 	return finish(sc, buf, 2, grid);
 }
 
+template <int KT>
+static void gram_h0_dispatch(const Scratch& sc, int grid, size_t shmem, bool vec, const GramH0Args& a, bool rms, uint32_t n)
+{
+	static bool lds_opt_in = false;
+	if (!lds_opt_in) {
+		const int bytes = (int) ((2 * kPairsMax + 2) * kTileLd * sizeof(double));
+		(void) hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_h0<KT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+		(void) hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_h0<KT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+		lds_opt_in = true;
+	}
+	if (vec) hipLaunchKernelGGL((k_gram_h0<KT, true>), dim3(grid), dim3(kBlock), shmem, sc.stream, a, rms, a.rmsprop_weight, 1 - a.rmsprop_weight, n, sc.rows_part[0]);
+	else     hipLaunchKernelGGL((k_gram_h0<KT, false>), dim3(grid), dim3(kBlock), shmem, sc.stream, a, rms, a.rmsprop_weight, 1 - a.rmsprop_weight, n, sc.rows_part[0]);
+}
+
 Partials launch_gram_h0(const Scratch& sc, size_t n, const GramH0Args& a)
 {
 	const int k = a.s_rows.count;
 	const int Q = 3 * k + k * (k + 1) / 2;
-	const size_t shmem = (size_t) (3 * k + 2) * kTileLd * sizeof(double);
+	const size_t shmem = (size_t) (2 * k + 2) * kTileLd * sizeof(double);
 	size_t tiles = (n + kTile - 1) / kTile;
-	size_t g = (size_t) sc.grid_cap * 2;              // LDS allows two resident workgroups per CU: one loads while one accumulates
+	size_t g = (size_t) sc.grid_cap * (sc.h0_per_cu > 0 ? sc.h0_per_cu : 2);   // workgroups that stage while others accumulate
 	if (g > tiles) g = tiles;
 	if (g > (size_t) kMaxGrid) g = kMaxGrid;
 	if (g < 1) g = 1;
 	const int grid = (int) g;
 	const bool rms = a.rmsprop_weight > 0 && a.rmsprop_weight < 1;
 	const bool vec = rows_aligned(a.s_rows) && rows_aligned(a.y_rows) && all_aligned(a.g, a.G, a.H0_out, a.frow_out) && n % 2 == 0;
-	static bool lds_opt_in = false;
-	if (!lds_opt_in) {     // up to (3*24+2) x 129 doubles = 76 KiB of dynamic LDS
-		const int bytes = (int) ((3 * kPairsMax + 2) * kTileLd * sizeof(double));
-		(void) hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_h0<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-		(void) hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_h0<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-		lds_opt_in = true;
-	}
 	{
 		ProfScope ps(sc, K_GRAM_H0);
-		if (vec) hipLaunchKernelGGL(k_gram_h0<true>, dim3(grid), dim3(kBlock), shmem, sc.stream, a, rms, a.rmsprop_weight, 1 - a.rmsprop_weight, (uint32_t) n, sc.rows_part[0]);
-		else     hipLaunchKernelGGL(k_gram_h0<false>, dim3(grid), dim3(kBlock), shmem, sc.stream, a, rms, a.rmsprop_weight, 1 - a.rmsprop_weight, (uint32_t) n, sc.rows_part[0]);
+		if (k <= 12) gram_h0_dispatch<12>(sc, grid, shmem, vec, a, rms, (uint32_t) n);
+		else if (k <= 20) gram_h0_dispatch<20>(sc, grid, shmem, vec, a, rms, (uint32_t) n);
+		else gram_h0_dispatch<24>(sc, grid, shmem, vec, a, rms, (uint32_t) n);
 	}
 	Partials raw{sc.rows_part[0], grid, kMaxGrid};
 	if (!sc.allreduce) return raw;

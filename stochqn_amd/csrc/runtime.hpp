@@ -28,7 +28,8 @@ struct Options {
 	int combine_batch = 8;       // packs a lane finishes in pass B before it stores them
 	bool reverse = true;
 	bool twopass = true;         // scalar-H0 two-loop in the two-pass (Gram) form when the ring has <= kPairsMax pairs
-	bool twopass_h0 = false;     // adaQN (diagonal H0) in the two-pass form as well
+	int h0_per_cu = 0;
+	bool twopass_h0 = true;      // adaQN (diagonal H0) in the two-pass form as well
 	bool strict_grad = true;
 };
 int default_grid_cap();

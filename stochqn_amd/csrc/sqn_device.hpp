@@ -93,6 +93,7 @@ struct Scratch {
 	int rows_grid;        // workgroups of a row-split rows-dot pass; 0 = CUs x resident workgroups per CU
 	bool rows_split;      // use the row-split rows-dot kernel for single-probe passes too
 	int combine_batch;    // packs a lane finishes in pass B before storing them (1, 2, 4, 8)
+	int h0_per_cu;        // workgroups per CU of the diagonal-H0 Gram pass (0 = 2)
 	bool nontemporal;     // stream S/Y/F rows with nt loads
 	bool reverse;         // alternate the traversal direction from sweep to sweep (Infinity-Cache reuse of q / r)
 	int* phase;           // sweep counter of the current API call (parity = direction)

@@ -28,7 +28,7 @@ def form(request, hip_backend):
     assert lib.stochqn_hip_set_option(b"twopass_h0", on) == 0
     yield request.param
     lib.stochqn_hip_set_option(b"twopass", 1.0)
-    lib.stochqn_hip_set_option(b"twopass_h0", 0.0)
+    lib.stochqn_hip_set_option(b"twopass_h0", 1.0)
 
 
 def torch_cuda():

@@ -139,12 +139,15 @@ def c4():
     nearly parallel gradients are degenerate), which flushes the ring and would understate the cost."""
     n, m, f = 100_000_000, 20, 128
     P = DeviceQuadratic(n)
-    for max_incr in (None, 1.01):
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    for name, val in [kv.split("=") for kv in os.environ.get("SQN_OPTS", "").split(",") if kv]:
+        assert lib.stochqn_hip_set_option(name.encode(), float(val)) == 0
+    for max_incr in (None,) if os.environ.get("C4_QUICK") else (None, 1.01):
         x = P.x0.clone()
         opt = adaQN_free(mem_size=m, fisher_size=f, bfgs_upd_freq=20, max_incr=max_incr, min_curvature=1e-4,
                          scal_reg=1e-4, rmsprop_weight=0.9, space="device")
         dt, calls = drive(opt, P, x, 1e-3, 40, 400)
-        report("C4", "adaQN n=1e8 m=20 fisher_size=128 L=20 rmsprop=0.9 max_incr=%s, device-resident" % max_incr, n, m, dt, 40, calls,
+        report("C4", "adaQN n=1e8 m=20 fisher_size=128 L=20 rmsprop=0.9 max_incr=%s, device-resident, opts=%s" % (max_incr, os.environ.get("SQN_OPTS", "")), n, m, dt, 40, calls,
                {"mem_used": opt.BFGS_mem.mem_used, "fisher_used": opt.Fisher_mem.mem_used, "f_end": P.f(x), "f_start": P.f(P.x0)})
 
 
