@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=10_000_000)
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-GPU code path (process group, RCCL communicator) even with one rank")
     ap.add_argument("--no-reference-form", action="store_true",
                     help="skip the extra untimed steps in the reference's sweep form")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -53,6 +55,11 @@ def parse():
 
 def main():
     args = parse()
+    # Everything that libraries print on fd 1 (RCCL's version banner, for one) goes to stderr; the one
+    # JSON line is written to the real stdout at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import stochqn_amd
     from stochqn_amd import _abi
@@ -76,9 +83,11 @@ def main():
         assert lib.stochqn_hip_set_option(name.encode(), float(val)) == 0, kv
 
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             buf = (C.c_ubyte * 128)()
@@ -303,7 +312,7 @@ def main():
             "kernels": detail,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         lib.stochqn_hip_comm_finalize()
         dist.destroy_process_group()
