@@ -58,6 +58,15 @@ void to_host(DevCtx* c, void* dst, const double* src, size_t count)
 	SQN_HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
 }
 
+// Copy a few scalars that were read back into the pinned block on to a caller buffer (buffer_rho,
+// buffer_alpha, buffer_y), which may itself live in host or in device memory.  After sync() only.
+void hand_back(double* dst, const double* pinned, size_t count)
+{
+	if (!dst || count == 0) return;
+	if (is_device_pointer(dst)) SQN_HIP_OK(hipMemcpy(dst, pinned, count * sizeof(double), hipMemcpyHostToDevice));
+	else std::memcpy(dst, pinned, count * sizeof(double));
+}
+
 bool bind_bfgs(DevCtx* c, bfgs_mem* b, bool import_rows)
 {
 	const size_t n = N(c), m = b->mem_size;
@@ -341,15 +350,9 @@ void enqueue_step(Call& io, const StepIn& in)
 bool step_was_bad(Call& io, bfgs_mem* b, size_t used_before, int check_nan)
 {
 	DevCtx* c = io.c;
-	if (used_before > 0) {
-		double* dst[2] = {b->buffer_rho, b->buffer_alpha};
-		for (int j = 0; j < 2; j++) {
-			if (!dst[j]) continue;
-			if (is_device_pointer(dst[j]))
-				SQN_HIP_OK(hipMemcpy(dst[j], c->pin + 8 + j * c->m, used_before * sizeof(double), hipMemcpyHostToDevice));
-			else
-				std::memcpy(dst[j], c->pin + 8 + j * c->m, used_before * sizeof(double));
-		}
+	if (used_before > 0) {                            // pinned block: report[8] | rho[m] | alpha[m]
+		hand_back(b->buffer_rho, c->pin + 8, used_before);
+		hand_back(b->buffer_alpha, c->pin + 8 + c->m, used_before);
 	}
 	return check_nan && c->pin[0] != 0.0;       // unguarded: the step is always taken
 }
@@ -727,12 +730,7 @@ static int run_adaQN_impl(real_t step_size, real_t x[], real_t f, real_t grad[],
 			Partials p = launch_fisher(c->sc, c->next_buf(), n, c->F.dev, fm->mem_used, row(c->S, st, c), c->fisher_t, row(c->Y, st, c));
 			if (fm->buffer_y) to_host(c, c->pin + 8 + 2 * c->m, c->fisher_t, fm->mem_used);
 			accept_or_reject(c, b, p, iter_info);
-			if (fm->buffer_y) {
-				if (is_device_pointer(fm->buffer_y))
-					SQN_HIP_OK(hipMemcpy(fm->buffer_y, c->pin + 8 + 2 * c->m, fm->mem_used * sizeof(double), hipMemcpyHostToDevice));
-				else
-					std::memcpy(fm->buffer_y, c->pin + 8 + 2 * c->m, fm->mem_used * sizeof(double));
-			}
+			hand_back(fm->buffer_y, c->pin + 8 + 2 * c->m, fm->mem_used);
 			if (*iter_info == no_problems_encountered) d2d(c, c->xprev.dev, c->xsum.dev, n);
 			zero(c, c->xsum.dev, n);
 			sync(c);
@@ -979,19 +977,13 @@ int stochqn_hip_two_loop(double grad[], int n, double H0[], double h0, double y_
 		(void) enqueue_two_pass(c, g, mem_used, mem_st_ix % mem_size, h0, nullptr);
 	} else {
 		FirstArgs fa{};
-		ApplyArgs none{};
-		(void) none;
 		(void) enqueue_two_loop(c, g, mem_used, mem_st_ix % mem_size, fa, h0, H0 ? c->H0.dev : nullptr, nullptr);
 	}
 	to_host(c, c->pin, c->sc.report, 8 + 2 * c->m);
 	if (g_host) to_host(c, grad, g, nn);
 	sync(c);
-	double* dst[2] = {buffer_rho, buffer_alpha};
-	for (int j = 0; j < 2; j++) {
-		if (!dst[j]) continue;
-		if (is_device_pointer(dst[j])) SQN_HIP_OK(hipMemcpy(dst[j], c->pin + 8 + j * c->m, mem_used * sizeof(double), hipMemcpyHostToDevice));
-		else std::memcpy(dst[j], c->pin + 8 + j * c->m, mem_used * sizeof(double));
-	}
+	hand_back(buffer_rho, c->pin + 8, mem_used);
+	hand_back(buffer_alpha, c->pin + 8 + c->m, mem_used);
 	return 0;
 }
 
@@ -1017,10 +1009,7 @@ int stochqn_hip_fisher_product(double F[], size_t fu, int n, double s[], double 
 	to_host(c, c->pin + 8 + 2 * c->m, c->fisher_t, fu);
 	if (y_host) to_host(c, y, yd, nn);
 	sync(c);
-	if (buffer_y) {
-		if (is_device_pointer(buffer_y)) SQN_HIP_OK(hipMemcpy(buffer_y, c->pin + 8 + 2 * c->m, fu * sizeof(double), hipMemcpyHostToDevice));
-		else std::memcpy(buffer_y, c->pin + 8 + 2 * c->m, fu * sizeof(double));
-	}
+	hand_back(buffer_y, c->pin + 8 + 2 * c->m, fu);
 	return 0;
 }
 
