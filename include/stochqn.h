@@ -24,18 +24,23 @@
  *  Host arrays are mirrored in device memory behind the ABI; device arrays are used in place.
  *  See DESIGN.md ("boundary") and INTEGRATION.md.  Device-only extras live in stochqn_hip.h.
  *
- *  Only double precision is built (the R package is double-only, reference src/Makevars:1;
- *  every BASELINE configuration is fp64).  Defining USE_FLOAT is rejected below.
+ *  libstochqn.so is the double-precision library (the R package is double-only, reference
+ *  src/Makevars:1; every BASELINE configuration is fp64).  Compiling a caller with -DUSE_FLOAT selects
+ *  the single-precision ABI, which libstochqn_f32.so implements: vectors are stored and streamed as
+ *  float, every inner product and scalar of the recursion is accumulated in double.
  */
 #ifndef STOCHQN_INCLUDE
 #define STOCHQN_INCLUDE
 
 #include <stddef.h>
 
+/* Precision switch of reference include/stochqn.h:62-76.  Symbol names are the same in both
+ * precisions; as with the reference, a float caller links its own copy: libstochqn_f32.so. */
 #if defined(USE_FLOAT) && !defined(USE_DOUBLE)
-#   error "libstochqn (MI355X build) provides the double-precision ABI only"
+#   define real_t float
+#else
+#   define real_t double
 #endif
-#define real_t double
 
 #ifdef __cplusplus
 extern "C" {

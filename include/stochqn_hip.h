@@ -9,6 +9,7 @@
 #define STOCHQN_HIP_INCLUDE
 
 #include <stddef.h>
+#include "stochqn.h"   /* real_t */
 
 #ifdef __cplusplus
 extern "C" {
@@ -25,12 +26,12 @@ int stochqn_hip_available(void);
  * 1/(y_i's_i) and the newest pair's s'y / y'y are cached per (s_mem, row): after changing rows
  * of s_mem / y_mem from outside the library call stochqn_hip_invalidate(s_mem).
  * Returns 0 on success, -1000 on invalid input / no device. */
-int stochqn_hip_two_loop(double grad[], int n, double H0[], double h0, double y_mem[], double s_mem[],
-	size_t mem_size, size_t mem_used, size_t mem_st_ix, double buffer_rho[], double buffer_alpha[]);
+int stochqn_hip_two_loop(real_t grad[], int n, real_t H0[], real_t h0, real_t y_mem[], real_t s_mem[],
+	size_t mem_size, size_t mem_used, size_t mem_st_ix, real_t buffer_rho[], real_t buffer_alpha[]);
 
 /* Empirical Fisher product y = F'(F s)/fu of reference src/stochqn.c:946-949 (update_y_fisher
  * without the curvature check).  F is [fu][n] row-major.  Device or host pointers. */
-int stochqn_hip_fisher_product(double F[], size_t fu, int n, double s[], double buffer_y[], double y[]);
+int stochqn_hip_fisher_product(real_t F[], size_t fu, int n, real_t s[], real_t buffer_y[], real_t y[]);
 
 /* ---- device-context management ------------------------------------------------------------------
  * State that mirrors caller-owned HOST arrays lives in a context keyed by the address of

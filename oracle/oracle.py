@@ -13,17 +13,28 @@ sys.path.insert(0, os.path.dirname(_HERE))
 from stochqn_amd import _abi  # noqa: E402  (declarations only; does not load the HIP library)
 
 SO = os.path.join(_HERE, "liboracle.so")
+SO_F32 = os.path.join(_HERE, "liboracle_f32.so")
 
 
-def build(force=False):
+def build(force=False, use_float=False):
     src = os.path.join(_HERE, "stochqn_oracle.c")
-    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
-    return SO
+    so = SO_F32 if use_float else SO
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(so)], stdout=subprocess.DEVNULL)
+    return so
 
 
 _lib = None
 _bound = None
+_bound_f32 = None
+
+
+def bound_f32():
+    """The float build of the oracle (liboracle_f32.so) behind the float ABI."""
+    global _bound_f32
+    if _bound_f32 is None:
+        _bound_f32 = _abi.Bound(C.CDLL(build(use_float=True)), prefix="oracle_", use_float=True)
+    return _bound_f32
 
 
 def cdll():

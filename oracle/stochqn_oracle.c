@@ -26,6 +26,10 @@
  *  the compiled reference in SURVEY.md section 4 (committed as tests/golden/known_answers.json)
  *  and by example/c_rosen.c's printed output; see tests/test_oracle_known_answers.py.
  *
+ *  Precision: compiled as is for the double ABI (liboracle.so) and with -DUSE_FLOAT for the float ABI
+ *  (liboracle_f32.so): vectors and element-wise arithmetic in real_t, as in the reference's float
+ *  build, inner products accumulated in double (a BLAS is free to do either).
+ *
  *  Symbols are prefixed `oracle_` so that the oracle and libstochqn.so can live in one process.
  */
 #include <stdlib.h>
@@ -54,19 +58,19 @@ int  oracle_get_threads(void) { return g_threads; }
 
 #define PAR_MIN 262144  /* below this a vector op stays on the calling thread */
 
-static double dot_chunk(const double *a, const double *b, size_t lo, size_t hi)
+static double dot_chunk(const real_t *a, const real_t *b, size_t lo, size_t hi)
 {
 	double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	size_t i = lo;
 	for (; i + 8 <= hi; i += 8)
-		for (int k = 0; k < 8; k++) acc[k] += a[i + k] * b[i + k];
+		for (int k = 0; k < 8; k++) acc[k] += (double) a[i + k] * (double) b[i + k];
 	double tail = 0;
-	for (; i < hi; i++) tail += a[i] * b[i];
+	for (; i < hi; i++) tail += (double) a[i] * (double) b[i];
 	return (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]))) + tail;
 }
 
 /* ddot (reference call sites: src/stochqn.c:676,677,686,687,705,892) */
-static double v_dot(size_t n, const double *a, const double *b)
+static double v_dot(size_t n, const real_t *a, const real_t *b)
 {
 	int nt = (n < PAR_MIN) ? 1 : g_threads;
 	if (nt == 1) return dot_chunk(a, b, 0, n);
@@ -83,21 +87,21 @@ static double v_dot(size_t n, const double *a, const double *b)
 }
 
 /* daxpy: y += a*x (src/stochqn.c:678,706,838,923) */
-static void v_axpy(size_t n, double a, const double *x, double *y)
+static void v_axpy(size_t n, real_t a, const real_t *x, real_t *y)
 {
 	#pragma omp parallel for num_threads(g_threads) schedule(static) if (n >= PAR_MIN)
 	for (size_t i = 0; i < n; i++) y[i] += a * x[i];
 }
 
 /* dscal: x *= a (src/stochqn.c:289,688,698,1006) */
-static void v_scal(size_t n, double a, double *x)
+static void v_scal(size_t n, real_t a, real_t *x)
 {
 	#pragma omp parallel for num_threads(g_threads) schedule(static) if (n >= PAR_MIN)
 	for (size_t i = 0; i < n; i++) x[i] *= a;
 }
 
 /* dnrm2 (src/stochqn.c:829): overflow-safe two-pass form */
-static double v_nrm2(size_t n, const double *x)
+static double v_nrm2(size_t n, const real_t *x)
 {
 	double big = 0;
 	for (size_t i = 0; i < n; i++) { double a = fabs(x[i]); if (a > big) big = a; }
@@ -108,8 +112,8 @@ static double v_nrm2(size_t n, const double *x)
 	return big * sqrt(s);
 }
 
-static void v_copy(size_t n, const double *src, double *dst) { memcpy(dst, src, n * sizeof(double)); } /* :145-169 */
-static void v_zero(size_t n, double *x) { memset(x, 0, n * sizeof(double)); }                          /* :171-194 */
+static void v_copy(size_t n, const real_t *src, real_t *dst) { memcpy(dst, src, n * sizeof(real_t)); } /* :145-169 */
+static void v_zero(size_t n, real_t *x) { memset(x, 0, n * sizeof(real_t)); }                          /* :171-194 */
 
 /* ------------------------------------------------------------------------------------------
  * Ring-buffer bookkeeping (src/stochqn.c:554-610)
@@ -123,7 +127,7 @@ static void ring_advance(bfgs_mem *b)                                           
 	b->mem_used = (b->mem_used + 1 >= b->mem_size) ? b->mem_size : b->mem_used + 1;
 }
 
-static void fisher_append(const double *g, fisher_mem *f, int n)                           /* :575-587 */
+static void fisher_append(const real_t *g, fisher_mem *f, int n)                           /* :575-587 */
 {
 	if (!f) return;
 	v_copy(n, g, f->F + f->mem_st_ix * (size_t) n);
@@ -145,14 +149,14 @@ static void pair_rollback(bfgs_mem *b, int n, info_enum *info)
 }
 
 /* x_avg_prev <- x_avg ; x_sum <- 0 (x_avg is the same array as x_sum; :134,606-610) */
-static void archive_average(double *x_sum, double *x_avg_prev, int n)
+static void archive_average(real_t *x_sum, real_t *x_avg_prev, int n)
 {
 	v_copy(n, x_sum, x_avg_prev);
 	v_zero(n, x_sum);
 }
 
 /* x_sum *= 1/L, skipped for L <= 1 (:286-291) */
-static void sum_to_average(double *x_sum, size_t L, int n)
+static void sum_to_average(real_t *x_sum, size_t L, int n)
 {
 	if (L > 1) v_scal(n, 1 / (double) L, x_sum);
 }
@@ -161,8 +165,8 @@ static void sum_to_average(double *x_sum, size_t L, int n)
  * Two-loop recursion (src/stochqn.c:663-708).  `st` is the physical row of the OLDEST pair;
  * logical pair i lives in row (st + i) % m.  rho/alpha are stored by logical index.
  * ------------------------------------------------------------------------------------------ */
-void oracle_two_loop(double *q, int n, const double *H0, double h0, const double *Y, const double *S,
-                     size_t m, size_t used, size_t st, double *rho, double *alpha)
+void oracle_two_loop(real_t *q, int n, const real_t *H0, real_t h0, const real_t *Y, const real_t *S,
+                     size_t m, size_t used, size_t st, real_t *rho, real_t *alpha)
 {
 	size_t N = (size_t) n;
 	for (size_t k = used; k-- > 0;) {                                  /* newest -> oldest, :671-679 */
@@ -191,7 +195,7 @@ void oracle_two_loop(double *q, int n, const double *H0, double h0, const double
 
 /* G <- w*G + (1-w)*g^2 for 0<w<1, else G <- G + g^2 (:720-747); then out <- g / sqrt(G + eps)
  * where out is `direction` or, when that is NULL, g itself (:762-783). */
-void oracle_diag_rescale(double *direction, double *g, double *G, int n, double eps, double w)
+void oracle_diag_rescale(real_t *direction, real_t *g, real_t *G, int n, real_t eps, real_t w)
 {
 	size_t N = (size_t) n;
 	if (w > 0 && w < 1) {
@@ -204,15 +208,15 @@ void oracle_diag_rescale(double *direction, double *g, double *G, int n, double 
 	else                   for (size_t i = 0; i < N; i++) direction[i] = g[i] / sqrt(G[i] + eps);
 }
 
-static int has_nonfinite(const double *a, size_t n)                    /* :228-266 */
+static int has_nonfinite(const real_t *a, size_t n)                    /* :228-266 */
 {
 	for (size_t i = 0; i < n; i++) if (isinf(a[i]) || isnan(a[i])) return 1;
 	return 0;
 }
 
 /* take_step (:802-840).  `G == NULL` means "no diagonal rescaling" (oLBFGS, SQN). */
-void oracle_take_step(double step, int n, double *x, double *g, bfgs_mem *b, double w, double *H0,
-                      double h0, double *G, double eps, int check_nan, info_enum *info)
+void oracle_take_step(real_t step, int n, real_t *x, real_t *g, bfgs_mem *b, real_t w, real_t *H0,
+                      real_t h0, real_t *G, real_t eps, int check_nan, info_enum *info)
 {
 	if (b->mem_used == 0) {
 		if (G != NULL) oracle_diag_rescale(NULL, g, G, n, eps, w);             /* :808-812 */
@@ -235,18 +239,18 @@ void oracle_take_step(double step, int n, double *x, double *g, bfgs_mem *b, dou
 /* ------------------------------------------------------------------------------------------
  * Correction-pair construction (src/stochqn.c:861-966)
  * ------------------------------------------------------------------------------------------ */
-static void make_s(double *x_sum, const double *x_avg_prev, int n, int needs_div, bfgs_mem *b) /* :861-870 */
+static void make_s(real_t *x_sum, const real_t *x_avg_prev, int n, int needs_div, bfgs_mem *b) /* :861-870 */
 {
 	pair_backup(b, n);
 	if (needs_div) sum_to_average(x_sum, b->upd_freq, n);
-	double *s = b->s_mem + b->mem_st_ix * (size_t) n;
+	real_t *s = b->s_mem + b->mem_st_ix * (size_t) n;
 	for (size_t i = 0; i < (size_t) n; i++) s[i] = x_sum[i] - x_avg_prev[i];
 }
 
 static void accept_or_reject(bfgs_mem *b, int n, info_enum *info)                              /* :883-900 */
 {
-	const double *s = b->s_mem + b->mem_st_ix * (size_t) n;
-	const double *y = b->y_mem + b->mem_st_ix * (size_t) n;
+	const real_t *s = b->s_mem + b->mem_st_ix * (size_t) n;
+	const real_t *y = b->y_mem + b->mem_st_ix * (size_t) n;
 	if (b->min_curvature > 0) {
 		double curv = v_dot((size_t) n, s, y) / v_dot((size_t) n, s, s);
 		if (curv <= b->min_curvature) { pair_rollback(b, n, info); return; }   /* NaN curvature passes */
@@ -254,17 +258,17 @@ static void accept_or_reject(bfgs_mem *b, int n, info_enum *info)               
 	ring_advance(b);
 }
 
-static void make_y_graddiff(const double *g, const double *g_prev, bfgs_mem *b, int n, info_enum *info) /* :915-926 */
+static void make_y_graddiff(const real_t *g, const real_t *g_prev, bfgs_mem *b, int n, info_enum *info) /* :915-926 */
 {
-	const double *s = b->s_mem + b->mem_st_ix * (size_t) n;
-	double *y = b->y_mem + b->mem_st_ix * (size_t) n;
+	const real_t *s = b->s_mem + b->mem_st_ix * (size_t) n;
+	real_t *y = b->y_mem + b->mem_st_ix * (size_t) n;
 	for (size_t i = 0; i < (size_t) n; i++) y[i] = g[i] - g_prev[i];
 	if (b->y_reg > 0) v_axpy((size_t) n, b->y_reg, s, y);
 	accept_or_reject(b, n, info);
 }
 
 /* y = F' (F s) / fu over the fu = mem_used stored gradients (row-major gemv N then T, :936-952) */
-void oracle_fisher_product(const double *F, size_t fu, int n, const double *s, double *t, double *y)
+void oracle_fisher_product(const real_t *F, size_t fu, int n, const real_t *s, real_t *t, real_t *y)
 {
 	size_t N = (size_t) n;
 	for (size_t k = 0; k < fu; k++) t[k] = v_dot(N, F + k * N, s);
@@ -272,20 +276,20 @@ void oracle_fisher_product(const double *F, size_t fu, int n, const double *s, d
 	#pragma omp parallel for num_threads(g_threads) schedule(static) if (N >= PAR_MIN)
 	for (size_t i = 0; i < N; i++) {
 		double acc = 0;
-		for (size_t k = 0; k < fu; k++) acc += F[k * N + i] * t[k];
-		y[i] = inv * acc;
+		for (size_t k = 0; k < fu; k++) acc += (double) F[k * N + i] * (double) t[k];
+		y[i] = (real_t) (inv * acc);
 	}
 }
 
 static void make_y_fisher(fisher_mem *f, bfgs_mem *b, int n, info_enum *info)
 {
-	const double *s = b->s_mem + b->mem_st_ix * (size_t) n;
-	double *y = b->y_mem + b->mem_st_ix * (size_t) n;
+	const real_t *s = b->s_mem + b->mem_st_ix * (size_t) n;
+	real_t *y = b->y_mem + b->mem_st_ix * (size_t) n;
 	oracle_fisher_product(f->F, f->mem_used, n, s, f->buffer_y, y);
 	accept_or_reject(b, n, info);
 }
 
-static void make_y_hessvec(const double *hv, bfgs_mem *b, info_enum *info, int n)              /* :962-966 */
+static void make_y_hessvec(const real_t *hv, bfgs_mem *b, info_enum *info, int n)              /* :962-966 */
 {
 	v_copy(n, hv, b->y_mem + b->mem_st_ix * (size_t) n);
 	accept_or_reject(b, n, info);
@@ -295,17 +299,17 @@ static void make_y_hessvec(const double *hv, bfgs_mem *b, info_enum *info, int n
  * Workspaces (src/stochqn.c:300-547).  Deviation, documented: s_bak/y_bak are zero-filled
  * (the reference leaves malloc garbage there and then reads it).
  * ------------------------------------------------------------------------------------------ */
-bfgs_mem* oracle_initialize_bfgs_mem(size_t m, int n, double min_curvature, double y_reg, size_t L)
+bfgs_mem* oracle_initialize_bfgs_mem(size_t m, int n, real_t min_curvature, real_t y_reg, size_t L)
 {
 	bfgs_mem *b = (bfgs_mem*) calloc(1, sizeof(bfgs_mem));
 	if (!b) return NULL;
-	b->s_mem = (double*) malloc(sizeof(double) * (size_t) n * m);
-	b->y_mem = (double*) malloc(sizeof(double) * (size_t) n * m);
-	b->buffer_rho = (double*) malloc(sizeof(double) * m);
-	b->buffer_alpha = (double*) malloc(sizeof(double) * m);
+	b->s_mem = (real_t*) malloc(sizeof(real_t) * (size_t) n * m);
+	b->y_mem = (real_t*) malloc(sizeof(real_t) * (size_t) n * m);
+	b->buffer_rho = (real_t*) malloc(sizeof(real_t) * m);
+	b->buffer_alpha = (real_t*) malloc(sizeof(real_t) * m);
 	if (min_curvature > 0) {
-		b->s_bak = (double*) calloc((size_t) n, sizeof(double));
-		b->y_bak = (double*) calloc((size_t) n, sizeof(double));
+		b->s_bak = (real_t*) calloc((size_t) n, sizeof(real_t));
+		b->y_bak = (real_t*) calloc((size_t) n, sizeof(real_t));
 	}
 	b->mem_size = m; b->upd_freq = L; b->y_reg = y_reg; b->min_curvature = min_curvature;
 	return b;
@@ -322,33 +326,33 @@ fisher_mem* oracle_initialize_fisher_mem(size_t f, int n)
 {
 	fisher_mem *o = (fisher_mem*) calloc(1, sizeof(fisher_mem));
 	if (!o) return NULL;
-	o->F = (double*) malloc(sizeof(double) * (size_t) n * f);
-	o->buffer_y = (double*) malloc(sizeof(double) * f);
+	o->F = (real_t*) malloc(sizeof(real_t) * (size_t) n * f);
+	o->buffer_y = (real_t*) malloc(sizeof(real_t) * f);
 	o->mem_size = f;
 	return o;
 }
 
 void oracle_dealloc_fisher_mem(fisher_mem *f) { if (f) { free(f->F); free(f->buffer_y); free(f); } }
 
-workspace_oLBFGS* oracle_initialize_oLBFGS(int n, size_t m, double hess_init, double y_reg,
-                                           double min_curvature, int check_nan, int nthreads)
+workspace_oLBFGS* oracle_initialize_oLBFGS(int n, size_t m, real_t hess_init, real_t y_reg,
+                                           real_t min_curvature, int check_nan, int nthreads)
 {
 	workspace_oLBFGS *w = (workspace_oLBFGS*) calloc(1, sizeof(*w));
 	w->bfgs_memory = oracle_initialize_bfgs_mem(m, n, min_curvature, y_reg, 1);
-	w->grad_prev = (double*) malloc(sizeof(double) * (size_t) n);
+	w->grad_prev = (real_t*) malloc(sizeof(real_t) * (size_t) n);
 	w->hess_init = hess_init; w->check_nan = check_nan; w->nthreads = nthreads; w->n = n;
 	return w;
 }
 void oracle_dealloc_oLBFGS(workspace_oLBFGS *w) { oracle_dealloc_bfgs_mem(w->bfgs_memory); free(w->grad_prev); free(w); }
 
-workspace_SQN* oracle_initialize_SQN(int n, size_t m, size_t L, double min_curvature, int use_grad_diff,
-                                     double y_reg, int check_nan, int nthreads)
+workspace_SQN* oracle_initialize_SQN(int n, size_t m, size_t L, real_t min_curvature, int use_grad_diff,
+                                     real_t y_reg, int check_nan, int nthreads)
 {
 	workspace_SQN *w = (workspace_SQN*) calloc(1, sizeof(*w));
 	w->bfgs_memory = oracle_initialize_bfgs_mem(m, n, min_curvature, y_reg, L);
-	w->grad_prev = use_grad_diff ? (double*) malloc(sizeof(double) * (size_t) n) : NULL;
-	w->x_sum = (double*) calloc((size_t) n, sizeof(double));
-	w->x_avg_prev = (double*) malloc(sizeof(double) * (size_t) n);
+	w->grad_prev = use_grad_diff ? (real_t*) malloc(sizeof(real_t) * (size_t) n) : NULL;
+	w->x_sum = (real_t*) calloc((size_t) n, sizeof(real_t));
+	w->x_avg_prev = (real_t*) malloc(sizeof(real_t) * (size_t) n);
 	w->use_grad_diff = use_grad_diff; w->check_nan = check_nan; w->nthreads = nthreads; w->n = n;
 	return w;
 }
@@ -357,18 +361,18 @@ void oracle_dealloc_SQN(workspace_SQN *w)
 	oracle_dealloc_bfgs_mem(w->bfgs_memory); free(w->grad_prev); free(w->x_sum); free(w->x_avg_prev); free(w);
 }
 
-workspace_adaQN* oracle_initialize_adaQN(int n, size_t m, size_t fisher_size, size_t L, double max_incr,
-                                         double min_curvature, double scal_reg, double rmsprop_weight,
-                                         int use_grad_diff, double y_reg, int check_nan, int nthreads)
+workspace_adaQN* oracle_initialize_adaQN(int n, size_t m, size_t fisher_size, size_t L, real_t max_incr,
+                                         real_t min_curvature, real_t scal_reg, real_t rmsprop_weight,
+                                         int use_grad_diff, real_t y_reg, int check_nan, int nthreads)
 {
 	workspace_adaQN *w = (workspace_adaQN*) calloc(1, sizeof(*w));
 	w->bfgs_memory = oracle_initialize_bfgs_mem(m, n, min_curvature, y_reg, L);
-	if (use_grad_diff) w->grad_prev = (double*) malloc(sizeof(double) * (size_t) n);
+	if (use_grad_diff) w->grad_prev = (real_t*) malloc(sizeof(real_t) * (size_t) n);
 	else               w->fisher_memory = oracle_initialize_fisher_mem(fisher_size, n);
-	w->H0 = (double*) malloc(sizeof(double) * (size_t) n);
-	w->x_sum = (double*) calloc((size_t) n, sizeof(double));
-	w->x_avg_prev = (double*) malloc(sizeof(double) * (size_t) n);
-	w->grad_sum_sq = (double*) calloc((size_t) n, sizeof(double));
+	w->H0 = (real_t*) malloc(sizeof(real_t) * (size_t) n);
+	w->x_sum = (real_t*) calloc((size_t) n, sizeof(real_t));
+	w->x_avg_prev = (real_t*) malloc(sizeof(real_t) * (size_t) n);
+	w->grad_sum_sq = (real_t*) calloc((size_t) n, sizeof(real_t));
 	w->max_incr = max_incr; w->scal_reg = scal_reg; w->rmsprop_weight = rmsprop_weight;
 	w->use_grad_diff = use_grad_diff; w->check_nan = check_nan; w->nthreads = nthreads; w->n = n;
 	return w;
@@ -385,7 +389,7 @@ void oracle_dealloc_adaQN(workspace_adaQN *w)
 
 /* oLBFGS (src/stochqn.c:978-1036): 0 -> ask grad; 1 -> step, s-slot, ask same-batch grad;
  * 2 -> y-slot, accept/reject, ask grad. */
-int oracle_run_oLBFGS(double step, double *x, double *g, double **req, task_enum *task,
+int oracle_run_oLBFGS(real_t step, real_t *x, real_t *g, real_t **req, task_enum *task,
                       workspace_oLBFGS *w, info_enum *info)
 {
 	bfgs_mem *b = w->bfgs_memory;
@@ -422,7 +426,7 @@ int oracle_run_oLBFGS(double step, double *x, double *g, double **req, task_enum
 }
 
 /* SQN (src/stochqn.c:1038-1153) */
-int oracle_run_SQN(double step, double *x, double *g, double *hv, double **req, double **req_vec,
+int oracle_run_SQN(real_t step, real_t *x, real_t *g, real_t *hv, real_t **req, real_t **req_vec,
                    task_enum *task, workspace_SQN *w, info_enum *info)
 {
 	bfgs_mem *b = w->bfgs_memory;
@@ -476,7 +480,7 @@ int oracle_run_SQN(double step, double *x, double *g, double *hv, double **req, 
 }
 
 /* adaQN (src/stochqn.c:1155-1315) */
-int oracle_run_adaQN(double step, double *x, double f, double *g, double **req, task_enum *task,
+int oracle_run_adaQN(real_t step, real_t *x, real_t f, real_t *g, real_t **req, task_enum *task,
                      workspace_adaQN *w, info_enum *info)
 {
 	bfgs_mem *b = w->bfgs_memory;

@@ -12,29 +12,32 @@ from . import _abi
 
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
 LIB_PATH = _os.path.join(_HERE, "lib", "libstochqn.so")
+LIB_PATH_F32 = _os.path.join(_HERE, "lib", "libstochqn_f32.so")
 
-_bound = None
-_cdll = None
+_bound = {}
+_cdll = {}
 
 
-def cdll():
-    """The raw ctypes handle of libstochqn.so (raises if it has not been built)."""
-    global _cdll
-    if _cdll is None:
-        if not _os.path.exists(LIB_PATH):
+def cdll(use_float=False):
+    """The raw ctypes handle of libstochqn.so / libstochqn_f32.so (raises if it has not been built).
+    The two precisions export the same symbol names, so each is loaded with local binding."""
+    key = bool(use_float)
+    if key not in _cdll:
+        path = LIB_PATH_F32 if key else LIB_PATH
+        if not _os.path.exists(path):
             raise ImportError(
                 "stochqn_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "or `make -C stochqn_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
-        _cdll = _C.CDLL(LIB_PATH, mode=_C.RTLD_GLOBAL)
-    return _cdll
+                "or `make -C stochqn_amd/csrc`.  There is no CPU fallback." % path)
+        _cdll[key] = _C.CDLL(path, mode=_C.RTLD_LOCAL)
+    return _cdll[key]
 
 
-def lib():
-    """The public C ABI (include/stochqn.h) bound with ctypes prototypes."""
-    global _bound
-    if _bound is None:
-        _bound = _abi.Bound(cdll(), prefix="")
-    return _bound
+def lib(use_float=False):
+    """The public C ABI (include/stochqn.h) bound with ctypes prototypes, for one precision."""
+    key = bool(use_float)
+    if key not in _bound:
+        _bound[key] = _abi.Bound(cdll(key), prefix="", use_float=key)
+    return _bound[key]
 
 
 from .free import oLBFGS_free, SQN_free, adaQN_free  # noqa: E402

@@ -8,56 +8,60 @@ same declarations.
 """
 import ctypes as C
 
-real_p = C.POINTER(C.c_double)
+
+def _make_structs(real):
+    """The five ABI structs for one precision (`real` = c_double or c_float; reference
+    include/stochqn.h:62-76 selects it with USE_DOUBLE / USE_FLOAT)."""
+
+    class bfgs_mem(C.Structure):
+        _fields_ = [
+            ("s_mem", C.c_void_p), ("y_mem", C.c_void_p),
+            ("buffer_rho", C.c_void_p), ("buffer_alpha", C.c_void_p),
+            ("s_bak", C.c_void_p), ("y_bak", C.c_void_p),
+            ("mem_size", C.c_size_t), ("mem_used", C.c_size_t), ("mem_st_ix", C.c_size_t),
+            ("upd_freq", C.c_size_t), ("y_reg", real), ("min_curvature", real),
+        ]
+
+    class fisher_mem(C.Structure):
+        _fields_ = [
+            ("F", C.c_void_p), ("buffer_y", C.c_void_p),
+            ("mem_size", C.c_size_t), ("mem_used", C.c_size_t), ("mem_st_ix", C.c_size_t),
+        ]
+
+    class workspace_oLBFGS(C.Structure):
+        _fields_ = [
+            ("bfgs_memory", C.POINTER(bfgs_mem)), ("grad_prev", C.c_void_p), ("hess_init", real),
+            ("niter", C.c_size_t), ("section", C.c_int), ("nthreads", C.c_int),
+            ("check_nan", C.c_int), ("n", C.c_int),
+        ]
+
+    class workspace_SQN(C.Structure):
+        _fields_ = [
+            ("bfgs_memory", C.POINTER(bfgs_mem)), ("grad_prev", C.c_void_p),
+            ("x_sum", C.c_void_p), ("x_avg_prev", C.c_void_p), ("use_grad_diff", C.c_int),
+            ("niter", C.c_size_t), ("section", C.c_int), ("nthreads", C.c_int),
+            ("check_nan", C.c_int), ("n", C.c_int),
+        ]
+
+    class workspace_adaQN(C.Structure):
+        _fields_ = [
+            ("bfgs_memory", C.POINTER(bfgs_mem)), ("fisher_memory", C.POINTER(fisher_mem)),
+            ("H0", C.c_void_p), ("grad_prev", C.c_void_p), ("x_sum", C.c_void_p),
+            ("x_avg_prev", C.c_void_p), ("grad_sum_sq", C.c_void_p),
+            ("f_prev", real), ("max_incr", real), ("scal_reg", real),
+            ("rmsprop_weight", real), ("use_grad_diff", C.c_int),
+            ("niter", C.c_size_t), ("section", C.c_int), ("nthreads", C.c_int),
+            ("check_nan", C.c_int), ("n", C.c_int),
+        ]
+
+    return bfgs_mem, fisher_mem, workspace_oLBFGS, workspace_SQN, workspace_adaQN
 
 
-class bfgs_mem(C.Structure):
-    _fields_ = [
-        ("s_mem", C.c_void_p), ("y_mem", C.c_void_p),
-        ("buffer_rho", C.c_void_p), ("buffer_alpha", C.c_void_p),
-        ("s_bak", C.c_void_p), ("y_bak", C.c_void_p),
-        ("mem_size", C.c_size_t), ("mem_used", C.c_size_t), ("mem_st_ix", C.c_size_t),
-        ("upd_freq", C.c_size_t), ("y_reg", C.c_double), ("min_curvature", C.c_double),
-    ]
-
-
-class fisher_mem(C.Structure):
-    _fields_ = [
-        ("F", C.c_void_p), ("buffer_y", C.c_void_p),
-        ("mem_size", C.c_size_t), ("mem_used", C.c_size_t), ("mem_st_ix", C.c_size_t),
-    ]
-
-
-class workspace_oLBFGS(C.Structure):
-    _fields_ = [
-        ("bfgs_memory", C.POINTER(bfgs_mem)), ("grad_prev", C.c_void_p), ("hess_init", C.c_double),
-        ("niter", C.c_size_t), ("section", C.c_int), ("nthreads", C.c_int),
-        ("check_nan", C.c_int), ("n", C.c_int),
-    ]
-
-
-class workspace_SQN(C.Structure):
-    _fields_ = [
-        ("bfgs_memory", C.POINTER(bfgs_mem)), ("grad_prev", C.c_void_p),
-        ("x_sum", C.c_void_p), ("x_avg_prev", C.c_void_p), ("use_grad_diff", C.c_int),
-        ("niter", C.c_size_t), ("section", C.c_int), ("nthreads", C.c_int),
-        ("check_nan", C.c_int), ("n", C.c_int),
-    ]
-
-
-class workspace_adaQN(C.Structure):
-    _fields_ = [
-        ("bfgs_memory", C.POINTER(bfgs_mem)), ("fisher_memory", C.POINTER(fisher_mem)),
-        ("H0", C.c_void_p), ("grad_prev", C.c_void_p), ("x_sum", C.c_void_p),
-        ("x_avg_prev", C.c_void_p), ("grad_sum_sq", C.c_void_p),
-        ("f_prev", C.c_double), ("max_incr", C.c_double), ("scal_reg", C.c_double),
-        ("rmsprop_weight", C.c_double), ("use_grad_diff", C.c_int),
-        ("niter", C.c_size_t), ("section", C.c_int), ("nthreads", C.c_int),
-        ("check_nan", C.c_int), ("n", C.c_int),
-    ]
-
+bfgs_mem, fisher_mem, workspace_oLBFGS, workspace_SQN, workspace_adaQN = _make_structs(C.c_double)
+STRUCTS_F32 = _make_structs(C.c_float)
 
 EXPECTED_SIZES = {bfgs_mem: 96, fisher_mem: 40, workspace_oLBFGS: 48, workspace_SQN: 64, workspace_adaQN: 120}
+EXPECTED_SIZES_F32 = dict(zip(STRUCTS_F32, (88, 40, 48, 64, 104)))
 
 # task_enum / info_enum / iter_status (reference include/stochqn.h:268-291)
 TASKS = {101: "calc_grad", 102: "calc_grad_same_batch", 103: "calc_grad_big_batch",
@@ -75,42 +79,47 @@ PUBLIC_SYMBOLS = [
 
 
 class Bound:
-    """The three run_* / initialize_* / dealloc_* families of one shared library."""
+    """The three run_* / initialize_* / dealloc_* families of one shared library, for one precision."""
 
-    def __init__(self, lib, prefix=""):
+    def __init__(self, lib, prefix="", use_float=False):
         self.lib = lib
         self.prefix = prefix
+        self.use_float = bool(use_float)
+        self.real = C.c_float if use_float else C.c_double
+        structs = STRUCTS_F32 if use_float else (bfgs_mem, fisher_mem, workspace_oLBFGS, workspace_SQN, workspace_adaQN)
+        self.bfgs_mem, self.fisher_mem, self.workspace_oLBFGS, self.workspace_SQN, self.workspace_adaQN = structs
+        workspace_oLBFGS_, workspace_SQN_, workspace_adaQN_ = structs[2:]
         g = lambda name: getattr(lib, prefix + name)
-        vp, d, i, sz = C.c_void_p, C.c_double, C.c_int, C.c_size_t
+        vp, d, i, sz = C.c_void_p, self.real, C.c_int, C.c_size_t
 
         self.initialize_oLBFGS = g("initialize_oLBFGS")
-        self.initialize_oLBFGS.restype = C.POINTER(workspace_oLBFGS)
+        self.initialize_oLBFGS.restype = C.POINTER(workspace_oLBFGS_)
         self.initialize_oLBFGS.argtypes = [i, sz, d, d, d, i, i]
         self.dealloc_oLBFGS = g("dealloc_oLBFGS")
         self.dealloc_oLBFGS.restype = None
-        self.dealloc_oLBFGS.argtypes = [C.POINTER(workspace_oLBFGS)]
+        self.dealloc_oLBFGS.argtypes = [C.POINTER(workspace_oLBFGS_)]
 
         self.initialize_SQN = g("initialize_SQN")
-        self.initialize_SQN.restype = C.POINTER(workspace_SQN)
+        self.initialize_SQN.restype = C.POINTER(workspace_SQN_)
         self.initialize_SQN.argtypes = [i, sz, sz, d, i, d, i, i]
         self.dealloc_SQN = g("dealloc_SQN")
         self.dealloc_SQN.restype = None
-        self.dealloc_SQN.argtypes = [C.POINTER(workspace_SQN)]
+        self.dealloc_SQN.argtypes = [C.POINTER(workspace_SQN_)]
 
         self.initialize_adaQN = g("initialize_adaQN")
-        self.initialize_adaQN.restype = C.POINTER(workspace_adaQN)
+        self.initialize_adaQN.restype = C.POINTER(workspace_adaQN_)
         self.initialize_adaQN.argtypes = [i, sz, sz, sz, d, d, d, d, i, d, i, i]
         self.dealloc_adaQN = g("dealloc_adaQN")
         self.dealloc_adaQN.restype = None
-        self.dealloc_adaQN.argtypes = [C.POINTER(workspace_adaQN)]
+        self.dealloc_adaQN.argtypes = [C.POINTER(workspace_adaQN_)]
 
         self.run_oLBFGS = g("run_oLBFGS")
         self.run_oLBFGS.restype = i
-        self.run_oLBFGS.argtypes = [d, vp, vp, C.POINTER(vp), C.POINTER(i), C.POINTER(workspace_oLBFGS), C.POINTER(i)]
+        self.run_oLBFGS.argtypes = [d, vp, vp, C.POINTER(vp), C.POINTER(i), C.POINTER(workspace_oLBFGS_), C.POINTER(i)]
         self.run_SQN = g("run_SQN")
         self.run_SQN.restype = i
         self.run_SQN.argtypes = [d, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i),
-                                 C.POINTER(workspace_SQN), C.POINTER(i)]
+                                 C.POINTER(workspace_SQN_), C.POINTER(i)]
         self.run_adaQN = g("run_adaQN")
         self.run_adaQN.restype = i
-        self.run_adaQN.argtypes = [d, vp, d, vp, C.POINTER(vp), C.POINTER(i), C.POINTER(workspace_adaQN), C.POINTER(i)]
+        self.run_adaQN.argtypes = [d, vp, d, vp, C.POINTER(vp), C.POINTER(i), C.POINTER(workspace_adaQN_), C.POINTER(i)]

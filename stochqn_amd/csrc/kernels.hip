@@ -35,33 +35,47 @@ constexpr int kUnroll = 2;
 constexpr int kWaves = kBlock / 64;
 
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef real rvec __attribute__((ext_vector_type(kVec)));     // one 16-byte pack of vector elements
+typedef real real2 __attribute__((ext_vector_type(2)));       // two neighbouring columns (Gram tile staging)
 
+// W elements of a vector, widened to double for the arithmetic.  W = kVec: one 16-byte access per
+// lane (needs 16-byte alignment); W = 1: one element.
 template <int W> struct Pack { double v[W]; };
 
-template <int W, bool NT> __device__ __forceinline__ Pack<W> ld(const double* p, uint32_t i)
+template <int W, bool NT> __device__ __forceinline__ Pack<W> ld(const real* p, uint32_t i)
 {
 	Pack<W> r;
-	if constexpr (W == 2) {
-		d2 t = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2*>(p + i))
-		          : *reinterpret_cast<const d2*>(p + i);
-		r.v[0] = t.x; r.v[1] = t.y;
+	if constexpr (W == kVec) {
+		const rvec t = NT ? __builtin_nontemporal_load(reinterpret_cast<const rvec*>(p + i))
+		                  : *reinterpret_cast<const rvec*>(p + i);
+		#pragma unroll
+		for (int k = 0; k < W; k++) r.v[k] = (double) t[k];
 	} else {
-		r.v[0] = NT ? __builtin_nontemporal_load(p + i) : p[i];
+		static_assert(W == 1, "packs are 16 bytes or one element");
+		r.v[0] = (double) (NT ? __builtin_nontemporal_load(p + i) : p[i]);
 	}
 	return r;
 }
 
-template <int W> __device__ __forceinline__ void st(double* p, uint32_t i, const Pack<W>& a)
+template <int W> __device__ __forceinline__ void st(real* p, uint32_t i, const Pack<W>& a)
 {
-	if constexpr (W == 2) { d2 t; t.x = a.v[0]; t.y = a.v[1]; *reinterpret_cast<d2*>(p + i) = t; }
-	else p[i] = a.v[0];
+	if constexpr (W == kVec) {
+		rvec t;
+		#pragma unroll
+		for (int k = 0; k < W; k++) t[k] = (real) a.v[k];
+		*reinterpret_cast<rvec*>(p + i) = t;
+	} else p[i] = (real) a.v[0];
 }
 
 // write-once outputs (new s / y rows, Fisher row): keep them out of the caches
-template <int W> __device__ __forceinline__ void st_nt(double* p, uint32_t i, const Pack<W>& a)
+template <int W> __device__ __forceinline__ void st_nt(real* p, uint32_t i, const Pack<W>& a)
 {
-	if constexpr (W == 2) { d2 t; t.x = a.v[0]; t.y = a.v[1]; __builtin_nontemporal_store(t, reinterpret_cast<d2*>(p + i)); }
-	else __builtin_nontemporal_store(a.v[0], p + i);
+	if constexpr (W == kVec) {
+		rvec t;
+		#pragma unroll
+		for (int k = 0; k < W; k++) t[k] = (real) a.v[k];
+		__builtin_nontemporal_store(t, reinterpret_cast<rvec*>(p + i));
+	} else __builtin_nontemporal_store((real) a.v[0], p + i);
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -205,9 +219,9 @@ template <bool NT> struct BwdOp {
 	const double* sy_row;     // s'y of pair i  (rho_i = 1 / s'y, :676)
 	double* alpha_out;        // &alpha[i]
 	double* rho_out;          // &rho[i]
-	const double* y;
-	double* q;
-	const double* s_prev;
+	const real* y;
+	real* q;
+	const real* s_prev;
 	double alpha;
 	template <int W> struct In { Pack<W> y, q, s; };
 
@@ -242,8 +256,8 @@ template <bool NT> struct MidOp {
 	const double* sy_row;
 	double* alpha_out;
 	double* rho_out;
-	const double* y;
-	double* q;
+	const real* y;
+	real* q;
 	MidScale ms;
 	double alpha, scal;
 	template <int W> struct In { Pack<W> y, q, h; };
@@ -284,9 +298,9 @@ template <bool NT, bool LAST, bool FUSE> struct FwdOp {
 	Partials in;
 	const double* sy_row;
 	const double* alpha_i;
-	const double* s;
-	double* r;
-	const double* y_next;   // !LAST
+	const real* s;
+	real* r;
+	const real* y_next;   // !LAST
 	ApplyArgs ap;           // FUSE
 	double coef;
 	template <int W> struct In { Pack<W> s, r, y, x, xs; };
@@ -347,8 +361,8 @@ struct ApplyOp {
 	Partials guard;
 	bool guarded;
 	double n_global;
-	const double* r;
-	double* grad_out;   // oLBFGS: -step*r is written back here (and to s_slot)
+	const real* r;
+	real* grad_out;   // oLBFGS: -step*r is written back here (and to s_slot)
 	ApplyArgs ap;
 	double* report;
 	bool bad;
@@ -401,11 +415,11 @@ struct ApplyOp {
 // ------------------------------------------------------------------------------------------------
 // s = x_avg - x_avg_prev, with x_avg = x_sum * (1/L) written back first (:286-291, :861-870)
 struct PairSOp {
-	double* x_sum;
+	real* x_sum;
 	double inv_L;
 	bool scale;
-	const double* x_avg_prev;
-	double* s_out;
+	const real* x_avg_prev;
+	real* s_out;
 	template <int W> struct In { Pack<W> xs, xp; };
 	__device__ void prologue(double*) {}
 	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
@@ -434,11 +448,11 @@ __device__ __forceinline__ void three_dots(double s, double y, double (&acc)[3])
 
 // y = g - g_prev (+ lambda s) ; s'y, s's, y'y   (:915-923 + the dots of :892 and of :676,:686-687)
 struct PairYDiffOp {
-	const double* g;
-	const double* g_prev;
-	const double* s;
+	const real* g;
+	const real* g_prev;
+	const real* s;
 	double lambda;
-	double* y_out;
+	real* y_out;
 	template <int W> struct In { Pack<W> g, gp, s; };
 	__device__ void prologue(double*) {}
 	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
@@ -461,11 +475,11 @@ struct PairYDiffOp {
 
 // y = hess_vec ; x_avg_prev <- x_avg ; x_sum <- 0 ; dots   (:1139-1140, :962-966)
 struct PairYHvOp {
-	const double* hv;
-	const double* s;
-	double* y_out;
-	double* x_sum;        // nullable
-	double* x_avg_prev;
+	const real* hv;
+	const real* s;
+	real* y_out;
+	real* x_sum;        // nullable
+	real* x_avg_prev;
 	template <int W> struct In { Pack<W> hv, s, xs; };
 	__device__ void prologue(double*) {}
 	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
@@ -492,8 +506,8 @@ struct PairYHvOp {
 };
 
 struct Dots3Op {
-	const double* s;
-	const double* y;
+	const real* s;
+	const real* y;
 	template <int W> struct In { Pack<W> s, y; };
 	__device__ void prologue(double*) {}
 	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
@@ -508,7 +522,7 @@ struct Dots3Op {
 };
 
 struct ScaleOp {
-	double* x;
+	real* x;
 	double a;
 	template <int W> struct In { Pack<W> x; };
 	__device__ void prologue(double*) {}
@@ -528,8 +542,8 @@ struct ScaleOp {
 // pass 1: blockIdx.y selects a group of kFisherRows rows; each lane keeps one accumulator per row
 // of the group while it strides over its columns, so F is read exactly once and s once per group.
 template <int W, bool NT>
-__global__ void __launch_bounds__(kBlock) k_fisher_t(const double* F, size_t ld_, uint32_t n, uint32_t fu,
-                                                     const double* s, double* parts)
+__global__ void __launch_bounds__(kBlock) k_fisher_t(const real* F, size_t ld_, uint32_t n, uint32_t fu,
+                                                     const real* s, double* parts)
 {
 	__shared__ double sh[kWaves];
 	const uint32_t row0 = blockIdx.y * kFisherRows;
@@ -539,7 +553,7 @@ __global__ void __launch_bounds__(kBlock) k_fisher_t(const double* F, size_t ld_
 	for (int k = 0; k < kFisherRows; k++) acc[k] = 0;
 	const uint32_t packs = n / W;
 	const uint32_t stride = gridDim.x * kBlock;
-	const double* Fg = F + (size_t) row0 * ld_;
+	const real* Fg = F + (size_t) row0 * ld_;
 	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
 		const Pack<W> sv = ld<W, false>(s, p * W);
 		Pack<W> f[kFisherRows];
@@ -568,8 +582,8 @@ __global__ void __launch_bounds__(kBlock) k_fisher_t(const double* F, size_t ld_
 // pass 2: y_j = (1/fu) * sum_k t_k F[k][j], rows accumulated in index order; fused with the
 // curvature dots of the new pair.
 template <int W, bool NT>
-__global__ void __launch_bounds__(kBlock) k_fisher_y(const double* F, size_t ld_, uint32_t n, uint32_t fu,
-                                                     const double* t, double inv_fu, const double* s, double* y,
+__global__ void __launch_bounds__(kBlock) k_fisher_y(const real* F, size_t ld_, uint32_t n, uint32_t fu,
+                                                     const double* t, double inv_fu, const real* s, real* y,
                                                      double* parts_out)
 {
 	extern __shared__ double t_sh[];   // fu doubles
@@ -629,13 +643,13 @@ __global__ void __launch_bounds__(kBlock) k_fisher_y(const double* F, size_t ld_
 // one accumulator per row and lane; the probe pack is loaded once and reused for every row.
 // NPR probes: quantity (pr * rows + j) = rows[j] . probe[pr].  With NPR = 3 the pass that computes
 // [S;Y]g for the recursion also produces the new pair's row of the Gram blocks (probes y_r, s_r).
-struct Probes { const double* p[3]; };
+struct Probes { const real* p[3]; };
 
 // Single-probe pass A: one accumulator per row and lane, NG groups of 8 rows; the compiler hoists
 // the row loads of a pack ahead of the arithmetic (one wave per SIMD, up to 512 registers per lane),
 // which measured faster than the row-split form below for a single probe (5.1 vs 5.8 ms, n=1e8, 40 rows).
 template <int W, int NG, bool NT>
-__global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, const double* probe, double* copy_out, uint32_t n, int rev,
+__global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, const real* probe, real* copy_out, uint32_t n, int rev,
                                                          double* parts)
 {
 	__shared__ double sh[kWaves];
@@ -685,7 +699,7 @@ __global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, const double
 // of a whole pack fit in registers (all issued before the first use).  The probe packs are read
 // by every wave with default-policy loads: one HBM fetch, three L2/L1 hits.
 template <int W, int RPW, int NPR, bool NT>
-__global__ void __launch_bounds__(kBlock) k_rows_dot(RowSet rs, Probes pr, double* copy_out, uint32_t n, int rev, double* parts)
+__global__ void __launch_bounds__(kBlock) k_rows_dot(RowSet rs, Probes pr, real* copy_out, uint32_t n, int rev, double* parts)
 {
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int row0 = wave * RPW;
@@ -714,15 +728,15 @@ __global__ void __launch_bounds__(kBlock) k_rows_dot(RowSet rs, Probes pr, doubl
 			}
 	}
 	if (W > 1) {
-		const uint32_t i = packs * W;
-		if (blockIdx.x == gridDim.x - 1 && lane == 0 && i < n) {       // odd tail element
+		const uint32_t i = packs * W + lane;                           // tail elements (n not a multiple of W)
+		if (blockIdx.x == gridDim.x - 1 && i < n) {
 			if (copy_out && wave == 0) copy_out[i] = pr.p[0][i];
 			#pragma unroll
 			for (int q = 0; q < NPR; q++) {
-				const double pv = pr.p[q][i];
+				const double pv = (double) pr.p[q][i];
 				#pragma unroll
 				for (int j = 0; j < RPW; j++)
-					if (row0 + j < rs.count) acc[q][j] = fma(rs.row[row0 + j][i], pv, acc[q][j]);
+					if (row0 + j < rs.count) acc[q][j] = fma((double) rs.row[row0 + j][i], pv, acc[q][j]);
 			}
 		}
 	}
@@ -817,7 +831,7 @@ __global__ void __launch_bounds__(kBlock) k_coef(const double* bparts, int count
 // A lane finishes T packs before it stores any of them: the single store stream (1 of 2k+2) costs
 // disproportionately when it trickles out between the loads, less when it leaves in groups.
 template <int W, bool NT, int T, bool H0V>
-__global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const double* coef, double* g, const double* H0,
+__global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const double* coef, real* g, const real* H0,
                                                     uint32_t n, int rev, double* parts)
 {
 	__shared__ double sh[kWaves];
@@ -927,23 +941,26 @@ __global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const 
 constexpr int kTile = 128;             // columns per tile: lane l stages columns 2l, 2l+1 and accumulates l, l+64
 constexpr int kTileLd = kTile + 2;     // LDS row stride in doubles (even: 16-B aligned pairs)
 
-// two neighbouring columns of a row: one 16-B access when every row is 16-B aligned (VEC), else two
-// 8-B accesses; columns at or beyond n read as `fill` and are never written
-template <bool VEC, bool NT> __device__ __forceinline__ d2 ld_cols(const double* p, uint32_t i, uint32_t n, double fill)
+// two neighbouring columns of a row, widened to double: one real2 access when the rows are aligned
+// (VEC), else two scalar accesses; columns at or beyond n read as `fill` and are never written
+template <bool VEC, bool NT> __device__ __forceinline__ d2 ld_cols(const real* p, uint32_t i, uint32_t n, double fill)
 {
 	d2 v = {fill, fill};
 	if constexpr (VEC) {
-		if (i + 1 < n) v = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2*>(p + i)) : *reinterpret_cast<const d2*>(p + i);
+		if (i + 1 < n) {
+			const real2 t = NT ? __builtin_nontemporal_load(reinterpret_cast<const real2*>(p + i)) : *reinterpret_cast<const real2*>(p + i);
+			v.x = (double) t.x; v.y = (double) t.y;
+		}
 	} else {
-		if (i < n) v.x = NT ? __builtin_nontemporal_load(p + i) : p[i];
-		if (i + 1 < n) v.y = NT ? __builtin_nontemporal_load(p + i + 1) : p[i + 1];
+		if (i < n) v.x = (double) (NT ? __builtin_nontemporal_load(p + i) : p[i]);
+		if (i + 1 < n) v.y = (double) (NT ? __builtin_nontemporal_load(p + i + 1) : p[i + 1]);
 	}
 	return v;
 }
-template <bool VEC> __device__ __forceinline__ void st_cols(double* p, uint32_t i, uint32_t n, d2 v)
+template <bool VEC> __device__ __forceinline__ void st_cols(real* p, uint32_t i, uint32_t n, d2 v)
 {
-	if constexpr (VEC) { if (i + 1 < n) *reinterpret_cast<d2*>(p + i) = v; }
-	else { if (i < n) p[i] = v.x; if (i + 1 < n) p[i + 1] = v.y; }
+	if constexpr (VEC) { if (i + 1 < n) { real2 t; t.x = (real) v.x; t.y = (real) v.y; *reinterpret_cast<real2*>(p + i) = t; } }
+	else { if (i < n) p[i] = (real) v.x; if (i + 1 < n) p[i + 1] = (real) v.y; }
 }
 
 // The body of k_gram_h0 for wave WAVE of the workgroup.  KT = ring size rounded up (compile time), so
@@ -1148,7 +1165,7 @@ void run_sweep(const Scratch& sc, int id, size_t n, bool vec, const Op& op, doub
 {
 	ProfScope ps(sc, id);
 	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
-	if (vec) hipLaunchKernelGGL((k_sweep<2, NP, Op>), dim3(grid), dim3(kBlock), 0, sc.stream, op, (uint32_t) n, rev, parts_out);
+	if (vec) hipLaunchKernelGGL((k_sweep<kVec, NP, Op>), dim3(grid), dim3(kBlock), 0, sc.stream, op, (uint32_t) n, rev, parts_out);
 	else     hipLaunchKernelGGL((k_sweep<1, NP, Op>), dim3(grid), dim3(kBlock), 0, sc.stream, op, (uint32_t) n, rev, parts_out);
 }
 
@@ -1197,7 +1214,7 @@ Partials launch_first(const Scratch& sc, int buf, size_t n, const FirstArgs& a)
 }
 
 Partials launch_bwd(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, int i,
-                    const double* y_i, double* q, const double* s_prev)
+                    const real* y_i, real* q, const real* s_prev)
 {
 	const int grid = sweep_grid(sc, n);
 	const bool vec = all_aligned(y_i, q, s_prev);
@@ -1206,8 +1223,8 @@ Partials launch_bwd(const Scratch& sc, int buf, size_t n, Partials in, const dou
 	return finish(sc, buf, 1, grid);
 }
 
-Partials launch_mid(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, const double* y_0,
-                    double* q, const MidScale& ms)
+Partials launch_mid(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, const real* y_0,
+                    real* q, const MidScale& ms)
 {
 	const int grid = sweep_grid(sc, n);
 	const bool vec = all_aligned(y_0, q, ms.H0);
@@ -1217,7 +1234,7 @@ Partials launch_mid(const Scratch& sc, int buf, size_t n, Partials in, const dou
 }
 
 Partials launch_fwd(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, int i,
-                    const double* s_i, double* r, const double* y_next)
+                    const real* s_i, real* r, const real* y_next)
 {
 	const int grid = sweep_grid(sc, n);
 	const bool vec = all_aligned(s_i, r, y_next);
@@ -1228,7 +1245,7 @@ Partials launch_fwd(const Scratch& sc, int buf, size_t n, Partials in, const dou
 }
 
 Partials launch_fwd_last(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, int i,
-                         const double* s_i, double* r, const ApplyArgs* fuse)
+                         const real* s_i, real* r, const ApplyArgs* fuse)
 {
 	const int grid = sweep_grid(sc, n);
 	if (fuse) {
@@ -1244,7 +1261,7 @@ Partials launch_fwd_last(const Scratch& sc, int buf, size_t n, Partials in, cons
 	return finish(sc, buf, 2, grid);
 }
 
-void launch_apply(const Scratch& sc, size_t n, double n_global, Partials guard, const double* r_in, double* grad_out,
+void launch_apply(const Scratch& sc, size_t n, double n_global, Partials guard, const real* r_in, real* grad_out,
                   const ApplyArgs& a, bool guarded)
 {
 	const int grid = sweep_grid(sc, n, 2);
@@ -1252,16 +1269,16 @@ void launch_apply(const Scratch& sc, size_t n, double n_global, Partials guard, 
 	run_sweep<0>(sc, K_APPLY, n, vec, ApplyOp{guard, guarded, n_global, r_in, grad_out, a, sc.report, false}, nullptr, grid);
 }
 
-void launch_pair_s(const Scratch& sc, size_t n, double* x_sum, double inv_L, bool scale, const double* x_avg_prev,
-                   double* s_out)
+void launch_pair_s(const Scratch& sc, size_t n, real* x_sum, double inv_L, bool scale, const real* x_avg_prev,
+                   real* s_out)
 {
 	const int grid = sweep_grid(sc, n);
 	const bool vec = all_aligned(x_sum, x_avg_prev, s_out);
 	run_sweep<0>(sc, K_PAIR_S, n, vec, PairSOp{x_sum, inv_L, scale, x_avg_prev, s_out}, nullptr, grid);
 }
 
-Partials launch_pair_y_diff(const Scratch& sc, int buf, size_t n, const double* g, const double* g_prev,
-                            const double* s, double lambda, double* y_out)
+Partials launch_pair_y_diff(const Scratch& sc, int buf, size_t n, const real* g, const real* g_prev,
+                            const real* s, double lambda, real* y_out)
 {
 	const int grid = sweep_grid(sc, n);
 	const bool vec = all_aligned(g, g_prev, s, y_out);
@@ -1269,8 +1286,8 @@ Partials launch_pair_y_diff(const Scratch& sc, int buf, size_t n, const double* 
 	return finish(sc, buf, 3, grid);
 }
 
-Partials launch_pair_y_hv(const Scratch& sc, int buf, size_t n, const double* hv, const double* s, double* y_out,
-                          double* x_sum, double* x_avg_prev)
+Partials launch_pair_y_hv(const Scratch& sc, int buf, size_t n, const real* hv, const real* s, real* y_out,
+                          real* x_sum, real* x_avg_prev)
 {
 	const int grid = sweep_grid(sc, n);
 	const bool vec = all_aligned(hv, s, y_out, x_sum, x_avg_prev);
@@ -1278,7 +1295,7 @@ Partials launch_pair_y_hv(const Scratch& sc, int buf, size_t n, const double* hv
 	return finish(sc, buf, 3, grid);
 }
 
-Partials launch_dots3(const Scratch& sc, int buf, size_t n, const double* s, const double* y)
+Partials launch_dots3(const Scratch& sc, int buf, size_t n, const real* s, const real* y)
 {
 	const int grid = sweep_grid(sc, n);
 	const bool vec = all_aligned(s, y);
@@ -1286,15 +1303,15 @@ Partials launch_dots3(const Scratch& sc, int buf, size_t n, const double* s, con
 	return finish(sc, buf, 3, grid);
 }
 
-Partials launch_fisher(const Scratch& sc, int buf, size_t n, const double* F, size_t fu, const double* s,
-                       double* t_dev, double* y_out)
+Partials launch_fisher(const Scratch& sc, int buf, size_t n, const real* F, size_t fu, const real* s,
+                       double* t_dev, real* y_out)
 {
 	const int grid = sweep_grid(sc, n);
-	const bool vec = all_aligned(F, s, y_out) && (n % 2 == 0);
+	const bool vec = all_aligned(F, s, y_out) && (n % kVec == 0);
 	const dim3 g1(grid, (unsigned) ((fu + kFisherRows - 1) / kFisherRows));
 	{
 		ProfScope ps(sc, K_FISHER_T);
-		if (vec) hipLaunchKernelGGL((k_fisher_t<2, true>), g1, dim3(kBlock), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part);
+		if (vec) hipLaunchKernelGGL((k_fisher_t<kVec, true>), g1, dim3(kBlock), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part);
 		else     hipLaunchKernelGGL((k_fisher_t<1, true>), g1, dim3(kBlock), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part);
 	}
 	launch_fin(sc, Partials{sc.fisher_part, grid, kMaxGrid}, (int) fu, t_dev);
@@ -1303,7 +1320,7 @@ Partials launch_fisher(const Scratch& sc, int buf, size_t n, const double* F, si
 		ProfScope ps(sc, K_FISHER_Y);
 		const size_t shmem = fu * sizeof(double);
 		const double inv = 1.0 / (double) fu;
-		if (vec) hipLaunchKernelGGL((k_fisher_y<2, true>), dim3(grid), dim3(kBlock), shmem, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, t_dev, inv, s, y_out, sc.part[buf]);
+		if (vec) hipLaunchKernelGGL((k_fisher_y<kVec, true>), dim3(grid), dim3(kBlock), shmem, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, t_dev, inv, s, y_out, sc.part[buf]);
 		else     hipLaunchKernelGGL((k_fisher_y<1, true>), dim3(grid), dim3(kBlock), shmem, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, t_dev, inv, s, y_out, sc.part[buf]);
 	}
 	return finish(sc, buf, 3, grid);
@@ -1327,7 +1344,7 @@ template <class K> static int resident_per_cu(K kernel)
 
 template <int W, int NPR>
 static int rows_dot_dispatch(const Scratch& sc, int slot, size_t max_grid, int rpw, const RowSet& rows, const Probes& pr,
-                             double* copy_out, uint32_t n, int rev)
+                             real* copy_out, uint32_t n, int rev)
 {
 	int grid = 1;
 	#define SQN_RD(RPW)                                                                                                  \
@@ -1350,8 +1367,8 @@ static int rows_dot_dispatch(const Scratch& sc, int slot, size_t max_grid, int r
 }
 
 template <int W>
-static void rows_dot_all_dispatch(const Scratch& sc, int slot, int grid, int ng, const RowSet& rows, const double* probe,
-                                  double* copy_out, uint32_t n, int rev)
+static void rows_dot_all_dispatch(const Scratch& sc, int slot, int grid, int ng, const RowSet& rows, const real* probe,
+                                  real* copy_out, uint32_t n, int rev)
 {
 	#define SQN_RA(NG) hipLaunchKernelGGL((k_rows_dot_all<W, NG, true>), dim3(grid), dim3(kBlock), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[slot])
 	switch (ng) {
@@ -1365,8 +1382,8 @@ static void rows_dot_all_dispatch(const Scratch& sc, int slot, int grid, int ng,
 	#undef SQN_RA
 }
 
-Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& rows, const double* probe, double* copy_out,
-                         int kernel_id, const double* probe_y, const double* probe_s)
+Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& rows, const real* probe, real* copy_out,
+                         int kernel_id, const real* probe_y, const real* probe_s)
 {
 	if (!probe_y && !sc.rows_split) {      // single probe: every lane keeps all rows
 		const int grid = sweep_grid(sc, n);
@@ -1374,7 +1391,7 @@ Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& ro
 		const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
 		{
 			ProfScope ps(sc, kernel_id);
-			if (vec) rows_dot_all_dispatch<2>(sc, slot, grid, (rows.count + 7) / 8, rows, probe, copy_out, (uint32_t) n, rev);
+			if (vec) rows_dot_all_dispatch<kVec>(sc, slot, grid, (rows.count + 7) / 8, rows, probe, copy_out, (uint32_t) n, rev);
 			else     rows_dot_all_dispatch<1>(sc, slot, grid, (rows.count + 7) / 8, rows, probe, copy_out, (uint32_t) n, rev);
 		}
 		Partials raw{sc.rows_part[slot], grid, kMaxGrid};
@@ -1387,7 +1404,7 @@ Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& ro
 	// a workgroup covers 64 packs per step here (its 4 waves split the rows), so it takes 4x the
 	// workgroups of a sweep to keep the same number of lanes on the columns
 	const bool vec = rows_aligned(rows) && all_aligned(probe, copy_out, probe_y, probe_s);
-	size_t max_grid = (n / (vec ? 2 : 1) + 63) / 64;         // a workgroup covers 64 packs per step here
+	size_t max_grid = (n / (vec ? kVec : 1) + 63) / 64;         // a workgroup covers 64 packs per step here
 	if (max_grid < 1) max_grid = 1;
 	int grid = 1;
 	const int ng = (rows.count + kWaves - 1) / kWaves;     // rows per wave
@@ -1397,10 +1414,10 @@ Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& ro
 	{
 		ProfScope ps(sc, kernel_id);
 		if (npr == 3) {
-			if (vec) grid = rows_dot_dispatch<2, 3>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
+			if (vec) grid = rows_dot_dispatch<kVec, 3>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
 			else     grid = rows_dot_dispatch<1, 3>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
 		} else {
-			if (vec) grid = rows_dot_dispatch<2, 1>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
+			if (vec) grid = rows_dot_dispatch<kVec, 1>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
 			else     grid = rows_dot_dispatch<1, 1>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
 		}
 	}
@@ -1432,7 +1449,7 @@ void launch_coef(const Scratch& sc, Partials b, const CoefArgs& a)
 	                   sc.coef);
 }
 
-Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, const RowSet& ss, double* g, const double* H0)
+Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, const RowSet& ss, real* g, const real* H0)
 {
 	const int grid = sweep_grid(sc, n, 2);
 	const bool vec = rows_aligned(ys) && rows_aligned(ss) && all_aligned(g, H0);
@@ -1442,10 +1459,10 @@ Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, 
 		#define SQN_CB(W, T, HV) hipLaunchKernelGGL((k_combine<W, true, T, HV>), dim3(grid), dim3(kBlock), 0, sc.stream, ys, ss, sc.coef, g, H0, (uint32_t) n, rev, sc.part[buf])
 		const int T = sc.combine_batch;
 		if (H0) {
-			if (vec) { if (T >= 4) SQN_CB(2, 4, true); else SQN_CB(2, 1, true); }
+			if (vec) { if (T >= 4) SQN_CB(kVec, 4, true); else SQN_CB(kVec, 1, true); }
 			else     { if (T >= 4) SQN_CB(1, 4, true); else SQN_CB(1, 1, true); }
 		} else {
-			if (vec) { if (T >= 8) SQN_CB(2, 8, false); else if (T >= 4) SQN_CB(2, 4, false); else if (T >= 2) SQN_CB(2, 2, false); else SQN_CB(2, 1, false); }
+			if (vec) { if (T >= 8) SQN_CB(kVec, 8, false); else if (T >= 4) SQN_CB(kVec, 4, false); else if (T >= 2) SQN_CB(kVec, 2, false); else SQN_CB(kVec, 1, false); }
 			else     { if (T >= 8) SQN_CB(1, 8, false); else if (T >= 4) SQN_CB(1, 4, false); else if (T >= 2) SQN_CB(1, 2, false); else SQN_CB(1, 1, false); }
 		}
 		#undef SQN_CB
@@ -1479,7 +1496,9 @@ Partials launch_gram_h0(const Scratch& sc, size_t n, const GramH0Args& a)
 	if (g < 1) g = 1;
 	const int grid = (int) g;
 	const bool rms = a.rmsprop_weight > 0 && a.rmsprop_weight < 1;
-	const bool vec = rows_aligned(a.s_rows) && rows_aligned(a.y_rows) && all_aligned(a.g, a.G, a.H0_out, a.frow_out) && n % 2 == 0;
+	auto pair_aligned = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % sizeof(real2)) == 0; };
+	bool vec = n % 2 == 0 && pair_aligned(a.g) && pair_aligned(a.G) && pair_aligned(a.H0_out) && pair_aligned(a.frow_out);
+	for (int j = 0; j < k && vec; j++) vec = pair_aligned(a.s_rows.row[j]) && pair_aligned(a.y_rows.row[j]);
 	{
 		ProfScope ps(sc, K_GRAM_H0);
 		if (k <= 12) gram_h0_dispatch<12>(sc, grid, shmem, vec, a, rms, (uint32_t) n);
@@ -1517,7 +1536,7 @@ void launch_set2(const Scratch& sc, double* a, double va, double* b, double vb)
 	hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, sc.stream, a, va, b, vb);
 }
 
-void launch_scale(const Scratch& sc, size_t n, double* x, double a)
+void launch_scale(const Scratch& sc, size_t n, real* x, double a)
 {
 	const int grid = sweep_grid(sc, n);
 	run_sweep<0>(sc, K_SMALL, n, aligned16(x), ScaleOp{x, a}, nullptr, grid);

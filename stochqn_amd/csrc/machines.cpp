@@ -19,9 +19,16 @@
 
 using namespace sqn;
 
+#ifndef SQN_USE_FLOAT
 static_assert(sizeof(bfgs_mem) == 96 && sizeof(fisher_mem) == 40, "ABI layout (reference include/stochqn.h:86-107)");
 static_assert(sizeof(workspace_oLBFGS) == 48 && sizeof(workspace_SQN) == 64 && sizeof(workspace_adaQN) == 120,
               "ABI layout (reference include/stochqn.h:109-151)");
+#else   // the same structs with real_t = float (reference -DUSE_FLOAT build)
+static_assert(sizeof(bfgs_mem) == 88 && sizeof(fisher_mem) == 40, "ABI layout, float (reference include/stochqn.h:86-107)");
+static_assert(sizeof(workspace_oLBFGS) == 48 && sizeof(workspace_SQN) == 64 && sizeof(workspace_adaQN) == 104,
+              "ABI layout, float (reference include/stochqn.h:109-151)");
+#endif
+static_assert(sizeof(real) == sizeof(real_t), "library element type and ABI real_t must agree");
 
 namespace {
 
@@ -29,42 +36,50 @@ namespace {
 struct Call {
 	DevCtx* c = nullptr;
 	bool host_caller = false;       // x lives in host memory: *req / *req_vec must be host-readable
-	double* x_caller = nullptr;
-	double* g_caller = nullptr;
-	double* x = nullptr;            // device views
-	double* g = nullptr;
+	real* x_caller = nullptr;
+	real* g_caller = nullptr;
+	real* x = nullptr;              // device views
+	real* g = nullptr;
 	bool g_host = false;
 };
 
 inline size_t N(const DevCtx* c) { return (size_t) c->n; }
-inline double* row(View& v, size_t r, const DevCtx* c) { return v.dev + r * N(c); }
+inline real* row(View& v, size_t r, const DevCtx* c) { return v.dev + r * N(c); }
 
-void d2d(DevCtx* c, double* dst, const double* src, size_t count)
+void d2d(DevCtx* c, real* dst, const real* src, size_t count)
 {
 	if (c->sc.prof) c->sc.prof->begin(K_COPY, c->sc.stream);
-	SQN_HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, c->sc.stream));
+	SQN_HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(real), hipMemcpyDeviceToDevice, c->sc.stream));
 	if (c->sc.prof) c->sc.prof->end(c->sc.stream);
 }
 
-void zero(DevCtx* c, double* dst, size_t count)
+void zero(DevCtx* c, real* dst, size_t count)
 {
 	if (c->sc.prof) c->sc.prof->begin(K_COPY, c->sc.stream);
-	SQN_HIP_OK(hipMemsetAsync(dst, 0, count * sizeof(double), c->sc.stream));
+	SQN_HIP_OK(hipMemsetAsync(dst, 0, count * sizeof(real), c->sc.stream));
 	if (c->sc.prof) c->sc.prof->end(c->sc.stream);
 }
 
-void to_host(DevCtx* c, void* dst, const double* src, size_t count)
+void to_host(DevCtx* c, void* dst, const double* src, size_t count)      // scalars of the recursion
 {
 	SQN_HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
 }
 
+void vec_to_host(DevCtx* c, real* dst, const real* src, size_t count)    // an n-vector
+{
+	SQN_HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(real), hipMemcpyDeviceToHost, c->sc.stream));
+}
+
 // Copy a few scalars that were read back into the pinned block on to a caller buffer (buffer_rho,
 // buffer_alpha, buffer_y), which may itself live in host or in device memory.  After sync() only.
-void hand_back(double* dst, const double* pinned, size_t count)
+void hand_back(real_t* dst, const double* pinned, size_t count)
 {
 	if (!dst || count == 0) return;
-	if (is_device_pointer(dst)) SQN_HIP_OK(hipMemcpy(dst, pinned, count * sizeof(double), hipMemcpyHostToDevice));
-	else std::memcpy(dst, pinned, count * sizeof(double));
+	real_t tmp[kRedMax];
+	if (count > (size_t) kRedMax) count = kRedMax;
+	for (size_t i = 0; i < count; i++) tmp[i] = (real_t) pinned[i];
+	if (is_device_pointer(dst)) SQN_HIP_OK(hipMemcpy(dst, tmp, count * sizeof(real_t), hipMemcpyHostToDevice));
+	else std::memcpy(dst, tmp, count * sizeof(real_t));
 }
 
 bool bind_bfgs(DevCtx* c, bfgs_mem* b, bool import_rows)
@@ -76,7 +91,7 @@ bool bind_bfgs(DevCtx* c, bfgs_mem* b, bool import_rows)
 }
 
 // Start a call: find the context, bind every struct array, classify and stage x / grad.
-bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resumed, double* x, double* grad,
+bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resumed, real* x, real* grad,
                size_t niter, int section)
 {
 	if (!b || !b->s_mem || !b->y_mem || n <= 0 || b->mem_size == 0) return false;
@@ -113,18 +128,18 @@ void stage_xg(Call& io, bool need_x, bool need_g)
 }
 
 // Make a workspace array readable where the caller expects to read `*req` from.
-double* publish(Call& io, View& v, size_t offset, int slot)
+real* publish(Call& io, View& v, size_t offset, int slot)
 {
 	DevCtx* c = io.c;
-	double* dev = v.dev + offset;
+	real* dev = v.dev + offset;
 	if (!io.host_caller) return dev;
 	if (v.mirror) {                       // caller's own host array: refresh it, hand it back
-		double* host = (double*) const_cast<void*>(v.caller) + offset;
-		to_host(c, host, dev, N(c));
+		real* host = (real*) const_cast<void*>(v.caller) + offset;
+		vec_to_host(c, host, dev, N(c));
 		return host;
 	}
-	if (!c->host_stage[slot]) SQN_HIP_OK(hipHostMalloc((void**) &c->host_stage[slot], N(c) * sizeof(double), hipHostMallocDefault));
-	to_host(c, c->host_stage[slot], dev, N(c));
+	if (!c->host_stage[slot]) SQN_HIP_OK(hipHostMalloc((void**) &c->host_stage[slot], N(c) * sizeof(real), hipHostMallocDefault));
+	vec_to_host(c, c->host_stage[slot], dev, N(c));
 	return c->host_stage[slot];
 }
 
@@ -132,8 +147,8 @@ double* publish(Call& io, View& v, size_t offset, int slot)
 void close_call(Call& io, bool x_changed, bool g_changed)
 {
 	DevCtx* c = io.c;
-	if (x_changed && io.host_caller && io.x) to_host(c, io.x_caller, io.x, N(c));
-	if (g_changed && io.g_host && io.g && options().strict_grad) to_host(c, io.g_caller, io.g, N(c));
+	if (x_changed && io.host_caller && io.x) vec_to_host(c, io.x_caller, io.x, N(c));
+	if (g_changed && io.g_host && io.g && options().strict_grad) vec_to_host(c, io.g_caller, io.g, N(c));
 	sync(c);
 }
 
@@ -166,23 +181,23 @@ void ensure_rho(DevCtx* c, size_t st, size_t used)
 
 struct StepIn {
 	double step = 0;
-	double* x = nullptr;
-	double* g = nullptr;
+	real* x = nullptr;
+	real* g = nullptr;
 	size_t used = 0, st_ix = 0;      // ring counters as the caller's struct has them
 	double h0 = 0;                   // oLBFGS hess_init
-	double* H0 = nullptr;            // adaQN diagonal target
-	double* G = nullptr;             // adaQN grad_sum_sq (NULL = no rescaling)
+	real* H0 = nullptr;              // adaQN diagonal target
+	real* G = nullptr;               // adaQN grad_sum_sq (NULL = no rescaling)
 	double w = 0, eps = 0;
-	double* gprev_out = nullptr;     // oLBFGS
-	double* frow_out = nullptr;      // adaQN Fisher row
-	double* x_sum = nullptr;         // SQN / adaQN
-	double* s_slot = nullptr;        // oLBFGS
+	real* gprev_out = nullptr;       // oLBFGS
+	real* frow_out = nullptr;        // adaQN Fisher row
+	real* x_sum = nullptr;           // SQN / adaQN
+	real* s_slot = nullptr;          // oLBFGS
 	int check_nan = 0;
 };
 
 // Returns the last-forward / guard partials; after this the direction is in `g`.
-Partials enqueue_two_loop(DevCtx* c, double* g, size_t used, size_t st, const FirstArgs& fa_in, double h0,
-                          double* H0, const ApplyArgs* fuse)
+Partials enqueue_two_loop(DevCtx* c, real* g, size_t used, size_t st, const FirstArgs& fa_in, double h0,
+                          real* H0, const ApplyArgs* fuse)
 {
 	const Scratch& sc = c->sc;
 	const size_t n = N(c), m = c->m, k = used;
@@ -208,7 +223,7 @@ Partials enqueue_two_loop(DevCtx* c, double* g, size_t used, size_t st, const Fi
 }
 
 // ---- two-pass form (scalar H0): Gram maintenance + rows-dot / coef / combine ----------------------
-bool twopass_ok(const DevCtx* c, size_t used, const double* H0_vec)
+bool twopass_ok(const DevCtx* c, size_t used, const real* H0_vec)
 {
 	return options().twopass && H0_vec == nullptr && used >= 1 && c->m <= (size_t) kPairsMax;
 }
@@ -236,7 +251,7 @@ void ensure_gram(DevCtx* c, size_t st, size_t used)
 }
 
 // Returns the guard partials (sum r^2, nonfinite); the direction replaces g.
-Partials enqueue_two_pass(DevCtx* c, double* g, size_t used, size_t st, double h0, double* gprev_out)
+Partials enqueue_two_pass(DevCtx* c, real* g, size_t used, size_t st, double h0, real* gprev_out)
 {
 	const size_t m = c->m, k = used;
 	RowSet rows{}, ys{}, ss{};
@@ -430,8 +445,8 @@ int no_device(task_enum* task, const char* who)
 void* dev_alloc(size_t count, bool zero_fill)
 {
 	void* p = nullptr;
-	if (hipMalloc(&p, count * sizeof(double)) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
-	if (zero_fill) SQN_HIP_OK(hipMemset(p, 0, count * sizeof(double)));
+	if (hipMalloc(&p, count * sizeof(real)) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+	if (zero_fill) SQN_HIP_OK(hipMemset(p, 0, count * sizeof(real)));
 	return p;
 }
 
@@ -590,7 +605,7 @@ static int run_SQN_impl(real_t step_size, real_t x[], real_t grad[], real_t hess
 		}
 		case 4: {                                                     // :1137-1142
 			const bool hv_host = !is_device_pointer(hess_vec);
-			double* hv = stage_in(c, 2, hess_vec, n, hv_host);
+			real* hv = stage_in(c, 2, hess_vec, n, hv_host);
 			const size_t st = b->mem_st_ix;
 			Partials p = launch_pair_y_hv(c->sc, c->next_buf(), n, hv, row(c->S, st, c), row(c->Y, st, c), c->xsum.dev, c->xprev.dev);
 			accept_or_reject(c, b, p, iter_info);
@@ -953,8 +968,8 @@ void dealloc_adaQN(workspace_adaQN* w)
 // =================================================================================================
 // isolated kernels of stochqn_hip.h
 // =================================================================================================
-int stochqn_hip_two_loop(double grad[], int n, double H0[], double h0, double y_mem[], double s_mem[],
-                         size_t mem_size, size_t mem_used, size_t mem_st_ix, double buffer_rho[], double buffer_alpha[])
+int stochqn_hip_two_loop(real_t grad[], int n, real_t H0[], real_t h0, real_t y_mem[], real_t s_mem[],
+                         size_t mem_size, size_t mem_used, size_t mem_st_ix, real_t buffer_rho[], real_t buffer_alpha[])
 {
 	if (!device_ready() || !grad || !y_mem || !s_mem || n <= 0 || mem_size == 0 || mem_used == 0 || mem_used > mem_size)
 		return -1000;
@@ -966,13 +981,13 @@ int stochqn_hip_two_loop(double grad[], int n, double H0[], double h0, double y_
 	    !bind(c, c->H0, H0, H0 ? nn : 0, true))
 		return -1000;
 	// host arrays may have changed since the last call: refresh the mirrors, drop the cached dots
-	if (c->H0.mirror) SQN_HIP_OK(hipMemcpyAsync(c->H0.dev, H0, nn * sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
-	if (c->S.mirror && !fresh) SQN_HIP_OK(hipMemcpyAsync(c->S.dev, s_mem, mem_size * nn * sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
-	if (c->Y.mirror && !fresh) SQN_HIP_OK(hipMemcpyAsync(c->Y.dev, y_mem, mem_size * nn * sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
+	if (c->H0.mirror) SQN_HIP_OK(hipMemcpyAsync(c->H0.dev, H0, nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
+	if (c->S.mirror && !fresh) SQN_HIP_OK(hipMemcpyAsync(c->S.dev, s_mem, mem_size * nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
+	if (c->Y.mirror && !fresh) SQN_HIP_OK(hipMemcpyAsync(c->Y.dev, y_mem, mem_size * nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
 	if (c->S.mirror || c->Y.mirror) { c->rho_ok.assign(c->m, 0); c->gram_ok.assign(c->m, 0); }
 	if (fresh) comm_attach(c);
 	const bool g_host = !is_device_pointer(grad);
-	double* g = stage_in(c, 1, grad, nn, g_host);
+	real* g = stage_in(c, 1, grad, nn, g_host);
 	if (twopass_ok(c, mem_used, H0 ? c->H0.dev : nullptr)) {
 		(void) enqueue_two_pass(c, g, mem_used, mem_st_ix % mem_size, h0, nullptr);
 	} else {
@@ -980,14 +995,14 @@ int stochqn_hip_two_loop(double grad[], int n, double H0[], double h0, double y_
 		(void) enqueue_two_loop(c, g, mem_used, mem_st_ix % mem_size, fa, h0, H0 ? c->H0.dev : nullptr, nullptr);
 	}
 	to_host(c, c->pin, c->sc.report, 8 + 2 * c->m);
-	if (g_host) to_host(c, grad, g, nn);
+	if (g_host) vec_to_host(c, grad, g, nn);
 	sync(c);
 	hand_back(buffer_rho, c->pin + 8, mem_used);
 	hand_back(buffer_alpha, c->pin + 8 + c->m, mem_used);
 	return 0;
 }
 
-int stochqn_hip_fisher_product(double F[], size_t fu, int n, double s[], double buffer_y[], double y[])
+int stochqn_hip_fisher_product(real_t F[], size_t fu, int n, real_t s[], real_t buffer_y[], real_t y[])
 {
 	if (!device_ready() || !F || !s || !y || n <= 0 || fu == 0) return -1000;
 	bool fresh = false;
@@ -997,17 +1012,17 @@ int stochqn_hip_fisher_product(double F[], size_t fu, int n, double s[], double 
 	if (fresh) comm_attach(c);
 	// F: used in place when on the device, else mirrored (re-uploaded every call: contents may have changed)
 	if (!bind(c, c->F, F, fu * nn, false)) return -1000;
-	if (c->F.mirror) SQN_HIP_OK(hipMemcpyAsync(c->F.dev, F, fu * nn * sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
+	if (c->F.mirror) SQN_HIP_OK(hipMemcpyAsync(c->F.dev, F, fu * nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
 	const bool s_host = !is_device_pointer(s), y_host = !is_device_pointer(y);
-	double* sd = stage_in(c, 0, s, nn, s_host);
-	double* yd = y;
+	real* sd = stage_in(c, 0, s, nn, s_host);
+	real* yd = y;
 	if (y_host) {
-		if (!c->stage[1]) SQN_HIP_OK(hipMalloc((void**) &c->stage[1], nn * sizeof(double)));
+		if (!c->stage[1]) SQN_HIP_OK(hipMalloc((void**) &c->stage[1], nn * sizeof(real)));
 		yd = c->stage[1];
 	}
 	launch_fisher(c->sc, c->next_buf(), nn, c->F.dev, fu, sd, c->fisher_t, yd);
 	to_host(c, c->pin + 8 + 2 * c->m, c->fisher_t, fu);
-	if (y_host) to_host(c, y, yd, nn);
+	if (y_host) vec_to_host(c, y, yd, nn);
 	sync(c);
 	hand_back(buffer_y, c->pin + 8 + 2 * c->m, fu);
 	return 0;

@@ -124,8 +124,8 @@ void destroy(DevCtx* c)
 	if (c->pool) SQN_HIP_OK(hipFree(c->pool));
 	if (c->sc.fisher_part) SQN_HIP_OK(hipFree(c->sc.fisher_part));
 	if (c->fisher_t) SQN_HIP_OK(hipFree(c->fisher_t));
-	for (double* p : c->stage) if (p) SQN_HIP_OK(hipFree(p));
-	for (double* p : c->host_stage) if (p) SQN_HIP_OK(hipHostFree(p));
+	for (real* p : c->stage) if (p) SQN_HIP_OK(hipFree(p));
+	for (real* p : c->host_stage) if (p) SQN_HIP_OK(hipHostFree(p));
 	if (c->pin) SQN_HIP_OK(hipHostFree(c->pin));
 	if (c->sc.stream) SQN_HIP_OK(hipStreamDestroy(c->sc.stream));
 	delete c;
@@ -280,7 +280,7 @@ void release_all()
 	g_ctx.clear();
 }
 
-bool bind(DevCtx* c, View& v, double* caller, size_t count, bool import)
+bool bind(DevCtx* c, View& v, real* caller, size_t count, bool import)
 {
 	(void) c;
 	if (caller == v.caller && count == v.count && (v.dev || count == 0)) return true;
@@ -289,28 +289,28 @@ bool bind(DevCtx* c, View& v, double* caller, size_t count, bool import)
 	v.count = count;
 	if (!caller || count == 0) return true;
 	if (is_device_pointer(caller)) { v.dev = caller; v.mirror = false; return true; }
-	if (hipMalloc((void**) &v.dev, count * sizeof(double)) != hipSuccess) {
-		std::fprintf(stderr, "stochqn: could not allocate a %zu-double device mirror\n", count);
+	if (hipMalloc((void**) &v.dev, count * sizeof(real)) != hipSuccess) {
+		std::fprintf(stderr, "stochqn: could not allocate a %zu-element device mirror\n", count);
 		v = View{};
 		return false;
 	}
 	v.mirror = true;
 	// without `import` the mirror starts with indeterminate contents, like the reference's malloc
-	if (import) SQN_HIP_OK(hipMemcpy(v.dev, caller, count * sizeof(double), hipMemcpyHostToDevice));
+	if (import) SQN_HIP_OK(hipMemcpy(v.dev, caller, count * sizeof(real), hipMemcpyHostToDevice));
 	return true;
 }
 
 void export_view(DevCtx* c, View& v)
 {
 	if (v.mirror && v.dev && v.caller)
-		SQN_HIP_OK(hipMemcpyAsync(const_cast<void*>(v.caller), v.dev, v.count * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
+		SQN_HIP_OK(hipMemcpyAsync(const_cast<void*>(v.caller), v.dev, v.count * sizeof(real), hipMemcpyDeviceToHost, c->sc.stream));
 }
 
-double* stage_in(DevCtx* c, int which, double* caller, size_t count, bool host)
+real* stage_in(DevCtx* c, int which, real* caller, size_t count, bool host)
 {
 	if (!host) return caller;
-	if (!c->stage[which]) SQN_HIP_OK(hipMalloc((void**) &c->stage[which], (size_t) c->n * sizeof(double)));
-	SQN_HIP_OK(hipMemcpyAsync(c->stage[which], caller, count * sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
+	if (!c->stage[which]) SQN_HIP_OK(hipMalloc((void**) &c->stage[which], (size_t) c->n * sizeof(real)));
+	SQN_HIP_OK(hipMemcpyAsync(c->stage[which], caller, count * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
 	return c->stage[which];
 }
 

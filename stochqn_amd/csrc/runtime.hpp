@@ -15,7 +15,7 @@ enum Kind { KIND_OLBFGS = 1, KIND_SQN = 2, KIND_ADAQN = 3, KIND_RAW = 4 };
 // when that is device memory `dev == caller`, otherwise `dev` is a mirror owned by the context.
 struct View {
 	const void* caller = nullptr;
-	double* dev = nullptr;
+	real* dev = nullptr;
 	size_t count = 0;
 	bool mirror = false;
 };
@@ -50,8 +50,8 @@ struct DevCtx {
 	int phase = 1;                     // sweep parity inside the current API call (reset by begin_call)
 	double* pool = nullptr;            // one allocation behind sc.part/red/sy/yy/alpha/rho/report
 	double* fisher_t = nullptr;        // [fsize] F*s on device
-	double* stage[3] = {nullptr, nullptr, nullptr};   // device staging for host x / grad / hess_vec
-	double* host_stage[2] = {nullptr, nullptr};       // pinned host landing zones for *req / *req_vec
+	real* stage[3] = {nullptr, nullptr, nullptr};     // device staging for host x / grad / hess_vec
+	real* host_stage[2] = {nullptr, nullptr};         // pinned host landing zones for *req / *req_vec
 	double* pin = nullptr;             // pinned host read-back block
 	size_t pin_count = 0;
 	// what the caller's struct looked like when the last call on this context returned; a call that
@@ -78,10 +78,10 @@ void release_all();
 
 // (Re)bind a view to the caller's pointer.  Host pointers get a device mirror of `count` doubles;
 // with `import` the host contents are uploaded into a newly created mirror.
-bool bind(DevCtx* c, View& v, double* caller, size_t count, bool import);
+bool bind(DevCtx* c, View& v, real* caller, size_t count, bool import);
 void export_view(DevCtx* c, View& v);                  // mirror -> caller's host array
 
-double* stage_in(DevCtx* c, int which, double* caller, size_t count, bool host);   // H2D if host
+real* stage_in(DevCtx* c, int which, real* caller, size_t count, bool host);       // H2D if host
 void begin_call(DevCtx* c);                            // refresh options, restart the sweep parity
 void sync(DevCtx* c);                                  // stream sync + profiler collection
 

@@ -10,6 +10,16 @@
 
 namespace sqn {
 
+// Element type of every n-vector (x, grad, rows of S / Y / F ...).  All arithmetic, every partial sum
+// and every scalar of the recursion is double in both builds; the float build (-DSQN_USE_FLOAT,
+// libstochqn_f32.so) only stores and streams the vectors in single precision.
+#ifdef SQN_USE_FLOAT
+typedef float real;
+#else
+typedef double real;
+#endif
+constexpr int kVec = 16 / (int) sizeof(real);    // elements per 16-byte pack: 2 doubles or 4 floats
+
 constexpr int kBlock = 256;       // threads per workgroup (4 wave64)
 constexpr int kMaxGrid = 2048;    // 256 CUs x 8 resident workgroups; also the partial-sum stride
 constexpr int kMaxSums = 3;       // sums one sweep can produce (s'y, s's, y'y)
@@ -110,60 +120,60 @@ int sweep_grid(const Scratch& sc, size_t n, int per_cu = 1);
 // first sweep: optional side effects on the raw gradient, then either the newest pair's s'q
 // (s_newest != NULL) or the guard sums (sum dir^2, nonfinite) of the plain / rescaled gradient.
 struct FirstArgs {
-	double* q;               // gradient, n
-	const double* s_newest;  // NULL when the ring is empty
-	double* gprev_out;       // oLBFGS: grad_prev <- g            (nullable)
-	double* frow_out;        // adaQN : Fisher row  <- g           (nullable)
-	double* G;               // adaQN : grad_sum_sq in/out         (nullable)
-	double* H0_out;          // adaQN : g/sqrt(G+eps) goes here; NULL -> into q itself
+	real* q;               // gradient, n
+	const real* s_newest;  // NULL when the ring is empty
+	real* gprev_out;       // oLBFGS: grad_prev <- g            (nullable)
+	real* frow_out;        // adaQN : Fisher row  <- g           (nullable)
+	real* G;               // adaQN : grad_sum_sq in/out         (nullable)
+	real* H0_out;          // adaQN : g/sqrt(G+eps) goes here; NULL -> into q itself
 	double rmsprop_weight, scal_reg;
 };
 Partials launch_first(const Scratch& sc, int buf, size_t n, const FirstArgs& a);
 
 // backward sweep i: alpha_i = rho_i * <in>; q -= alpha_i*y_i; out = s_prev'q
 Partials launch_bwd(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, int logical_i,
-                    const double* y_i, double* q, const double* s_prev);
+                    const real* y_i, real* q, const real* s_prev);
 
 // middle sweep: alpha_0; q -= alpha_0*y_0; r = H0-scaling(q); out = y_0'r
 struct MidScale {
 	const double* sy_newest;  // gamma = *sy_newest / *yy_newest when both non-NULL
 	const double* yy_newest;
 	double h0;                // else scalar h0 when H0 == NULL
-	const double* H0;         // else element-wise
+	const real* H0;         // else element-wise
 };
 Partials launch_mid(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row,
-                    const double* y_0, double* q, const MidScale& ms);
+                    const real* y_0, real* q, const MidScale& ms);
 
 // forward sweep i: beta = rho_i*<in>; r += (alpha_i-beta)*s_i; out = y_next'r
 Partials launch_fwd(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, int logical_i,
-                    const double* s_i, double* r, const double* y_next);
+                    const real* s_i, real* r, const real* y_next);
 
 // last forward sweep; out = (sum r^2, nonfinite).  With `fuse` non-NULL (check_nan == 0) the
 // position update is applied in the same pass and nothing is produced.
 struct ApplyArgs {
-	double* x;            // n
-	double* x_sum;        // nullable (SQN / adaQN)
-	double* s_slot;       // nullable (oLBFGS: s <- -step*r, grad <- -step*r)
+	real* x;            // n
+	real* x_sum;        // nullable (SQN / adaQN)
+	real* s_slot;       // nullable (oLBFGS: s <- -step*r, grad <- -step*r)
 	double step;
 };
 Partials launch_fwd_last(const Scratch& sc, int buf, size_t n, Partials in, const double* sy_row, int logical_i,
-                         const double* s_i, double* r, const ApplyArgs* fuse);
+                         const real* s_i, real* r, const ApplyArgs* fuse);
 
 // guarded position update: bad = nonfinite>0 || sqrt(sum r^2) > 1e3*n_global; writes report[0..2]
-void launch_apply(const Scratch& sc, size_t n, double n_global, Partials guard, const double* r_in, double* grad_out,
+void launch_apply(const Scratch& sc, size_t n, double n_global, Partials guard, const real* r_in, real* grad_out,
                   const ApplyArgs& a, bool guarded);
 
 // ---- correction pairs ---------------------------------------------------------------------------
-void launch_pair_s(const Scratch& sc, size_t n, double* x_sum, double inv_L, bool scale, const double* x_avg_prev,
-                   double* s_out);
-Partials launch_pair_y_diff(const Scratch& sc, int buf, size_t n, const double* g, const double* g_prev,
-                            const double* s, double lambda, double* y_out);
-Partials launch_pair_y_hv(const Scratch& sc, int buf, size_t n, const double* hv, const double* s, double* y_out,
-                          double* x_sum, double* x_avg_prev);
-Partials launch_dots3(const Scratch& sc, int buf, size_t n, const double* s, const double* y);
+void launch_pair_s(const Scratch& sc, size_t n, real* x_sum, double inv_L, bool scale, const real* x_avg_prev,
+                   real* s_out);
+Partials launch_pair_y_diff(const Scratch& sc, int buf, size_t n, const real* g, const real* g_prev,
+                            const real* s, double lambda, real* y_out);
+Partials launch_pair_y_hv(const Scratch& sc, int buf, size_t n, const real* hv, const real* s, real* y_out,
+                          real* x_sum, real* x_avg_prev);
+Partials launch_dots3(const Scratch& sc, int buf, size_t n, const real* s, const real* y);
 // Fisher product y = F'(F s)/fu; returns the (s'y, s's, y'y) partials; t_out[fu] receives F s.
-Partials launch_fisher(const Scratch& sc, int buf, size_t n, const double* F, size_t fu, const double* s,
-                       double* t_dev, double* y_out);
+Partials launch_fisher(const Scratch& sc, int buf, size_t n, const real* F, size_t fu, const real* s,
+                       double* t_dev, real* y_out);
 
 // ---- two-pass ("Gram") form of the two-loop recursion for scalar H0 -------------------------------
 // The recursion only needs the inner products of g with every stored s_i, y_i and the inner
@@ -174,14 +184,14 @@ Partials launch_fisher(const Scratch& sc, int buf, size_t n, const double* F, si
 // = (4k+3) n words instead of 8k n.  Same quantities as reference src/stochqn.c:663-708, other
 // association of the floating-point sums (measured difference ~1e-15 relative).
 struct RowSet {
-	const double* row[kRowsMax];
+	const real* row[kRowsMax];
 	int count;
 };
 // out partials: quantity j = rows.row[j]' probe.  Optional copy of the probe (oLBFGS grad_prev).
 // With probe_y / probe_s (the pair just accepted into ring row r) the same pass also yields
 // rows[j]'probe_y (quantities count..2count-1) and rows[j]'probe_s (2count..3count-1).
-Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& rows, const double* probe, double* copy_out,
-                         int kernel_id = K_ROWS_DOT, const double* probe_y = nullptr, const double* probe_s = nullptr);
+Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& rows, const real* probe, real* copy_out,
+                         int kernel_id = K_ROWS_DOT, const real* probe_y = nullptr, const real* probe_s = nullptr);
 // scatter the dots of one ring row against all rows into the Gram blocks
 void launch_gram_store(const Scratch& sc, Partials sy_yy /*2m: s_j'y_r then y_j'y_r*/, Partials ys /*m: y_j's_r*/, int m, int r);
 struct CoefArgs {
@@ -194,8 +204,8 @@ void launch_gram_store_fused(const Scratch& sc, Partials p /*3 x 2k quantities o
 void launch_coef(const Scratch& sc, Partials b /*2k: s_i'g then y_i'g, logical order*/, const CoefArgs& a);
 // r (in place of g) and the guard sums (sum r^2, nonfinite).  With H0 != NULL (adaQN):
 // r = H0 .* (g + sum cy_j y_j) + sum cs_j s_j, else r = coef[0] g + sum cy_j y_j + sum cs_j s_j.
-Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& y_rows, const RowSet& s_rows, double* g,
-                        const double* H0 = nullptr);
+Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& y_rows, const RowSet& s_rows, real* g,
+                        const real* H0 = nullptr);
 
 // ---- two-pass form with the diagonal H0 of adaQN -----------------------------------------------------
 // r_0 = H0 .* q_0 makes the forward loop need H0-weighted inner products: u_i = sum y_i H0 g and
@@ -204,10 +214,10 @@ Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& y_ro
 // (G <- update, H0 <- g/sqrt(G+eps), Fisher row <- g; reference src/stochqn.c:738-781,1174).
 struct GramH0Args {
 	RowSet s_rows, y_rows;     // the k pairs in use, logical order
-	const double* g;
-	double* G;
-	double* H0_out;
-	double* frow_out;          // nullable
+	const real* g;
+	real* G;
+	real* H0_out;
+	real* frow_out;          // nullable
 	double rmsprop_weight, scal_reg;
 };
 // quantities: [0,k) s_i'g, [k,2k) y_i'g, [2k,3k) u_i, then W_ij for i <= j row by row
@@ -220,6 +230,6 @@ void launch_fin(const Scratch& sc, Partials in, int nsums, double* out);
 void launch_commit(const Scratch& sc, Partials in, double* sy_dst, double* yy_dst);
 // tiny helpers
 void launch_set2(const Scratch& sc, double* a, double va, double* b, double vb);
-void launch_scale(const Scratch& sc, size_t n, double* x, double a);
+void launch_scale(const Scratch& sc, size_t n, real* x, double a);
 
 }  // namespace sqn

@@ -27,10 +27,12 @@ from . import _abi
 class _HostSpace:
     name = "host"
 
-    @staticmethod
-    def empty(n):
+    def __init__(self, use_float=False):
+        self.dtype = np.float32 if use_float else np.float64
+
+    def empty(self, n):
         # the reference uses np.empty; zeros keeps runs reproducible and is a legal instance of it
-        return np.zeros(int(n), dtype=np.float64)
+        return np.zeros(int(n), dtype=self.dtype)
 
     zeros = empty
 
@@ -38,25 +40,25 @@ class _HostSpace:
     def ptr(a):
         return a.ctypes.data
 
-    @staticmethod
-    def assign(dst, src):
-        dst[:] = np.asarray(src, dtype=np.float64).reshape(-1)
+    def assign(self, dst, src):
+        dst[:] = np.asarray(src, dtype=self.dtype).reshape(-1)
 
-    @staticmethod
-    def is_array(a):
-        return isinstance(a, np.ndarray) and a.dtype == np.float64
+    def is_array(self, a):
+        return isinstance(a, np.ndarray) and a.dtype == self.dtype
 
 
 class _DeviceSpace:
     name = "device"
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, use_float=False):
         import torch
         self.torch = torch
         self.device = torch.device(device if device is not None else "cuda")
+        self.dtype = np.float32 if use_float else np.float64
+        self.tdtype = torch.float32 if use_float else torch.float64
 
     def empty(self, n):
-        return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)
+        return self.torch.zeros(int(n), dtype=self.tdtype, device=self.device)
 
     zeros = empty
 
@@ -66,18 +68,18 @@ class _DeviceSpace:
 
     def assign(self, dst, src):
         if not isinstance(src, self.torch.Tensor):
-            src = self.torch.as_tensor(np.asarray(src, dtype=np.float64))
+            src = self.torch.as_tensor(np.asarray(src, dtype=self.dtype))
         dst.copy_(src.reshape(-1))
 
     def is_array(self, a):
-        return isinstance(a, self.torch.Tensor) and a.dtype == self.torch.float64 and a.is_cuda
+        return isinstance(a, self.torch.Tensor) and a.dtype == self.tdtype and a.is_cuda
 
 
-def _space(space, device=None):
+def _space(space, device=None, use_float=False):
     if space == "host":
-        return _HostSpace()
+        return _HostSpace(use_float)
     if space == "device":
-        return _DeviceSpace(device)
+        return _DeviceSpace(device, use_float)
     raise ValueError("space must be 'host' or 'device'")
 
 
@@ -88,8 +90,8 @@ class _BFGS_mem_holder:
     def __init__(self, sp, mem_size, n, min_curvature, y_reg, upd_freq):
         self.s_mem = sp.empty(n * mem_size)
         self.y_mem = sp.empty(n * mem_size)
-        self.buffer_rho = np.zeros(mem_size)      # tiny, always host: read back by callers
-        self.buffer_alpha = np.zeros(mem_size)
+        self.buffer_rho = np.zeros(mem_size, dtype=sp.dtype)      # tiny, always host: read back by callers
+        self.buffer_alpha = np.zeros(mem_size, dtype=sp.dtype)
         k = n if min_curvature > 0 else 1
         self.s_bak = sp.empty(k)
         self.y_bak = sp.empty(k)
@@ -97,8 +99,8 @@ class _BFGS_mem_holder:
         self.upd_freq = int(upd_freq)
         self.y_reg, self.min_curvature = float(y_reg), float(min_curvature)
 
-    def c_struct(self, sp):
-        return _abi.bfgs_mem(sp.ptr(self.s_mem), sp.ptr(self.y_mem),
+    def c_struct(self, sp, be):
+        return be.bfgs_mem(sp.ptr(self.s_mem), sp.ptr(self.y_mem),
                              self.buffer_rho.ctypes.data, self.buffer_alpha.ctypes.data,
                              sp.ptr(self.s_bak), sp.ptr(self.y_bak),
                              self.mem_size, self.mem_used, self.mem_st_ix, self.upd_freq,
@@ -108,11 +110,11 @@ class _BFGS_mem_holder:
 class _Fisher_mem_holder:
     def __init__(self, sp, mem_size, n):
         self.F = sp.empty(n * mem_size)
-        self.buffer_y = np.zeros(mem_size)
+        self.buffer_y = np.zeros(mem_size, dtype=sp.dtype)
         self.mem_size, self.mem_used, self.mem_st_ix = int(mem_size), 0, 0
 
-    def c_struct(self, sp):
-        return _abi.fisher_mem(sp.ptr(self.F), self.buffer_y.ctypes.data,
+    def c_struct(self, sp, be):
+        return be.fisher_mem(sp.ptr(self.F), self.buffer_y.ctypes.data,
                                self.mem_size, self.mem_used, self.mem_st_ix)
 
 
@@ -123,7 +125,8 @@ _INFO = _abi.INFOS
 class _StochQN_free:
     """Shared argument handling (reference stochqn/_optimizers.py:881-935)."""
 
-    def _take_common_inputs(self, mem_size, min_curvature, y_reg, check_nan, nthreads, space, device, backend):
+    def _take_common_inputs(self, mem_size, min_curvature, y_reg, check_nan, nthreads, space, device, backend,
+                            use_float=False):
         assert isinstance(mem_size, int) and mem_size > 0
         if min_curvature is not None:
             assert min_curvature > 0
@@ -140,10 +143,12 @@ class _StochQN_free:
         self.y_reg = y_reg
         self.check_nan = bool(check_nan)
         self.nthreads = int(nthreads)
-        self._sp = _space(space, device)
+        self.use_float = bool(use_float)
+        self._sp = _space(space, device, self.use_float)
         if backend is None:
             from . import lib
-            backend = lib()
+            backend = lib(use_float=self.use_float)
+        assert bool(getattr(backend, "use_float", False)) == self.use_float, "backend precision mismatch"
         self._be = backend
         self.initialized = False
 
@@ -179,8 +184,9 @@ class _StochQN_free:
         for arr in candidates:
             base = self._sp.ptr(arr)
             size = arr.shape[0]
-            if base <= ptr < base + 8 * size:
-                off = (ptr - base) // 8
+            esz = 4 if self.use_float else 8
+            if base <= ptr < base + esz * size:
+                off = (ptr - base) // esz
                 return arr[off:off + n]
         raise RuntimeError("library returned a request pointer outside the caller's arrays")
 
@@ -195,8 +201,8 @@ class oLBFGS_free(_StochQN_free):
     """oLBFGS optimizer, free mode (reference stochqn/_optimizers.py:937-1044)."""
 
     def __init__(self, mem_size=10, hess_init=None, min_curvature=1e-4, y_reg=None, check_nan=True,
-                 nthreads=-1, space="host", device=None, backend=None):
-        self._take_common_inputs(mem_size, min_curvature, y_reg, check_nan, nthreads, space, device, backend)
+                 nthreads=-1, use_float=False, space="host", device=None, backend=None):
+        self._take_common_inputs(mem_size, min_curvature, y_reg, check_nan, nthreads, space, device, backend, use_float)
         if hess_init is not None:
             assert hess_init > 0
         else:
@@ -215,8 +221,8 @@ class oLBFGS_free(_StochQN_free):
     def run_optimizer(self, x, step_size):
         self._check_x(x)
         sp = self._sp
-        b = self.BFGS_mem.c_struct(sp)
-        w = _abi.workspace_oLBFGS(C.pointer(b), sp.ptr(self.grad_prev), self.hess_init, self.niter,
+        b = self.BFGS_mem.c_struct(sp, self._be)
+        w = self._be.workspace_oLBFGS(C.pointer(b), sp.ptr(self.grad_prev), self.hess_init, self.niter,
                                   self.section, self.nthreads, int(self.check_nan), self._n)
         req, task, info = C.c_void_p(), C.c_int(), C.c_int()
         changed = self._be.run_oLBFGS(step_size, sp.ptr(x), sp.ptr(self.gradient), C.byref(req), C.byref(task),
@@ -232,8 +238,8 @@ class SQN_free(_StochQN_free):
     """SQN optimizer, free mode (reference stochqn/_optimizers.py:1046-1190)."""
 
     def __init__(self, mem_size=10, bfgs_upd_freq=20, min_curvature=1e-4, y_reg=None, use_grad_diff=False,
-                 check_nan=True, nthreads=-1, space="host", device=None, backend=None):
-        self._take_common_inputs(mem_size, min_curvature, y_reg, check_nan, nthreads, space, device, backend)
+                 check_nan=True, nthreads=-1, use_float=False, space="host", device=None, backend=None):
+        self._take_common_inputs(mem_size, min_curvature, y_reg, check_nan, nthreads, space, device, backend, use_float)
         assert bfgs_upd_freq > 0
         self.bfgs_upd_freq = int(bfgs_upd_freq)
         self.use_grad_diff = bool(use_grad_diff)
@@ -257,8 +263,8 @@ class SQN_free(_StochQN_free):
     def run_optimizer(self, x, step_size):
         self._check_x(x)
         sp = self._sp
-        b = self.BFGS_mem.c_struct(sp)
-        w = _abi.workspace_SQN(C.pointer(b), sp.ptr(self.grad_prev), sp.ptr(self.x_sum), sp.ptr(self.x_avg_prev),
+        b = self.BFGS_mem.c_struct(sp, self._be)
+        w = self._be.workspace_SQN(C.pointer(b), sp.ptr(self.grad_prev), sp.ptr(self.x_sum), sp.ptr(self.x_avg_prev),
                                int(self.use_grad_diff), self.niter, self.section, self.nthreads,
                                int(self.check_nan), self._n)
         req, req_vec, task, info = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
@@ -280,8 +286,8 @@ class adaQN_free(_StochQN_free):
 
     def __init__(self, mem_size=10, fisher_size=100, bfgs_upd_freq=20, max_incr=1.01, min_curvature=1e-4,
                  scal_reg=1e-4, rmsprop_weight=None, y_reg=None, use_grad_diff=False, check_nan=True,
-                 nthreads=-1, space="host", device=None, backend=None):
-        self._take_common_inputs(mem_size, min_curvature, y_reg, check_nan, nthreads, space, device, backend)
+                 nthreads=-1, use_float=False, space="host", device=None, backend=None):
+        self._take_common_inputs(mem_size, min_curvature, y_reg, check_nan, nthreads, space, device, backend, use_float)
         assert bfgs_upd_freq > 0
         if not use_grad_diff:
             assert fisher_size > 0
@@ -331,9 +337,9 @@ class adaQN_free(_StochQN_free):
     def run_optimizer(self, x, step_size):
         self._check_x(x)
         sp = self._sp
-        b = self.BFGS_mem.c_struct(sp)
-        fm = self.Fisher_mem.c_struct(sp)
-        w = _abi.workspace_adaQN(C.pointer(b), C.pointer(fm), sp.ptr(self.H0), sp.ptr(self.grad_prev),
+        b = self.BFGS_mem.c_struct(sp, self._be)
+        fm = self.Fisher_mem.c_struct(sp, self._be)
+        w = self._be.workspace_adaQN(C.pointer(b), C.pointer(fm), sp.ptr(self.H0), sp.ptr(self.grad_prev),
                                  sp.ptr(self.x_sum), sp.ptr(self.x_avg_prev), sp.ptr(self.grad_sum_sq),
                                  self.f_prev, self.max_incr, self.scal_reg, self.rmsprop_weight,
                                  int(self.use_grad_diff), self.niter, self.section, self.nthreads,

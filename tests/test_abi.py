@@ -27,7 +27,7 @@ def declared_functions(header):
 
 def test_struct_layouts_match_reference():
     # sizes/offsets of reference include/stochqn.h:86-151 on x86-64 LP64
-    for st, size in _abi.EXPECTED_SIZES.items():
+    for st, size in list(_abi.EXPECTED_SIZES.items()) + list(_abi.EXPECTED_SIZES_F32.items()):
         assert C.sizeof(st) == size, st
     assert _abi.bfgs_mem.mem_size.offset == 48 and _abi.bfgs_mem.min_curvature.offset == 88
     assert _abi.fisher_mem.mem_st_ix.offset == 32
@@ -37,8 +37,9 @@ def test_struct_layouts_match_reference():
     assert _abi.workspace_adaQN.n.offset == 116
 
 
-def test_library_exports_every_declared_symbol():
-    lib = stochqn_amd.cdll()
+@pytest.mark.parametrize("use_float", [False, True])
+def test_library_exports_every_declared_symbol(use_float):
+    lib = stochqn_amd.cdll(use_float)
     for header in ("stochqn.h", "stochqn_hip.h"):
         names = declared_functions(header)
         assert len(names) >= 9

@@ -596,3 +596,68 @@ def test_library_owned_workspaces_all_three(form, hip_backend, oracle_backend):
         for i, (gg, ww) in enumerate(zip(got, want)):
             assert gg[:3] == ww[:3], (name, i, gg[:3], ww[:3])
             assert rel_err(gg[3], ww[3]) <= TOL, (name, i)
+
+
+# ---------------------------------------------------------------------------------------------
+# single-precision ABI (libstochqn_f32.so; reference -DUSE_FLOAT build)
+# ---------------------------------------------------------------------------------------------
+F32_TOL = 2e-4      # vectors are stored as float (6e-8 per rounding); the oracle rounds after every axpy,
+                    # the GPU accumulates in double and rounds once per sweep / pass
+F32_CONFIGS = ["olbfgs_default", "olbfgs_nocurv_hess_init", "sqn_hessvec", "sqn_graddiff", "sqn_nan", "sqn_ring20",
+               "adaqn_fisher_rms", "adaqn_graddiff_nomaxincr", "adaqn_nonan_check"]
+
+
+@pytest.fixture(scope="session")
+def hip_backend_f32():
+    import stochqn_amd
+    be = stochqn_amd.lib(use_float=True)
+    assert stochqn_amd.cdll(use_float=True).stochqn_hip_available() == 1
+    return be
+
+
+@pytest.fixture(params=["twopass", "sweeps"])
+def form_f32(request, hip_backend_f32):
+    import stochqn_amd
+    lib = stochqn_amd.cdll(use_float=True)
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    on = 1.0 if request.param == "twopass" else 0.0
+    lib.stochqn_hip_set_option(b"twopass", on)
+    lib.stochqn_hip_set_option(b"twopass_h0", on)
+    yield request.param
+    lib.stochqn_hip_set_option(b"twopass", 1.0)
+    lib.stochqn_hip_set_option(b"twopass_h0", 1.0)
+
+
+@pytest.mark.parametrize("n", [5, 64, 1000, 4099])
+@pytest.mark.parametrize("name", F32_CONFIGS)
+def test_float_lockstep_parity(name, n, form_f32, hip_backend_f32):
+    """Same lock-step protocol as the fp64 test, float arrays on both sides (oracle built -DUSE_FLOAT)."""
+    import stochqn_amd
+    from oracle import oracle
+    cfg = [c for c in CONFIGS if c[0] == name][0]
+    _, optname, kw, step, calls, pkw = cfg
+    P = NoisyQuadratic(n, seed=11, **pkw)
+    ref = OPTIMIZERS[optname](backend=oracle.bound_f32(), space="host", use_float=True, **kw)
+    opt = OPTIMIZERS[optname](backend=hip_backend_f32, space="device", use_float=True, **kw)
+    x_ref = P.x0().astype(np.float32)
+    x_dev = torch_cuda().as_tensor(x_ref.copy(), device="cuda")
+    lib = stochqn_amd.cdll(use_float=True)
+    inval = lambda o: lib.stochqn_hip_invalidate(C.c_void_p(o._sp.ptr(o.BFGS_mem.s_mem)))
+    run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 50), F32_TOL, on_sync=inval)
+
+
+@pytest.mark.parametrize("space", ["host", "device"])
+def test_float_known_answer_trajectory(space, form_f32, hip_backend_f32):
+    """The reference's 2-D Rosenbrock SQN run (tests/golden/known_answers.json) in single precision:
+    same iteration / request counts, x within float accuracy of the double answer."""
+    k = GOLD["SQN_rosen2d"]
+    from harness import Rosenbrock2D
+    opt = OPTIMIZERS["SQN"](backend=hip_backend_f32, space=space, use_float=True)
+    P = Rosenbrock2D()
+    x = P.x0().astype(np.float32)
+    if space == "device":
+        x = torch_cuda().as_tensor(x, device="cuda")
+    tr = run_trace(opt, P, x, k["step"], k["calls"])
+    assert tr[-1]["niter"] == k["niter"] and tr[-1]["mem_used"] == k["mem_used"]
+    assert sum(r["task"] == "calc_hess_vec" for r in tr) == k["n_hess_vec"]
+    assert np.allclose(tr[-1]["x"], k["x"], rtol=2e-3)

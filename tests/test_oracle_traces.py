@@ -57,3 +57,15 @@ def test_two_loop_satisfies_secant_equation():
     q = Y[newest * n:(newest + 1) * n].copy()
     oracle.two_loop(q, None, 0.0, Y, S, m, m, st)
     assert rel_err(q, S[newest * n:(newest + 1) * n]) < 1e-11
+
+
+def test_float_oracle_tracks_double_oracle():
+    """The -DUSE_FLOAT build of the oracle (checker of libstochqn_f32.so) follows the double one to
+    float accuracy on a contractive problem, with identical request sequences."""
+    from oracle import oracle
+    cfg = [c for c in CONFIGS if c[0] == "sqn_hessvec"][0]
+    P = NoisyQuadratic(200, seed=7)
+    d = run_trace(OPTIMIZERS["SQN"](backend=oracle.bound(), **cfg[2]), P, P.x0(), cfg[3], 40)
+    f = run_trace(OPTIMIZERS["SQN"](backend=oracle.bound_f32(), use_float=True, **cfg[2]), P, P.x0().astype(np.float32), cfg[3], 40)
+    assert [r["task"] for r in f] == [r["task"] for r in d]
+    assert rel_err(f[-1]["x"], d[-1]["x"]) < 1e-4
