@@ -57,6 +57,24 @@ template <int W, bool NT> __device__ __forceinline__ Pack<W> ld(const real* p, u
 	return r;
 }
 
+// The same load without widening: kernels that keep many row packs in flight (rows-dot, Fisher,
+// combine) hold them as loaded (a float pack is 4 registers, widened it would be 8) and widen at use.
+template <int W> struct RPack { real v[W]; };
+
+template <int W, bool NT> __device__ __forceinline__ RPack<W> ldr(const real* p, uint32_t i)
+{
+	RPack<W> r;
+	if constexpr (W == kVec) {
+		const rvec t = NT ? __builtin_nontemporal_load(reinterpret_cast<const rvec*>(p + i))
+		                  : *reinterpret_cast<const rvec*>(p + i);
+		#pragma unroll
+		for (int k = 0; k < W; k++) r.v[k] = t[k];
+	} else {
+		r.v[0] = NT ? __builtin_nontemporal_load(p + i) : p[i];
+	}
+	return r;
+}
+
 template <int W> __device__ __forceinline__ void st(real* p, uint32_t i, const Pack<W>& a)
 {
 	if constexpr (W == kVec) {
@@ -556,15 +574,15 @@ __global__ void __launch_bounds__(kBlock) k_fisher_t(const real* F, size_t ld_, 
 	const real* Fg = F + (size_t) row0 * ld_;
 	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
 		const Pack<W> sv = ld<W, false>(s, p * W);
-		Pack<W> f[kFisherRows];
+		RPack<W> f[kFisherRows];
 		#pragma unroll
 		for (int k = 0; k < kFisherRows; k++)
-			if ((uint32_t) k < nrows) f[k] = ld<W, NT>(Fg + (size_t) k * ld_, p * W);
+			if ((uint32_t) k < nrows) f[k] = ldr<W, NT>(Fg + (size_t) k * ld_, p * W);
 		#pragma unroll
 		for (int k = 0; k < kFisherRows; k++)
 			if ((uint32_t) k < nrows) {
 				#pragma unroll
-				for (int j = 0; j < W; j++) acc[k] = fma(f[k].v[j], sv.v[j], acc[k]);
+				for (int j = 0; j < W; j++) acc[k] = fma((double) f[k].v[j], sv.v[j], acc[k]);
 			}
 	}
 	if (W > 1) {
@@ -601,13 +619,13 @@ __global__ void __launch_bounds__(kBlock) k_fisher_y(const real* F, size_t ld_, 
 		const Pack<W> sv = ld<W, false>(s, p * W);
 		uint32_t k = 0;
 		for (; k + R <= fu; k += R) {
-			Pack<W> f[R];
+			RPack<W> f[R];
 			#pragma unroll
-			for (int u = 0; u < R; u++) f[u] = ld<W, NT>(F + (size_t) (k + u) * ld_, p * W);
+			for (int u = 0; u < R; u++) f[u] = ldr<W, NT>(F + (size_t) (k + u) * ld_, p * W);
 			#pragma unroll
 			for (int u = 0; u < R; u++) {
 				#pragma unroll
-				for (int j = 0; j < W; j++) a.v[j] = fma(f[u].v[j], t_sh[k + u], a.v[j]);
+				for (int j = 0; j < W; j++) a.v[j] = fma((double) f[u].v[j], t_sh[k + u], a.v[j]);
 			}
 		}
 		for (; k < fu; k++) {
@@ -663,15 +681,15 @@ __global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, const real* 
 		if (copy_out) st<W>(copy_out, i, pv);
 		#pragma unroll
 		for (int g = 0; g < NG; g++) {
-			Pack<W> f[8];
+			RPack<W> f[8];
 			#pragma unroll
 			for (int u = 0; u < 8; u++)
-				if (g * 8 + u < rs.count) f[u] = ld<W, NT>(rs.row[g * 8 + u], i);
+				if (g * 8 + u < rs.count) f[u] = ldr<W, NT>(rs.row[g * 8 + u], i);
 			#pragma unroll
 			for (int u = 0; u < 8; u++)
 				if (g * 8 + u < rs.count) {
 					#pragma unroll
-					for (int k = 0; k < W; k++) acc[g * 8 + u] = fma(f[u].v[k], pv.v[k], acc[g * 8 + u]);
+					for (int k = 0; k < W; k++) acc[g * 8 + u] = fma((double) f[u].v[k], pv.v[k], acc[g * 8 + u]);
 				}
 		}
 	}
@@ -711,12 +729,13 @@ __global__ void __launch_bounds__(kBlock) k_rows_dot(RowSet rs, Probes pr, real*
 	const uint32_t packs = n / W, stride = gridDim.x * 64, last = packs - 1;
 	for (uint32_t p = blockIdx.x * 64 + lane; p < packs; p += stride) {
 		const uint32_t i = (rev ? last - p : p) * W;
-		Pack<W> pv[NPR], f[RPW];
+		Pack<W> pv[NPR];
+		RPack<W> f[RPW];
 		#pragma unroll
 		for (int q = 0; q < NPR; q++) pv[q] = ld<W, false>(pr.p[q], i);
 		#pragma unroll
 		for (int j = 0; j < RPW; j++)
-			if (row0 + j < rs.count) f[j] = ld<W, NT>(rs.row[row0 + j], i);
+			if (row0 + j < rs.count) f[j] = ldr<W, NT>(rs.row[row0 + j], i);
 		if (copy_out && wave == 0) st<W>(copy_out, i, pv[0]);
 		#pragma unroll
 		for (int j = 0; j < RPW; j++)
@@ -724,7 +743,7 @@ __global__ void __launch_bounds__(kBlock) k_rows_dot(RowSet rs, Probes pr, real*
 				#pragma unroll
 				for (int q = 0; q < NPR; q++)
 					#pragma unroll
-					for (int k = 0; k < W; k++) acc[q][j] = fma(f[j].v[k], pv[q].v[k], acc[q][j]);
+					for (int k = 0; k < W; k++) acc[q][j] = fma((double) f[j].v[k], pv[q].v[k], acc[q][j]);
 			}
 	}
 	if (W > 1) {
@@ -853,46 +872,46 @@ __global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const 
 					// q_0 = g - sum alpha_j y_j (newest pair first), r_0 = q_0 .* H0, then the s terms
 					const Pack<W> h = ld<W, false>(H0, i);
 					for (int j0 = k; j0 > 0; j0 -= 4) {
-						Pack<W> fy[4];
+						RPack<W> fy[4];
 						#pragma unroll
 						for (int u = 0; u < 4; u++)
-							if (j0 - 1 - u >= 0) fy[u] = ld<W, NT>(ys.row[j0 - 1 - u], i);
+							if (j0 - 1 - u >= 0) fy[u] = ldr<W, NT>(ys.row[j0 - 1 - u], i);
 						#pragma unroll
 						for (int u = 0; u < 4; u++)
 							if (j0 - 1 - u >= 0) {
 								#pragma unroll
-								for (int e = 0; e < W; e++) r.v[e] = fma(cf[1 + j0 - 1 - u], fy[u].v[e], r.v[e]);
+								for (int e = 0; e < W; e++) r.v[e] = fma(cf[1 + j0 - 1 - u], (double) fy[u].v[e], r.v[e]);
 							}
 					}
 					#pragma unroll
 					for (int e = 0; e < W; e++) r.v[e] = r.v[e] * h.v[e];
 					for (int j0 = 0; j0 < k; j0 += 4) {
-						Pack<W> fs[4];
+						RPack<W> fs[4];
 						#pragma unroll
 						for (int u = 0; u < 4; u++)
-							if (j0 + u < k) fs[u] = ld<W, NT>(ss.row[j0 + u], i);
+							if (j0 + u < k) fs[u] = ldr<W, NT>(ss.row[j0 + u], i);
 						#pragma unroll
 						for (int u = 0; u < 4; u++)
 							if (j0 + u < k) {
 								#pragma unroll
-								for (int e = 0; e < W; e++) r.v[e] = fma(cf[1 + k + j0 + u], fs[u].v[e], r.v[e]);
+								for (int e = 0; e < W; e++) r.v[e] = fma(cf[1 + k + j0 + u], (double) fs[u].v[e], r.v[e]);
 							}
 					}
 				} else {
 					#pragma unroll
 					for (int e = 0; e < W; e++) r.v[e] = cf[0] * r.v[e];
 					for (int j0 = 0; j0 < k; j0 += 4) {
-						Pack<W> fy[4], fs[4];
+						RPack<W> fy[4], fs[4];
 						#pragma unroll
 						for (int u = 0; u < 4; u++)
-							if (j0 + u < k) { fy[u] = ld<W, NT>(ys.row[j0 + u], i); fs[u] = ld<W, NT>(ss.row[j0 + u], i); }
+							if (j0 + u < k) { fy[u] = ldr<W, NT>(ys.row[j0 + u], i); fs[u] = ldr<W, NT>(ss.row[j0 + u], i); }
 						#pragma unroll
 						for (int u = 0; u < 4; u++)
 							if (j0 + u < k) {
 								#pragma unroll
 								for (int e = 0; e < W; e++) {
-									r.v[e] = fma(cf[1 + j0 + u], fy[u].v[e], r.v[e]);
-									r.v[e] = fma(cf[1 + k + j0 + u], fs[u].v[e], r.v[e]);
+									r.v[e] = fma(cf[1 + j0 + u], (double) fy[u].v[e], r.v[e]);
+									r.v[e] = fma(cf[1 + k + j0 + u], (double) fs[u].v[e], r.v[e]);
 								}
 							}
 					}

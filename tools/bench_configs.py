@@ -151,6 +151,27 @@ def c4():
                {"mem_used": opt.BFGS_mem.mem_used, "fisher_used": opt.Fisher_mem.mem_used, "f_end": P.f(x), "f_start": P.f(P.x0)})
 
 
+def c3f32():
+    """SQN n=1e8 m=20 L=10 through the single-precision ABI (libstochqn_f32.so), device-resident."""
+    global lib
+    lib64 = lib
+    lib = stochqn_amd.cdll(use_float=True)
+    lib.stochqn_hip_profile_name.restype = C.c_char_p
+    n, m = 100_000_000, 20
+    P = DeviceQuadratic(n)
+    P.d, P.dn, P.x0 = P.d.float(), [a.float() for a in P.dn], P.x0.float()
+    x = P.x0.clone()
+    opt = SQN_free(mem_size=m, bfgs_upd_freq=1, min_curvature=None, use_float=True, space="device")
+    drive(opt, P, x, 0.05, 1, 25)
+    opt.BFGS_mem.upd_freq = 10
+    opt.bfgs_upd_freq = 10
+    opt.niter = 10 * ((opt.niter + 9) // 10)
+    dt, calls = drive(opt, P, x, 0.05, 40, 2)
+    report("C3-f32", "SQN n=1e8 m=20 L=10 fp32 storage (libstochqn_f32.so), Hv = d*v, device-resident", n, m, dt, 40, calls,
+           {"mem_used": opt.BFGS_mem.mem_used, "f_end": float(0.5 * torch.sum(P.d.double() * x.double() ** 2))})
+    lib = lib64
+
+
 def rccl1():
     """Exercise the all-reduce code path with a 1-rank RCCL communicator."""
     buf = (C.c_ubyte * 128)()
