@@ -661,3 +661,45 @@ def test_float_known_answer_trajectory(space, form_f32, hip_backend_f32):
     assert tr[-1]["niter"] == k["niter"] and tr[-1]["mem_used"] == k["mem_used"]
     assert sum(r["task"] == "calc_hess_vec" for r in tr) == k["n_hess_vec"]
     assert np.allclose(tr[-1]["x"], k["x"], rtol=2e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# randomised hyper-parameters (deterministic seeds): lock-step parity on configurations nobody hand-picked
+# ---------------------------------------------------------------------------------------------
+def _random_config(optname, rng):
+    kw = dict(mem_size=int(rng.integers(1, 9)), check_nan=bool(rng.integers(0, 2)),
+              min_curvature=[None, 1e-6, 1e-2][rng.integers(0, 3)], y_reg=[None, 1e-3][rng.integers(0, 2)])
+    if optname == "oLBFGS":
+        kw["hess_init"] = [None, 0.3][rng.integers(0, 2)]
+        step = 0.1
+    elif optname == "SQN":
+        kw["bfgs_upd_freq"] = int(rng.integers(1, 6))
+        kw["use_grad_diff"] = bool(rng.integers(0, 2))
+        step = 0.1
+    else:
+        kw["bfgs_upd_freq"] = int(rng.integers(1, 6))
+        kw["use_grad_diff"] = bool(rng.integers(0, 2))
+        kw["fisher_size"] = int(rng.integers(1, 12))
+        kw["max_incr"] = [None, 1.01, 1.5][rng.integers(0, 3)]
+        kw["rmsprop_weight"] = [None, 0.9, 0.5][rng.integers(0, 3)]
+        kw["scal_reg"] = [1e-4, 1e-2][rng.integers(0, 2)]
+        step = 0.02
+    return kw, step
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("optname", ["oLBFGS", "SQN", "adaQN"])
+def test_lockstep_random_hyperparameters(optname, seed, form, hip_backend, oracle_backend):
+    import stochqn_amd
+    rng = np.random.default_rng([seed, len(optname)])
+    kw, step = _random_config(optname, rng)
+    n = int(rng.choice([6, 31, 256, 1025, 5000]))
+    nan_calls = (int(rng.integers(5, 30)),) if rng.integers(0, 4) == 0 else ()
+    P = NoisyQuadratic(n, seed=100 + seed, nan_calls=nan_calls)
+    ref = OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw)
+    opt = OPTIMIZERS[optname](backend=hip_backend, space="device", **kw)
+    x_ref = P.x0()
+    x_dev = torch_cuda().as_tensor(P.x0(), device="cuda")
+    lib = stochqn_amd.cdll()
+    inval = lambda o: lib.stochqn_hip_invalidate(C.c_void_p(o._sp.ptr(o.BFGS_mem.s_mem)))
+    run_lockstep(ref, opt, P, x_ref, x_dev, step, 36, TOL, on_sync=inval)
