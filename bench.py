@@ -292,7 +292,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "optimizer steps/sec (SQN, Hessian-vector pairs, two-loop at n=1e8 m=20 fp64)",
+            "metric": "optimizer steps/sec + achieved HBM GB/s, two-loop at n=10^8 m=20 fp64",
             "value": round(value, 3),
             "unit": "steps/s" if world == 1 else "steps/s normalised to n=1e8 (steps/s * n_total/1e8)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -703,3 +703,37 @@ def test_lockstep_random_hyperparameters(optname, seed, form, hip_backend, oracl
     lib = stochqn_amd.cdll()
     inval = lambda o: lib.stochqn_hip_invalidate(C.c_void_p(o._sp.ptr(o.BFGS_mem.s_mem)))
     run_lockstep(ref, opt, P, x_ref, x_dev, step, 36, TOL, on_sync=inval)
+
+
+@pytest.mark.parametrize("n", [2147483646, 2147483647])
+def test_two_loop_at_the_int_limit(n, form, hip_backend):
+    """n is an `int` in the ABI (reference include/stochqn.h:172-174): the largest even and the largest
+    odd n (16-byte packs vs single elements, 32-bit pack indices at their limit).  Secant equation:
+    the two-loop maps the newest y onto the newest s."""
+    import stochqn_amd
+    torch = torch_cuda()
+    lib = stochqn_amd.cdll()
+    m = 2
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    S = torch.empty(m * n, dtype=torch.float64, device="cuda")
+    Y = torch.empty(m * n, dtype=torch.float64, device="cuda")
+    chunk = 1 << 28
+    for k in range(m):
+        for lo in range(0, n, chunk):
+            hi = min(n, lo + chunk)
+            s = 1e-3 * (torch.rand(hi - lo, dtype=torch.float64, device="cuda", generator=gen) - 0.5)
+            d = 0.5 + torch.rand(hi - lo, dtype=torch.float64, device="cuda", generator=gen)
+            S[k * n + lo:k * n + hi] = s
+            Y[k * n + lo:k * n + hi] = d * s
+            del s, d
+    q = Y[n:2 * n].clone()                      # newest pair = row 1 (st = 0, used = 2)
+    hip_two_loop(lib, q, None, 0.0, Y, S, n, m, m, 0)
+    num = 0.0
+    den = 0.0
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        s_new = S[n + lo:n + hi]
+        num += float(torch.sum((q[lo:hi] - s_new) ** 2))
+        den += float(torch.sum(s_new ** 2))
+    lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))
+    assert (num / den) ** 0.5 <= TOL
