@@ -75,11 +75,14 @@ void vec_to_host(DevCtx* c, real* dst, const real* src, size_t count)    // an n
 void hand_back(real_t* dst, const double* pinned, size_t count)
 {
 	if (!dst || count == 0) return;
-	real_t tmp[kRedMax];
-	if (count > (size_t) kRedMax) count = kRedMax;
-	for (size_t i = 0; i < count; i++) tmp[i] = (real_t) pinned[i];
-	if (is_device_pointer(dst)) SQN_HIP_OK(hipMemcpy(dst, tmp, count * sizeof(real_t), hipMemcpyHostToDevice));
-	else std::memcpy(dst, tmp, count * sizeof(real_t));
+	const bool on_device = is_device_pointer(dst);
+	real_t tmp[256];
+	for (size_t done = 0; done < count; done += 256) {           // converts double -> real_t on the way
+		const size_t k = count - done < 256 ? count - done : 256;
+		for (size_t i = 0; i < k; i++) tmp[i] = (real_t) pinned[done + i];
+		if (on_device) SQN_HIP_OK(hipMemcpy(dst + done, tmp, k * sizeof(real_t), hipMemcpyHostToDevice));
+		else std::memcpy(dst + done, tmp, k * sizeof(real_t));
+	}
 }
 
 bool bind_bfgs(DevCtx* c, bfgs_mem* b, bool import_rows)

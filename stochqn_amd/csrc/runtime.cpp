@@ -94,16 +94,19 @@ void loopback_hook(void*, double* buf, int count, hipStream_t stream)
 {
 	double tmp[kRedMax];
 	SQN_HIP_OK(hipStreamSynchronize(stream));
-	SQN_HIP_OK(hipMemcpy(tmp, buf, (size_t) count * sizeof(double), hipMemcpyDeviceToHost));
-	std::memcpy(&g_loop.slots[(size_t) t_loop_rank * kRedMax], tmp, (size_t) count * sizeof(double));
-	loop_barrier();
-	for (int j = 0; j < count; j++) {
-		double s = 0;
-		for (int r = 0; r < g_loop.nranks; r++) s += g_loop.slots[(size_t) r * kRedMax + j];
-		tmp[j] = s;
+	for (int done = 0; done < count; done += kRedMax) {            // Fisher products reduce fisher_size scalars
+		const int k = count - done < kRedMax ? count - done : kRedMax;
+		SQN_HIP_OK(hipMemcpy(tmp, buf + done, (size_t) k * sizeof(double), hipMemcpyDeviceToHost));
+		std::memcpy(&g_loop.slots[(size_t) t_loop_rank * kRedMax], tmp, (size_t) k * sizeof(double));
+		loop_barrier();
+		for (int j = 0; j < k; j++) {
+			double s = 0;
+			for (int r = 0; r < g_loop.nranks; r++) s += g_loop.slots[(size_t) r * kRedMax + j];
+			tmp[j] = s;
+		}
+		loop_barrier();             // nobody overwrites a slot before everybody has read it
+		SQN_HIP_OK(hipMemcpy(buf + done, tmp, (size_t) k * sizeof(double), hipMemcpyHostToDevice));
 	}
-	loop_barrier();                 // nobody overwrites a slot before everybody has read it
-	SQN_HIP_OK(hipMemcpy(buf, tmp, (size_t) count * sizeof(double), hipMemcpyHostToDevice));
 }
 
 void free_view(View& v)

@@ -79,6 +79,8 @@ CONFIGS = [
     ("adaqn_func_increased", "adaQN", dict(mem_size=3, fisher_size=6, bfgs_upd_freq=4), 0.05, 90, dict(f_spike_calls=range(40, 60))),
     ("adaqn_nan", "adaQN", dict(mem_size=3, fisher_size=6, bfgs_upd_freq=4), 0.05, 70, dict(nan_calls=(33,))),
     ("adaqn_nonan_check", "adaQN", dict(mem_size=3, fisher_size=6, bfgs_upd_freq=4, check_nan=False), 0.05, 70, {}),
+    # a Fisher ring larger than any fixed-size scalar buffer in the library (and never full in this run)
+    ("adaqn_fisher500", "adaQN", dict(mem_size=3, fisher_size=500, bfgs_upd_freq=4, max_incr=None), 0.05, 40, {}),
     # rings beyond the 24 pairs the two-pass form handles fall back to the sweep form.  (The adaQN ring
     # configs stop after ~30 calls: later the iterates jitter around the optimum, s = x_avg - x_avg_prev
     # has mixed signs and F s cancels to ~1e-6 of its terms, so ANY two summation orders differ by
@@ -230,7 +232,7 @@ def test_two_loop_host_pointers(hip_backend):
 # empirical Fisher product (reference src/stochqn.c:936-952)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 65, 4096, 100001])
-@pytest.mark.parametrize("fu", [1, 7, 8, 9, 32, 100])
+@pytest.mark.parametrize("fu", [1, 7, 8, 9, 32, 100, 500])
 def test_fisher_product_matches_oracle(n, fu, hip_backend):
     import stochqn_amd
     from oracle import oracle
@@ -495,7 +497,7 @@ def _sharded_run(optname, kw, P_full, nshards, step, calls, hip_backend):
 
 
 @pytest.mark.parametrize("nshards", [2, 3])
-@pytest.mark.parametrize("name", ["sqn_hessvec", "olbfgs_default", "sqn_graddiff", "adaqn_fisher_rms", "sqn_nan", "olbfgs_reject_all"])
+@pytest.mark.parametrize("name", ["sqn_hessvec", "olbfgs_default", "sqn_graddiff", "adaqn_fisher_rms", "sqn_nan", "olbfgs_reject_all", "adaqn_fisher500"])
 def test_sharded_library_equals_unsharded_oracle(name, nshards, form, hip_backend, oracle_backend):
     """Every shard runs the real kernels on its slice; every reduction goes k_fin -> all-reduce
     (loop-back) -> consumer, exactly as with RCCL.  All shards must take the same decisions as the
