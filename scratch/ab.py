@@ -59,7 +59,7 @@ if __name__ == "__main__":
     if kind == "sqn":
         opt.BFGS_mem.upd_freq = opt.bfgs_upd_freq = 10
         opt.niter = 10 * ((opt.niter + 9) // 10)
-    base = {"grid_cap": 0, "rows_grid": 0, "rows_split": 0, "reverse": 1, "twopass": 1, "nontemporal": 1, "combine_batch": 8, "twopass_h0": 0, "h0_per_cu": 0}
+    base = {"grid_cap": 0, "rows_grid": 0, "rows_split": 0, "reverse": 1, "twopass": 1, "nontemporal": 1, "combine_batch": 8, "twopass_h0": 1, "h0_per_cu": 0, "rows_waves": 0}
     for rep in range(2):
         for v in variants:
             o = dict(base); o.update(v)

@@ -716,8 +716,8 @@ __global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, const real* 
 // (wave w owns rows [w*RPW, (w+1)*RPW)), so a lane carries only RPW*NPR accumulators and the loads
 // of a whole pack fit in registers (all issued before the first use).  The probe packs are read
 // by every wave with default-policy loads: one HBM fetch, three L2/L1 hits.
-template <int W, int RPW, int NPR, bool NT>
-__global__ void __launch_bounds__(kBlock) k_rows_dot(RowSet rs, Probes pr, real* copy_out, uint32_t n, int rev, double* parts)
+template <int W, int RPW, int NPR, bool NT, int NW>
+__global__ void __launch_bounds__(64 * NW) k_rows_dot(RowSet rs, Probes pr, real* copy_out, uint32_t n, int rev, double* parts)
 {
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int row0 = wave * RPW;
@@ -1354,33 +1354,31 @@ static bool rows_aligned(const RowSet& r)
 // Workgroups of the row-split kernel that are resident per CU (register-limited: 3 at 10 rows per
 // wave and 3 probes).  The grid is a whole number of such rounds: 1024 workgroups at 3 per CU ran
 // 40 % slower than 768 (a second, quarter-full round).
-template <class K> static int resident_per_cu(K kernel)
+template <class K> static int resident_per_cu(K kernel, int threads)
 {
 	int blocks = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, kBlock, 0) != hipSuccess || blocks < 1) blocks = 1;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, threads, 0) != hipSuccess || blocks < 1) blocks = 1;
 	return blocks > 8 ? 8 : blocks;
 }
 
-template <int W, int NPR>
+template <int W, int NPR, int NW>
 static int rows_dot_dispatch(const Scratch& sc, int slot, size_t max_grid, int rpw, const RowSet& rows, const Probes& pr,
                              real* copy_out, uint32_t n, int rev)
 {
 	int grid = 1;
 	#define SQN_RD(RPW)                                                                                                  \
 		{                                                                                                                \
-			static const int per_cu = resident_per_cu(k_rows_dot<W, RPW, NPR, true>);                                      \
+			static const int per_cu = resident_per_cu(k_rows_dot<W, RPW, NPR, true, NW>, 64 * NW);                         \
 			size_t g = sc.rows_grid > 0 ? (size_t) sc.rows_grid : (size_t) sc.grid_cap * per_cu;                          \
 			if (g > max_grid) g = max_grid;                                                                              \
 			if (g > (size_t) kMaxGrid) g = kMaxGrid;                                                                     \
 			grid = (int) g;                                                                                              \
-			hipLaunchKernelGGL((k_rows_dot<W, RPW, NPR, true>), dim3(grid), dim3(kBlock), 0, sc.stream, rows, pr, copy_out, n, rev, sc.rows_part[slot]); \
+			hipLaunchKernelGGL((k_rows_dot<W, RPW, NPR, true, NW>), dim3(grid), dim3(64 * NW), 0, sc.stream, rows, pr, copy_out, n, rev, sc.rows_part[slot]); \
 		}
 	if (rpw <= 2) SQN_RD(2)
 	else if (rpw <= 4) SQN_RD(4)
 	else if (rpw <= 6) SQN_RD(6)
-	else if (rpw <= 8) SQN_RD(8)
-	else if (rpw <= 10) SQN_RD(10)
-	else SQN_RD(12)
+	else if constexpr (NW == 4) { if (rpw <= 8) SQN_RD(8) else if (rpw <= 10) SQN_RD(10) else SQN_RD(12) }
 	#undef SQN_RD
 	return grid;
 }
@@ -1426,19 +1424,21 @@ Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& ro
 	size_t max_grid = (n / (vec ? kVec : 1) + 63) / 64;         // a workgroup covers 64 packs per step here
 	if (max_grid < 1) max_grid = 1;
 	int grid = 1;
-	const int ng = (rows.count + kWaves - 1) / kWaves;     // rows per wave
+	// waves of a workgroup that split the rows; measured: 8 for a single probe (4.94 vs 5.10 ms of the
+	// all-rows form, n = 1e8, 40 rows), 4 with three probes (7.00 vs 7.08 ms)
+	const int npr_ = probe_y ? 3 : 1;
+	const int nw = sc.rows_waves == 8 ? 8 : (sc.rows_waves == 4 ? kWaves : (npr_ == 1 ? 8 : kWaves));
+	const int ng = (rows.count + nw - 1) / nw;              // rows per wave
 	const int npr = probe_y ? 3 : 1;
 	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
 	const Probes pr{{probe, probe_y, probe_s}};
 	{
 		ProfScope ps(sc, kernel_id);
-		if (npr == 3) {
-			if (vec) grid = rows_dot_dispatch<kVec, 3>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
-			else     grid = rows_dot_dispatch<1, 3>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
-		} else {
-			if (vec) grid = rows_dot_dispatch<kVec, 1>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
-			else     grid = rows_dot_dispatch<1, 1>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
-		}
+		#define SQN_GO(WW, PP) (nw == 8 ? rows_dot_dispatch<WW, PP, 8>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev) \
+		                                : rows_dot_dispatch<WW, PP, 4>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev))
+		if (npr == 3) grid = vec ? SQN_GO(kVec, 3) : SQN_GO(1, 3);
+		else          grid = vec ? SQN_GO(kVec, 1) : SQN_GO(1, 1);
+		#undef SQN_GO
 	}
 	const int nq = npr * rows.count;
 	Partials raw{sc.rows_part[slot], grid, kMaxGrid};

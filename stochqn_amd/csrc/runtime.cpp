@@ -161,6 +161,7 @@ void begin_call(DevCtx* c)
 	c->sc.rows_grid = g_opt.rows_grid;
 	c->sc.reverse = g_opt.reverse;
 	c->sc.rows_split = g_opt.rows_split;
+	c->sc.rows_waves = g_opt.rows_waves;
 	c->sc.combine_batch = g_opt.combine_batch;
 	c->sc.h0_per_cu = g_opt.h0_per_cu;
 	c->sc.prof = g_profile ? &c->prof : nullptr;
@@ -385,6 +386,7 @@ int stochqn_hip_set_option(const char* name, double value)
 		g_opt.rows_grid = g;
 	}
 	else if (!std::strcmp(name, "rows_split")) g_opt.rows_split = value != 0;
+	else if (!std::strcmp(name, "rows_waves")) g_opt.rows_waves = (int) value;
 	else if (!std::strcmp(name, "combine_batch")) g_opt.combine_batch = (int) value;
 	else if (!std::strcmp(name, "h0_per_cu")) g_opt.h0_per_cu = (int) value;
 	else if (!std::strcmp(name, "reverse")) g_opt.reverse = value != 0;

@@ -24,7 +24,10 @@ struct Options {
 	bool nontemporal = true;
 	int grid_cap = 0;            // 0 = one workgroup per compute unit (measured optimum)
 	int rows_grid = 0;           // 0 = four workgroups per compute unit for the row-split rows-dot pass
-	bool rows_split = sizeof(real) == 4;   // single-probe passes: all rows per lane (fp64: 5.1 vs 5.8 ms), waves split the rows (fp32: 3.4 vs 5.9 ms)
+	// single-probe pass A: every lane keeps all rows (fp64: 5.1-5.2 ms; the row-split form is within
+	// +-3 % of it depending on the device) or the waves of a workgroup split the rows (fp32: 2.5 vs 5.9 ms)
+	bool rows_split = sizeof(real) == 4;
+	int rows_waves = 0;          // waves per workgroup of the row-split rows-dot kernel (0 = 8 for one probe, 4 for three)
 	int combine_batch = 8;       // packs a lane finishes in pass B before it stores them
 	bool reverse = true;
 	bool twopass = true;         // scalar-H0 two-loop in the two-pass (Gram) form when the ring has <= kPairsMax pairs

@@ -102,6 +102,7 @@ struct Scratch {
 	int grid_cap;         // max workgroups per sweep (<= kMaxGrid); default = one per CU
 	int rows_grid;        // workgroups of a row-split rows-dot pass; 0 = CUs x resident workgroups per CU
 	bool rows_split;      // use the row-split rows-dot kernel for single-probe passes too
+	int rows_waves;       // waves per workgroup of the row-split kernel: 4 or 8
 	int combine_batch;    // packs a lane finishes in pass B before storing them (1, 2, 4, 8)
 	int h0_per_cu;        // workgroups per CU of the diagonal-H0 Gram pass (0 = 2)
 	bool nontemporal;     // stream S/Y/F rows with nt loads
