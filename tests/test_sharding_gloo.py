@@ -75,8 +75,11 @@ def worker(rank, world, port, n, m, st, out_dir):
 @pytest.mark.parametrize("n,m,st", [(1001, 5, 3), (4096, 3, 0)])
 def test_sharded_recursion_equals_unsharded_oracle(tmp_path, n, m, st):
     from oracle import oracle
+    import socket
     world = 2
-    port = 29500 + (os.getpid() % 2000)
+    with socket.socket() as sock:                      # a port nobody is listening on
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     mp.spawn(worker, args=(world, port, n, m, st, str(tmp_path)), nprocs=world, join=True)
     rng = np.random.default_rng(123)
     d = 0.5 + rng.random(n)
