@@ -739,3 +739,66 @@ def test_two_loop_at_the_int_limit(n, form, hip_backend):
         den += float(torch.sum(s_new ** 2))
     lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))
     assert (num / den) ** 0.5 <= TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# out-of-bounds writes: every caller array sits between guard zones that must survive
+# ---------------------------------------------------------------------------------------------
+class _GuardedSpace:
+    """Device arrays carved out of larger allocations with sentinel-filled guards on both sides.  The
+    payload keeps the alignment class of a plain allocation when `shift` is 0 and is deliberately
+    misaligned (8-byte only) when `shift` is 1."""
+    GUARD = 64
+    SENTINEL = -777.25
+
+    def __init__(self, base_space, shift):
+        self._b = base_space
+        self.torch = base_space.torch
+        self.device = base_space.device
+        self.dtype = base_space.dtype
+        self.tdtype = base_space.tdtype
+        self.name = "device"
+        self.shift = shift
+        self.bases = []
+
+    def empty(self, n):
+        n = int(n)
+        base = self.torch.full((n + 2 * self.GUARD + 2,), self.SENTINEL, dtype=self.tdtype, device=self.device)
+        lo = self.GUARD + self.shift
+        base[lo:lo + n] = 0
+        self.bases.append((base, lo, n))
+        return base[lo:lo + n]
+
+    zeros = empty
+
+    def ptr(self, a):
+        return a.data_ptr()
+
+    def assign(self, dst, src):
+        self._b.assign(dst, src)
+
+    def is_array(self, a):
+        return self._b.is_array(a)
+
+    def check(self):
+        for base, lo, n in self.bases:
+            assert bool((base[:lo] == self.SENTINEL).all()), "write below an array"
+            assert bool((base[lo + n:] == self.SENTINEL).all()), "write beyond an array"
+
+
+@pytest.mark.parametrize("shift", [0, 1])
+@pytest.mark.parametrize("n", [1, 127, 128, 129, 1000, 4099])
+@pytest.mark.parametrize("name", ["olbfgs_default", "sqn_hessvec", "sqn_graddiff", "adaqn_fisher_rms", "adaqn_graddiff", "sqn_ring20"])
+def test_no_out_of_bounds_writes(name, n, shift, form, hip_backend):
+    cfg = [c for c in CONFIGS if c[0] == name][0]
+    _, optname, kw, step, calls, pkw = cfg
+    P = NoisyQuadratic(n, seed=3, **pkw)
+    opt = OPTIMIZERS[optname](backend=hip_backend, space="device", **kw)
+    guarded = _GuardedSpace(opt._sp, shift)
+    opt._sp = guarded
+    x = guarded.empty(n)
+    x.copy_(torch_cuda().as_tensor(P.x0()))
+    run_trace(opt, P, x, step, min(calls, 45))
+    torch_cuda().cuda.synchronize()
+    guarded.check()
+    assert bool(torch_cuda().isfinite(x).all()) or "nan" in name
