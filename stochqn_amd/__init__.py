@@ -23,7 +23,7 @@ def cdll(use_float=False):
     The two precisions export the same symbol names, so each is loaded with local binding."""
     key = bool(use_float)
     if key not in _cdll:
-        path = LIB_PATH_F32 if key else LIB_PATH
+        path = LIB_PATH_F32 if key else _os.environ.get("STOCHQN_LIB", LIB_PATH)    # STOCHQN_LIB: A/B of library builds
         if not _os.path.exists(path):
             raise ImportError(
                 "stochqn_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
