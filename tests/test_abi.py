@@ -151,3 +151,53 @@ def test_reference_cython_shim_builds_against_the_new_library(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     out = subprocess.check_output([os.sys.executable, "-c", code], env=env).decode()
     assert out.strip() == "ok"
+
+
+# The few R API names the reference's .Call shim uses, declared (not implemented) so that the shim
+# can be COMPILED where R is not installed.  This is a compile/link check of a caller, not a build
+# of the reference's algorithm: src/stochqn.c is not part of it.
+_R_API_DECLS = {
+    "R.h": "#pragma once\n#include <stddef.h>\n#ifndef TRUE\n#define TRUE 1\n#define FALSE 0\n#endif\n",
+    "Rinternals.h": ("#pragma once\ntypedef struct SEXPREC *SEXP;\nextern SEXP R_NilValue;\n"
+                     "double *REAL(SEXP x);\nint *INTEGER(SEXP x);\n"),
+    "R_ext/Rdynload.h": ("#pragma once\ntypedef void *(*DL_FUNC)();\ntypedef struct _DllInfo DllInfo;\n"
+                         "typedef struct { const char *name; DL_FUNC fun; int numArgs; } R_CallMethodDef;\n"
+                         "int R_registerRoutines(DllInfo *info, const void *c, const R_CallMethodDef *call, const void *f, const void *e);\n"
+                         "int R_useDynamicSymbols(DllInfo *info, int value);\n"
+                         "void R_RegisterCCallable(const char *package, const char *name, DL_FUNC fptr);\n"),
+}
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_reference_r_shim_compiles_and_links_against_the_new_library(tmp_path):
+    """Link-level drop-in proof for the R binding (INTEGRATION.md "R package"): the
+    reference's own src/Rwrapper.c, read where it lies, compiles against this repository's header
+    with the package's flags (-D_FOR_R -DUSE_DOUBLE) and links against libstochqn.so with
+    stochqn.o dropped from the objects; every run_* / initialize_* / dealloc_* it calls or
+    re-exports is left undefined for libstochqn.so, and the only other undefined names are R's."""
+    for name, text in _R_API_DECLS.items():
+        path = tmp_path / "rapi" / name
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_text(text)
+    obj, so = tmp_path / "Rwrapper.o", tmp_path / "stochQN.so"
+    subprocess.check_call(["gcc", "-std=gnu99", "-O1", "-fPIC", "-Wall", "-Werror=implicit-function-declaration",
+                           "-Werror=incompatible-pointer-types", "-D_FOR_R", "-DUSE_DOUBLE",
+                           "-I", os.path.join(ROOT, "include"), "-I", str(tmp_path / "rapi"),
+                           "-c", os.path.join(REF, "src", "Rwrapper.c"), "-o", str(obj)])
+    libdir = os.path.dirname(stochqn_amd.LIB_PATH)
+    subprocess.check_call(["gcc", "-shared", str(obj), "-L", libdir, "-lstochqn", "-Wl,-rpath," + libdir,
+                           "-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(so)])
+    undefined = {line.split()[-1].split("@")[0] for line in
+                 subprocess.check_output(["nm", "-D", "-u", str(so)]).decode().splitlines() if line.strip()}
+    ours = {p + k for p in ("initialize_", "dealloc_", "run_") for k in ("oLBFGS", "SQN", "adaQN")}
+    assert ours <= undefined
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", stochqn_amd.LIB_PATH]).decode()
+    assert all((" T " + s) in exported for s in ours)
+    r_names = {"REAL", "INTEGER", "R_NilValue", "R_registerRoutines", "R_useDynamicSymbols", "R_RegisterCCallable"}
+    leftovers = {u for u in undefined - ours - r_names if not u.startswith(("__", "_ITM", "_Jv")) and u not in ("memcpy",)}
+    assert not leftovers, leftovers
+    needed = subprocess.check_output(["readelf", "-d", str(so)]).decode()
+    assert "libstochqn.so" in needed
+    defined = subprocess.check_output(["nm", "-D", "--defined-only", str(so)]).decode()
+    for entry in ("r_run_oLBFGS", "r_run_SQN", "r_run_adaQN", "R_init_stochQN"):
+        assert entry in defined
