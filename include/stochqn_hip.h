@@ -57,6 +57,8 @@ int stochqn_hip_export(const void *s_mem);
  *                            effects on the raw gradient (needs "twopass" = 1 as well)
  * "rows_grid", "rows_split", "combine_batch", "h0_per_cu": kernel-shape knobs, see DESIGN.md 3.2
  * "strict_grad" (default 1)  host callers: copy the search direction back into `grad`
+ * "fail_alloc_after" (default -1 = off)  fault injection for tests: the (value+1)-th device or
+ *                             pinned allocation from now fails once
  * Returns 0, or -1 for an unknown name. Applies to contexts created afterwards and existing ones. */
 int stochqn_hip_set_option(const char *name, double value);
 

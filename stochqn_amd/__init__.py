@@ -6,7 +6,9 @@ only the host-side mirror of the reference's Python free-mode objects over that 
 the loader below.  There is no CPU fallback: if the HIP library is missing, loading fails.
 """
 import ctypes as _C
+import importlib.util as _ilu
 import os as _os
+import sys as _sys
 
 from . import _abi
 
@@ -16,6 +18,28 @@ LIB_PATH_F32 = _os.path.join(_HERE, "lib", "libstochqn_f32.so")
 
 _bound = {}
 _cdll = {}
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  torch's wheels bundle their own libamdhip64.so / libhsa-runtime64.so
+    (same SONAMEs as /opt/rocm's).  If libstochqn.so is loaded first it brings in /opt/rocm's copies and a
+    later `import torch` adds the bundled ones: two runtimes, torch.cuda then reports no device and torch's
+    device pointers mean nothing to the library (measured on the GPU box, scratch/probe_order.py).  Loading
+    the bundled copies first makes the dynamic loader resolve libstochqn's NEEDED entries to them by SONAME,
+    whichever of the two is imported first.  Without torch installed nothing happens."""
+    if "torch" in _sys.modules:
+        return
+    try:
+        spec = _ilu.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = _os.path.join(_os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = _os.path.join(libdir, name)
+        if _os.path.exists(path):
+            _C.CDLL(path, mode=_C.RTLD_GLOBAL)
 
 
 def cdll(use_float=False):
@@ -28,6 +52,7 @@ def cdll(use_float=False):
             raise ImportError(
                 "stochqn_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C stochqn_amd/csrc`.  There is no CPU fallback." % path)
+        _share_hip_runtime_with_torch()
         _cdll[key] = _C.CDLL(path, mode=_C.RTLD_LOCAL)
     return _cdll[key]
 

@@ -41,6 +41,7 @@ struct Call {
 	real* x = nullptr;              // device views
 	real* g = nullptr;
 	bool g_host = false;
+	bool fresh = false;             // the device context was created by this call
 };
 
 inline size_t N(const DevCtx* c) { return (size_t) c->n; }
@@ -110,7 +111,10 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 		if (!c) return false;
 	}
 	io.c = c;
-	if (!bind_bfgs(c, b, fresh && resumed)) return false;
+	io.fresh = fresh;
+	// a context that could not be completed is dropped again: the next call starts over (and
+	// re-imports host arrays) instead of continuing on half-bound views
+	if (!bind_bfgs(c, b, fresh && resumed)) { release(b->s_mem); return false; }
 	if (fresh) {
 		comm_attach(c);
 		c->rho_ok.assign(c->m, 0);
@@ -120,6 +124,11 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 	io.g_caller = grad;
 	io.host_caller = !is_device_pointer(x);
 	io.g_host = !is_device_pointer(grad);
+	// staging vectors for host x / grad exist before anything is enqueued: stage_xg cannot fail later
+	if ((io.host_caller && !ensure_stage(c, 0)) || (io.g_host && !ensure_stage(c, 1))) {
+		if (fresh) release(b->s_mem);
+		return false;
+	}
 	return true;
 }
 
@@ -141,9 +150,13 @@ real* publish(Call& io, View& v, size_t offset, int slot)
 		vec_to_host(c, host, dev, N(c));
 		return host;
 	}
-	if (!c->host_stage[slot]) SQN_HIP_OK(hipHostMalloc((void**) &c->host_stage[slot], N(c) * sizeof(real), hipHostMallocDefault));
-	vec_to_host(c, c->host_stage[slot], dev, N(c));
-	return c->host_stage[slot];
+	real* landing = host_landing(c, slot);
+	if (!landing) {                       // no host memory left: nothing sensible to hand out
+		std::fprintf(stderr, "stochqn: could not allocate a host buffer for the requested vector\n");
+		return nullptr;
+	}
+	vec_to_host(c, landing, dev, N(c));
+	return landing;
 }
 
 // End of a call that touched x / grad: bring host copies up to date, then synchronise.
@@ -431,6 +444,14 @@ void archive_average(DevCtx* c)                                          // arch
 	zero(c, c->xsum.dev, N(c));
 }
 
+int invalid(task_enum* task, const char* who);
+// failure after open_call succeeded (a view could not be bound)
+int abandon(Call& io, const bfgs_mem* b, task_enum* task, const char* who)
+{
+	if (io.fresh) release(b->s_mem);
+	return invalid(task, who);
+}
+
 int invalid(task_enum* task, const char* who)
 {
 	*task = invalid_input;
@@ -448,7 +469,7 @@ int no_device(task_enum* task, const char* who)
 void* dev_alloc(size_t count, bool zero_fill)
 {
 	void* p = nullptr;
-	if (hipMalloc(&p, count * sizeof(real)) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+	if (!device_alloc(&p, count * sizeof(real))) return nullptr;
 	if (zero_fill) SQN_HIP_OK(hipMemset(p, 0, count * sizeof(real)));
 	return p;
 }
@@ -490,7 +511,7 @@ static int run_oLBFGS_impl(real_t step_size, real_t x[], real_t grad[], real_t**
 	Call io;
 	if (!open_call(io, KIND_OLBFGS, w->n, b, 0, w->niter > 0 || b->mem_used > 0, x, grad, w->niter, w->section)) return invalid(task, "oLBFGS");
 	DevCtx* c = io.c;
-	if (!bind(c, c->gprev, w->grad_prev, N(c), true)) return invalid(task, "oLBFGS");
+	if (!bind(c, c->gprev, w->grad_prev, N(c), true)) return abandon(io, b, task, "oLBFGS");
 
 	if (w->section == 1) {                     // step; s-slot; ask for the gradient on the same batch
 		stage_xg(io, true, true);
@@ -549,7 +570,7 @@ static int run_SQN_impl(real_t step_size, real_t x[], real_t grad[], real_t hess
 		const size_t n = N(c);
 		if (!bind(c, c->gprev, w->grad_prev, w->use_grad_diff ? n : 0, true) ||
 		    !bind(c, c->xsum, w->x_sum, n, true) || !bind(c, c->xprev, w->x_avg_prev, n, true))
-			return invalid(task, "SQN");
+			return abandon(io, b, task, "SQN");
 
 		switch (w->section) {
 		case 1: {
@@ -609,6 +630,7 @@ static int run_SQN_impl(real_t step_size, real_t x[], real_t grad[], real_t hess
 		case 4: {                                                     // :1137-1142
 			const bool hv_host = !is_device_pointer(hess_vec);
 			real* hv = stage_in(c, 2, hess_vec, n, hv_host);
+			if (!hv) return invalid(task, "SQN");
 			const size_t st = b->mem_st_ix;
 			Partials p = launch_pair_y_hv(c->sc, c->next_buf(), n, hv, row(c->S, st, c), row(c->Y, st, c), c->xsum.dev, c->xprev.dev);
 			accept_or_reject(c, b, p, iter_info);
@@ -650,7 +672,7 @@ static int run_adaQN_impl(real_t step_size, real_t x[], real_t f, real_t grad[],
 		    !bind(c, c->xsum, w->x_sum, n, true) || !bind(c, c->xprev, w->x_avg_prev, n, true) ||
 		    !bind(c, c->H0, w->H0, n, false) || !bind(c, c->G, w->grad_sum_sq, n, true) ||
 		    !bind(c, c->F, fm ? fm->F : nullptr, fsize * n, resumed && fm && fm->mem_used > 0))
-			return invalid(task, "adaQN");
+			return abandon(io, b, task, "adaQN");
 
 		switch (w->section) {
 		case 1: {
@@ -991,6 +1013,7 @@ int stochqn_hip_two_loop(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 	if (fresh) comm_attach(c);
 	const bool g_host = !is_device_pointer(grad);
 	real* g = stage_in(c, 1, grad, nn, g_host);
+	if (!g) return -1000;
 	if (twopass_ok(c, mem_used, H0 ? c->H0.dev : nullptr)) {
 		(void) enqueue_two_pass(c, g, mem_used, mem_st_ix % mem_size, h0, nullptr);
 	} else {
@@ -1018,11 +1041,8 @@ int stochqn_hip_fisher_product(real_t F[], size_t fu, int n, real_t s[], real_t 
 	if (c->F.mirror) SQN_HIP_OK(hipMemcpyAsync(c->F.dev, F, fu * nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
 	const bool s_host = !is_device_pointer(s), y_host = !is_device_pointer(y);
 	real* sd = stage_in(c, 0, s, nn, s_host);
-	real* yd = y;
-	if (y_host) {
-		if (!c->stage[1]) SQN_HIP_OK(hipMalloc((void**) &c->stage[1], nn * sizeof(real)));
-		yd = c->stage[1];
-	}
+	if (!sd || (y_host && !ensure_stage(c, 1))) return -1000;
+	real* yd = y_host ? c->stage[1] : y;
 	launch_fisher(c->sc, c->next_buf(), nn, c->F.dev, fu, sd, c->fisher_t, yd);
 	to_host(c, c->pin + 8 + 2 * c->m, c->fisher_t, fu);
 	if (y_host) vec_to_host(c, y, yd, nn);

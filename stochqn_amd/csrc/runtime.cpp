@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
@@ -19,6 +20,16 @@ namespace {
 std::mutex g_mu;
 std::unordered_map<const void*, DevCtx*> g_ctx;
 Options g_opt;
+std::atomic<long> g_fail_alloc_after{-1};       // fault injection: < 0 off, else allocations left before one fails
+
+bool alloc_should_fail()
+{
+	long left = g_fail_alloc_after.load();
+	while (left >= 0) {
+		if (g_fail_alloc_after.compare_exchange_weak(left, left - 1)) return left == 0;
+	}
+	return false;
+}
 bool g_profile = false;
 double g_retired_ms[K_COUNT] = {0};
 long long g_retired_launches[K_COUNT] = {0};
@@ -128,7 +139,10 @@ void destroy(DevCtx* c)
 	if (c->sc.fisher_part) SQN_HIP_OK(hipFree(c->sc.fisher_part));
 	if (c->fisher_t) SQN_HIP_OK(hipFree(c->fisher_t));
 	for (real* p : c->stage) if (p) SQN_HIP_OK(hipFree(p));
-	for (real* p : c->host_stage) if (p) SQN_HIP_OK(hipHostFree(p));
+	for (int i = 0; i < 2; i++) {
+		if (c->host_stage[i] && c->host_stage_pinned[i]) SQN_HIP_OK(hipHostFree(c->host_stage[i]));
+		else std::free(c->host_stage[i]);
+	}
 	if (c->pin) SQN_HIP_OK(hipHostFree(c->pin));
 	if (c->sc.stream) SQN_HIP_OK(hipStreamDestroy(c->sc.stream));
 	delete c;
@@ -140,6 +154,29 @@ void at_exit() { /* device memory dies with the process; destroying streams here
 }  // namespace
 
 Options& options() { return g_opt; }
+
+bool device_alloc(void** p, size_t bytes)
+{
+	*p = nullptr;
+	if (alloc_should_fail() || hipMalloc(p, bytes ? bytes : 1) != hipSuccess) {
+		(void) hipGetLastError();
+		*p = nullptr;
+		std::fprintf(stderr, "stochqn: could not allocate %zu bytes of device memory\n", bytes);
+		return false;
+	}
+	return true;
+}
+
+bool pinned_alloc(void** p, size_t bytes)
+{
+	*p = nullptr;
+	if (alloc_should_fail() || hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+		(void) hipGetLastError();
+		*p = nullptr;
+		return false;
+	}
+	return true;
+}
 
 int default_grid_cap()
 {
@@ -219,10 +256,13 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	const size_t part = (size_t) kMaxSums * kMaxGrid;
 	const size_t rows_part = (size_t) kRedMax * kMaxGrid;
 	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + 2 * m * m + (2 + 2 * kPairsMax);
-	if (hipMalloc((void**) &c->pool, total * sizeof(double)) != hipSuccess) {
-		std::fprintf(stderr, "stochqn: could not allocate device scratch\n");
-		(void) hipStreamDestroy(c->sc.stream);
-		delete c;
+	c->pin_count = 16 + 2 * m + fsize;
+	if (!device_alloc((void**) &c->pool, total * sizeof(double)) ||
+	    !pinned_alloc((void**) &c->pin, c->pin_count * sizeof(double)) ||
+	    (fsize > 0 && (!device_alloc((void**) &c->sc.fisher_part, fsize * kMaxGrid * sizeof(double)) ||
+	                   !device_alloc((void**) &c->fisher_t, fsize * sizeof(double))))) {
+		std::fprintf(stderr, "stochqn: could not allocate the scratch of a device context\n");
+		destroy(c);
 		return nullptr;
 	}
 	SQN_HIP_OK(hipMemset(c->pool, 0, total * sizeof(double)));
@@ -241,12 +281,6 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	c->sc.gsy = p; p += m * m;
 	c->sc.gyy = p; p += m * m;
 	c->sc.coef = p;
-	c->pin_count = 16 + 2 * m + fsize;
-	SQN_HIP_OK(hipHostMalloc((void**) &c->pin, c->pin_count * sizeof(double), hipHostMallocDefault));
-	if (fsize > 0) {
-		SQN_HIP_OK(hipMalloc((void**) &c->sc.fisher_part, fsize * kMaxGrid * sizeof(double)));
-		SQN_HIP_OK(hipMalloc((void**) &c->fisher_t, fsize * sizeof(double)));
-	}
 	c->rho_ok.assign(m, 0);
 	c->gram_ok.assign(m, 0);
 	begin_call(c);
@@ -293,7 +327,7 @@ bool bind(DevCtx* c, View& v, real* caller, size_t count, bool import)
 	v.count = count;
 	if (!caller || count == 0) return true;
 	if (is_device_pointer(caller)) { v.dev = caller; v.mirror = false; return true; }
-	if (hipMalloc((void**) &v.dev, count * sizeof(real)) != hipSuccess) {
+	if (!device_alloc((void**) &v.dev, count * sizeof(real))) {
 		std::fprintf(stderr, "stochqn: could not allocate a %zu-element device mirror\n", count);
 		v = View{};
 		return false;
@@ -310,10 +344,24 @@ void export_view(DevCtx* c, View& v)
 		SQN_HIP_OK(hipMemcpyAsync(const_cast<void*>(v.caller), v.dev, v.count * sizeof(real), hipMemcpyDeviceToHost, c->sc.stream));
 }
 
+bool ensure_stage(DevCtx* c, int which)
+{
+	return c->stage[which] || device_alloc((void**) &c->stage[which], (size_t) c->n * sizeof(real));
+}
+
+real* host_landing(DevCtx* c, int slot)
+{
+	if (c->host_stage[slot]) return c->host_stage[slot];
+	const size_t bytes = (size_t) c->n * sizeof(real);
+	c->host_stage_pinned[slot] = pinned_alloc((void**) &c->host_stage[slot], bytes);
+	if (!c->host_stage_pinned[slot]) c->host_stage[slot] = (real*) std::malloc(bytes);    // slower copies, same result
+	return c->host_stage[slot];
+}
+
 real* stage_in(DevCtx* c, int which, real* caller, size_t count, bool host)
 {
 	if (!host) return caller;
-	if (!c->stage[which]) SQN_HIP_OK(hipMalloc((void**) &c->stage[which], (size_t) c->n * sizeof(real)));
+	if (!ensure_stage(c, which)) return nullptr;
 	SQN_HIP_OK(hipMemcpyAsync(c->stage[which], caller, count * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
 	return c->stage[which];
 }
@@ -393,6 +441,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "twopass")) g_opt.twopass = value != 0;
 	else if (!std::strcmp(name, "twopass_h0")) g_opt.twopass_h0 = value != 0;
 	else if (!std::strcmp(name, "strict_grad")) g_opt.strict_grad = value != 0;
+	else if (!std::strcmp(name, "fail_alloc_after")) g_fail_alloc_after.store((long) value);
 	else return -1;
 	return 0;
 }

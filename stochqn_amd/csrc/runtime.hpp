@@ -54,7 +54,8 @@ struct DevCtx {
 	double* pool = nullptr;            // one allocation behind sc.part/red/sy/yy/alpha/rho/report
 	double* fisher_t = nullptr;        // [fsize] F*s on device
 	real* stage[3] = {nullptr, nullptr, nullptr};     // device staging for host x / grad / hess_vec
-	real* host_stage[2] = {nullptr, nullptr};         // pinned host landing zones for *req / *req_vec
+	real* host_stage[2] = {nullptr, nullptr};         // host landing zones for *req / *req_vec
+	bool host_stage_pinned[2] = {false, false};       // (pageable when pinned memory ran out)
 	double* pin = nullptr;             // pinned host read-back block
 	size_t pin_count = 0;
 	// what the caller's struct looked like when the last call on this context returned; a call that
@@ -70,6 +71,11 @@ struct DevCtx {
 };
 
 bool device_ready();                                   // a HIP device exists and is usable
+// Every device / pinned-host allocation of the library goes through these two: they report failure
+// instead of printing and carrying on, and honour the fault-injection option "fail_alloc_after"
+// (tests: the k-th allocation from now fails once).
+bool device_alloc(void** p, size_t bytes);
+bool pinned_alloc(void** p, size_t bytes);
 bool is_device_pointer(const void* p);
 
 // Find or create the context of a workspace.  `fresh` tells the caller whether it was created now.
@@ -84,7 +90,9 @@ void release_all();
 bool bind(DevCtx* c, View& v, real* caller, size_t count, bool import);
 void export_view(DevCtx* c, View& v);                  // mirror -> caller's host array
 
-real* stage_in(DevCtx* c, int which, real* caller, size_t count, bool host);       // H2D if host
+bool ensure_stage(DevCtx* c, int which);               // device staging vector `which` exists
+real* stage_in(DevCtx* c, int which, real* caller, size_t count, bool host);       // H2D if host; nullptr = out of memory
+real* host_landing(DevCtx* c, int slot);               // host landing zone for *req / *req_vec (pinned if possible)
 void begin_call(DevCtx* c);                            // refresh options, restart the sweep parity
 void sync(DevCtx* c);                                  // stream sync + profiler collection
 

@@ -201,3 +201,24 @@ def test_reference_r_shim_compiles_and_links_against_the_new_library(tmp_path):
     defined = subprocess.check_output(["nm", "-D", "--defined-only", str(so)]).decode()
     for entry in ("r_run_oLBFGS", "r_run_SQN", "r_run_adaQN", "R_init_stochQN"):
         assert entry in defined
+
+
+_ONE_RUNTIME = r"""
+import sys
+sys.path.insert(0, %r)
+import stochqn_amd
+lib = stochqn_amd.cdll()                     # the library BEFORE torch
+import torch
+maps = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})
+assert len(maps) == 1, maps
+print('one-runtime', torch.cuda.is_available() == bool(lib.stochqn_hip_available()))
+"""
+
+
+def test_library_and_torch_share_one_hip_runtime():
+    """torch bundles its own libamdhip64.so; loaded after libstochqn.so it used to become a second HIP
+    runtime in the process (torch.cuda then sees no device).  stochqn_amd.cdll() loads the bundled
+    copy first, so there is one runtime whichever import comes first, and both agree on the GPU."""
+    pytest.importorskip("torch")
+    out = subprocess.check_output([os.sys.executable, "-c", _ONE_RUNTIME % ROOT], stderr=subprocess.STDOUT).decode()
+    assert "one-runtime True" in out, out

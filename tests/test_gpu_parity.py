@@ -802,3 +802,119 @@ def test_no_out_of_bounds_writes(name, n, shift, form, hip_backend):
     torch_cuda().cuda.synchronize()
     guarded.check()
     assert bool(torch_cuda().isfinite(x).all()) or "nan" in name
+
+
+# ---------------------------------------------------------------------------------------------
+# allocation failures (reference src/stochqn.c:479,504,545: print, clean up, report -- never crash)
+# ---------------------------------------------------------------------------------------------
+class _RetryOnce:
+    """Wraps an optimiser: a call refused with "invalid workspace" while an allocation failure is
+    injected is repeated once with the injection off.  A refused call must not have touched x, the
+    counters or the device state, so the trace has to come out as if nothing had happened."""
+
+    def __init__(self, opt, setopt):
+        self.__dict__["_opt"], self.__dict__["_setopt"], self.__dict__["refused"] = opt, setopt, 0
+
+    def __getattr__(self, name):
+        return getattr(self._opt, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._opt, name, value)
+
+    def run_optimizer(self, x, step):
+        try:
+            return self._opt.run_optimizer(x, step)
+        except ValueError:
+            self._setopt(b"fail_alloc_after", -1.0)
+            self.__dict__["refused"] += 1
+            return self._opt.run_optimizer(x, step)
+
+
+@pytest.mark.parametrize("space", ["host", "device"])
+@pytest.mark.parametrize("cfgname", ["olbfgs_default", "sqn_hessvec", "sqn_graddiff", "adaqn_fisher_rms"])
+def test_allocation_failures_are_refused_cleanly(cfgname, space, hip_backend, oracle_backend, capfd):
+    """Fault injection (option fail_alloc_after = k: the (k+1)-th device / pinned allocation from now
+    fails once).  For every k until the run needs no more allocations: the call that hits the
+    failure returns -1000 with task = invalid_input and a message on stderr, leaves the optimiser
+    untouched, and the same call repeated afterwards succeeds -- the whole trace still equals the
+    oracle's."""
+    import stochqn_amd
+    lib = stochqn_amd.cdll()
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    cfg = {c[0]: c for c in CONFIGS}[cfgname]
+    _, optname, kw, step, calls, pkw = cfg
+    n = 300
+    P = NoisyQuadratic(n, seed=7, **pkw)
+    want = run_trace(OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw), P, P.x0(), step, calls)
+    refused_total = 0
+    try:
+        for k in range(40):
+            opt = _RetryOnce(OPTIMIZERS[optname](backend=hip_backend, space=space, **kw), lib.stochqn_hip_set_option)
+            x = P.x0() if space == "host" else torch_cuda().as_tensor(P.x0(), device="cuda")
+            lib.stochqn_hip_set_option(b"fail_alloc_after", float(k))
+            got = run_trace(opt, P, x, step, calls)
+            lib.stochqn_hip_set_option(b"fail_alloc_after", -1.0)
+            compare_traces(got, want, FREE_RUN_TOL.get(cfgname, TOL))
+            refused_total += opt.refused
+            opt._opt.release()
+            if opt.refused == 0:          # k allocations were not even reached: nothing left to break
+                break
+        else:
+            raise AssertionError("more than 40 allocations in one short run")
+    finally:
+        lib.stochqn_hip_set_option(b"fail_alloc_after", -1.0)
+    assert refused_total >= 2            # at least the scratch pool and the pinned read-back block
+    assert "could not allocate" in capfd.readouterr().err
+
+
+def test_initialize_reports_allocation_failure(hip_backend, capfd):
+    """initialize_* with an allocation that fails -> NULL + message, nothing leaked that a later
+    call would trip over (reference src/stochqn.c:479,504,545)."""
+    import stochqn_amd
+    lib = stochqn_amd.cdll()
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    lib.initialize_SQN.restype = C.c_void_p
+    lib.initialize_SQN.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int]
+    lib.initialize_adaQN.restype = C.c_void_p
+    lib.initialize_adaQN.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double,
+                                     C.c_double, C.c_int, C.c_double, C.c_int, C.c_int]
+    lib.dealloc_SQN.argtypes = [C.c_void_p]
+    lib.dealloc_adaQN.argtypes = [C.c_void_p]
+    try:
+        for k in range(6):
+            lib.stochqn_hip_set_option(b"fail_alloc_after", float(k))
+            assert lib.initialize_SQN(1000, 5, 10, 1e-4, 0, 0.0, 1, 1) is None
+        for k in range(9):
+            lib.stochqn_hip_set_option(b"fail_alloc_after", float(k))
+            assert lib.initialize_adaQN(1000, 5, 16, 10, 1.01, 1e-4, 1e-4, 0.9, 0, 0.0, 1, 1) is None
+    finally:
+        lib.stochqn_hip_set_option(b"fail_alloc_after", -1.0)
+    assert "Could not allocate memory" in capfd.readouterr().err
+    # far beyond the 288 GB of the device: the real thing, not the injected one
+    assert lib.initialize_SQN(2**31 - 1, 64, 10, 0.0, 0, 0.0, 1, 1) is None
+    w = lib.initialize_SQN(1000, 5, 10, 1e-4, 0, 0.0, 1, 1)
+    assert w is not None
+    lib.dealloc_SQN(w)
+
+
+def test_library_loaded_before_torch_still_takes_torch_tensors():
+    """Import order must not matter (stochqn_amd._share_hip_runtime_with_torch): a fresh process loads
+    libstochqn.so first, runs a host-caller optimisation, then imports torch and hands the library
+    torch device tensors."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np, stochqn_amd\n"
+        "from harness import NoisyQuadratic, run_trace, OPTIMIZERS\n"
+        "be = stochqn_amd.lib(); P = NoisyQuadratic(300, seed=7)\n"
+        "h = run_trace(OPTIMIZERS['SQN'](backend=be, space='host', mem_size=3, bfgs_upd_freq=4), P, P.x0(), 0.1, 40)\n"
+        "import torch\n"
+        "assert torch.cuda.is_available()\n"
+        "x = torch.as_tensor(P.x0(), device='cuda')\n"
+        "d = run_trace(OPTIMIZERS['SQN'](backend=be, space='device', mem_size=3, bfgs_upd_freq=4), P, x, 0.1, 40)\n"
+        "assert np.array_equal(h[-1]['x'], d[-1]['x']) and h[-1]['niter'] == d[-1]['niter']\n"
+        "print('order-ok')\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "order-ok" in out.stdout, out.stdout + out.stderr
