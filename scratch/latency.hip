@@ -1,0 +1,61 @@
+// scratch/latency.hip -- fixed per-call cost of the C ABI with a device-resident caller (not product).
+// build: hipcc --offload-arch=gfx950 -O2 -I include scratch/latency.hip -L stochqn_amd/lib -lstochqn -Wl,-rpath,$PWD/stochqn_amd/lib -o scratch/latency
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "stochqn.h"
+#include "stochqn_hip.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+__global__ void k_grad(const double* d, const double* x, double* g, int n, double noise)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) g[i] = d[i] * x[i] * (1.0 + noise * ((i * 2654435761u >> 8 & 1023) / 1024.0 - 0.5));
+}
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char** argv)
+{
+	const char* kind = argc > 1 ? argv[1] : "olbfgs";
+	const int n = argc > 2 ? (int) atof(argv[2]) : 1000;
+	const int m = argc > 3 ? atoi(argv[3]) : 10;
+	const int steps = argc > 4 ? atoi(argv[4]) : 500;
+	std::vector<double> hd(n), hx(n);
+	for (int i = 0; i < n; i++) { hd[i] = 0.5 + (i % 97) / 97.0; hx[i] = 1.0 + (i % 89) / 89.0; }
+	double *d, *x, *g, *hv;
+	CK(hipMalloc(&d, n * 8.0)); CK(hipMalloc(&x, n * 8.0)); CK(hipMalloc(&g, n * 8.0)); CK(hipMalloc(&hv, n * 8.0));
+	CK(hipMemcpy(d, hd.data(), n * 8.0, hipMemcpyHostToDevice)); CK(hipMemcpy(x, hx.data(), n * 8.0, hipMemcpyHostToDevice));
+	double* req = nullptr; double* req_vec = nullptr; task_enum task; info_enum info;
+	const bool sqn = kind[0] == 's';
+	workspace_oLBFGS* wo = sqn ? nullptr : initialize_oLBFGS(n, m, 0, 0, 0, 1, 1);
+	workspace_SQN* ws = sqn ? initialize_SQN(n, m, 10, 0, 0, 0, 1, 1) : nullptr;
+	auto iter = [&](long& calls) {
+		const size_t target = (sqn ? ws->niter : wo->niter) + 1;
+		while ((sqn ? ws->niter : wo->niter) < target) {
+			if (sqn) run_SQN(0.01, x, g, hv, &req, &req_vec, &task, ws, &info); else run_oLBFGS(0.01, x, g, &req, &task, wo, &info);
+			calls++;
+			if (task == calc_grad || task == calc_grad_same_batch) hipLaunchKernelGGL(k_grad, dim3((n + 255) / 256), dim3(256), 0, 0, d, req, g, n, task == calc_grad ? 0.01 : 0.0);
+			else if (task == calc_hess_vec) hipLaunchKernelGGL(k_grad, dim3((n + 255) / 256), dim3(256), 0, 0, d, req_vec, hv, n, 0.0);
+		}
+	};
+	long calls = 0;
+	for (int i = 0; i < 3 * m + 25; i++) iter(calls);
+	CK(hipDeviceSynchronize());
+	stochqn_hip_profile_enable(1); stochqn_hip_profile_reset();
+	calls = 0;
+	const double t0 = now();
+	for (int i = 0; i < steps; i++) iter(calls);
+	CK(hipDeviceSynchronize());
+	const double dt = now() - t0;
+	stochqn_hip_profile_enable(0);
+	double ksum = 0;
+	printf("%s n=%d m=%d: %.1f us/step, %.2f calls/step;", kind, n, m, 1e6 * dt / steps, (double) calls / steps);
+	for (int i = 0; i < stochqn_hip_profile_kernels(); i++) {
+		long long cnt; double ms;
+		stochqn_hip_profile_get(i, &cnt, &ms);
+		if (cnt) { printf(" %s %.1fx%.1fus", stochqn_hip_profile_name(i), (double) cnt / steps, 1e3 * ms / cnt); ksum += ms; }
+	}
+	printf("; kernels %.1f us/step\n", 1e3 * ksum / steps);
+	return 0;
+}

@@ -125,13 +125,21 @@ __device__ __forceinline__ double total_of(const double* parts, int count, doubl
 	return block_sum(a, sh);
 }
 
+// Sum over the wave, returned to every lane.
+__device__ __forceinline__ double wave_sum_all(double v) { return __shfl(wave_sum(v), 0, 64); }
+
 // Total of one partial array computed by ONE wave (lane-strided adds, then the shuffle tree); lets
 // the 1-workgroup scalar kernels reduce kWaves quantities at a time without workgroup barriers.
 __device__ __forceinline__ double wave_total_of(const double* parts, int count)
 {
-	double a = 0;
-	for (int i = threadIdx.x & 63; i < count; i += 64) a += parts[i];
-	a = wave_sum(a);
+	const int lane = threadIdx.x & 63;
+	double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+	int i = lane;
+	for (; i + 192 < count; i += 256) {       // four independent loads in flight per lane
+		a0 += parts[i]; a1 += parts[i + 64]; a2 += parts[i + 128]; a3 += parts[i + 192];
+	}
+	for (; i < count; i += 64) a0 += parts[i];
+	const double a = wave_sum((a0 + a1) + (a2 + a3));
 	return __shfl(a, 0, 64);
 }
 
@@ -768,26 +776,6 @@ __global__ void __launch_bounds__(64 * NW) k_rows_dot(RowSet rs, Probes pr, real
 		}
 }
 
-// Fused Gram maintenance: pass A ran over the k pairs in use (rows 0..k-1 = S, k..2k-1 = Y, logical
-// order) with probes (g, y_r, s_r); quantities 2k.. are the dots with y_r, 4k.. the dots with s_r.
-__global__ void __launch_bounds__(kBlock) k_gram_store_fused(const double* parts, int count, int stride, CoefArgs a, int r,
-                                                             double* gsy, double* gyy)
-{
-	const int k = a.k, m = a.m, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	for (int i = wave; i < k; i += kWaves) {
-		const int j = a.rows[i];
-		const double sjyr = wave_total_of(parts + (size_t) (2 * k + i) * stride, count);       // s_j'y_r
-		const double yjyr = wave_total_of(parts + (size_t) (2 * k + k + i) * stride, count);   // y_j'y_r
-		const double yjsr = wave_total_of(parts + (size_t) (4 * k + k + i) * stride, count);   // y_j's_r
-		if (lane == 0) {
-			gsy[(size_t) j * m + r] = sjyr;
-			gsy[(size_t) r * m + j] = yjsr;
-			gyy[(size_t) j * m + r] = yjyr;
-			gyy[(size_t) r * m + j] = yjyr;
-		}
-	}
-}
-
 // Gram maintenance for ring row r: a[j] = s_j'y_r (j < m), a[m+j] = y_j'y_r, b[j] = y_j's_r
 __global__ void __launch_bounds__(kBlock) k_gram_store(const double* a, int a_count, int a_stride, const double* b, int b_count,
                                                        int b_stride, int m, int r, double* gsy, double* gyy)
@@ -808,41 +796,64 @@ __global__ void __launch_bounds__(kBlock) k_gram_store(const double* a, int a_co
 
 // The scalar part of the recursion (reference src/stochqn.c:671-707 with every inner product
 // expanded over the cached Gram blocks).  One workgroup; lane 0 runs the O(k^2) recursion from LDS.
-__global__ void __launch_bounds__(kBlock) k_coef(const double* bparts, int count, int stride, CoefArgs a, const double* gsy,
-                                                 const double* gyy, double* alpha_out, double* rho_out, double* coef)
+// `fresh_row` >= 0: pass A was the 3-probe form over the k pairs in use (rows 0..k-1 = S, k..2k-1 = Y,
+// logical order) with probes (g, y_r, s_r), r = fresh_row: quantities 2k.. are the dots with y_r,
+// 4k.. the dots with s_r.  Ring row r's Gram row and column are stored first (no kernel of their own).
+__global__ void __launch_bounds__(kCoefBlock) k_coef(const double* bparts, int count, int stride, CoefArgs a, int fresh_row,
+                                                     double* gsy, double* gyy, double* alpha_out, double* rho_out, double* coef)
 {
 	__shared__ double SY[kPairsMax * kPairsMax], YY[kPairsMax * kPairsMax], bS[kPairsMax], bY[kPairsMax];
-	__shared__ double al[kPairsMax], rho[kPairsMax], c[kPairsMax];
 	const int k = a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	for (int e = threadIdx.x; e < k * k; e += kBlock) {      // logical-order copies of the Gram blocks
+	if (fresh_row >= 0) {
+		const int m = a.m, r = fresh_row;
+		for (int i = wave; i < k; i += kCoefWaves) {
+			const int j = a.rows[i];
+			const double sjyr = wave_total_of(bparts + (size_t) (2 * k + i) * stride, count);       // s_j'y_r
+			const double yjyr = wave_total_of(bparts + (size_t) (2 * k + k + i) * stride, count);   // y_j'y_r
+			const double yjsr = wave_total_of(bparts + (size_t) (4 * k + k + i) * stride, count);   // y_j's_r
+			if (lane == 0) {
+				gsy[(size_t) j * m + r] = sjyr;
+				gsy[(size_t) r * m + j] = yjsr;
+				gyy[(size_t) j * m + r] = yjyr;
+				gyy[(size_t) r * m + j] = yjyr;
+			}
+		}
+		__threadfence_block();
+		__syncthreads();                                     // the copies below read what was just stored
+	}
+	for (int e = threadIdx.x; e < k * k; e += kCoefBlock) {  // logical-order copies of the Gram blocks
 		const int i = e / k, j = e % k;
 		SY[e] = gsy[(size_t) a.rows[i] * a.m + a.rows[j]];
 		YY[e] = gyy[(size_t) a.rows[i] * a.m + a.rows[j]];
 	}
-	for (int q = wave; q < 2 * k; q += kWaves) {             // b = [S;Y]g, one wave per quantity
+	for (int q = wave; q < 2 * k; q += kCoefWaves) {         // b = [S;Y]g, one wave per quantity
 		const double t = wave_total_of(bparts + (size_t) q * stride, count);
 		if (lane == 0) { if (q < k) bS[q] = t; else bY[q - k] = t; }
 	}
 	__syncthreads();
-	if (threadIdx.x != 0) return;
+	if (wave != 0) return;
+	// The recursion proper, by one wave: lane j keeps alpha_j and c_j, every inner sum over the pairs
+	// is one product per lane and a shuffle reduction (k <= kPairsMax < 64).
+	const bool mine = lane < k;
+	double al = 0, c = 0;
 	for (int i = k - 1; i >= 0; i--) {                       // backward loop: alpha_i = rho_i s_i'q_{i+1}
-		double sq = bS[i];
-		for (int j = k - 1; j > i; j--) sq = fma(-al[j], SY[i * k + j], sq);
-		rho[i] = 1.0 / SY[i * k + i];
-		al[i] = rho[i] * sq;
-		alpha_out[i] = al[i];
-		rho_out[i] = rho[i];
+		const double t = (mine && lane > i) ? al * SY[i * k + lane] : 0.0;
+		const double sq = bS[i] - wave_sum_all(t);
+		const double rho_i = 1.0 / SY[i * k + i];
+		if (lane == i) { al = rho_i * sq; alpha_out[i] = al; rho_out[i] = rho_i; }
 	}
 	const double gamma = (a.h0 > 0) ? a.h0 : SY[(k - 1) * k + (k - 1)] / YY[(k - 1) * k + (k - 1)];
-	coef[0] = gamma;
 	for (int i = 0; i < k; i++) {                            // forward loop: beta_i = rho_i y_i'r_i
-		double yq = bY[i];
-		for (int j = k - 1; j >= 0; j--) yq = fma(-al[j], YY[i * k + j], yq);     // y_i'q_0
-		double yr = gamma * yq;
-		for (int j = 0; j < i; j++) yr = fma(c[j], SY[j * k + i], yr);            // + sum_{j<i} c_j s_j'y_i
-		c[i] = al[i] - rho[i] * yr;
-		coef[1 + i] = -(gamma * al[i]);                      // coefficient of y_i
-		coef[1 + k + i] = c[i];                              // coefficient of s_i
+		// y_i'r_i = gamma (y_i'g - sum_j alpha_j y_i'y_j) + sum_{j<i} c_j s_j'y_i
+		double t = mine ? -gamma * (al * YY[i * k + lane]) : 0.0;
+		if (lane < i) t = fma(c, SY[lane * k + i], t);
+		const double yr = fma(gamma, bY[i], wave_sum_all(t));
+		if (lane == i) c = al - (1.0 / SY[i * k + i]) * yr;         // alpha_i - rho_i y_i'r_i
+	}
+	if (lane == 0) coef[0] = gamma;
+	if (mine) {
+		coef[1 + lane] = -(gamma * al);                      // coefficient of y_lane
+		coef[1 + k + lane] = c;                              // coefficient of s_lane
 	}
 }
 
@@ -1100,19 +1111,18 @@ __global__ void __launch_bounds__(kBlock) k_gram_h0(GramH0Args a, bool rms, doub
 
 // Scalar recursion for the diagonal-H0 form.  Backward loop as in k_coef; forward loop with
 // y_i'r_0 = u_i - sum_j alpha_j W_ij.  coef: [1+j] = -alpha_j (inside the H0 bracket), [1+k+j] = c_j.
-__global__ void __launch_bounds__(kBlock) k_coef_h0(const double* bparts, int count, int stride, CoefArgs a, const double* gsy,
-                                                    double* alpha_out, double* rho_out, double* coef)
+__global__ void __launch_bounds__(kCoefBlock) k_coef_h0(const double* bparts, int count, int stride, CoefArgs a, const double* gsy,
+                                                        double* alpha_out, double* rho_out, double* coef)
 {
 	__shared__ double SY[kPairsMax * kPairsMax], Wm[kPairsMax * kPairsMax], bS[kPairsMax], U[kPairsMax];
-	__shared__ double al[kPairsMax], rho[kPairsMax], c[kPairsMax];
 	const int k = a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int Q = 3 * k + k * (k + 1) / 2;
-	for (int e = threadIdx.x; e < k * k; e += kBlock) SY[e] = gsy[(size_t) a.rows[e / k] * a.m + a.rows[e % k]];
-	for (int q = wave; q < Q; q += kWaves) {
+	for (int e = threadIdx.x; e < k * k; e += kCoefBlock) SY[e] = gsy[(size_t) a.rows[e / k] * a.m + a.rows[e % k]];
+	for (int q = wave; q < Q; q += kCoefWaves) {
+		if (q >= k && q < 2 * k) continue;                   // y_i'g: not needed by this form
 		const double t = wave_total_of(bparts + (size_t) q * stride, count);
 		if (lane == 0) {
 			if (q < k) bS[q] = t;
-			else if (q < 2 * k) { /* y_i'g: not needed by this form */ }
 			else if (q < 3 * k) U[q - 2 * k] = t;
 			else {
 				int r = q - 3 * k, i = 0;
@@ -1123,23 +1133,26 @@ __global__ void __launch_bounds__(kBlock) k_coef_h0(const double* bparts, int co
 		}
 	}
 	__syncthreads();
-	if (threadIdx.x != 0) return;
+	if (wave != 0) return;
+	const bool mine = lane < k;                              // lane j keeps alpha_j and c_j (see k_coef)
+	double al = 0, c = 0;
 	for (int i = k - 1; i >= 0; i--) {
-		double sq = bS[i];
-		for (int j = k - 1; j > i; j--) sq = fma(-al[j], SY[i * k + j], sq);
-		rho[i] = 1.0 / SY[i * k + i];
-		al[i] = rho[i] * sq;
-		alpha_out[i] = al[i];
-		rho_out[i] = rho[i];
+		const double t = (mine && lane > i) ? al * SY[i * k + lane] : 0.0;
+		const double sq = bS[i] - wave_sum_all(t);
+		const double rho_i = 1.0 / SY[i * k + i];
+		if (lane == i) { al = rho_i * sq; alpha_out[i] = al; rho_out[i] = rho_i; }
 	}
-	coef[0] = 1.0;
 	for (int i = 0; i < k; i++) {
-		double yr = U[i];
-		for (int j = k - 1; j >= 0; j--) yr = fma(-al[j], Wm[i * k + j], yr);     // y_i'(H0 .* q_0)
-		for (int j = 0; j < i; j++) yr = fma(c[j], SY[j * k + i], yr);
-		c[i] = al[i] - rho[i] * yr;
-		coef[1 + i] = -al[i];
-		coef[1 + k + i] = c[i];
+		// y_i'r_i = y_i'(H0 .* g) - sum_j alpha_j y_i'(H0 .* y_j) + sum_{j<i} c_j s_j'y_i
+		double t = mine ? -(al * Wm[i * k + lane]) : 0.0;
+		if (lane < i) t = fma(c, SY[lane * k + i], t);
+		const double yr = U[i] + wave_sum_all(t);
+		if (lane == i) c = al - (1.0 / SY[i * k + i]) * yr;         // alpha_i - rho_i y_i'r_i
+	}
+	if (lane == 0) coef[0] = 1.0;
+	if (mine) {
+		coef[1 + lane] = -al;
+		coef[1 + k + lane] = c;
 	}
 }
 
@@ -1160,10 +1173,20 @@ __global__ void __launch_bounds__(kBlock) k_commit(const double* parts, int coun
 	if (threadIdx.x == 0) { *sy_dst = a; *yy_dst = b; }
 }
 
-__global__ void k_set2(double* a, double va, double* b, double vb)
+// check_min_curvature on the device (reference src/stochqn.c:883-900): totals of the pair's three
+// dots (s'y, s's, y'y), the accept / reject decision, the commit of s'y and y'y for an accepted pair.
+// out = { s'y, s's, y'y, rejected ? 1 : 0 } for the host's bookkeeping.
+__global__ void __launch_bounds__(kBlock) k_verdict(const double* parts, int count, int stride, double min_curvature,
+                                                    double* sy_dst, double* yy_dst, double* out)
 {
-	if (a) *a = va;
-	if (b) *b = vb;
+	__shared__ double sh[kWaves];
+	const double sy = total_of(parts, count, sh);
+	const double ss = total_of(parts + (size_t) stride, count, sh);
+	const double yy = total_of(parts + 2 * (size_t) stride, count, sh);
+	if (threadIdx.x != 0) return;
+	const bool rejected = min_curvature > 0 && sy / ss <= min_curvature;      // NaN curvature is accepted
+	if (!rejected) { *sy_dst = sy; *yy_dst = yy; }
+	out[0] = sy; out[1] = ss; out[2] = yy; out[3] = rejected ? 1.0 : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1448,12 +1471,6 @@ Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& ro
 	return Partials{sc.red[slot], 1, 1};
 }
 
-void launch_gram_store_fused(const Scratch& sc, Partials p, const CoefArgs& a, int r)
-{
-	ProfScope ps(sc, K_SMALL);
-	hipLaunchKernelGGL(k_gram_store_fused, dim3(1), dim3(kBlock), 0, sc.stream, p.parts, p.count, p.stride, a, r, sc.gsy, sc.gyy);
-}
-
 void launch_gram_store(const Scratch& sc, Partials a, Partials b, int m, int r)
 {
 	ProfScope ps(sc, K_SMALL);
@@ -1461,11 +1478,11 @@ void launch_gram_store(const Scratch& sc, Partials a, Partials b, int m, int r)
 	                   m, r, sc.gsy, sc.gyy);
 }
 
-void launch_coef(const Scratch& sc, Partials b, const CoefArgs& a)
+void launch_coef(const Scratch& sc, Partials b, const CoefArgs& a, int fresh_row)
 {
 	ProfScope ps(sc, K_COEF);
-	hipLaunchKernelGGL(k_coef, dim3(1), dim3(kBlock), 0, sc.stream, b.parts, b.count, b.stride, a, sc.gsy, sc.gyy, sc.alpha, sc.rho,
-	                   sc.coef);
+	hipLaunchKernelGGL(k_coef, dim3(1), dim3(kCoefBlock), 0, sc.stream, b.parts, b.count, b.stride, a, fresh_row, sc.gsy, sc.gyy,
+	                   sc.alpha, sc.rho, sc.coef);
 }
 
 Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, const RowSet& ss, real* g, const real* H0)
@@ -1535,7 +1552,7 @@ Partials launch_gram_h0(const Scratch& sc, size_t n, const GramH0Args& a)
 void launch_coef_h0(const Scratch& sc, Partials b, const CoefArgs& a)
 {
 	ProfScope ps(sc, K_COEF);
-	hipLaunchKernelGGL(k_coef_h0, dim3(1), dim3(kBlock), 0, sc.stream, b.parts, b.count, b.stride, a, sc.gsy, sc.alpha, sc.rho, sc.coef);
+	hipLaunchKernelGGL(k_coef_h0, dim3(1), dim3(kCoefBlock), 0, sc.stream, b.parts, b.count, b.stride, a, sc.gsy, sc.alpha, sc.rho, sc.coef);
 }
 
 void launch_fin(const Scratch& sc, Partials in, int nsums, double* out)
@@ -1550,10 +1567,10 @@ void launch_commit(const Scratch& sc, Partials in, double* sy_dst, double* yy_ds
 	hipLaunchKernelGGL(k_commit, dim3(1), dim3(kBlock), 0, sc.stream, in.parts, in.count, in.stride, sy_dst, yy_dst);
 }
 
-void launch_set2(const Scratch& sc, double* a, double va, double* b, double vb)
+void launch_verdict(const Scratch& sc, Partials in, double min_curvature, double* sy_dst, double* yy_dst, double* out)
 {
 	ProfScope ps(sc, K_SMALL);
-	hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, sc.stream, a, va, b, vb);
+	hipLaunchKernelGGL(k_verdict, dim3(1), dim3(kBlock), 0, sc.stream, in.parts, in.count, in.stride, min_curvature, sy_dst, yy_dst, out);
 }
 
 void launch_scale(const Scratch& sc, size_t n, real* x, double a)

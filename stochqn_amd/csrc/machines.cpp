@@ -290,13 +290,13 @@ Partials enqueue_two_pass(DevCtx* c, real* g, size_t used, size_t st, double h0,
 		// the usual case -- exactly one pair entered the ring since the last step: its Gram row comes
 		// out of the same pass over S and Y that computes [S;Y]g (2 extra probe vectors, no extra pass)
 		b = launch_rows_dot(c->sc, 0, N(c), rows, g, gprev_out, K_ROWS_DOT3, row(c->Y, stale_row, c), row(c->S, stale_row, c));
-		launch_gram_store_fused(c->sc, b, a, stale_row);
-		c->gram_ok[stale_row] = 1;
+		c->gram_ok[stale_row] = 1;                       // stored by the coefficient kernel, ahead of the recursion
 	} else {
 		ensure_gram(c, st, k);
 		b = launch_rows_dot(c->sc, 0, N(c), rows, g, gprev_out);
+		stale_row = -1;
 	}
-	launch_coef(c->sc, b, a);
+	launch_coef(c->sc, b, a, stale == 1 ? stale_row : -1);
 	return launch_combine(c->sc, c->next_buf(), N(c), ys, ss, g);
 }
 
@@ -412,22 +412,19 @@ void make_s(DevCtx* c, bfgs_mem* b, bool needs_div)
 void accept_or_reject(DevCtx* c, bfgs_mem* b, Partials p, info_enum* info)
 {
 	const size_t st = b->mem_st_ix;
-	const double* src = p.parts;
-	if (p.stride != 1) { launch_fin(c->sc, p, 3, c->sc.red[0]); src = c->sc.red[0]; }   // raw per-workgroup partials
-	to_host(c, c->pin + 4, src, 3);
+	// one kernel reduces the three dots, decides and commits s'y / y'y of an accepted pair; the host
+	// only needs the verdict for its bookkeeping (and for the rare rollback)
+	double* verdict = c->sc.report + 4;                                // report[4..7] <-> pin[4..7]
+	launch_verdict(c->sc, p, (double) b->min_curvature, c->sc.sy + st, c->sc.yy + st, verdict);
+	to_host(c, c->pin + 4, verdict, 4);
 	sync(c);
-	const double sy = c->pin[4], ss = c->pin[5], yy = c->pin[6];
-	if (b->min_curvature > 0) {
-		const double curv = sy / ss;
-		if (curv <= b->min_curvature) {                                // NaN curvature is accepted
-			d2d(c, row(c->S, st, c), c->sbak.dev, N(c));                // "rollback" = bak -> slot (:597-604)
-			d2d(c, row(c->Y, st, c), c->ybak.dev, N(c));
-			c->touch_row(st);
-			*info = curvature_too_small;
-			return;
-		}
+	if (c->pin[7] != 0.0) {
+		d2d(c, row(c->S, st, c), c->sbak.dev, N(c));                    // "rollback" = bak -> slot (:597-604)
+		d2d(c, row(c->Y, st, c), c->ybak.dev, N(c));
+		c->touch_row(st);
+		*info = curvature_too_small;
+		return;
 	}
-	launch_set2(c->sc, c->sc.sy + st, sy, c->sc.yy + st, yy);
 	c->rho_ok[st] = 1;
 	c->gram_ok[st] = 0;            // cross products with the other rows: refreshed lazily by ensure_gram
 	ring_advance(b);

@@ -21,6 +21,8 @@ typedef double real;
 constexpr int kVec = 16 / (int) sizeof(real);    // elements per 16-byte pack: 2 doubles or 4 floats
 
 constexpr int kBlock = 256;       // threads per workgroup (4 wave64)
+constexpr int kCoefBlock = 1024;  // the one-workgroup coefficient kernels: 16 waves to total the partials of pass A
+constexpr int kCoefWaves = kCoefBlock / 64;
 constexpr int kMaxGrid = 2048;    // 256 CUs x 8 resident workgroups; also the partial-sum stride
 constexpr int kMaxSums = 3;       // sums one sweep can produce (s'y, s's, y'y)
 constexpr int kFisherRows = 8;    // Fisher rows one workgroup accumulates per pass-1 sweep
@@ -201,8 +203,8 @@ struct CoefArgs {
 	int rows[kPairsMax];      // physical row of logical pair i (oldest first)
 	double h0;                // > 0: scalar H0, else gamma from the newest pair
 };
-void launch_gram_store_fused(const Scratch& sc, Partials p /*3 x 2k quantities of a 3-probe pass A*/, const CoefArgs& a, int r);
-void launch_coef(const Scratch& sc, Partials b /*2k: s_i'g then y_i'g, logical order*/, const CoefArgs& a);
+// fresh_row >= 0: b comes from a 3-probe pass A; ring row fresh_row's Gram row / column is stored first
+void launch_coef(const Scratch& sc, Partials b /*2k: s_i'g then y_i'g, logical order*/, const CoefArgs& a, int fresh_row = -1);
 // r (in place of g) and the guard sums (sum r^2, nonfinite).  With H0 != NULL (adaQN):
 // r = H0 .* (g + sum cy_j y_j) + sum cs_j s_j, else r = coef[0] g + sum cy_j y_j + sum cs_j s_j.
 Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& y_rows, const RowSet& s_rows, real* g,
@@ -229,8 +231,10 @@ void launch_coef_h0(const Scratch& sc, Partials b, const CoefArgs& a);
 void launch_fin(const Scratch& sc, Partials in, int nsums, double* out);
 // sy_dst <- total of quantity 0, yy_dst <- total of quantity 2 (device-side commit of a pair's dots)
 void launch_commit(const Scratch& sc, Partials in, double* sy_dst, double* yy_dst);
+// totals of (s'y, s's, y'y), accept / reject against min_curvature, commit of s'y and y'y when accepted;
+// out[0..3] = s'y, s's, y'y, rejected flag
+void launch_verdict(const Scratch& sc, Partials in, double min_curvature, double* sy_dst, double* yy_dst, double* out);
 // tiny helpers
-void launch_set2(const Scratch& sc, double* a, double va, double* b, double vb);
 void launch_scale(const Scratch& sc, size_t n, real* x, double a);
 
 }  // namespace sqn
