@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--bsize", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=10_000_000)
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline: number of steps (0 = as many as fit in --cpu-seconds)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: size of the timed sample")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, RCCL communicator) even with one rank")
@@ -343,7 +344,7 @@ def cpu_baseline(args, m, L):
     from oracle import oracle
     from stochqn_amd import _abi
     nc = min(args.cpu_n, args.n)
-    threads = min(os.cpu_count() or 1, 64)
+    threads = oracle.usable_cpus()            # affinity capped by the cgroup quota (16 on the GPU boxes)
     oracle.set_threads(threads)
     be = oracle.bound()
     rng = np.random.default_rng(SEED)
@@ -379,14 +380,16 @@ def cpu_baseline(args, m, L):
 
     one_step()
     t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
-        one_step()
+    done = 0
+    while (done < args.cpu_steps) if args.cpu_steps > 0 else (done < 2 * L or time.perf_counter() - t0 < args.cpu_seconds):
+        one_step()                                     # at least two full L-cycles, then up to the time bound
+        done += 1
     dt = time.perf_counter() - t0
-    rate = args.cpu_steps / dt * (nc / 1e8)
+    rate = done / dt * (nc / 1e8)
     return {"value": round(rate, 4), "unit": "steps/s at n=1e8 (scaled)", "cores": threads, "kind": "port",
             "sample": "oracle/liboracle.so (CPU restatement, OpenMP, %d threads), SQN m=%d L=%d at n=%g for %d steps "
                       "(%.2f s); rate scaled by n/1e8 (cost is linear in n); Hessian product = d*v"
-                      % (threads, m, L, nc, args.cpu_steps, dt)}
+                      % (threads, m, L, nc, done, dt)}
 
 
 if __name__ == "__main__":

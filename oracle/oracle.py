@@ -52,6 +52,7 @@ def cdll():
         _lib.oracle_fisher_product.argtypes = [vp, sz, i, vp, vp, vp]
         _lib.oracle_take_step.restype = None
         _lib.oracle_take_step.argtypes = [d, i, vp, vp, C.POINTER(_abi.bfgs_mem), d, vp, d, vp, d, i, C.POINTER(i)]
+        _lib.oracle_set_threads(usable_cpus())
     return _lib
 
 
@@ -61,6 +62,29 @@ def bound():
     if _bound is None:
         _bound = _abi.Bound(cdll(), prefix="oracle_")
     return _bound
+
+
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota.  On the GPU
+    boxes os.cpu_count() is 256 but the quota is 16 CPUs; 64 OpenMP threads there ran the two-loop 6x
+    slower than 16 (throttling), which would understate the CPU baseline."""
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]            # cgroup v2
+        if quota != "max":
+            cpus = min(cpus, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())               # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                cpus = min(cpus, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return cpus
 
 
 def set_threads(n):

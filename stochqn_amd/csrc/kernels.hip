@@ -678,7 +678,7 @@ template <int W, int NG, bool NT>
 __global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, const real* probe, real* copy_out, uint32_t n, int rev,
                                                          double* parts)
 {
-	__shared__ double sh[kWaves];
+	__shared__ double sh[NG * 8 * kWaves];
 	double acc[NG * 8];
 	#pragma unroll
 	for (int j = 0; j < NG * 8; j++) acc[j] = 0;
@@ -711,12 +711,21 @@ __global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, const real* 
 				if (j < rs.count) acc[j] = fma(rs.row[j][i], pv, acc[j]);
 		}
 	}
+	// all quantities through the shuffle tree first, then ONE barrier (same tree and wave order as
+	// block_sum, so the same bits; 2 barriers per quantity made this epilogue the whole kernel at small n)
 	#pragma unroll
 	for (int j = 0; j < NG * 8; j++) {
 		if (j < rs.count) {           // uniform
-			const double t = block_sum(acc[j], sh);
-			if (threadIdx.x == 0) parts[(size_t) j * kMaxGrid + blockIdx.x] = t;
+			const double t = wave_sum(acc[j]);
+			if ((threadIdx.x & 63) == 0) sh[j * kWaves + (threadIdx.x >> 6)] = t;
 		}
+	}
+	__syncthreads();
+	for (int j = threadIdx.x; j < rs.count; j += kBlock) {
+		double t = sh[j * kWaves];
+		#pragma unroll
+		for (int w = 1; w < kWaves; w++) t += sh[j * kWaves + w];
+		parts[(size_t) j * kMaxGrid + blockIdx.x] = t;
 	}
 }
 

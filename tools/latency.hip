@@ -1,5 +1,6 @@
-// scratch/latency.hip -- fixed per-call cost of the C ABI with a device-resident caller (not product).
-// build: hipcc --offload-arch=gfx950 -O2 -I include scratch/latency.hip -L stochqn_amd/lib -lstochqn -Wl,-rpath,$PWD/stochqn_amd/lib -o scratch/latency
+// tools/latency.hip -- per-step wall time of the C ABI with a device-resident caller, as a function of n
+// (the fixed per-call cost dominates below n ~ 1e6).  Driven by tools/latency_table.py.
+// build: hipcc --offload-arch=gfx950 -O2 -I include tools/latency.hip -L stochqn_amd/lib -lstochqn -Wl,-rpath,$PWD/stochqn_amd/lib -o tools/latency
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -42,7 +43,8 @@ int main(int argc, char** argv)
 	long calls = 0;
 	for (int i = 0; i < 3 * m + 25; i++) iter(calls);
 	CK(hipDeviceSynchronize());
-	stochqn_hip_profile_enable(1); stochqn_hip_profile_reset();
+	const bool prof = !(argc > 5 && atoi(argv[5]) == 0);
+	stochqn_hip_profile_enable(prof ? 1 : 0); stochqn_hip_profile_reset();
 	calls = 0;
 	const double t0 = now();
 	for (int i = 0; i < steps; i++) iter(calls);
