@@ -37,17 +37,25 @@ constexpr int kWaves = kBlock / 64;
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef real rvec __attribute__((ext_vector_type(kVec)));     // one 16-byte pack of vector elements
 typedef real real2 __attribute__((ext_vector_type(2)));       // two neighbouring columns (Gram tile staging)
+// The same packs as they sit in memory: element-aligned only.  Row j of the ring starts at element
+// j*n, so for odd n every other row of S, Y and F is off the 16-byte grid.  gfx950 executes
+// global_load / global_store_dwordx4 at any element alignment (the compiler emits them for these
+// types); measured on the rows-dot pass at n = 1e8: 5.39 ms with every other row misaligned against
+// 5.15 ms aligned -- and 13.8 ms for the element-wise path that alignment gating used to fall back
+// to (scratch/tune5.hip).
+typedef rvec rvec_u __attribute__((aligned(sizeof(real))));
+typedef real2 real2_u __attribute__((aligned(sizeof(real))));
 
 // W elements of a vector, widened to double for the arithmetic.  W = kVec: one 16-byte access per
-// lane (needs 16-byte alignment); W = 1: one element.
+// lane (any element alignment); W = 1: one element.
 template <int W> struct Pack { double v[W]; };
 
 template <int W, bool NT> __device__ __forceinline__ Pack<W> ld(const real* p, uint32_t i)
 {
 	Pack<W> r;
 	if constexpr (W == kVec) {
-		const rvec t = NT ? __builtin_nontemporal_load(reinterpret_cast<const rvec*>(p + i))
-		                  : *reinterpret_cast<const rvec*>(p + i);
+		const rvec t = NT ? __builtin_nontemporal_load(reinterpret_cast<const rvec_u*>(p + i))
+		                  : *reinterpret_cast<const rvec_u*>(p + i);
 		#pragma unroll
 		for (int k = 0; k < W; k++) r.v[k] = (double) t[k];
 	} else {
@@ -65,8 +73,8 @@ template <int W, bool NT> __device__ __forceinline__ RPack<W> ldr(const real* p,
 {
 	RPack<W> r;
 	if constexpr (W == kVec) {
-		const rvec t = NT ? __builtin_nontemporal_load(reinterpret_cast<const rvec*>(p + i))
-		                  : *reinterpret_cast<const rvec*>(p + i);
+		const rvec t = NT ? __builtin_nontemporal_load(reinterpret_cast<const rvec_u*>(p + i))
+		                  : *reinterpret_cast<const rvec_u*>(p + i);
 		#pragma unroll
 		for (int k = 0; k < W; k++) r.v[k] = t[k];
 	} else {
@@ -81,7 +89,7 @@ template <int W> __device__ __forceinline__ void st(real* p, uint32_t i, const P
 		rvec t;
 		#pragma unroll
 		for (int k = 0; k < W; k++) t[k] = (real) a.v[k];
-		*reinterpret_cast<rvec*>(p + i) = t;
+		*reinterpret_cast<rvec_u*>(p + i) = t;
 	} else p[i] = (real) a.v[0];
 }
 
@@ -92,7 +100,7 @@ template <int W> __device__ __forceinline__ void st_nt(real* p, uint32_t i, cons
 		rvec t;
 		#pragma unroll
 		for (int k = 0; k < W; k++) t[k] = (real) a.v[k];
-		__builtin_nontemporal_store(t, reinterpret_cast<rvec*>(p + i));
+		__builtin_nontemporal_store(t, reinterpret_cast<rvec_u*>(p + i));
 	} else __builtin_nontemporal_store((real) a.v[0], p + i);
 }
 
@@ -980,16 +988,17 @@ __global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const 
 constexpr int kTile = 128;             // columns per tile: lane l stages columns 2l, 2l+1 and accumulates l, l+64
 constexpr int kTileLd = kTile + 2;     // LDS row stride in doubles (even: 16-B aligned pairs)
 
-// two neighbouring columns of a row, widened to double: one real2 access when the rows are aligned
-// (VEC), else two scalar accesses; columns at or beyond n read as `fill` and are never written
+// two neighbouring columns of a row, widened to double: one real2 access (VEC; any element alignment,
+// the last column of an odd n on its own), else two scalar accesses; columns at or beyond n read as
+// `fill` and are never written
 template <bool VEC, bool NT> __device__ __forceinline__ d2 ld_cols(const real* p, uint32_t i, uint32_t n, double fill)
 {
 	d2 v = {fill, fill};
 	if constexpr (VEC) {
 		if (i + 1 < n) {
-			const real2 t = NT ? __builtin_nontemporal_load(reinterpret_cast<const real2*>(p + i)) : *reinterpret_cast<const real2*>(p + i);
+			const real2 t = NT ? __builtin_nontemporal_load(reinterpret_cast<const real2_u*>(p + i)) : *reinterpret_cast<const real2_u*>(p + i);
 			v.x = (double) t.x; v.y = (double) t.y;
-		}
+		} else if (i < n) v.x = (double) p[i];
 	} else {
 		if (i < n) v.x = (double) (NT ? __builtin_nontemporal_load(p + i) : p[i]);
 		if (i + 1 < n) v.y = (double) (NT ? __builtin_nontemporal_load(p + i + 1) : p[i + 1]);
@@ -998,8 +1007,10 @@ template <bool VEC, bool NT> __device__ __forceinline__ d2 ld_cols(const real* p
 }
 template <bool VEC> __device__ __forceinline__ void st_cols(real* p, uint32_t i, uint32_t n, d2 v)
 {
-	if constexpr (VEC) { if (i + 1 < n) { real2 t; t.x = (real) v.x; t.y = (real) v.y; *reinterpret_cast<real2*>(p + i) = t; } }
-	else { if (i < n) p[i] = (real) v.x; if (i + 1 < n) p[i + 1] = (real) v.y; }
+	if constexpr (VEC) {
+		if (i + 1 < n) { real2 t; t.x = (real) v.x; t.y = (real) v.y; *reinterpret_cast<real2_u*>(p + i) = t; }
+		else if (i < n) p[i] = (real) v.x;
+	} else { if (i < n) p[i] = (real) v.x; if (i + 1 < n) p[i + 1] = (real) v.y; }
 }
 
 // The body of k_gram_h0 for wave WAVE of the workgroup.  KT = ring size rounded up (compile time), so
@@ -1201,9 +1212,11 @@ __global__ void __launch_bounds__(kBlock) k_verdict(const double* parts, int cou
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
-inline bool aligned16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// The vector path needs element alignment only (see rvec_u); a pointer that is not even that goes
+// through the element-wise instantiation.
+inline bool elem_aligned(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % sizeof(real)) == 0; }
 
-template <class... P> inline bool all_aligned(P... ps) { return (aligned16(ps) && ...); }
+template <class... P> inline bool all_aligned(P... ps) { return (elem_aligned(ps) && ...); }
 
 struct ProfScope {
 	const Scratch& sc;
@@ -1358,7 +1371,7 @@ Partials launch_fisher(const Scratch& sc, int buf, size_t n, const real* F, size
                        double* t_dev, real* y_out)
 {
 	const int grid = sweep_grid(sc, n);
-	const bool vec = all_aligned(F, s, y_out) && (n % kVec == 0);
+	const bool vec = all_aligned(F, s, y_out);
 	const dim3 g1(grid, (unsigned) ((fu + kFisherRows - 1) / kFisherRows));
 	{
 		ProfScope ps(sc, K_FISHER_T);
@@ -1379,7 +1392,7 @@ Partials launch_fisher(const Scratch& sc, int buf, size_t n, const real* F, size
 
 static bool rows_aligned(const RowSet& r)
 {
-	for (int j = 0; j < r.count; j++) if (!aligned16(r.row[j])) return false;
+	for (int j = 0; j < r.count; j++) if (!elem_aligned(r.row[j])) return false;
 	return true;
 }
 
@@ -1541,9 +1554,7 @@ Partials launch_gram_h0(const Scratch& sc, size_t n, const GramH0Args& a)
 	if (g < 1) g = 1;
 	const int grid = (int) g;
 	const bool rms = a.rmsprop_weight > 0 && a.rmsprop_weight < 1;
-	auto pair_aligned = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % sizeof(real2)) == 0; };
-	bool vec = n % 2 == 0 && pair_aligned(a.g) && pair_aligned(a.G) && pair_aligned(a.H0_out) && pair_aligned(a.frow_out);
-	for (int j = 0; j < k && vec; j++) vec = pair_aligned(a.s_rows.row[j]) && pair_aligned(a.y_rows.row[j]);
+	const bool vec = all_aligned(a.g, a.G, a.H0_out, a.frow_out) && rows_aligned(a.s_rows) && rows_aligned(a.y_rows);
 	{
 		ProfScope ps(sc, K_GRAM_H0);
 		if (k <= 12) gram_h0_dispatch<12>(sc, grid, shmem, vec, a, rms, (uint32_t) n);
@@ -1585,7 +1596,7 @@ void launch_verdict(const Scratch& sc, Partials in, double min_curvature, double
 void launch_scale(const Scratch& sc, size_t n, real* x, double a)
 {
 	const int grid = sweep_grid(sc, n);
-	run_sweep<0>(sc, K_SMALL, n, aligned16(x), ScaleOp{x, a}, nullptr, grid);
+	run_sweep<0>(sc, K_SMALL, n, elem_aligned(x), ScaleOp{x, a}, nullptr, grid);
 }
 
 }  // namespace sqn
