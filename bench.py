@@ -288,7 +288,7 @@ def main():
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample ---------------------------------
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:     # a reported baseline of the N = 1 line only
         cpu = cpu_baseline(args, m, L)
 
     if rank == 0:
