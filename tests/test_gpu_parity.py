@@ -920,3 +920,41 @@ def test_library_loaded_before_torch_still_takes_torch_tensors():
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "order-ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_concurrent_workspaces_from_two_threads(form, hip_backend, oracle_backend):
+    """Threading contract of SURVEY.md 8b: no global optimiser state, re-entrant across DISTINCT
+    workspaces.  Three host threads drive three different optimisers at the same time (ctypes drops the
+    GIL inside run_*; every context has its own stream); each trace must equal the oracle's."""
+    import threading
+    torch = torch_cuda()
+    by_name = {c[0]: c for c in CONFIGS}
+    picks = [("sqn_hessvec", "device"), ("adaqn_fisher_rms", "host"), ("olbfgs_default", "device")]
+    n = 2000
+    wants, results, errors = {}, {}, []
+    for name, _ in picks:
+        _, optname, kw, step, calls, pkw = by_name[name]
+        P = NoisyQuadratic(n, seed=7, **pkw)
+        wants[name] = run_trace(OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw), P, P.x0(), step, calls)
+
+    def work(name, space):
+        try:
+            _, optname, kw, step, calls, pkw = by_name[name]
+            P = NoisyQuadratic(n, seed=7, **pkw)
+            for rep in range(3):                       # several optimiser objects per thread, back to back
+                opt = OPTIMIZERS[optname](backend=hip_backend, space=space, **kw)
+                x = P.x0() if space == "host" else torch.as_tensor(P.x0(), device="cuda")
+                results[(name, rep)] = run_trace(opt, P, x, step, calls)
+                opt.release()
+        except Exception as e:                         # surfaced in the main thread
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=work, args=p) for p in picks]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for (name, rep), got in results.items():
+        compare_traces(got, wants[name], FREE_RUN_TOL.get(name, TOL))
+    assert len(results) == 9
