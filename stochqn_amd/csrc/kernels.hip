@@ -1,6 +1,6 @@
 // kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the stochastic quasi-Newton step.
 //
-// Every kernel is one *sweep*: a grid-stride pass over n doubles that fuses an element-wise
+// The first half: every kernel is one *sweep*: a grid-stride pass over n doubles that fuses an element-wise
 // update with the dot product the NEXT step of the recursion needs, so that each n-vector is
 // read once and written at most once per sweep.  The chain for one two-loop recursion
 // (reference src/stochqn.c:663-708) over k stored pairs is
@@ -22,7 +22,12 @@
 // instruction), `kUnroll` independent packs per lane in flight; correction-pair rows and Fisher
 // rows are streamed with non-temporal loads (they are dead until the next optimiser step) so
 // that q / r keep what cache residency they can.  These are BLAS-1 reductions at 0.25 flop/B:
-// no MFMA, no LDS tiling -- LDS only carries the per-workgroup reduction.
+// no MFMA; in the sweeps LDS only carries the per-workgroup reduction.
+//
+// The second half of the file is the default two-pass (Gram) form of the same recursion -- pass A
+// (rows-dot: [S;Y]g and, after a new pair, its Gram row), the coefficient recursion in one
+// workgroup, pass B (combine) -- and adaQN's variant with the diagonal H0 inside the Gram
+// quantities (k_gram_h0, the one kernel that tiles through LDS).  DESIGN.md section 3.
 #include "sqn_device.hpp"
 
 #include <cmath>
@@ -813,7 +818,7 @@ __global__ void __launch_bounds__(kBlock) k_gram_store(const double* a, int a_co
 }
 
 // The scalar part of the recursion (reference src/stochqn.c:671-707 with every inner product
-// expanded over the cached Gram blocks).  One workgroup; lane 0 runs the O(k^2) recursion from LDS.
+// expanded over the cached Gram blocks).  One workgroup of 16 waves; one wave runs the recursion from LDS.
 // `fresh_row` >= 0: pass A was the 3-probe form over the k pairs in use (rows 0..k-1 = S, k..2k-1 = Y,
 // logical order) with probes (g, y_r, s_r), r = fresh_row: quantities 2k.. are the dots with y_r,
 // 4k.. the dots with s_r.  Ring row r's Gram row and column are stored first (no kernel of their own).
