@@ -958,3 +958,36 @@ def test_concurrent_workspaces_from_two_threads(form, hip_backend, oracle_backen
     for (name, rep), got in results.items():
         compare_traces(got, wants[name], FREE_RUN_TOL.get(name, TOL))
     assert len(results) == 9
+
+
+def test_contexts_do_not_leak_device_memory(hip_backend):
+    """R and Python never call dealloc_*: contexts are dropped by release(), by a new optimiser at the same
+    address (section 0) or by stochqn_hip_release_all().  Two hundred host-caller optimisers (mirrors of
+    S, Y, Fisher ring, staging and pinned buffers each) must leave the device's free memory where it was."""
+    import stochqn_amd
+    torch = torch_cuda()
+    lib = stochqn_amd.cdll()
+    n = 50_000
+    P = NoisyQuadratic(n, seed=3)
+
+    def cycle(release_how):
+        for optname, kw in (("SQN", dict(mem_size=8, bfgs_upd_freq=3)),
+                            ("adaQN", dict(mem_size=6, fisher_size=12, bfgs_upd_freq=3, max_incr=None)),
+                            ("oLBFGS", dict(mem_size=8))):
+            opt = OPTIMIZERS[optname](backend=hip_backend, space="host", **kw)
+            run_trace(opt, P, P.x0(), 0.05, 12)
+            if release_how == "release":
+                opt.release()
+            # else: left to __del__ / release_all
+
+    cycle("release")                                 # warm the allocator caches of the runtime
+    lib.stochqn_hip_release_all()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for rep in range(70):
+        cycle("release" if rep % 2 else "gc")
+    lib.stochqn_hip_release_all()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    per_object = 2 * 8 * n * 8                       # roughly the S/Y mirrors of one optimiser
+    assert free0 - free1 < per_object, "device memory shrank by %d bytes over 210 optimiser objects" % (free0 - free1)
