@@ -137,6 +137,24 @@ def test_lockstep_parity(cfg, n, form, hip_backend, oracle_backend):
     run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 60), TOL, on_sync=inval)
 
 
+@pytest.mark.parametrize("cfgname", ["sqn_ring20", "adaqn_ring20", "olbfgs_default", "sqn_ring30"])
+def test_lockstep_parity_full_grids(cfgname, form, hip_backend, oracle_backend):
+    """The same lock-step comparison at a size where every kernel runs its full launch shape: one
+    workgroup per CU in the sweeps, 768 workgroups in the row-split pass A, whole LDS tiles plus a ragged
+    last one in the diagonal-H0 Gram kernel, and -- n odd -- every other ring row off the 16-byte grid."""
+    import stochqn_amd
+    name, optname, kw, step, calls, pkw = {c[0]: c for c in CONFIGS}[cfgname]
+    n = 1_000_003
+    P = NoisyQuadratic(n, seed=11, **pkw)
+    ref = OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw)
+    opt = OPTIMIZERS[optname](backend=hip_backend, space="device", **kw)
+    x_ref = P.x0()
+    x_dev = torch_cuda().as_tensor(P.x0(), device="cuda")
+    lib = stochqn_amd.cdll()
+    inval = lambda o: lib.stochqn_hip_invalidate(C.c_void_p(o._sp.ptr(o.BFGS_mem.s_mem)))
+    run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 30), TOL, on_sync=inval)
+
+
 @pytest.mark.parametrize("n", [2, 65, 1000])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_trace_parity_host_arrays(cfg, n, form, hip_backend, oracle_backend):
