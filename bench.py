@@ -36,7 +36,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=100_000_000, help="variables per GPU")
+    ap.add_argument("--n", "--vars-per-gpu", dest="n", type=int, default=100_000_000,
+                    help="variables per GPU (--vars-per-gpu under torch.distributed.run, whose parser takes --n for itself)")
     ap.add_argument("--mem", type=int, default=20)
     ap.add_argument("--upd-freq", type=int, default=10)
     ap.add_argument("--bsize", type=int, default=32)
@@ -47,6 +48,11 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, RCCL communicator) even with one rank")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="rehearsal of the N > 1 control flow on a box with ONE GPU: every rank uses cuda:0, "
+                         "torch.distributed runs over gloo and the library's all-reduce goes through a gloo callback "
+                         "(stochqn_hip_comm_init_custom).  Exercises exactly the code the N-GPU run takes, minus RCCL; "
+                         "the number it prints is not a measurement.")
     ap.add_argument("--no-reference-form", action="store_true",
                     help="skip the extra untimed steps in the reference's sweep form")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -72,6 +78,8 @@ def main():
         raise SystemExit("--gpus must equal WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the library has no CPU path)")
+    if args.rehearse:
+        local_rank = 0                                   # all ranks share the one GPU of the box
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -88,16 +96,35 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            buf = (C.c_ubyte * 128)()
-            assert lib.stochqn_hip_comm_unique_id(buf) == 0
-            uid = torch.tensor(list(buf), dtype=torch.uint8)
-        uid = uid.to(dev)
-        dist.broadcast(uid, 0)
-        raw = bytes(uid.cpu().tolist())
-        assert lib.stochqn_hip_comm_init(rank, world, raw) == 0, "RCCL communicator init failed"
+        if args.rehearse:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))   # the runtime already loaded
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            REDUCER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+            def gloo_allreduce(user, buf, count, stream):
+                # hipMemcpy on the null stream orders itself after the library's (blocking) stream and
+                # before whatever the library enqueues next; the sum itself travels over gloo on the CPU
+                host = torch.empty(count, dtype=torch.float64)
+                if hip.hipMemcpy(host.data_ptr(), buf, 8 * count, 2) != 0:
+                    return 1
+                dist.all_reduce(host)
+                return 0 if hip.hipMemcpy(buf, host.data_ptr(), 8 * count, 1) == 0 else 1
+
+            main.keep_alive = REDUCER(gloo_allreduce)
+            lib.stochqn_hip_comm_init_custom.argtypes = [C.c_int, C.c_int, REDUCER, C.c_void_p]
+            assert lib.stochqn_hip_comm_init_custom(rank, world, main.keep_alive, None) == 0
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                buf = (C.c_ubyte * 128)()
+                assert lib.stochqn_hip_comm_unique_id(buf) == 0
+                uid = torch.tensor(list(buf), dtype=torch.uint8)
+            uid = uid.to(dev)
+            dist.broadcast(uid, 0)
+            raw = bytes(uid.cpu().tolist())
+            assert lib.stochqn_hip_comm_init(rank, world, raw) == 0, "RCCL communicator init failed"
 
     n, m, L, bs = args.n, args.mem, args.upd_freq, args.bsize
     f64 = torch.float64
@@ -184,13 +211,13 @@ def main():
     lib.stochqn_hip_profile_enable(0)
 
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=f64, device=dev)
+        te = torch.tensor([elapsed], dtype=f64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
     f1 = float(0.5 * torch.sum(d * x * x))
     if dist is not None:
-        tf = torch.tensor([f0, f1], dtype=f64, device=dev)
+        tf = torch.tensor([f0, f1], dtype=f64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(tf)
         f0, f1 = tf.tolist()
     assert np.isfinite(f1) and f1 < f0, "optimiser diverged on the synthetic quadratic: %r -> %r" % (f0, f1)
@@ -302,7 +329,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "SQN n=%g per GPU (n_total=%g), m=%d, L=%d, Hessian-vector pairs via A'(Av)/%d, "
                                    "check_nan=1, ring full, fp64" % (n, n_total, m, L, bs),
-                       "parallelism": "n sharded over %d GPU(s); one RCCL all-reduce per dot product" % world,
+                       "parallelism": ("n sharded over %d GPU(s); one RCCL all-reduce per dot product" % world) if not args.rehearse else
+                                      ("REHEARSAL: %d ranks sharing one GPU, all-reduce over gloo -- not a measurement" % world),
                        "calls": counters["calls"], "hess_vec_requests": counters["hv"],
                        "rejected_steps": counters["bad"], "rejected_pairs": counters["rejected"],
                        "options": args.opt,

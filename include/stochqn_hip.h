@@ -83,6 +83,16 @@ int stochqn_hip_comm_init(int rank, int nranks, const void *unique_id128);
 int stochqn_hip_comm_nranks(void);
 void stochqn_hip_comm_finalize(void);
 
+/* ---- caller-supplied reducer (MPI, gloo, a fabric RCCL does not speak) ------------------------------
+ * Same sharding, but every reduction is handed to `fn`: sum device_buf[0..count) over all ranks, in
+ * place, identically on every rank (count <= max(384, fisher_size)).  `device_buf` is device memory; `hip_stream` is
+ * the library's stream (a hipStream_t), on which the producing kernel has been enqueued and the
+ * consuming kernel will be.  The simplest conforming reducer synchronises that stream, reduces any
+ * way it likes (GPU-aware MPI_Allreduce on device_buf, or a copy through the host) and returns with
+ * the result in place.  Returns 0 on success.  Mutually exclusive with stochqn_hip_comm_init. */
+typedef int (*stochqn_hip_allreduce_fn)(void *user, double *device_buf, int count, void *hip_stream);
+int stochqn_hip_comm_init_custom(int rank, int nranks, stochqn_hip_allreduce_fn fn, void *user);
+
 /* ---- loop-back reducer (rehearsal of the sharded path on ONE GPU) -----------------------------------
  * P host threads each drive one shard (its own arrays, its own context) on the same device; the
  * all-reduce becomes a host-side rendezvous of those threads that sums in rank order.  Protocol:

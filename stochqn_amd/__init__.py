@@ -21,25 +21,22 @@ _cdll = {}
 
 
 def _share_hip_runtime_with_torch():
-    """One HIP runtime per process.  torch's wheels bundle their own libamdhip64.so / libhsa-runtime64.so
-    (same SONAMEs as /opt/rocm's).  If libstochqn.so is loaded first it brings in /opt/rocm's copies and a
-    later `import torch` adds the bundled ones: two runtimes, torch.cuda then reports no device and torch's
-    device pointers mean nothing to the library (measured on the GPU box, scratch/probe_order.py).  Loading
-    the bundled copies first makes the dynamic loader resolve libstochqn's NEEDED entries to them by SONAME,
-    whichever of the two is imported first.  Without torch installed nothing happens."""
+    """One ROCm runtime per process.  torch's wheels bundle their own libamdhip64.so, libhsa-runtime64.so and
+    librccl.so (same SONAMEs as /opt/rocm's).  Measured on the GPU box (scratch/probe_order.py):
+      * libstochqn.so loaded first brings in /opt/rocm's HIP; a later `import torch` adds the bundled one --
+        two runtimes, torch.cuda then reports no device and torch's device pointers mean nothing to the library;
+      * any librccl.so loaded before torch (libstochqn dlopen()s RCCL when a communicator is asked for; even
+        torch's own copy preloaded by path) ends the process with a double free at exit.
+    With torch imported first the dynamic loader resolves libstochqn's NEEDED / dlopen names to the bundled
+    copies by SONAME and there is exactly one of each.  So: if torch is installed, import it before the
+    library is loaded.  Without torch nothing happens (C / R callers link /opt/rocm directly)."""
     if "torch" in _sys.modules:
         return
     try:
-        spec = _ilu.find_spec("torch")
+        if _ilu.find_spec("torch") is not None:
+            import torch  # noqa: F401
     except (ImportError, ValueError):
-        spec = None
-    if spec is None or not spec.origin:
-        return
-    libdir = _os.path.join(_os.path.dirname(spec.origin), "lib")
-    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
-        path = _os.path.join(libdir, name)
-        if _os.path.exists(path):
-            _C.CDLL(path, mode=_C.RTLD_GLOBAL)
+        pass
 
 
 def cdll(use_float=False):

@@ -75,6 +75,19 @@ void allreduce_hook(void*, double* buf, int count, hipStream_t stream)
 		std::fprintf(stderr, "stochqn: ncclAllReduce failed: %s\n", g_comm.GetErrorString ? g_comm.GetErrorString(r) : "?");
 }
 
+// ---- caller-supplied reducer -------------------------------------------------------------------
+struct Custom {
+	stochqn_hip_allreduce_fn fn = nullptr;
+	void* user = nullptr;
+	int rank = 0, nranks = 1;
+} g_custom;
+
+void custom_hook(void*, double* buf, int count, hipStream_t stream)
+{
+	if (g_custom.fn(g_custom.user, buf, count, (void*) stream) != 0)
+		std::fprintf(stderr, "stochqn: the caller-supplied all-reduce reported a failure\n");
+}
+
 // ---- loop-back reducer: P shards of one problem driven by P host threads on ONE GPU ------------
 // Rehearses the sharded path where only one device is available (tests): the all-reduce is a
 // host-side rendezvous of the calling threads, summed in rank order.
@@ -372,13 +385,18 @@ void sync(DevCtx* c)
 	if (c->sc.prof) c->prof.collect();
 }
 
-int comm_nranks() { return g_comm.comm ? g_comm.nranks : (g_loop.nranks > 1 && t_loop_rank >= 0 ? g_loop.nranks : 1); }
+int comm_nranks()
+{
+	if (g_comm.comm) return g_comm.nranks;
+	if (g_custom.fn) return g_custom.nranks;
+	return (g_loop.nranks > 1 && t_loop_rank >= 0) ? g_loop.nranks : 1;
+}
 
 void comm_attach(DevCtx* c)
 {
 	const bool loop = g_loop.nranks > 1 && t_loop_rank >= 0;
-	if (!g_comm.comm && !loop) { c->sc.allreduce = nullptr; c->n_global = (double) c->n; return; }
-	c->sc.allreduce = loop ? loopback_hook : allreduce_hook;
+	if (!g_comm.comm && !g_custom.fn && !loop) { c->sc.allreduce = nullptr; c->n_global = (double) c->n; return; }
+	c->sc.allreduce = loop ? loopback_hook : (g_custom.fn ? custom_hook : allreduce_hook);
 	// global problem size for the ||dir|| > 1e3*n guard (reference src/stochqn.c:829)
 	double nn = (double) c->n;
 	SQN_HIP_OK(hipMemcpyAsync(c->sc.red[0], &nn, sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
@@ -486,7 +504,7 @@ int stochqn_hip_comm_unique_id(void* out128)
 
 int stochqn_hip_comm_init(int rank, int nranks, const void* unique_id128)
 {
-	if (!device_ready() || !load_rccl()) return -1;
+	if (!device_ready() || g_custom.fn || !load_rccl()) return -1;
 	if (g_comm.comm) return 0;
 	ncclUniqueId id;
 	std::memcpy(&id, unique_id128, sizeof(id));
@@ -498,6 +516,16 @@ int stochqn_hip_comm_init(int rank, int nranks, const void* unique_id128)
 	}
 	g_comm.rank = rank;
 	g_comm.nranks = nranks;
+	return 0;
+}
+
+int stochqn_hip_comm_init_custom(int rank, int nranks, stochqn_hip_allreduce_fn fn, void* user)
+{
+	if (!device_ready() || !fn || nranks < 1 || rank < 0 || rank >= nranks || g_comm.comm) return -1;
+	g_custom.fn = fn;
+	g_custom.user = user;
+	g_custom.rank = rank;
+	g_custom.nranks = nranks;
 	return 0;
 }
 
@@ -531,6 +559,7 @@ void stochqn_hip_comm_finalize(void)
 {
 	release_all();
 	if (g_comm.comm) { g_comm.CommDestroy(g_comm.comm); g_comm.comm = nullptr; g_comm.nranks = 1; g_comm.rank = 0; }
+	g_custom = Custom{};
 }
 
 }  // extern "C"

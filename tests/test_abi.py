@@ -21,6 +21,7 @@ def declared_functions(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = src.split("#ifdef __cplusplus\n#include <new>")[0]          # C part only
+    src = re.sub(r"\btypedef\b[^;{}]*\([^;{}]*\)\s*;", "", src)          # function-pointer typedefs are not functions
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", src)
     return sorted(set(n for n in names if not n.startswith("defined")))
 

@@ -1009,3 +1009,31 @@ def test_contexts_do_not_leak_device_memory(hip_backend):
     free1, _ = torch.cuda.mem_get_info()
     per_object = 2 * 8 * n * 8                       # roughly the S/Y mirrors of one optimiser
     assert free0 - free1 < per_object, "device memory shrank by %d bytes over 210 optimiser objects" % (free0 - free1)
+
+
+def test_bench_multi_process_control_flow_on_one_gpu(tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed
+    with 3 ranks on the one GPU of the test box: `--rehearse` puts every rank on cuda:0, runs
+    torch.distributed over gloo and feeds the library's reductions through stochqn_hip_comm_init_custom.
+    Everything else -- sharded data, per-rank contexts, identical decisions on all ranks, barriers, MAX over
+    ranks, the untimed reference-form steps, one JSON line from rank 0 -- is the code of the real N-GPU run."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "3", "--rehearse", "--vars-per-gpu", "3000001",
+           "--steps", "12", "--warmup", "3", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["steps"] == 12 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["config"]["f_end"] < d["config"]["f_start"]
+    assert d["config"]["hess_vec_requests"] >= 1 and d["config"]["rejected_steps"] == 0
+    assert d["reference_form"] is not None and d["cpu_baseline"] is None
+    assert "REHEARSAL" in d["config"]["parallelism"]
