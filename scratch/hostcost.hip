@@ -1,5 +1,6 @@
 // scratch/hostcost.hip -- cost of the host-side pieces of one API call (not product)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +37,10 @@ int main()
 		t0 = now();
 		for (int i = 0; i < R; i++) { for (int k = 0; k < 4; k++) { CK(hipEventRecord(e0, st)); hipLaunchKernelGGL(k_write, dim3(1), dim3(64), 0, st, dev, (double) i); CK(hipEventRecord(e1, st)); } CK(hipStreamSynchronize(st)); }
 		printf("4 x (event, kernel, event) + sync: %.2f us\n", 1e6 * (now() - t0) / R);
+		t0 = now();
+		float acc_ms = 0;
+		for (int i = 0; i < R; i++) { for (int k = 0; k < 4; k++) hipExtLaunchKernelGGL(k_write, dim3(1), dim3(64), 0, st, e0, e1, 0, dev, (double) i); CK(hipStreamSynchronize(st)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); acc_ms += ms; }
+		printf("4 x hipExtLaunchKernelGGL(start, stop events) + sync: %.2f us (kernel %.2f us by its events)\n", 1e6 * (now() - t0) / R, 1e3 * acc_ms / R);
 	}
 	return 0;
 }
