@@ -14,6 +14,7 @@
 #include "stochqn_hip.h"
 
 #include <cmath>
+#include <exception>
 #include <cstdlib>
 #include <cstring>
 
@@ -483,6 +484,23 @@ template <class W> void after_call(W* w)
 	if (w && w->bfgs_memory) note_state(w->bfgs_memory->s_mem, w->niter, w->section);
 }
 
+// No C++ exception may cross the C ABI (R, Cython and C callers sit on
+// the other side): anything thrown inside (std::bad_alloc from the registry, say) becomes the
+// reference's own error convention, -1000 with task = invalid_input.
+template <class F> int no_throw(task_enum* task, const char* who, F&& body)
+{
+	try {
+		return body();
+	} catch (const std::exception& e) {
+		std::fprintf(stderr, "%s: %s\n", who, e.what());
+	} catch (...) {
+		std::fprintf(stderr, "%s: unexpected failure\n", who);
+	}
+	if (task) *task = invalid_input;
+	return -1000;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -779,32 +797,38 @@ static int run_adaQN_impl(real_t step_size, real_t x[], real_t f, real_t grad[],
 	return ret;
 }
 
-// The exported entry points.
+// The exported entry points (exception barrier: no_throw, above).
 int run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_enum* task, workspace_oLBFGS* w,
                info_enum* iter_info)
 {
-	before_call(w);
-	const int rc = run_oLBFGS_impl(step_size, x, grad, req, task, w, iter_info);
-	after_call(w);
-	return rc;
+	return no_throw(task, "run_oLBFGS", [&] {
+		before_call(w);
+		const int rc = run_oLBFGS_impl(step_size, x, grad, req, task, w, iter_info);
+		after_call(w);
+		return rc;
+	});
 }
 
 int run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real_t** req, real_t** req_vec, task_enum* task,
             workspace_SQN* w, info_enum* iter_info)
 {
-	before_call(w);
-	const int rc = run_SQN_impl(step_size, x, grad, hess_vec, req, req_vec, task, w, iter_info);
-	after_call(w);
-	return rc;
+	return no_throw(task, "run_SQN", [&] {
+		before_call(w);
+		const int rc = run_SQN_impl(step_size, x, grad, hess_vec, req, req_vec, task, w, iter_info);
+		after_call(w);
+		return rc;
+	});
 }
 
 int run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** req, task_enum* task, workspace_adaQN* w,
               info_enum* iter_info)
 {
-	before_call(w);
-	const int rc = run_adaQN_impl(step_size, x, f, grad, req, task, w, iter_info);
-	after_call(w);
-	return rc;
+	return no_throw(task, "run_adaQN", [&] {
+		before_call(w);
+		const int rc = run_adaQN_impl(step_size, x, f, grad, req, task, w, iter_info);
+		after_call(w);
+		return rc;
+	});
 }
 
 // =================================================================================================
@@ -990,7 +1014,7 @@ void dealloc_adaQN(workspace_adaQN* w)
 // =================================================================================================
 // isolated kernels of stochqn_hip.h
 // =================================================================================================
-int stochqn_hip_two_loop(real_t grad[], int n, real_t H0[], real_t h0, real_t y_mem[], real_t s_mem[],
+static int two_loop_impl(real_t grad[], int n, real_t H0[], real_t h0, real_t y_mem[], real_t s_mem[],
                          size_t mem_size, size_t mem_used, size_t mem_st_ix, real_t buffer_rho[], real_t buffer_alpha[])
 {
 	if (!device_ready() || !grad || !y_mem || !s_mem || n <= 0 || mem_size == 0 || mem_used == 0 || mem_used > mem_size)
@@ -1025,7 +1049,15 @@ int stochqn_hip_two_loop(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 	return 0;
 }
 
-int stochqn_hip_fisher_product(real_t F[], size_t fu, int n, real_t s[], real_t buffer_y[], real_t y[])
+int stochqn_hip_two_loop(real_t grad[], int n, real_t H0[], real_t h0, real_t y_mem[], real_t s_mem[],
+                         size_t mem_size, size_t mem_used, size_t mem_st_ix, real_t buffer_rho[], real_t buffer_alpha[])
+{
+	return no_throw(nullptr, "stochqn_hip_two_loop", [&] {
+		return two_loop_impl(grad, n, H0, h0, y_mem, s_mem, mem_size, mem_used, mem_st_ix, buffer_rho, buffer_alpha);
+	});
+}
+
+static int fisher_product_impl(real_t F[], size_t fu, int n, real_t s[], real_t buffer_y[], real_t y[])
 {
 	if (!device_ready() || !F || !s || !y || n <= 0 || fu == 0) return -1000;
 	bool fresh = false;
@@ -1046,6 +1078,11 @@ int stochqn_hip_fisher_product(real_t F[], size_t fu, int n, real_t s[], real_t 
 	sync(c);
 	hand_back(buffer_y, c->pin + 8 + 2 * c->m, fu);
 	return 0;
+}
+
+int stochqn_hip_fisher_product(real_t F[], size_t fu, int n, real_t s[], real_t buffer_y[], real_t y[])
+{
+	return no_throw(nullptr, "stochqn_hip_fisher_product", [&] { return fisher_product_impl(F, fu, n, s, buffer_y, y); });
 }
 
 }  // extern "C"

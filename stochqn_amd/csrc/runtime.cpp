@@ -193,14 +193,13 @@ bool pinned_alloc(void** p, size_t bytes)
 
 int default_grid_cap()
 {
-	static int cus = 0;
-	if (!cus) {
+	static const int cus = [] {
 		int dev = 0, n = 0;
 		if (hipGetDevice(&dev) == hipSuccess &&
-		    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-		else cus = 256;
-		if (cus > kMaxGrid) cus = kMaxGrid;
-	}
+		    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+			return n > kMaxGrid ? kMaxGrid : n;
+		return 256;
+	}();
 	return cus;
 }
 
@@ -221,14 +220,13 @@ void begin_call(DevCtx* c)
 
 bool device_ready()
 {
-	static int state = -1;
-	if (state < 0) {
+	static const bool ready = [] {               // evaluated once, thread-safe (C++11 static initialisation)
 		int count = 0;
-		hipError_t e = hipGetDeviceCount(&count);
-		state = (e == hipSuccess && count > 0) ? 1 : 0;
-		if (!state) (void) hipGetLastError();
-	}
-	return state == 1;
+		const hipError_t e = hipGetDeviceCount(&count);
+		if (e != hipSuccess || count <= 0) { (void) hipGetLastError(); return false; }
+		return true;
+	}();
+	return ready;
 }
 
 bool is_device_pointer(const void* p)
