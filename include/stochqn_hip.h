@@ -59,6 +59,8 @@ int stochqn_hip_export(const void *s_mem);
  * "strict_grad" (default 1)  host callers: copy the search direction back into `grad`
  * "fail_alloc_after" (default -1 = off)  fault injection for tests: the (value+1)-th device or
  *                             pinned allocation from now fails once
+ * "inject_device_fault" (default 0)      fault injection for tests: the next stream synchronisation
+ *                             behaves as if a kernel launch had failed
  * Returns 0, or -1 for an unknown name. Applies to contexts created afterwards and existing ones. */
 int stochqn_hip_set_option(const char *name, double value);
 

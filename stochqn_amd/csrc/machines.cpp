@@ -100,6 +100,7 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
                size_t niter, int section)
 {
 	if (!b || !b->s_mem || !b->y_mem || n <= 0 || b->mem_size == 0) return false;
+	(void) hipGetLastError();        // errors other code left behind on this thread are not ours (see sync())
 	bool fresh = false;
 	DevCtx* c = acquire(b->s_mem, kind, n, b->mem_size, fsize, &fresh);
 	if (!c) return false;
@@ -479,9 +480,13 @@ template <class W> void before_call(W* w)
 {
 	if (w && w->bfgs_memory && w->section == 0) release(w->bfgs_memory->s_mem);
 }
-template <class W> void after_call(W* w)
+template <class W> int after_call(W* w, int rc, task_enum* task)
 {
-	if (w && w->bfgs_memory) note_state(w->bfgs_memory->s_mem, w->niter, w->section);
+	if (w && w->bfgs_memory && note_state(w->bfgs_memory->s_mem, w->niter, w->section)) {
+		*task = invalid_input;                    // a HIP error surfaced during this call
+		return -1000;
+	}
+	return rc;
 }
 
 // No C++ exception may cross the C ABI (R, Cython and C callers sit on
@@ -804,8 +809,7 @@ int run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_e
 	return no_throw(task, "run_oLBFGS", [&] {
 		before_call(w);
 		const int rc = run_oLBFGS_impl(step_size, x, grad, req, task, w, iter_info);
-		after_call(w);
-		return rc;
+		return after_call(w, rc, task);
 	});
 }
 
@@ -815,8 +819,7 @@ int run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real
 	return no_throw(task, "run_SQN", [&] {
 		before_call(w);
 		const int rc = run_SQN_impl(step_size, x, grad, hess_vec, req, req_vec, task, w, iter_info);
-		after_call(w);
-		return rc;
+		return after_call(w, rc, task);
 	});
 }
 
@@ -826,8 +829,7 @@ int run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** re
 	return no_throw(task, "run_adaQN", [&] {
 		before_call(w);
 		const int rc = run_adaQN_impl(step_size, x, f, grad, req, task, w, iter_info);
-		after_call(w);
-		return rc;
+		return after_call(w, rc, task);
 	});
 }
 
@@ -1019,6 +1021,7 @@ static int two_loop_impl(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 {
 	if (!device_ready() || !grad || !y_mem || !s_mem || n <= 0 || mem_size == 0 || mem_used == 0 || mem_used > mem_size)
 		return -1000;
+	(void) hipGetLastError();
 	bool fresh = false;
 	DevCtx* c = acquire(s_mem, KIND_RAW, n, mem_size, 0, &fresh);
 	if (!c) return -1000;
@@ -1044,6 +1047,7 @@ static int two_loop_impl(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 	to_host(c, c->pin, c->sc.report, 8 + 2 * c->m);
 	if (g_host) vec_to_host(c, grad, g, nn);
 	sync(c);
+	if (c->fault) { c->fault = false; return -1000; }
 	hand_back(buffer_rho, c->pin + 8, mem_used);
 	hand_back(buffer_alpha, c->pin + 8 + c->m, mem_used);
 	return 0;
@@ -1060,6 +1064,7 @@ int stochqn_hip_two_loop(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 static int fisher_product_impl(real_t F[], size_t fu, int n, real_t s[], real_t buffer_y[], real_t y[])
 {
 	if (!device_ready() || !F || !s || !y || n <= 0 || fu == 0) return -1000;
+	(void) hipGetLastError();
 	bool fresh = false;
 	DevCtx* c = acquire(F, KIND_RAW, n, 1, fu, &fresh);
 	if (!c) return -1000;
@@ -1076,6 +1081,7 @@ static int fisher_product_impl(real_t F[], size_t fu, int n, real_t s[], real_t 
 	to_host(c, c->pin + 8 + 2 * c->m, c->fisher_t, fu);
 	if (y_host) vec_to_host(c, y, yd, nn);
 	sync(c);
+	if (c->fault) { c->fault = false; return -1000; }
 	hand_back(buffer_y, c->pin + 8 + 2 * c->m, fu);
 	return 0;
 }

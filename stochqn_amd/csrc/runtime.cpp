@@ -21,6 +21,7 @@ std::mutex g_mu;
 std::unordered_map<const void*, DevCtx*> g_ctx;
 Options g_opt;
 std::atomic<long> g_fail_alloc_after{-1};       // fault injection: < 0 off, else allocations left before one fails
+std::atomic<int> g_inject_device_fault{0};      // fault injection: the next stream synchronisation reports a failure
 
 bool alloc_should_fail()
 {
@@ -303,14 +304,17 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	return c;
 }
 
-void note_state(const void* key, size_t niter, int section)
+bool note_state(const void* key, size_t niter, int section)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
 	auto it = g_ctx.find(key);
-	if (it == g_ctx.end()) return;
+	if (it == g_ctx.end()) return false;
 	it->second->has_last = true;
 	it->second->last_niter = niter;
 	it->second->last_section = section;
+	const bool fault = it->second->fault;
+	it->second->fault = false;
+	return fault;
 }
 
 void release(const void* key)
@@ -379,7 +383,15 @@ real* stage_in(DevCtx* c, int which, real* caller, size_t count, bool host)
 
 void sync(DevCtx* c)
 {
-	SQN_HIP_OK(hipStreamSynchronize(c->sc.stream));
+	// a kernel that could not be launched (or failed) leaves its outputs stale: never hand that back
+	// as a result -- the call reports invalid_input / -1000 instead (machines.cpp: after_call)
+	const hipError_t e = hipStreamSynchronize(c->sc.stream);
+	hipError_t l = hipGetLastError();
+	if (g_inject_device_fault.exchange(0)) l = hipErrorLaunchFailure;
+	if (e != hipSuccess || l != hipSuccess) {
+		std::fprintf(stderr, "stochqn: device work failed: %s\n", hipGetErrorString(e != hipSuccess ? e : l));
+		c->fault = true;
+	}
 	if (c->sc.prof) c->prof.collect();
 }
 
@@ -458,6 +470,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "twopass_h0")) g_opt.twopass_h0 = value != 0;
 	else if (!std::strcmp(name, "strict_grad")) g_opt.strict_grad = value != 0;
 	else if (!std::strcmp(name, "fail_alloc_after")) g_fail_alloc_after.store((long) value);
+	else if (!std::strcmp(name, "inject_device_fault")) g_inject_device_fault.store(value != 0);
 	else return -1;
 	return 0;
 }

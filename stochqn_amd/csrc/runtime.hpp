@@ -60,6 +60,7 @@ struct DevCtx {
 	size_t pin_count = 0;
 	// what the caller's struct looked like when the last call on this context returned; a call that
 	// does not continue from there belongs to a different optimiser object at the same address
+	bool fault = false;                // a launch or the stream reported an error: the call that saw it fails loudly
 	bool has_last = false;
 	size_t last_niter = 0;
 	int last_section = 0;
@@ -81,7 +82,8 @@ bool is_device_pointer(const void* p);
 // Find or create the context of a workspace.  `fresh` tells the caller whether it was created now.
 DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* fresh);
 DevCtx* lookup(const void* key);
-void note_state(const void* key, size_t niter, int section);   // remember the caller-visible state on return
+// remember the caller-visible state on return; true if the context saw a HIP error during the call
+bool note_state(const void* key, size_t niter, int section);
 void release(const void* key);
 void release_all();
 

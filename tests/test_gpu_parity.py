@@ -1037,3 +1037,35 @@ def test_bench_multi_process_control_flow_on_one_gpu(tmp_path):
     assert d["config"]["hess_vec_requests"] >= 1 and d["config"]["rejected_steps"] == 0
     assert d["reference_form"] is not None and d["cpu_baseline"] is None
     assert "REHEARSAL" in d["config"]["parallelism"]
+
+
+def test_device_errors_fail_the_call_loudly(hip_backend, capfd):
+    """A kernel that cannot be launched leaves its outputs stale; handing those back as a result would be
+    a silent wrong answer.  Every synchronisation checks the stream and the runtime's last error, and the
+    call that saw one returns -1000 with task = invalid_input (fault injected here)."""
+    import stochqn_amd
+    lib = stochqn_amd.cdll()
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    P = NoisyQuadratic(500, seed=5)
+    opt = OPTIMIZERS["SQN"](backend=hip_backend, space="device", mem_size=4, bfgs_upd_freq=3)
+    x = torch_cuda().as_tensor(P.x0(), device="cuda")
+    run_trace(opt, P, x, 0.1, 10)
+    lib.stochqn_hip_set_option(b"inject_device_fault", 1.0)
+    with pytest.raises(ValueError):
+        opt.run_optimizer(x, 0.1)
+    assert "device work failed" in capfd.readouterr().err
+    # the raw entry points as well
+    from oracle import oracle  # noqa: F401  (only to reuse make_pairs' shapes below)
+    rng = np.random.default_rng(0)
+    S, Y = make_pairs(rng, 300, 3)
+    dS, dY, dg = (torch_cuda().as_tensor(a, device="cuda") for a in (S, Y, rng.random(300)))
+    lib.stochqn_hip_set_option(b"inject_device_fault", 1.0)
+    rho, alpha = np.zeros(3), np.zeros(3)
+    lib.stochqn_hip_two_loop.restype = C.c_int
+    lib.stochqn_hip_two_loop.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+    assert lib.stochqn_hip_two_loop(dg.data_ptr(), 300, None, 0.0, dY.data_ptr(), dS.data_ptr(), 3, 3, 0,
+                                    rho.ctypes.data, alpha.ctypes.data) == -1000
+    assert lib.stochqn_hip_two_loop(dg.data_ptr(), 300, None, 0.0, dY.data_ptr(), dS.data_ptr(), 3, 3, 0,
+                                    rho.ctypes.data, alpha.ctypes.data) == 0
+    lib.stochqn_hip_release(C.c_void_p(dS.data_ptr()))
