@@ -313,6 +313,43 @@ def main():
                                      "traffic_source": src, "alg_bytes_per_launch": 4 * n * 8,
                                      "avg_launch_ms": round(ms / cnt, 4)}}
 
+    # ---- the two-loop recursion on its own (SURVEY.md 8d "two-loop micro-benchmark"): the ring as the
+    # run left it (m pairs, oldest in row mem_st_ix), H0 = NULL, h0 = 0; 3 warm-up + 20 timed calls of
+    # stochqn_hip_two_loop per form, median wall clock of the synchronous call --------------------------
+    micro = None
+    if not args.no_reference_form:
+        lib.stochqn_hip_two_loop.restype = C.c_int
+        lib.stochqn_hip_two_loop.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        g0 = torch.mul(dn[0], x)
+        gq = torch.empty_like(g0)
+        micro = {"note": "stochqn_hip_two_loop alone: mem_used=%d, oldest pair in row %d, H0=NULL, 3 warm-up + 20 calls, median; "
+                         "reference-form bytes = SURVEY 8d's 64*m*n (the sweeps form moves exactly those; the two-pass form moves (4m+3)*n*8)" % (m, b.mem_st_ix)}
+        for form, flag in (("two_pass", 1.0), ("sweeps", 0.0)):
+            lib.stochqn_hip_set_option(b"twopass", flag)
+            ts = []
+            for rep in range(23):
+                gq.copy_(g0)
+                barrier()
+                tq = time.perf_counter()
+                rc = lib.stochqn_hip_two_loop(gq.data_ptr(), n, None, 0.0, Y.data_ptr(), S.data_ptr(), m, m, b.mem_st_ix,
+                                              rho_h.ctypes.data, alpha_h.ctypes.data)
+                assert rc == 0
+                ts.append(time.perf_counter() - tq)
+            med = sorted(ts[3:])[10]
+            if dist is not None:
+                tm = torch.tensor([med], dtype=f64, device="cpu" if args.rehearse else dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                med = float(tm.item())
+            moved = ((4 * m + 3) if form == "two_pass" else 8 * m) * n * 8        # bytes this form has to stream
+            micro[form] = {"median_ms": round(1e3 * med, 3), "bytes_moved": moved,
+                           "GBps_on_bytes_moved": round(moved / med / 1e9, 1),
+                           "frac_of_8TBps_on_bytes_moved": round(moved / med / 1e9 / PEAK, 4),
+                           "GBps_on_reference_form_bytes": round(64.0 * m * n / med / 1e9, 1)}
+        lib.stochqn_hip_set_option(b"twopass", 1.0)
+        lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))      # the raw context keyed by S; the optimiser is finished
+        del g0, gq
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample ---------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:     # a reported baseline of the N = 1 line only
@@ -337,6 +374,7 @@ def main():
                        "f_start": f0, "f_end": f1},
             "roofline": roof,
             "two_loop": two_loop,
+            "two_loop_micro": micro,
             "reference_form": ref_form,
             "kernels": detail,
             "cpu_baseline": cpu,
