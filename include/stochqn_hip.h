@@ -67,6 +67,9 @@ int stochqn_hip_set_option(const char *name, double value);
 /* ---- built-in HIP-event profiler -----------------------------------------------------------------
  * When enabled every kernel launch is bracketed by two events on the library's stream; durations
  * are accumulated per kernel id.  Ids 0..stochqn_hip_profile_kernels()-1. */
+/* Callers that cannot reach this API (an R or Python session on top of a binding): with
+ * STOCHQN_HIP_PROFILE=1 in the environment the profiler is on from the first call and a per-kernel
+ * table (launches, total and average ms) is printed to stderr when the process exits. */
 void stochqn_hip_profile_enable(int on);
 void stochqn_hip_profile_reset(void);
 int stochqn_hip_profile_kernels(void);

@@ -162,8 +162,22 @@ void destroy(DevCtx* c)
 	delete c;
 }
 
-void at_exit() { /* device memory dies with the process; destroying streams here can race with the
-                    HIP runtime's own teardown, so contexts are simply abandoned */ }
+// STOCHQN_HIP_PROFILE=1 in the environment (R / Python users cannot easily call the profile API):
+// the event profiler is on from the first context and a per-kernel table goes to stderr at exit.
+void at_exit()
+{
+	if (std::getenv("STOCHQN_HIP_PROFILE")) {
+		std::fprintf(stderr, "stochqn: per-kernel device time (HIP events)\n");
+		for (int id = 0; id < K_COUNT; id++) {
+			long long l = g_retired_launches[id];
+			double ms = g_retired_ms[id];
+			for (auto& kv : g_ctx) { l += kv.second->prof.launches[id]; ms += kv.second->prof.total_ms[id]; }
+			if (l > 0) std::fprintf(stderr, "  %-12s %8lld launches  %12.3f ms total  %10.4f ms avg\n", kernel_name(id), l, ms, ms / (double) l);
+		}
+	}
+	/* device memory dies with the process; destroying streams here can race with the HIP runtime's own
+	   teardown, so contexts are simply abandoned */
+}
 
 }  // namespace
 
@@ -299,7 +313,11 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	c->sc.allreduce = nullptr;
 	c->sc.user = c;
 	g_ctx[key] = c;
-	if (!g_atexit) { g_atexit = true; std::atexit(at_exit); }
+	if (!g_atexit) {
+		g_atexit = true;
+		std::atexit(at_exit);
+		if (std::getenv("STOCHQN_HIP_PROFILE")) { g_profile = true; c->sc.prof = &c->prof; }
+	}
 	*fresh = true;
 	return c;
 }
