@@ -40,7 +40,8 @@ def bound_f32():
 def cdll():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        # ORACLE_SO: another build of the same source (tests/test_oracle_sanitized.py: -fsanitize=address,undefined)
+        _lib = C.CDLL(os.environ.get("ORACLE_SO") or build())
         d, vp, i, sz = C.c_double, C.c_void_p, C.c_int, C.c_size_t
         _lib.oracle_set_threads.argtypes = [i]
         _lib.oracle_get_threads.restype = i
