@@ -70,6 +70,8 @@ int stochqn_hip_set_option(const char *name, double value);
 /* Callers that cannot reach this API (an R or Python session on top of a binding): with
  * STOCHQN_HIP_PROFILE=1 in the environment the profiler is on from the first call and a per-kernel
  * table (launches, total and average ms) is printed to stderr when the process exits. */
+/* With STOCHQN_HIP_ROCTX=1 every run_* call is a named roctx range ("run_SQN section 1") for
+ * `rocprofv3 --marker-trace`. */
 void stochqn_hip_profile_enable(int on);
 void stochqn_hip_profile_reset(void);
 int stochqn_hip_profile_kernels(void);

@@ -807,6 +807,7 @@ int run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_e
                info_enum* iter_info)
 {
 	return no_throw(task, "run_oLBFGS", [&] {
+		ApiRange range("run_oLBFGS", w ? w->section : -1);
 		before_call(w);
 		const int rc = run_oLBFGS_impl(step_size, x, grad, req, task, w, iter_info);
 		return after_call(w, rc, task);
@@ -817,6 +818,7 @@ int run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real
             workspace_SQN* w, info_enum* iter_info)
 {
 	return no_throw(task, "run_SQN", [&] {
+		ApiRange range("run_SQN", w ? w->section : -1);
 		before_call(w);
 		const int rc = run_SQN_impl(step_size, x, grad, hess_vec, req, req_vec, task, w, iter_info);
 		return after_call(w, rc, task);
@@ -827,6 +829,7 @@ int run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** re
               info_enum* iter_info)
 {
 	return no_throw(task, "run_adaQN", [&] {
+		ApiRange range("run_adaQN", w ? w->section : -1);
 		before_call(w);
 		const int rc = run_adaQN_impl(step_size, x, f, grad, req, task, w, iter_info);
 		return after_call(w, rc, task);

@@ -233,6 +233,44 @@ void begin_call(DevCtx* c)
 	c->phase = 1;
 }
 
+namespace {
+struct Roctx {
+	int (*push)(const char*) = nullptr;
+	int (*pop)() = nullptr;
+} g_roctx;
+
+bool roctx_ready()
+{
+	static const bool ok = [] {
+		if (!std::getenv("STOCHQN_HIP_ROCTX")) return false;
+		for (const char* nm : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+			if (void* h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)) {
+				g_roctx.push = (int (*)(const char*)) dlsym(h, "roctxRangePushA");
+				g_roctx.pop = (int (*)()) dlsym(h, "roctxRangePop");
+				if (g_roctx.push && g_roctx.pop) return true;
+			}
+		}
+		std::fprintf(stderr, "stochqn: STOCHQN_HIP_ROCTX is set but no roctx library could be loaded\n");
+		return false;
+	}();
+	return ok;
+}
+}  // namespace
+
+ApiRange::ApiRange(const char* name, int section)
+{
+	if (!roctx_ready()) return;
+	char label[64];
+	std::snprintf(label, sizeof label, "%s section %d", name, section);
+	g_roctx.push(label);
+	on = true;
+}
+
+ApiRange::~ApiRange()
+{
+	if (on) g_roctx.pop();
+}
+
 bool device_ready()
 {
 	static const bool ready = [] {               // evaluated once, thread-safe (C++11 static initialisation)

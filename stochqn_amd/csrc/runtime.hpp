@@ -98,6 +98,14 @@ real* host_landing(DevCtx* c, int slot);               // host landing zone for 
 void begin_call(DevCtx* c);                            // refresh options, restart the sweep parity
 void sync(DevCtx* c);                                  // stream sync + profiler collection
 
+// One named range per API call for `rocprofv3 --marker-trace` (roctx), only with STOCHQN_HIP_ROCTX=1 in the
+// environment; the marker library is dlopen()ed then, never linked.
+struct ApiRange {
+	ApiRange(const char* name, int section);
+	~ApiRange();
+	bool on = false;
+};
+
 // multi-GPU
 int comm_nranks();
 void comm_attach(DevCtx* c);                           // install the all-reduce hook, compute n_global
