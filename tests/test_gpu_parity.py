@@ -668,6 +668,26 @@ def test_float_lockstep_parity(name, n, form_f32, hip_backend_f32):
     run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 50), F32_TOL, on_sync=inval)
 
 
+# (adaqn_ring20 is left out here: its Fisher pairs cancel to ~1e-6 of their terms, and at n = 1e6 the float
+# oracle's own float accumulation of y = F't/fu is then 3e-4 away from the library's double accumulation)
+@pytest.mark.parametrize("name", ["sqn_ring20", "adaqn_fisher_rms", "olbfgs_default"])
+def test_float_lockstep_parity_full_grids(name, form_f32, hip_backend_f32):
+    """Single precision at full launch shapes: n = 1,000,003 puts three ring rows in four off the 16-byte grid
+    (float4 packs read at 4-byte alignment), the row-split pass A runs its whole-rounds grid."""
+    import stochqn_amd
+    from oracle import oracle
+    _, optname, kw, step, calls, pkw = [c for c in CONFIGS if c[0] == name][0]
+    n = 1_000_003
+    P = NoisyQuadratic(n, seed=11, **pkw)
+    ref = OPTIMIZERS[optname](backend=oracle.bound_f32(), space="host", use_float=True, **kw)
+    opt = OPTIMIZERS[optname](backend=hip_backend_f32, space="device", use_float=True, **kw)
+    x_ref = P.x0().astype(np.float32)
+    x_dev = torch_cuda().as_tensor(x_ref.copy(), device="cuda")
+    lib = stochqn_amd.cdll(use_float=True)
+    inval = lambda o: lib.stochqn_hip_invalidate(C.c_void_p(o._sp.ptr(o.BFGS_mem.s_mem)))
+    run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 26), F32_TOL, on_sync=inval)
+
+
 @pytest.mark.parametrize("space", ["host", "device"])
 def test_float_known_answer_trajectory(space, form_f32, hip_backend_f32):
     """The reference's 2-D Rosenbrock SQN run (tests/golden/known_answers.json) in single precision:
