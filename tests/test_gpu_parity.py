@@ -320,6 +320,40 @@ def test_two_loop_properties_at_baseline_size(n, m, form, hip_backend):
     lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))
 
 
+def test_two_loop_matches_the_oracle_at_full_size(hip_backend):
+    """The headline shape itself against the oracle: n = 1e8, m = 20, ring full and wrapped, fp64.  The oracle
+    needs the 32 GB of S and Y in host memory and ~4 s per two-loop on the box's 16 CPUs, so this is done once,
+    for both forms of the recursion, plus the diagonal-H0 variant."""
+    import stochqn_amd
+    from oracle import oracle
+    torch = torch_cuda()
+    lib = stochqn_amd.cdll()
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    n, m, st = 100_000_000, 20, 3
+    d, S, Y, gen = device_pairs(torch, n, m, 20240611)
+    g = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) - 0.5
+    H0 = 0.5 + torch.rand(n, dtype=torch.float64, device="cuda", generator=gen)
+    S_h, Y_h = S.cpu().numpy(), Y.cpu().numpy()
+    try:
+        for H0_d in (None, H0):
+            want = g.cpu().numpy().copy()
+            rho_w, alpha_w = oracle.two_loop(want, None if H0_d is None else H0_d.cpu().numpy(), 0.0, Y_h, S_h, m, m, st)
+            for twopass in (1.0, 0.0):
+                lib.stochqn_hip_set_option(b"twopass", twopass)
+                lib.stochqn_hip_set_option(b"twopass_h0", twopass)
+                q = g.clone()
+                rho, alpha = hip_two_loop(lib, q, H0_d, 0.0, Y, S, n, m, m, st)
+                got = q.cpu().numpy()
+                assert rel_err(got, want) <= TOL, (H0_d is not None, twopass, rel_err(got, want))
+                assert np.allclose(rho, rho_w, rtol=TOL, atol=0)
+                assert np.allclose(alpha, alpha_w, rtol=1e-9, atol=1e-13 * np.abs(alpha_w).max())
+                del q, got
+    finally:
+        lib.stochqn_hip_set_option(b"twopass", 1.0)
+        lib.stochqn_hip_set_option(b"twopass_h0", 1.0)
+        lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))
+
+
 @pytest.mark.parametrize("optname,kw,iters,step,tol", [
     ("SQN", dict(mem_size=20, bfgs_upd_freq=1, min_curvature=None), 30, 0.05, TOL),
     ("oLBFGS", dict(mem_size=20, min_curvature=None), 30, 0.05, TOL),
