@@ -272,6 +272,26 @@ def test_fisher_product_matches_oracle(n, fu, hip_backend):
     assert rel_err(dy.cpu().numpy(), y_w) <= TOL
 
 
+def test_fisher_product_matches_the_oracle_at_full_size(hip_backend):
+    """n = 1e8 with the 32-row batch of the headline benchmark's Hessian-vector product (25.6 GB of F)."""
+    import stochqn_amd
+    from oracle import oracle
+    torch = torch_cuda()
+    lib = stochqn_amd.cdll()
+    n, fu = 100_000_000, 32
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    dF = torch.randn(fu * n, dtype=torch.float64, device="cuda", generator=gen)
+    ds = torch.randn(n, dtype=torch.float64, device="cuda", generator=gen)
+    dy = torch.zeros(n, dtype=torch.float64, device="cuda")
+    t = np.zeros(fu)
+    lib.stochqn_hip_fisher_product.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.stochqn_hip_fisher_product(dF.data_ptr(), fu, n, ds.data_ptr(), t.ctypes.data, dy.data_ptr()) == 0
+    lib.stochqn_hip_release(C.c_void_p(dF.data_ptr()))
+    t_w, y_w = oracle.fisher_product(dF.cpu().numpy(), fu, ds.cpu().numpy())
+    assert rel_err(t, t_w) <= TOL
+    assert rel_err(dy.cpu().numpy(), y_w) <= TOL
+
+
 # ---------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE sizes (the oracle is too slow / too big there)
 # ---------------------------------------------------------------------------------------------
