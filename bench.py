@@ -7,12 +7,20 @@ Hessian-vector correction pairs, n = 1e8 variables per GPU, m = 20 stored pairs,
 check_nan = 1, synthetic noisy-quadratic gradients.  One *step* = everything the library does
 from one `niter` to the next: one `run_SQN` call with the two-loop recursion, the guard and the
 position update, plus -- every L-th step -- the calls that build the new correction pair.
+`--config c5` is BASELINE.json configs[4]'s per-GPU shard (n = 1.25e8 per GPU: n_total = 1e9 on 8 GPUs).
 
 All inputs live in HBM before the timed region starts (torch tensors handed to the C ABI as
 device pointers); the library is driven through run_SQN exactly like the reference's callers do.
+Inputs come from a counter-based generator (stochqn_hip_synth_*: element i depends only on i, the
+seed and a stream id), so rank p of P holds exactly its slice of the one-rank problem.
 
-N > 1: one process per GPU (torch.distributed.run), the n dimension is sharded, every dot
-product inside the library is a local partial + one RCCL all-reduce (stochqn_hip_comm_init).
+N > 1: one process per GPU, the n dimension is sharded, every dot product inside the library is a
+local partial + one RCCL all-reduce (stochqn_hip_comm_init).  `python bench.py --gpus N` WITHOUT a
+launcher starts the N ranks itself (a fresh `python -m torch.distributed.run` child, decided before
+this process touches torch or HIP) and relays rank 0's JSON line; under a launcher (WORLD_SIZE set)
+it is one of the ranks.  It never falls through to a 1-GPU run labelled `--gpus N`.
+`--in-process`: the same N shards driven by ONE host process through the library's single-process
+multi-device mode (option "devices"; what a C / R caller of the reference ABI gets).
 Weak scaling: n per GPU is fixed, so `value` is normalised to the n = 1e8 problem
 (value = steps/s * n_total / 1e8) to stay an aggregate that grows with N.
 
@@ -22,6 +30,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,23 +39,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 20240611
+PEAK = 8000.0  # GB/s, MI355X HBM3E (MI355X_MICROARCH.md)
+CONFIGS = {"c3": 100_000_000, "c5": 125_000_000}
+# counter-based generator streams (stochqn_hip.h): which vector a draw belongs to
+ST_D, ST_S, ST_X0, ST_NOISE = 0, 1, 3, 4
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=160, help="timed steps (default: about 2 s of device time)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", "--vars-per-gpu", dest="n", type=int, default=100_000_000,
-                    help="variables per GPU (--vars-per-gpu under torch.distributed.run, whose parser takes --n for itself)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3",
+                    help="c3: n = 1e8 per GPU (the headline configuration); c5: n = 1.25e8 per GPU (n_total = 1e9 on 8 GPUs)")
+    ap.add_argument("--n", "--vars-per-gpu", dest="n", type=int, default=0,
+                    help="variables per GPU, overrides --config (--vars-per-gpu under torch.distributed.run, whose parser takes --n for itself)")
     ap.add_argument("--mem", type=int, default=20)
     ap.add_argument("--upd-freq", type=int, default=10)
     ap.add_argument("--bsize", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=10_000_000)
-    ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline: number of steps (0 = as many as fit in --cpu-seconds)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: size of the timed sample")
-    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--cpu-n", type=int, default=0, help="CPU baseline: problem size (0 = n when host memory allows, else the largest that fits)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the second, HIP-event-profiled pass (no roofline object)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, RCCL communicator) even with one rank")
     ap.add_argument("--rehearse", action="store_true",
@@ -53,20 +67,79 @@ def parse():
                          "torch.distributed runs over gloo and the library's all-reduce goes through a gloo callback "
                          "(stochqn_hip_comm_init_custom).  Exercises exactly the code the N-GPU run takes, minus RCCL; "
                          "the number it prints is not a measurement.")
+    ap.add_argument("--in-process", action="store_true",
+                    help="N shards inside ONE process: the library's single-process multi-device mode (option 'devices')")
+    ap.add_argument("--virtual-devices", action="store_true",
+                    help="with --in-process: allow more shards than GPUs (all on the visible devices, host-side reducer); rehearsal only")
     ap.add_argument("--no-reference-form", action="store_true",
-                    help="skip the extra untimed steps in the reference's sweep form")
+                    help="skip the extra untimed steps in the reference's sweep form and the two-loop micro-benchmark")
+    ap.add_argument("--dump-x", default="", help="write the final x of this rank to <path>.<rank>.npy (sharded-vs-unsharded checks)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
-                    help="stochqn_hip_set_option before the run (grid_cap, reverse, nontemporal)")
+                    help="stochqn_hip_set_option before the run (grid_cap, reverse, nontemporal, twopass ...)")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves, from a process that has not touched the GPU
+# ------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """Start `--gpus N` ranks as a fresh torch.distributed.run child, relay rank 0's JSON line.
+    Returns the exit code: non-zero if any rank failed, fewer than N devices are visible, or no
+    result line came back."""
+    if not args.rehearse:
+        import torch                                   # device_count() does not initialise HIP
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d asked for but only %d device(s) are visible; refusing to run a "
+                             "smaller job under that label\n" % (args.gpus, have))
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    cmd += [a if a != "--n" else "--vars-per-gpu" for a in sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in child.stdout:
+        if out.startswith('{"metric"'):
+            line = out
+        else:
+            sys.stderr.write(out)
+    rc = child.wait()
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank job failed (exit code %d)\n" % (args.gpus, rc))
+        return rc
+    if line is None:
+        sys.stderr.write("bench.py: the %d-rank job printed no result line\n" % args.gpus)
+        return 1
+    got = json.loads(line)
+    if got.get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py: asked for %d GPUs, the job reports %r\n" % (args.gpus, got.get("n_gpus")))
+        return 1
+    sys.stdout.write(line)
+    sys.stdout.flush()
+    return 0
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.in_process:
+        raise SystemExit(self_launch(args))
+    run(args)
+
+
+def run(args):
     # Everything that libraries print on fd 1 (RCCL's version banner, for one) goes to stderr; the one
     # JSON line is written to the real stdout at the very end.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    import numpy as np
     import torch
     import stochqn_amd
     from stochqn_amd import _abi
@@ -74,8 +147,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
+    shards = args.gpus if args.in_process else 1       # shards inside this process
+    if args.in_process:
+        raise SystemExit("--in-process: use tools/bench_devices.py (host caller through the plain ABI, PCIe-inclusive)")
+    if not args.in_process and world != args.gpus:
+        raise SystemExit("--gpus (%d) must equal WORLD_SIZE (%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the library has no CPU path)")
     if args.rehearse:
@@ -90,6 +166,10 @@ def main():
     for kv in args.opt:
         name, val = kv.split("=")
         assert lib.stochqn_hip_set_option(name.encode(), float(val)) == 0, kv
+    if args.in_process:
+        if args.virtual_devices:
+            assert lib.stochqn_hip_set_option(b"virtual_devices", 1.0) == 0
+        assert lib.stochqn_hip_set_option(b"devices", float(shards)) == 0, "this build has no single-process multi-device mode"
 
     dist = None
     if world > 1 or args.force_dist:
@@ -111,9 +191,9 @@ def main():
                 dist.all_reduce(host)
                 return 0 if hip.hipMemcpy(buf, host.data_ptr(), 8 * count, 1) == 0 else 1
 
-            main.keep_alive = REDUCER(gloo_allreduce)
+            run.keep_alive = REDUCER(gloo_allreduce)
             lib.stochqn_hip_comm_init_custom.argtypes = [C.c_int, C.c_int, REDUCER, C.c_void_p]
-            assert lib.stochqn_hip_comm_init_custom(rank, world, main.keep_alive, None) == 0
+            assert lib.stochqn_hip_comm_init_custom(rank, world, run.keep_alive, None) == 0
         else:
             dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
             uid = torch.zeros(128, dtype=torch.uint8)
@@ -125,41 +205,48 @@ def main():
             dist.broadcast(uid, 0)
             raw = bytes(uid.cpu().tolist())
             assert lib.stochqn_hip_comm_init(rank, world, raw) == 0, "RCCL communicator init failed"
+    cpu_or_dev = "cpu" if args.rehearse else dev
 
-    n, m, L, bs = args.n, args.mem, args.upd_freq, args.bsize
+    n_gpu = args.n if args.n > 0 else CONFIGS[args.config]     # variables per GPU
+    n = n_gpu * shards                                         # variables this process holds
+    n_total = n * world
+    first = rank * n                                           # global index of this rank's first variable
+    m, L, bs = args.mem, args.upd_freq, args.bsize
     f64 = torch.float64
-    gen = torch.Generator(device=dev).manual_seed(SEED + rank)
-    rnd = lambda k: torch.rand(k, dtype=f64, device=dev, generator=gen)
+    u64 = C.c_ulonglong
+    lib.stochqn_hip_synth_uniform.argtypes = [C.c_void_p, C.c_size_t, u64, u64, u64, u64, C.c_double, C.c_double]
+    lib.stochqn_hip_synth_noisy_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64, u64, u64, u64, C.c_double]
+    lib.stochqn_hip_synth_batch_row.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, u64, C.c_uint, C.c_uint]
 
-    # ---- synthetic problem: f(x) = 1/2 sum d_i x_i^2, noisy gradients, Hessian batch A ------------
-    d = 0.5 + rnd(n)
-    x = 1.0 + rnd(n)
-    NOISE = 4
-    dn = [d * (1.0 + 0.01 * (2.0 * rnd(n) - 1.0)) for _ in range(NOISE)]      # g_t = dn[t % 4] * x
+    def uniform(out, stream, t, a, b):
+        assert lib.stochqn_hip_synth_uniform(out.data_ptr(), out.numel(), first, SEED, stream, t, a, b) == 0
+        return out
+
+    # ---- synthetic problem: f(x) = 1/2 sum d_i x_i^2, noisy gradients, Hessian batch A ----
+    d = uniform(torch.empty(n, dtype=f64, device=dev), ST_D, 0, 0.5, 1.0)          # d_i = 0.5 + u(i,0,0)
+    x = uniform(torch.empty(n, dtype=f64, device=dev), ST_X0, 0, 1.0, 1.0)         # x0_i = 1 + u(i,3,0)
     # Hessian mini-batch of `bs` sample vectors, stored dense [bs][n].  The samples have disjoint
     # supports (a_k,i = sqrt(bs*d_i) for i = k mod bs, else 0) so that A'A/bs = diag(d) exactly:
     # the product streams the full dense batch (2*bs*n words, like any real mini-batch) while the
     # optimiser sees the true Hessian of the quadratic and stays in a sane regime for any n >> bs.
-    A = torch.zeros(bs * n, dtype=f64, device=dev)
-    sq = torch.sqrt(bs * d)
+    A = torch.empty(bs * n, dtype=f64, device=dev)
     for k in range(bs):
-        A[k * n + k:(k + 1) * n:bs] = sq[k::bs]
-    del sq
+        assert lib.stochqn_hip_synth_batch_row(A.data_ptr() + 8 * k * n, d.data_ptr(), n, first, k, bs) == 0
 
     # ---- optimiser state, owned by the caller (profile B), ring already full ------------------------
     S = torch.empty(m * n, dtype=f64, device=dev)
     Y = torch.empty(m * n, dtype=f64, device=dev)
-    for k in range(m):
-        s = 1e-3 * (rnd(n) - 0.5)
-        S[k * n:(k + 1) * n] = s
-        Y[k * n:(k + 1) * n] = d * s
-    del s
+
+    def fill_ring():
+        for k in range(m):                                        # s_k,i = 1e-3 (u(i,1,k) - 0.5), y_k = d .* s_k
+            sk = uniform(S[k * n:(k + 1) * n], ST_S, k, -0.5e-3, 1e-3)
+            torch.mul(d, sk, out=Y[k * n:(k + 1) * n])
+    fill_ring()
     grad = torch.empty(n, dtype=f64, device=dev)
     hv = torch.empty(n, dtype=f64, device=dev)
     x_sum = torch.zeros(n, dtype=f64, device=dev)
     x_avg_prev = x.clone()
     t_buf = torch.zeros(bs, dtype=f64, device=dev)
-    import numpy as np
     rho_h, alpha_h = np.zeros(m), np.zeros(m)
     dummy = torch.zeros(1, dtype=f64, device=dev)
 
@@ -177,8 +264,9 @@ def main():
         """Advance the optimiser by exactly one iteration (niter + 1)."""
         target = w.niter + 1
         while w.niter < target:
-            if task.value == 101:                                  # calc_grad at *req
-                torch.mul(dn[t % NOISE], ptr2t[req.value], out=grad)
+            if task.value == 101:                                  # calc_grad at *req: g = d x (1 + 0.01 (2 u(i,4,t) - 1))
+                at = ptr2t[req.value]
+                assert lib.stochqn_hip_synth_noisy_grad(grad.data_ptr(), d.data_ptr(), at.data_ptr(), n, first, SEED, ST_NOISE, t, 0.01) == 0
             elif task.value == 104:                                # calc_hess_vec: A'(A v)/bs at x_avg
                 counters["hv"] += 1
                 rc = lib.stochqn_hip_fisher_product(A.data_ptr(), bs, n, req_vec.value, t_buf.data_ptr(), hv.data_ptr())
@@ -196,45 +284,77 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    f0 = float(0.5 * torch.sum(d * x * x))
-    for t in range(args.warmup):
-        one_step(t)
-    if not args.no_profile:
-        lib.stochqn_hip_profile_enable(1)
-        lib.stochqn_hip_profile_reset()
+    def objective():
+        v = float(0.5 * torch.sum(d * x * x))
+        if dist is not None:
+            tv = torch.tensor([v], dtype=f64, device=cpu_or_dev)
+            dist.all_reduce(tv)
+            v = float(tv.item())
+        return v
+
+    def kernel_table():
+        kern = {}
+        lib.stochqn_hip_profile_name.restype = C.c_char_p
+        for i in range(lib.stochqn_hip_profile_kernels()):
+            cnt, ms = C.c_longlong(), C.c_double()
+            lib.stochqn_hip_profile_get(i, C.byref(cnt), C.byref(ms))
+            if cnt.value:
+                kern[lib.stochqn_hip_profile_name(i).decode()] = (cnt.value, ms.value)
+        return kern
+
+    # ---- the measurement: W warm-up steps, then EXACTLY K steps, profiler off -----------------------
+    f0 = objective()
+    t_idx = 0
+    for _ in range(args.warmup):
+        one_step(t_idx)
+        t_idx += 1
+    lib.stochqn_hip_profile_enable(0)
     barrier()
     t0 = time.perf_counter()
-    for t in range(args.warmup, args.warmup + args.steps):
-        one_step(t)
+    for _ in range(args.steps):
+        one_step(t_idx)
+        t_idx += 1
     barrier()
-    elapsed = time.perf_counter() - t0
-    lib.stochqn_hip_profile_enable(0)
-
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    per_rank_ms = [round(1e3 * elapsed_local / args.steps, 3)]
+    rccl_nranks = lib.stochqn_hip_comm_nranks()
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=f64, device="cpu" if args.rehearse else dev)
+        te = torch.tensor([elapsed], dtype=f64, device=cpu_or_dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-
-    f1 = float(0.5 * torch.sum(d * x * x))
-    if dist is not None:
-        tf = torch.tensor([f0, f1], dtype=f64, device="cpu" if args.rehearse else dev)
-        dist.all_reduce(tf)
-        f0, f1 = tf.tolist()
+        gathered = [torch.zeros(1, dtype=f64, device=cpu_or_dev) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([elapsed_local], dtype=f64, device=cpu_or_dev))
+        per_rank_ms = [round(1e3 * float(g.item()) / args.steps, 3) for g in gathered]
+        tn = torch.tensor([rccl_nranks], dtype=torch.int64, device=cpu_or_dev)
+        dist.all_reduce(tn, op=dist.ReduceOp.MIN)
+        rccl_nranks = int(tn.item())
+    f1 = objective()
     assert np.isfinite(f1) and f1 < f0, "optimiser diverged on the synthetic quadratic: %r -> %r" % (f0, f1)
+    timed_counters = dict(counters)
+    if args.dump_x:
+        np.save("%s.%d.npy" % (args.dump_x, rank), x.cpu().numpy())
 
-    # ---- per-kernel HIP-event timings -> roofline of the dominant kernel ----------------------------
-    kern = {}
-    nk = lib.stochqn_hip_profile_kernels()
-    lib.stochqn_hip_profile_name.restype = C.c_char_p
-    for i in range(nk):
-        cnt, ms = C.c_longlong(), C.c_double()
-        lib.stochqn_hip_profile_get(i, C.byref(cnt), C.byref(ms))
-        if cnt.value:
-            kern[lib.stochqn_hip_profile_name(i).decode()] = (cnt.value, ms.value)
-    PEAK = 8000.0  # GB/s, MI355X HBM3E (MI355X_MICROARCH.md)
+    # ---- second pass, same workload, every launch bracketed by HIP events on the library's stream:
+    # per-kernel durations -> roofline of the dominant kernel --------------------------------------
+    kern, prof_elapsed, prof_steps = {}, None, 0
+    if not args.no_profile:
+        prof_steps = max(L, min(args.steps, 4 * L)) // L * L                # whole L-cycles: the pair-building calls in proportion
+        lib.stochqn_hip_profile_enable(1)
+        lib.stochqn_hip_profile_reset()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(prof_steps):
+            one_step(t_idx)
+            t_idx += 1
+        barrier()
+        prof_elapsed = time.perf_counter() - t1
+        lib.stochqn_hip_profile_enable(0)
+        kern = kernel_table()
     # algorithmic n-words per launch
     words = {"first": 2, "bwd": 4, "mid": 3, "fwd": 4, "fwd_last": 3, "apply": 5,
-             "rows_dot": 2 * m + 1, "rows_dot3": 2 * m + 3, "combine": 2 * m + 2}
+             "rows_dot": 2 * m + 1, "rows_dot3": 2 * m + 3, "combine": 2 * m + 2,
+             "fisher_t": bs + 1, "fisher_y": bs + 2, "pair_s": 4, "pair_y_hv": 6}
     what = {"bwd": "fused backward sweep: read y_i, q, s_{i-1}; write q",
             "fwd": "fused forward sweep: read s_i, r, y_{i+1}; write r",
             "combine": "two-pass form, pass B: read g and the %d rows of S and Y; write r" % (2 * m),
@@ -244,87 +364,86 @@ def main():
         avg = ms / cnt
         e = {"launches": cnt, "avg_ms": round(avg, 4)}
         if name in words:
-            e["alg_GBps"] = round(words[name] * n * 8 / (avg * 1e-3) / 1e9, 1)
+            e["alg_GBps"] = round(words[name] * n_gpu * 8 / (avg * 1e-3) / 1e9, 1)
         detail[name] = e
     roof = None
     cands = [k for k in what if k in kern]
     if cands:
         dom = max(cands, key=lambda k: kern[k][1])               # largest share of device time
         cnt, ms = kern[dom]
-        alg = words[dom] * n * 8
+        alg = words[dom] * n_gpu * 8
         ach = alg / (ms / cnt * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(dom, n, m)
+        traffic, traffic_src = pmc_traffic(dom, n_gpu, m)
         roof = {"bound": "hbm", "kernel": "%s (%s)" % (dom, what[dom]),
                 "achieved": round(ach, 1), "peak": PEAK, "unit": "GB/s", "frac": round(ach / PEAK, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "alg_bytes_per_launch": alg, "avg_launch_ms": round(ms / cnt, 4)}
+                "alg_bytes_per_launch": alg, "avg_launch_ms": round(ms / cnt, 4),
+                "measured": "HIP events on the library's stream, %d steps of the same workload right after the timed "
+                            "region (the timed region itself runs with the event profiler off)" % prof_steps}
     chain = ("first", "bwd", "mid", "fwd", "fwd_last", "rows_dot", "rows_dot3", "coef", "combine")
-    two_loop_ms = sum(kern[k][1] for k in chain if k in kern) / max(args.steps, 1)
+    two_loop_ms = sum(kern[k][1] for k in chain if k in kern) / max(prof_steps * shards, 1)
     two_loop = None
     if two_loop_ms > 0:
         form = "two-pass" if "combine" in kern else "sweeps"
         own = (4 * m + 3) if form == "two-pass" else 8 * m           # n-words this form has to move
         two_loop = {"form": form, "ms": round(two_loop_ms, 3),
-                    "bytes_moved": own * n * 8, "GBps_on_bytes_moved": round(own * n * 8 / (two_loop_ms * 1e-3) / 1e9, 1),
-                    "frac_of_8TBps_on_bytes_moved": round(own * n * 8 / (two_loop_ms * 1e-3) / 1e9 / PEAK, 4),
-                    "reference_form_bytes": 64 * m * n,
-                    "effective_GBps_vs_reference_form": round(64.0 * m * n / (two_loop_ms * 1e-3) / 1e9, 1)}
+                    "bytes_moved": own * n_gpu * 8, "GBps_on_bytes_moved": round(own * n_gpu * 8 / (two_loop_ms * 1e-3) / 1e9, 1),
+                    "frac_of_8TBps_on_bytes_moved": round(own * n_gpu * 8 / (two_loop_ms * 1e-3) / 1e9 / PEAK, 4),
+                    "reference_form_bytes": 64 * m * n_gpu,
+                    "effective_GBps_vs_reference_form": round(64.0 * m * n_gpu / (two_loop_ms * 1e-3) / 1e9, 1)}
 
     steps_per_s = args.steps / elapsed
-    n_total = n * world
     value = steps_per_s * n_total / 1e8
 
     # ---- outside the timed region: the same workload in the reference's own dependency structure
     # (2m+1 dependent fused sweeps, 64*m*n algorithmic bytes) for the roofline the north star names --
     ref_form = None
-    if "combine" in kern and not args.no_profile and not args.no_reference_form:
+    if "combine" in kern and not args.no_reference_form:
         lib.stochqn_hip_set_option(b"twopass", 0.0)
-        for t in range(2):
-            one_step(args.warmup + args.steps + t)
+        for _ in range(2):
+            one_step(t_idx)
+            t_idx += 1
         lib.stochqn_hip_profile_enable(1)
         lib.stochqn_hip_profile_reset()
         barrier()
         t1 = time.perf_counter()
         extra = 10
-        for t in range(extra):
-            one_step(args.warmup + args.steps + 2 + t)
+        for _ in range(extra):
+            one_step(t_idx)
+            t_idx += 1
         barrier()
         el2 = time.perf_counter() - t1
         lib.stochqn_hip_profile_enable(0)
         lib.stochqn_hip_set_option(b"twopass", 1.0)
-        k2 = {}
-        for i in range(nk):
-            cnt, ms = C.c_longlong(), C.c_double()
-            lib.stochqn_hip_profile_get(i, C.byref(cnt), C.byref(ms))
-            if cnt.value:
-                k2[lib.stochqn_hip_profile_name(i).decode()] = (cnt.value, ms.value)
+        k2 = kernel_table()
         if "bwd" in k2:
             cnt, ms = k2["bwd"]
-            ach = 4 * n * 8 / (ms / cnt * 1e-3) / 1e9
-            tl = sum(k2[k][1] for k in ("first", "bwd", "mid", "fwd", "fwd_last") if k in k2) / extra
-            tr, src = pmc_traffic("bwd", n, m)
+            ach = 4 * n_gpu * 8 / (ms / cnt * 1e-3) / 1e9
+            tl = sum(k2[k][1] for k in ("first", "bwd", "mid", "fwd", "fwd_last") if k in k2) / (extra * shards)
+            tr, src = pmc_traffic("bwd", n_gpu, m)
             ref_form = {"note": "same workload with --opt twopass=0, %d steps after the timed region" % extra,
                         "steps_per_s": round(extra / el2 * n_total / 1e8, 3),
-                        "two_loop_ms": round(tl, 3), "two_loop_alg_bytes": 64 * m * n,
-                        "two_loop_alg_GBps": round(64.0 * m * n / (tl * 1e-3) / 1e9, 1),
-                        "two_loop_frac_of_8TBps": round(64.0 * m * n / (tl * 1e-3) / 1e9 / PEAK, 4),
+                        "two_loop_ms": round(tl, 3), "two_loop_alg_bytes": 64 * m * n_gpu,
+                        "two_loop_alg_GBps": round(64.0 * m * n_gpu / (tl * 1e-3) / 1e9, 1),
+                        "two_loop_frac_of_8TBps": round(64.0 * m * n_gpu / (tl * 1e-3) / 1e9 / PEAK, 4),
                         "roofline": {"bound": "hbm", "kernel": "bwd (%s)" % what["bwd"], "achieved": round(ach, 1),
                                      "peak": PEAK, "unit": "GB/s", "frac": round(ach / PEAK, 4), "traffic": tr,
-                                     "traffic_source": src, "alg_bytes_per_launch": 4 * n * 8,
+                                     "traffic_source": src, "alg_bytes_per_launch": 4 * n_gpu * 8,
                                      "avg_launch_ms": round(ms / cnt, 4)}}
 
     # ---- the two-loop recursion on its own (SURVEY.md 8d "two-loop micro-benchmark"): the ring as the
     # run left it (m pairs, oldest in row mem_st_ix), H0 = NULL, h0 = 0; 3 warm-up + 20 timed calls of
     # stochqn_hip_two_loop per form, median wall clock of the synchronous call --------------------------
     micro = None
-    if not args.no_reference_form:
+    if not args.no_reference_form and not args.in_process:
         lib.stochqn_hip_two_loop.restype = C.c_int
         lib.stochqn_hip_two_loop.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
                                              C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
-        g0 = torch.mul(dn[0], x)
+        g0 = uniform(torch.empty(n, dtype=f64, device=dev), 2, 0, -0.5, 1.0)          # g_i = u(i,2,t) - 0.5
         gq = torch.empty_like(g0)
         micro = {"note": "stochqn_hip_two_loop alone: mem_used=%d, oldest pair in row %d, H0=NULL, 3 warm-up + 20 calls, median; "
                          "reference-form bytes = SURVEY 8d's 64*m*n (the sweeps form moves exactly those; the two-pass form moves (4m+3)*n*8)" % (m, b.mem_st_ix)}
+        lib.stochqn_hip_set_option(b"raw_reuse_cache", 1.0)      # S and Y do not change between these calls
         for form, flag in (("two_pass", 1.0), ("sweeps", 0.0)):
             lib.stochqn_hip_set_option(b"twopass", flag)
             ts = []
@@ -338,7 +457,7 @@ def main():
                 ts.append(time.perf_counter() - tq)
             med = sorted(ts[3:])[10]
             if dist is not None:
-                tm = torch.tensor([med], dtype=f64, device="cpu" if args.rehearse else dev)
+                tm = torch.tensor([med], dtype=f64, device=cpu_or_dev)
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 med = float(tm.item())
             moved = ((4 * m + 3) if form == "two_pass" else 8 * m) * n * 8        # bytes this form has to stream
@@ -347,31 +466,48 @@ def main():
                            "frac_of_8TBps_on_bytes_moved": round(moved / med / 1e9 / PEAK, 4),
                            "GBps_on_reference_form_bytes": round(64.0 * m * n / med / 1e9, 1)}
         lib.stochqn_hip_set_option(b"twopass", 1.0)
+        lib.stochqn_hip_set_option(b"raw_reuse_cache", 0.0)
         lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))      # the raw context keyed by S; the optimiser is finished
         del g0, gq
 
-    # ---- CPU baseline: the oracle on the host cores, bounded sample ---------------------------------
+    # ---- CPU baseline: the oracle on the host cores, the same workload, bounded sample --------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:     # a reported baseline of the N = 1 line only
-        cpu = cpu_baseline(args, m, L)
+    if rank == 0 and world == 1 and shards == 1 and not args.no_cpu_baseline:     # a reported baseline of the N = 1 line only
+        lib.stochqn_hip_release_all()
+        fill_ring()                                          # the state the GPU leg started from
+        uniform(x, ST_X0, 0, 1.0, 1.0)
+        torch.cuda.synchronize()
+        gpu = {"S": S, "Y": Y, "A": A, "d": d, "x": x, "noise": lambda t, out: uniform(out, ST_NOISE, t, 0.99, 0.02)}
+        cpu = cpu_baseline(args, gpu, n, m, L, bs, step_size)
 
     if rank == 0:
+        par = ("n sharded over %d GPU(s), one process per GPU; one RCCL all-reduce per dot product" % world)
+        if args.in_process:
+            par = "n sharded over %d device shard(s) inside ONE process (library option devices=%d%s)" % (
+                shards, shards, ", virtual devices: rehearsal, not a measurement" if args.virtual_devices else "")
+        if args.rehearse:
+            par = "REHEARSAL: %d ranks sharing one GPU, all-reduce over gloo -- not a measurement" % world
         out = {
             "metric": "optimizer steps/sec + achieved HBM GB/s, two-loop at n=10^8 m=20 fp64",
             "value": round(value, 3),
-            "unit": "steps/s" if world == 1 else "steps/s normalised to n=1e8 (steps/s * n_total/1e8)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "steps/s" if n_total == 100_000_000 else "steps/s normalised to n=1e8 (steps/s * n_total/1e8)",
+            "n_gpus": world * shards, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "SQN n=%g per GPU (n_total=%g), m=%d, L=%d, Hessian-vector pairs via A'(Av)/%d, "
-                                   "check_nan=1, ring full, fp64" % (n, n_total, m, L, bs),
-                       "parallelism": ("n sharded over %d GPU(s); one RCCL all-reduce per dot product" % world) if not args.rehearse else
-                                      ("REHEARSAL: %d ranks sharing one GPU, all-reduce over gloo -- not a measurement" % world),
-                       "calls": counters["calls"], "hess_vec_requests": counters["hv"],
-                       "rejected_steps": counters["bad"], "rejected_pairs": counters["rejected"],
+                                   "check_nan=1, ring full, fp64" % (n_gpu, n_total, m, L, bs),
+                       "name": args.config if args.n <= 0 else "custom",
+                       "parallelism": par,
+                       "inputs": "counter-based generator (stochqn_hip_synth_*, seed %d): shard-invariant" % SEED,
+                       "calls": timed_counters["calls"], "hess_vec_requests": timed_counters["hv"],
+                       "rejected_steps": timed_counters["bad"], "rejected_pairs": timed_counters["rejected"],
                        "options": args.opt,
                        "f_start": f0, "f_end": f1},
+            "rccl_nranks": rccl_nranks,
+            "per_rank_ms_per_step": per_rank_ms,
+            "steps_per_s_unnormalised": round(steps_per_s, 3),
+            "profiled_pass": None if prof_elapsed is None else {"steps": prof_steps, "ms_per_step": round(1e3 * prof_elapsed / prof_steps, 3)},
             "roofline": roof,
             "two_loop": two_loop,
             "two_loop_micro": micro,
@@ -379,10 +515,31 @@ def main():
             "kernels": detail,
             "cpu_baseline": cpu,
         }
+        if args.config == "c5" or n_gpu == CONFIGS["c5"]:
+            out["shard_reference_1gpu"] = shard_reference(world * shards, steps_per_s)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         lib.stochqn_hip_comm_finalize()
         dist.destroy_process_group()
+    lib.stochqn_hip_release_all()
+
+
+def shard_reference(n_gpus, steps_per_s):
+    """C5's yardstick: one GPU at the same per-GPU shard, n = 1.25e8, m = 20.  With one
+    GPU this run IS that measurement; with more it is quoted from the newest committed 1-GPU profile."""
+    import glob
+    if n_gpus == 1:
+        return {"steps_per_s": round(steps_per_s, 3), "source": "this run", "within_15pct_means_at_least": round(0.85 * steps_per_s, 3)}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c5_shard_1gpu.json")), reverse=True):
+        try:
+            ref = json.load(open(f))
+            sps = ref.get("steps_per_s_unnormalised") or ref["value"] / 1.25
+            return {"steps_per_s": round(sps, 3), "source": os.path.relpath(f, ROOT),
+                    "within_15pct_means_at_least": round(0.85 * sps, 3),
+                    "this_run_over_reference": round(steps_per_s / sps, 4)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def pmc_traffic(kernel, n, m):
@@ -404,26 +561,69 @@ def pmc_traffic(kernel, n, m):
     return None, None
 
 
-def cpu_baseline(args, m, L):
-    """Same SQN workload on the CPU oracle (kind 'port'), at a bounded size, scaled to n = 1e8."""
+# ------------------------------------------------------------------------------------------------
+# CPU baseline
+# ------------------------------------------------------------------------------------------------
+def host_facts():
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            cur = int(open("/sys/fs/cgroup/memory.current").read())
+            avail = min(avail, int(lim) - cur) if avail is not None else int(lim) - cur
+    except (OSError, ValueError):
+        pass
+    quota = "?"
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().strip()
+    except OSError:
+        pass
+    return model, avail, quota
+
+
+def cpu_baseline(args, gpu, n, m, L, bs, step_size):
+    """The same SQN workload (same inputs, copied from the GPU; Hessian-vector product A'(Av)/bs through
+    oracle_fisher_product) on the CPU oracle (kind 'port'), at n itself when host memory allows.  Timed:
+    the seconds spent inside the oracle (run_SQN + the Hessian-vector product), not the caller's gradient.
+    All usable cores: one whole L-cycle.  One thread: one ordinary step and one L-th step (the one that
+    builds a pair), composed into a cycle -- a 1-thread step at n = 1e8 takes ~10 s."""
     import numpy as np
+    import torch
     from oracle import oracle
     from stochqn_amd import _abi
-    nc = min(args.cpu_n, args.n)
+    model, avail, quota = host_facts()
+    need = lambda k: (2 * m + bs + 8) * k * 8
+    nc = args.cpu_n if args.cpu_n > 0 else n
+    if args.cpu_n <= 0 and avail is not None:
+        while nc > 1_000_000 and need(nc) > 0.7 * avail:
+            nc //= 2
+    nc = min(nc, n)
     threads = oracle.usable_cpus()            # affinity capped by the cgroup quota (16 on the GPU boxes)
-    oracle.set_threads(threads)
     be = oracle.bound()
-    rng = np.random.default_rng(SEED)
-    d = 0.5 + rng.random(nc)
-    x = 1.0 + rng.random(nc)
-    dn = d * (1.0 + 0.01 * (2.0 * rng.random(nc) - 1.0))
-    S = np.empty(m * nc)
-    Y = np.empty(m * nc)
-    for k in range(m):
-        s = 1e-3 * (rng.random(nc) - 0.5)
-        S[k * nc:(k + 1) * nc] = s
-        Y[k * nc:(k + 1) * nc] = d * s
-    grad, hv = np.empty(nc), np.empty(nc)
+    olib = oracle.cdll()
+
+    def rows_to_host(t, rows):                # the first nc columns of every row of a [rows][n] device array
+        return t.view(rows, n)[:, :nc].cpu().numpy().reshape(-1) if nc < n else t.cpu().numpy()
+    t_copy = time.perf_counter()
+    S, Y, A = rows_to_host(gpu["S"], m), rows_to_host(gpu["Y"], m), rows_to_host(gpu["A"], bs)
+    d, x = gpu["d"][:nc].cpu().numpy(), gpu["x"][:nc].cpu().numpy()
+    t_copy = time.perf_counter() - t_copy
+    noise_dev = torch.empty(n, dtype=torch.float64, device=gpu["d"].device)
+    grad, hv, tb = np.empty(nc), np.empty(nc), np.zeros(bs)
     x_sum, x_avg_prev = np.zeros(nc), x.copy()
     rho_h, alpha_h, dummy = np.zeros(m), np.zeros(m), np.zeros(1)
     b = _abi.bfgs_mem(S.ctypes.data, Y.ctypes.data, rho_h.ctypes.data, alpha_h.ctypes.data,
@@ -434,28 +634,58 @@ def cpu_baseline(args, m, L):
     def view(p):
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), (nc,))
 
-    def one_step():
-        target = w.niter + 1
-        while w.niter < target:
-            if task.value == 101:
-                np.multiply(dn, view(req.value), out=grad)
-            elif task.value == 104:
-                np.multiply(d, view(req_vec.value), out=hv)    # plumbing variant of the Hessian product
-            be.run_SQN(0.05, x.ctypes.data, grad.ctypes.data, hv.ctypes.data, C.byref(req), C.byref(req_vec),
-                       C.byref(task), C.byref(w), C.byref(info))
+    clock = {"lib": 0.0}
+    tstep = [0]
 
-    one_step()
-    t0 = time.perf_counter()
-    done = 0
-    while (done < args.cpu_steps) if args.cpu_steps > 0 else (done < 2 * L or time.perf_counter() - t0 < args.cpu_seconds):
-        one_step()                                     # at least two full L-cycles, then up to the time bound
-        done += 1
-    dt = time.perf_counter() - t0
-    rate = done / dt * (nc / 1e8)
-    return {"value": round(rate, 4), "unit": "steps/s at n=1e8 (scaled)", "cores": threads, "kind": "port",
-            "sample": "oracle/liboracle.so (CPU restatement, OpenMP, %d threads), SQN m=%d L=%d at n=%g for %d steps "
-                      "(%.2f s); rate scaled by n/1e8 (cost is linear in n); Hessian product = d*v"
-                      % (threads, m, L, nc, done, dt)}
+    def one_step():
+        # one iteration INCLUDING the pair-building calls it triggers (they follow the niter increment), so
+        # that a single timed step is self-contained: on until the next request is a plain gradient again
+        target = w.niter + 1
+        while w.niter < target or task.value != 101:
+            if task.value == 101:             # the caller's gradient (not timed): d x (1 + 0.01 (2u - 1)), noise from the GPU generator
+                noise = gpu["noise"](tstep[0], noise_dev)[:nc].cpu().numpy()
+                np.multiply(d, view(req.value), out=grad)
+                np.multiply(grad, noise, out=grad)
+            t0 = time.perf_counter()
+            if task.value == 104:
+                olib.oracle_fisher_product(A.ctypes.data, bs, nc, req_vec.value, tb.ctypes.data, hv.ctypes.data)
+            be.run_SQN(step_size, x.ctypes.data, grad.ctypes.data, hv.ctypes.data, C.byref(req), C.byref(req_vec),
+                       C.byref(task), C.byref(w), C.byref(info))
+            clock["lib"] += time.perf_counter() - t0
+        tstep[0] += 1
+
+    def timed(k):
+        clock["lib"] = 0.0
+        for _ in range(k):
+            one_step()
+        return clock["lib"]
+
+    # niter starts at L.  All cores: L-2 steps to reach niter = 2L-2 (the first is the warm-up, the rest are timed);
+    # one thread: step 2L-1 (ordinary) and step 2L (builds a pair); all cores: one whole cycle 2L+1 .. 3L.
+    oracle.set_threads(threads)
+    timed(1)
+    t_pre = timed(L - 3) if L > 3 else 0.0
+    oracle.set_threads(1)
+    t1_ord = timed(1)
+    t1_pair = timed(1)
+    oracle.set_threads(threads)
+    t_cycle = timed(L)
+    cycle_1t = (L - 1) * t1_ord + t1_pair
+    scale = nc / 1e8
+    out = {"value": round(L / t_cycle * scale, 4), "unit": "steps/s at n=1e8" + ("" if nc == 100_000_000 else " (measured at n=%g, scaled by n/1e8)" % nc),
+           "cores": threads, "kind": "port",
+           "value_allcores": round(L / t_cycle * scale, 4), "value_1thread": round(L / cycle_1t * scale, 4),
+           "n_measured": nc, "cpu_model": model, "nproc": os.cpu_count(), "cgroup_cpu_max": quota,
+           "host_mem_available_GB": None if avail is None else round(avail / 1e9, 1),
+           "allcores_cycle_s": round(t_cycle, 3), "one_thread_ordinary_step_s": round(t1_ord, 3),
+           "one_thread_pair_step_s": round(t1_pair, 3),
+           "sample": "oracle/liboracle.so (CPU restatement of the reference, gcc -O2 -fopenmp, own BLAS-1 loops, no BLAS library), "
+                     "SQN m=%d L=%d bsize=%d at n=%g, the GPU leg's own inputs copied to the host (%.1f s); seconds inside "
+                     "run_SQN + the Hessian-vector product A'(Av)/%d (oracle_fisher_product), caller's gradient excluded. "
+                     "All usable cores (%d threads): one whole L-cycle = %d steps incl. one pair (%.2f s; %d earlier steps: %.2f s). "
+                     "One thread: one ordinary step (%.2f s) and one pair-building step (%.2f s), composed into a cycle."
+                     % (m, L, bs, nc, t_copy, bs, threads, L, t_cycle, max(L - 3, 0), t_pre, t1_ord, t1_pair)}
+    return out
 
 
 if __name__ == "__main__":

@@ -23,11 +23,28 @@ int stochqn_hip_available(void);
  * src/stochqn.c:663-708), same argument meaning.  `mem_st_ix` is the row of the OLDEST pair, as
  * take_step passes it (reference src/stochqn.c:820).  grad/H0/y_mem/s_mem may be device or host
  * pointers; buffer_rho/buffer_alpha receive rho_i and alpha_i by logical index.
- * 1/(y_i's_i) and the newest pair's s'y / y'y are cached per (s_mem, row): after changing rows
- * of s_mem / y_mem from outside the library call stochqn_hip_invalidate(s_mem).
+ * Like the function it stands for, every call recomputes every inner product from the arrays as they
+ * are (a pure function of its arguments).  A caller that calls repeatedly on UNCHANGED s_mem / y_mem may
+ * set option "raw_reuse_cache" = 1: s'y, y'y and the Gram blocks of the two-pass form are then kept per
+ * (s_mem, row) between calls (stochqn_hip_invalidate(s_mem) after changing rows).  With a caller-supplied
+ * diagonal H0 the recursion always runs as the chain of dependent sweeps (the two-pass form needs the
+ * H0-weighted Gram entries, which it can only fuse when it builds H0 itself: stochqn_hip_take_step).
+ * The state behind these isolated entries is separate from any optimiser's using the same arrays and
+ * is freed by stochqn_hip_release(s_mem) / stochqn_hip_release_all().
  * Returns 0 on success, -1000 on invalid input / no device. */
 int stochqn_hip_two_loop(real_t grad[], int n, real_t H0[], real_t h0, real_t y_mem[], real_t s_mem[],
 	size_t mem_size, size_t mem_used, size_t mem_st_ix, real_t buffer_rho[], real_t buffer_alpha[]);
+
+/* take_step of reference src/stochqn.c:802-840 (static inline there), same argument meaning: with pairs in
+ * memory [H0 <- grad / sqrt(G + scal_reg) after G <- update(G, grad) when grad_sum_sq != NULL] -> two-loop
+ * recursion -> guard (check_nan: non-finite or ||dir|| > 1e3 n: memory flushed, *iter_info =
+ * search_direction_was_nan, x untouched) -> x -= step_size * dir.  grad is overwritten with the direction;
+ * bfgs_memory->mem_used / mem_st_ix are the caller's counters (mem_st_ix as stored in the struct, reference
+ * :820), buffer_rho / buffer_alpha are filled.  grad_sum_sq == NULL: oLBFGS / SQN step (h0 as in two_loop, H0
+ * ignored); else adaQN's step -- the diagonal-H0 kernels of the two-pass form when the "twopass" options
+ * are on.  Device or host pointers.  Cache policy as for stochqn_hip_two_loop.  Returns 0 or -1000. */
+int stochqn_hip_take_step(real_t step_size, int n, real_t x[], real_t grad[], bfgs_mem *bfgs_memory, real_t rmsprop_weight,
+	real_t H0[], real_t h0, real_t grad_sum_sq[], real_t scal_reg, int check_nan, info_enum *iter_info);
 
 /* Empirical Fisher product y = F'(F s)/fu of reference src/stochqn.c:946-949 (update_y_fisher
  * without the curvature check).  F is [fu][n] row-major.  Device or host pointers. */
@@ -57,6 +74,8 @@ int stochqn_hip_export(const void *s_mem);
  *                            effects on the raw gradient (needs "twopass" = 1 as well)
  * "rows_grid", "rows_split", "combine_batch", "h0_per_cu": kernel-shape knobs, see DESIGN.md 3.2
  * "strict_grad" (default 1)  host callers: copy the search direction back into `grad`
+ * "raw_reuse_cache" (default 0)  stochqn_hip_two_loop / _take_step keep cached inner products between calls
+ * "devices", "virtual_devices", "devices_min_n": single-process multi-device mode, see below
  * "fail_alloc_after" (default -1 = off)  fault injection for tests: the (value+1)-th device or
  *                             pinned allocation from now fails once
  * "inject_device_fault" (default 0)      fault injection for tests: the next stream synchronisation
@@ -78,6 +97,23 @@ int stochqn_hip_profile_kernels(void);
 const char* stochqn_hip_profile_name(int kernel_id);
 int stochqn_hip_profile_get(int kernel_id, long long *launches, double *total_ms);
 
+/* ---- synthetic inputs for measurement --------------------------------------------
+ * Counter-based generator: element i of a vector depends only on (i, seed, stream, t), so rank p of P
+ * produces exactly its slice [first_index, first_index + count) of the one-rank problem.
+ *   u(i, stream, t) = (splitmix64_finalise(key + i * 0x9E3779B97F4A7C15) >> 11) / 2^53,
+ *   key = seed ^ stream * 0x9E3779B97F4A7C15 ^ t * 0xD1B54A32D192ED03     (all arithmetic mod 2^64)
+ * uniform    : out_j  = a + b * u(first_index + j)
+ * noisy_grad : grad_j = d_j x_j (1 + amp (2 u(first_index + j) - 1)), the stochastic gradient of 1/2 sum d x^2
+ * batch_row  : row k of a `bs`-sample Hessian mini-batch with disjoint supports, a_j = sqrt(bs d_j) if
+ *              (first_index + j) mod bs == k else 0, so that A'A/bs = diag(d)
+ * Device pointers only; the kernels are enqueued on the null stream and NOT synchronised. 0 or -1000. */
+int stochqn_hip_synth_uniform(real_t *out, size_t count, unsigned long long first_index, unsigned long long seed,
+	unsigned long long stream, unsigned long long t, double a, double b);
+int stochqn_hip_synth_noisy_grad(real_t *grad, const real_t *d, const real_t *x, size_t count,
+	unsigned long long first_index, unsigned long long seed, unsigned long long stream, unsigned long long t, double amp);
+int stochqn_hip_synth_batch_row(real_t *row, const real_t *d, size_t count, unsigned long long first_index,
+	unsigned k, unsigned bs);
+
 /* ---- sharding n across GPUs (one process per GPU, RCCL over xGMI) ---------------------------------
  * Every rank owns a contiguous slice of all n-vectors and of every row of S, Y, F and passes its
  * LOCAL n to initialize_* / run_*.  After comm_init every dot product inside the library becomes
@@ -89,6 +125,23 @@ int stochqn_hip_comm_unique_id(void *out128);
 int stochqn_hip_comm_init(int rank, int nranks, const void *unique_id128);
 int stochqn_hip_comm_nranks(void);
 void stochqn_hip_comm_finalize(void);
+
+/* ---- sharding n across the GPUs of ONE process (single-process multi-device mode) -------------------------
+ * What a caller of the plain reference ABI gets -- an R session through .Call (reference src/Rwrapper.c:98-125),
+ * a C program like reference example/c_rosen.c:100-125, the Cython binding: ONE host process, one run_* call
+ * per step, and the library drives P devices.  Switched on with stochqn_hip_set_option("devices", P) or
+ * STOCHQN_HIP_DEVICES=P in the environment.  It applies to workspaces whose arrays are HOST memory (profile
+ * B) and to workspaces made by initialize_* while the option is on (profile A: the struct's array fields
+ * are then opaque non-NULL tokens, the arrays exist only as per-device slices, so n is bounded by the SUM of
+ * the devices' memories: initialize_SQN(n = 1e9, m = 20) needs 8 GPUs).  Workspaces whose arrays are device
+ * pointers, and problems with n < "devices_min_n" (default 2^20), keep running on one device.
+ * Per call every shard's host thread uploads its slice of x / grad / hess_vec and brings back its slice of
+ * x, of the direction (grad) and of *req / *req_vec; reductions are RCCL all-reduces between the shards'
+ * streams (ncclCommInitAll).  "virtual_devices" = 1 (STOCHQN_HIP_VIRTUAL_DEVICES=1) allows more shards than
+ * devices with a host-side reducer: a rehearsal of the mode on one GPU, not a way to go faster.
+ * stochqn_hip_export / _release / _invalidate take the workspace's s_mem as for one device. */
+int stochqn_hip_devices_active(const void *s_mem);    /* shards this workspace runs on (0: single-device path) */
+int stochqn_hip_devices_reducer(const void *s_mem);   /* 1 = RCCL, 3 = host-side rendezvous (virtual devices), 0 = none */
 
 /* ---- caller-supplied reducer (MPI, gloo, a fabric RCCL does not speak) ------------------------------
  * Same sharding, but every reduction is handed to `fn`: sum device_buf[0..count) over all ranks, in

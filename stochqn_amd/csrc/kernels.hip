@@ -1222,6 +1222,46 @@ __global__ void __launch_bounds__(kBlock) k_verdict(const double* parts, int cou
 }
 
 // ------------------------------------------------------------------------------------------------
+// synthetic inputs for measurement: a counter-based generator, so that a shard
+// [first, first + count) of a vector is the same numbers whoever generates it and however n is split.
+//   u(i, stream, t) = top 53 bits of splitmix64-finalise(key + i * golden) / 2^53,
+//   key = seed ^ stream * 0x9E3779B97F4A7C15 ^ t * 0xD1B54A32D192ED03            (host: synth_key)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double synth_u(uint64_t key, uint64_t i)
+{
+	uint64_t z = key + i * 0x9E3779B97F4A7C15ull;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	z = z ^ (z >> 31);
+	return (double) (z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// out_j = a + b * u(first + j)
+__global__ void __launch_bounds__(kBlock) k_synth_uniform(real* out, size_t count, uint64_t first, uint64_t key, double a, double b)
+{
+	for (size_t j = blockIdx.x * (size_t) kBlock + threadIdx.x; j < count; j += (size_t) gridDim.x * kBlock)
+		out[j] = (real) (a + b * synth_u(key, first + j));
+}
+
+// g_j = d_j x_j (1 + amp (2 u(first + j) - 1)): the noisy gradient of f = 1/2 sum d x^2 (3 n words)
+__global__ void __launch_bounds__(kBlock) k_synth_grad(real* g, const real* d, const real* x, size_t count, uint64_t first,
+                                                      uint64_t key, double amp)
+{
+	for (size_t j = blockIdx.x * (size_t) kBlock + threadIdx.x; j < count; j += (size_t) gridDim.x * kBlock) {
+		const double noise = 1.0 + amp * (2.0 * synth_u(key, first + j) - 1.0);
+		g[j] = (real) (((double) d[j] * (double) x[j]) * noise);
+	}
+}
+
+// One sample row of the Hessian mini-batch with disjoint supports: a_j = sqrt(bs d_j) where
+// (first + j) mod bs == k, else 0 -- A'A/bs = diag(d) exactly (bench.py)
+__global__ void __launch_bounds__(kBlock) k_synth_batch_row(real* row, const real* d, size_t count, uint64_t first, uint32_t k, uint32_t bs)
+{
+	for (size_t j = blockIdx.x * (size_t) kBlock + threadIdx.x; j < count; j += (size_t) gridDim.x * kBlock)
+		row[j] = ((first + j) % bs == k) ? (real) sqrt((double) bs * (double) d[j]) : (real) 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
 // The vector path needs element alignment only (see rvec_u); a pointer that is not even that goes
@@ -1603,6 +1643,32 @@ void launch_verdict(const Scratch& sc, Partials in, double min_curvature, double
 {
 	ProfScope ps(sc, K_SMALL);
 	hipLaunchKernelGGL(k_verdict, dim3(1), dim3(kBlock), 0, sc.stream, in.parts, in.count, in.stride, min_curvature, sy_dst, yy_dst, out);
+}
+
+uint64_t synth_key(uint64_t seed, uint64_t stream, uint64_t t)
+{
+	return seed ^ (stream * 0x9E3779B97F4A7C15ull) ^ (t * 0xD1B54A32D192ED03ull);
+}
+
+static int synth_grid(size_t count)
+{
+	size_t g = (count + kBlock - 1) / kBlock;
+	return (int) (g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+void launch_synth_uniform(hipStream_t stream, real* out, size_t count, uint64_t first, uint64_t key, double a, double b)
+{
+	hipLaunchKernelGGL(k_synth_uniform, dim3(synth_grid(count)), dim3(kBlock), 0, stream, out, count, first, key, a, b);
+}
+
+void launch_synth_grad(hipStream_t stream, real* g, const real* d, const real* x, size_t count, uint64_t first, uint64_t key, double amp)
+{
+	hipLaunchKernelGGL(k_synth_grad, dim3(synth_grid(count)), dim3(kBlock), 0, stream, g, d, x, count, first, key, amp);
+}
+
+void launch_synth_batch_row(hipStream_t stream, real* row, const real* d, size_t count, uint64_t first, uint32_t k, uint32_t bs)
+{
+	hipLaunchKernelGGL(k_synth_batch_row, dim3(synth_grid(count)), dim3(kBlock), 0, stream, row, d, count, first, k, bs);
 }
 
 void launch_scale(const Scratch& sc, size_t n, real* x, double a)

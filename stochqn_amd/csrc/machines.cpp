@@ -10,7 +10,7 @@
 //   * struct arrays that are device pointers are used in place; host arrays are mirrored in HBM
 //     (context keyed by bfgs_mem.s_mem) and only x, grad, *req, *req_vec are kept in step;
 //   * x / grad / hess_vec are classified per call; host ones are staged over PCIe.
-#include "runtime.hpp"
+#include "machines.hpp"
 #include "stochqn_hip.h"
 
 #include <cmath>
@@ -802,9 +802,13 @@ static int run_adaQN_impl(real_t step_size, real_t x[], real_t f, real_t grad[],
 	return ret;
 }
 
-// The exported entry points (exception barrier: no_throw, above).
-int run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_enum* task, workspace_oLBFGS* w,
-               info_enum* iter_info)
+}  // extern "C"
+
+// One shard's call (group.cpp) or the whole call (below): the state machine between the two hooks that
+// tie a device context to the caller-visible state.
+namespace sqn {
+int local_run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_enum* task, workspace_oLBFGS* w,
+                     info_enum* iter_info)
 {
 	return no_throw(task, "run_oLBFGS", [&] {
 		ApiRange range("run_oLBFGS", w ? w->section : -1);
@@ -814,8 +818,8 @@ int run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_e
 	});
 }
 
-int run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real_t** req, real_t** req_vec, task_enum* task,
-            workspace_SQN* w, info_enum* iter_info)
+int local_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real_t** req, real_t** req_vec, task_enum* task,
+                  workspace_SQN* w, info_enum* iter_info)
 {
 	return no_throw(task, "run_SQN", [&] {
 		ApiRange range("run_SQN", w ? w->section : -1);
@@ -825,8 +829,8 @@ int run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real
 	});
 }
 
-int run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** req, task_enum* task, workspace_adaQN* w,
-              info_enum* iter_info)
+int local_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** req, task_enum* task, workspace_adaQN* w,
+                    info_enum* iter_info)
 {
 	return no_throw(task, "run_adaQN", [&] {
 		ApiRange range("run_adaQN", w ? w->section : -1);
@@ -834,6 +838,36 @@ int run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** re
 		const int rc = run_adaQN_impl(step_size, x, f, grad, req, task, w, iter_info);
 		return after_call(w, rc, task);
 	});
+}
+}  // namespace sqn
+
+extern "C" {
+
+// The exported entry points (exception barrier: no_throw, above).  With option "devices" >= 2 a workspace
+// whose arrays are host memory or library-owned shards runs on all devices (group.cpp); everything
+// else -- device pointers in the structs, one device, small n -- takes the single-device path.
+int run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_enum* task, workspace_oLBFGS* w,
+               info_enum* iter_info)
+{
+	if (w && w->bfgs_memory && device_ready() && group_applies(w->bfgs_memory, w->n))
+		return no_throw(task, "run_oLBFGS", [&] { return group_run_oLBFGS(step_size, x, grad, req, task, w, iter_info); });
+	return local_run_oLBFGS(step_size, x, grad, req, task, w, iter_info);
+}
+
+int run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[], real_t** req, real_t** req_vec, task_enum* task,
+            workspace_SQN* w, info_enum* iter_info)
+{
+	if (w && w->bfgs_memory && device_ready() && group_applies(w->bfgs_memory, w->n))
+		return no_throw(task, "run_SQN", [&] { return group_run_SQN(step_size, x, grad, hess_vec, req, req_vec, task, w, iter_info); });
+	return local_run_SQN(step_size, x, grad, hess_vec, req, req_vec, task, w, iter_info);
+}
+
+int run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** req, task_enum* task, workspace_adaQN* w,
+              info_enum* iter_info)
+{
+	if (w && w->bfgs_memory && device_ready() && group_applies(w->bfgs_memory, w->n))
+		return no_throw(task, "run_adaQN", [&] { return group_run_adaQN(step_size, x, f, grad, req, task, w, iter_info); });
+	return local_run_adaQN(step_size, x, f, grad, req, task, w, iter_info);
 }
 
 // =================================================================================================
@@ -914,6 +948,11 @@ workspace_oLBFGS* initialize_oLBFGS(const int n, const size_t mem_size, const re
                                     const real_t min_curvature, const int check_nan, const int nthreads)
 {
 	if (!gpu_or_complain("initialize_oLBFGS")) return nullptr;
+	if (mem_size > 0 && group_mode_for(n)) {                  // option "devices": sharded over the devices of this process
+		workspace_oLBFGS* gw = group_initialize_oLBFGS(n, mem_size, hess_init, y_reg, min_curvature, check_nan, nthreads);
+		if (!gw) std::fprintf(stderr, "Error: Could not allocate memory for oLBFGS.\n");
+		return gw;
+	}
 	workspace_oLBFGS* w = (workspace_oLBFGS*) std::calloc(1, sizeof(*w));
 	if (!w) return nullptr;
 	w->bfgs_memory = initialize_bfgs_mem(mem_size, n, min_curvature, y_reg, 1);
@@ -930,9 +969,22 @@ workspace_oLBFGS* initialize_oLBFGS(const int n, const size_t mem_size, const re
 	return w;
 }
 
+// a workspace made in group mode: the struct's array fields are tokens, the arrays are the shards
+static bool dealloc_group(bfgs_mem* b, fisher_mem* f)
+{
+	if (!b || !group_owns(b->s_mem)) return false;
+	group_dealloc(b->s_mem);
+	std::free(b->buffer_rho);
+	std::free(b->buffer_alpha);
+	std::free(b);
+	if (f) { std::free(f->buffer_y); std::free(f); }
+	return true;
+}
+
 void dealloc_oLBFGS(workspace_oLBFGS* w)
 {
 	if (!w) return;
+	if (dealloc_group(w->bfgs_memory, nullptr)) { std::free(w); return; }
 	dealloc_bfgs_mem(w->bfgs_memory);
 	if (w->grad_prev) (void) hipFree(w->grad_prev);
 	std::free(w);
@@ -942,6 +994,11 @@ workspace_SQN* initialize_SQN(const int n, const size_t mem_size, const size_t b
                               const int use_grad_diff, const real_t y_reg, const int check_nan, const int nthreads)
 {
 	if (!gpu_or_complain("initialize_SQN")) return nullptr;
+	if (mem_size > 0 && group_mode_for(n)) {
+		workspace_SQN* gw = group_initialize_SQN(n, mem_size, bfgs_upd_freq, min_curvature, use_grad_diff, y_reg, check_nan, nthreads);
+		if (!gw) std::fprintf(stderr, "Error: Could not allocate memory for SQN.\n");
+		return gw;
+	}
 	workspace_SQN* w = (workspace_SQN*) std::calloc(1, sizeof(*w));
 	if (!w) return nullptr;
 	const size_t nn = (size_t) (n > 0 ? n : 1);
@@ -964,6 +1021,7 @@ workspace_SQN* initialize_SQN(const int n, const size_t mem_size, const size_t b
 void dealloc_SQN(workspace_SQN* w)
 {
 	if (!w) return;
+	if (dealloc_group(w->bfgs_memory, nullptr)) { std::free(w); return; }
 	dealloc_bfgs_mem(w->bfgs_memory);
 	if (w->grad_prev) (void) hipFree(w->grad_prev);
 	if (w->x_sum) (void) hipFree(w->x_sum);
@@ -977,6 +1035,12 @@ workspace_adaQN* initialize_adaQN(const int n, const size_t mem_size, const size
                                   const int check_nan, const int nthreads)
 {
 	if (!gpu_or_complain("initialize_adaQN")) return nullptr;
+	if (mem_size > 0 && group_mode_for(n)) {
+		workspace_adaQN* gw = group_initialize_adaQN(n, mem_size, fisher_size, bfgs_upd_freq, max_incr, min_curvature, scal_reg,
+		                                             rmsprop_weight, use_grad_diff, y_reg, check_nan, nthreads);
+		if (!gw) std::fprintf(stderr, "Error: Could not allocate memory for adaQN.\n");
+		return gw;
+	}
 	workspace_adaQN* w = (workspace_adaQN*) std::calloc(1, sizeof(*w));
 	if (!w) return nullptr;
 	const size_t nn = (size_t) (n > 0 ? n : 1);
@@ -1006,6 +1070,7 @@ workspace_adaQN* initialize_adaQN(const int n, const size_t mem_size, const size
 void dealloc_adaQN(workspace_adaQN* w)
 {
 	if (!w) return;
+	if (dealloc_group(w->bfgs_memory, w->fisher_memory)) { std::free(w); return; }
 	dealloc_bfgs_mem(w->bfgs_memory);
 	dealloc_fisher_mem(w->fisher_memory);
 	if (w->H0) (void) hipFree(w->H0);
@@ -1019,6 +1084,27 @@ void dealloc_adaQN(workspace_adaQN* w)
 // =================================================================================================
 // isolated kernels of stochqn_hip.h
 // =================================================================================================
+// Context of an isolated entry point: keyed apart from the optimiser context of the same arrays (an odd
+// address is never an array of reals), so a raw call never tears down a live optimiser's state.
+static DevCtx* raw_context(real_t s_mem[], real_t y_mem[], int n, size_t mem_size, bool* fresh)
+{
+	DevCtx* c = acquire(raw_key(s_mem), KIND_RAW, n, mem_size, 0, fresh);
+	if (!c) return nullptr;
+	const size_t nn = (size_t) n;
+	if (!bind(c, c->S, s_mem, mem_size * nn, true) || !bind(c, c->Y, y_mem, mem_size * nn, true)) return nullptr;
+	// host arrays may have changed since the last call: refresh the mirrors
+	if (c->S.mirror && !*fresh) SQN_HIP_OK(hipMemcpyAsync(c->S.dev, s_mem, mem_size * nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
+	if (c->Y.mirror && !*fresh) SQN_HIP_OK(hipMemcpyAsync(c->Y.dev, y_mem, mem_size * nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
+	// The pure functions these entries stand for (approx_inv_hess_grad, take_step) recompute every inner
+	// product on every call.  Here s'y, y'y and the Gram blocks are cached per row, and nothing tells the
+	// library that a caller rewrote S / Y in place (or that an allocator handed the same address to new
+	// arrays): so the caches are dropped on every call unless the caller vouches for the arrays with
+	// option "raw_reuse_cache" = 1 (the two-loop micro-benchmark does).
+	if (!options().raw_reuse_cache || c->S.mirror || c->Y.mirror) { c->rho_ok.assign(c->m, 0); c->gram_ok.assign(c->m, 0); }
+	if (*fresh) comm_attach(c);
+	return c;
+}
+
 static int two_loop_impl(real_t grad[], int n, real_t H0[], real_t h0, real_t y_mem[], real_t s_mem[],
                          size_t mem_size, size_t mem_used, size_t mem_st_ix, real_t buffer_rho[], real_t buffer_alpha[])
 {
@@ -1026,18 +1112,11 @@ static int two_loop_impl(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 		return -1000;
 	(void) hipGetLastError();
 	bool fresh = false;
-	DevCtx* c = acquire(s_mem, KIND_RAW, n, mem_size, 0, &fresh);
+	DevCtx* c = raw_context(s_mem, y_mem, n, mem_size, &fresh);
 	if (!c) return -1000;
 	const size_t nn = (size_t) n;
-	if (!bind(c, c->S, s_mem, mem_size * nn, true) || !bind(c, c->Y, y_mem, mem_size * nn, true) ||
-	    !bind(c, c->H0, H0, H0 ? nn : 0, true))
-		return -1000;
-	// host arrays may have changed since the last call: refresh the mirrors, drop the cached dots
+	if (!bind(c, c->H0, H0, H0 ? nn : 0, true)) return -1000;
 	if (c->H0.mirror) SQN_HIP_OK(hipMemcpyAsync(c->H0.dev, H0, nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
-	if (c->S.mirror && !fresh) SQN_HIP_OK(hipMemcpyAsync(c->S.dev, s_mem, mem_size * nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
-	if (c->Y.mirror && !fresh) SQN_HIP_OK(hipMemcpyAsync(c->Y.dev, y_mem, mem_size * nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
-	if (c->S.mirror || c->Y.mirror) { c->rho_ok.assign(c->m, 0); c->gram_ok.assign(c->m, 0); }
-	if (fresh) comm_attach(c);
 	const bool g_host = !is_device_pointer(grad);
 	real* g = stage_in(c, 1, grad, nn, g_host);
 	if (!g) return -1000;
@@ -1064,12 +1143,64 @@ int stochqn_hip_two_loop(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 	});
 }
 
+// take_step of reference src/stochqn.c:802-840 on its own: [diagonal rescale ->] two-loop -> guard -> x update.
+// With grad_sum_sq != NULL this is adaQN's step (H0 receives g/sqrt(G+eps), G is updated), i.e. the
+// diagonal-H0 kernels of the two-pass form when the "twopass" options are on.
+static int take_step_impl(real_t step_size, int n, real_t x[], real_t grad[], bfgs_mem* b, real_t rmsprop_weight, real_t H0[],
+                          real_t h0, real_t grad_sum_sq[], real_t scal_reg, int check_nan, info_enum* iter_info)
+{
+	if (iter_info) *iter_info = no_problems_encountered;
+	if (!device_ready() || !x || !grad || !b || !b->s_mem || !b->y_mem || n <= 0 || b->mem_size == 0 || b->mem_used > b->mem_size ||
+	    b->mem_st_ix >= b->mem_size || (grad_sum_sq && b->mem_used > 0 && !H0))
+		return -1000;
+	(void) hipGetLastError();
+	bool fresh = false;
+	DevCtx* c = raw_context(b->s_mem, b->y_mem, n, b->mem_size, &fresh);
+	if (!c) return -1000;
+	const size_t nn = (size_t) n;
+	real_t* H0_used = grad_sum_sq ? H0 : nullptr;          // a caller-supplied diagonal is approx_inv_hess_grad's business (two_loop)
+	if (!bind(c, c->H0, H0_used, H0_used ? nn : 0, false) || !bind(c, c->G, grad_sum_sq, grad_sum_sq ? nn : 0, true)) return -1000;
+	if (c->G.mirror && !fresh) SQN_HIP_OK(hipMemcpyAsync(c->G.dev, grad_sum_sq, nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
+	Call io;
+	io.c = c;
+	io.x_caller = x; io.g_caller = grad;
+	io.host_caller = !is_device_pointer(x);
+	io.g_host = !is_device_pointer(grad);
+	if ((io.host_caller && !ensure_stage(c, 0)) || (io.g_host && !ensure_stage(c, 1))) return -1000;
+	stage_xg(io, true, true);
+	StepIn in;
+	in.step = step_size; in.x = io.x; in.g = io.g;
+	in.used = b->mem_used; in.st_ix = b->mem_st_ix;
+	in.h0 = h0;
+	in.H0 = c->H0.dev; in.G = c->G.dev;
+	in.w = rmsprop_weight; in.eps = scal_reg;
+	in.check_nan = check_nan;
+	enqueue_step(io, in);
+	if (c->G.mirror) export_view(c, c->G);
+	if (c->H0.mirror && b->mem_used > 0) export_view(c, c->H0);
+	close_call(io, true, true);
+	if (c->fault) { c->fault = false; return -1000; }
+	if (step_was_bad(io, b, b->mem_used, check_nan)) {
+		ring_reset(b);                                         // :831
+		if (iter_info) *iter_info = search_direction_was_nan;
+	}
+	return 0;
+}
+
+int stochqn_hip_take_step(real_t step_size, int n, real_t x[], real_t grad[], bfgs_mem* bfgs_memory, real_t rmsprop_weight,
+                          real_t H0[], real_t h0, real_t grad_sum_sq[], real_t scal_reg, int check_nan, info_enum* iter_info)
+{
+	return no_throw(nullptr, "stochqn_hip_take_step", [&] {
+		return take_step_impl(step_size, n, x, grad, bfgs_memory, rmsprop_weight, H0, h0, grad_sum_sq, scal_reg, check_nan, iter_info);
+	});
+}
+
 static int fisher_product_impl(real_t F[], size_t fu, int n, real_t s[], real_t buffer_y[], real_t y[])
 {
 	if (!device_ready() || !F || !s || !y || n <= 0 || fu == 0) return -1000;
 	(void) hipGetLastError();
 	bool fresh = false;
-	DevCtx* c = acquire(F, KIND_RAW, n, 1, fu, &fresh);
+	DevCtx* c = acquire(raw_key(F), KIND_RAW, n, 1, fu, &fresh);
 	if (!c) return -1000;
 	const size_t nn = (size_t) n;
 	if (fresh) comm_attach(c);

@@ -1,11 +1,12 @@
 // runtime.cpp -- context registry, pointer residency, mirrors, RCCL hook, options, profiler API.
-#include "runtime.hpp"
+#include "machines.hpp"
 #include "stochqn_hip.h"
 
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
@@ -43,6 +44,7 @@ struct Comm {
 	int rank = 0, nranks = 1;
 	ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
 	ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
 	ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
 	const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -59,21 +61,36 @@ bool load_rccl()
 	if (!g_comm.dl) { std::fprintf(stderr, "stochqn: cannot dlopen RCCL: %s\n", dlerror()); return false; }
 	g_comm.GetUniqueId = (decltype(g_comm.GetUniqueId)) dlsym(g_comm.dl, "ncclGetUniqueId");
 	g_comm.CommInitRank = (decltype(g_comm.CommInitRank)) dlsym(g_comm.dl, "ncclCommInitRank");
+	g_comm.CommInitAll = (decltype(g_comm.CommInitAll)) dlsym(g_comm.dl, "ncclCommInitAll");
 	g_comm.AllReduce = (decltype(g_comm.AllReduce)) dlsym(g_comm.dl, "ncclAllReduce");
 	g_comm.CommDestroy = (decltype(g_comm.CommDestroy)) dlsym(g_comm.dl, "ncclCommDestroy");
 	g_comm.GetErrorString = (decltype(g_comm.GetErrorString)) dlsym(g_comm.dl, "ncclGetErrorString");
-	if (!g_comm.GetUniqueId || !g_comm.CommInitRank || !g_comm.AllReduce || !g_comm.CommDestroy) {
+	if (!g_comm.GetUniqueId || !g_comm.CommInitRank || !g_comm.CommInitAll || !g_comm.AllReduce || !g_comm.CommDestroy) {
 		std::fprintf(stderr, "stochqn: RCCL library lacks the expected symbols\n");
+		dlclose(g_comm.dl);                      // a later attempt starts over instead of calling NULL pointers
+		g_comm = Comm{};
 		return false;
 	}
 	return true;
 }
 
-void allreduce_hook(void*, double* buf, int count, hipStream_t stream)
+// A reduction that failed leaves un-reduced local partial sums where the next kernel expects global
+// ones: the step would finish with wrong alpha / beta and the ranks would take different decisions.
+// Mark the context instead: the call that saw it returns -1000 / invalid_input (machines.cpp: after_call).
+void reducer_failed(void* user, const char* what)
 {
-	ncclResult_t r = g_comm.AllReduce(buf, buf, (size_t) count, ncclDouble, ncclSum, g_comm.comm, stream);
-	if (r != ncclSuccess)
-		std::fprintf(stderr, "stochqn: ncclAllReduce failed: %s\n", g_comm.GetErrorString ? g_comm.GetErrorString(r) : "?");
+	std::fprintf(stderr, "stochqn: %s -- the call fails (-1000) instead of continuing on un-reduced sums\n", what);
+	if (user) static_cast<DevCtx*>(user)->fault = true;
+}
+
+void allreduce_hook(void* user, double* buf, int count, hipStream_t stream)
+{
+	DevCtx* c = static_cast<DevCtx*>(user);
+	ncclResult_t r = g_comm.AllReduce(buf, buf, (size_t) count, ncclDouble, ncclSum, (ncclComm_t) c->red.comm, stream);
+	if (r != ncclSuccess) {
+		std::fprintf(stderr, "stochqn: ncclAllReduce: %s\n", g_comm.GetErrorString ? g_comm.GetErrorString(r) : "?");
+		reducer_failed(user, "ncclAllReduce failed");
+	}
 }
 
 // ---- caller-supplied reducer -------------------------------------------------------------------
@@ -83,53 +100,58 @@ struct Custom {
 	int rank = 0, nranks = 1;
 } g_custom;
 
-void custom_hook(void*, double* buf, int count, hipStream_t stream)
+void custom_hook(void* user, double* buf, int count, hipStream_t stream)
 {
 	if (g_custom.fn(g_custom.user, buf, count, (void*) stream) != 0)
-		std::fprintf(stderr, "stochqn: the caller-supplied all-reduce reported a failure\n");
+		reducer_failed(user, "the caller-supplied all-reduce reported a failure");
 }
 
 // ---- loop-back reducer: P shards of one problem driven by P host threads on ONE GPU ------------
 // Rehearses the sharded path where only one device is available (tests): the all-reduce is a
 // host-side rendezvous of the calling threads, summed in rank order.
-struct Loopback {
-	int nranks = 0;
-	std::mutex mu;
-	std::condition_variable cv;
-	int arrived = 0;
-	long generation = 0;
-	std::vector<double> slots;      // [nranks][kRedMax]
-} g_loop;
-thread_local int t_loop_rank = -1;
+Loopback g_loop;                     // the instance behind stochqn_hip_loopback_* (tests)
+thread_local Reducer t_reducer;      // what contexts created by this thread reduce through (default: the process-wide one)
 
-void loop_barrier()
+// false: a shard never arrived (it failed on its own and left the call early).  The rendezvous is then
+// broken for good -- every later reduction fails at once instead of waiting -- and the calls return -1000.
+bool loop_barrier(Loopback& lp)
 {
-	std::unique_lock<std::mutex> lk(g_loop.mu);
-	const long gen = g_loop.generation;
-	if (++g_loop.arrived == g_loop.nranks) {
-		g_loop.arrived = 0;
-		g_loop.generation++;
-		g_loop.cv.notify_all();
-	} else {
-		g_loop.cv.wait(lk, [&] { return g_loop.generation != gen; });
+	std::unique_lock<std::mutex> lk(lp.mu);
+	if (lp.broken) return false;
+	const long gen = lp.generation;
+	if (++lp.arrived == lp.nranks) {
+		lp.arrived = 0;
+		lp.generation++;
+		lp.cv.notify_all();
+		return true;
 	}
+	if (!lp.cv.wait_for(lk, std::chrono::seconds(lp.patience_s), [&] { return lp.generation != gen || lp.broken; }) || lp.broken) {
+		lp.broken = true;
+		lp.cv.notify_all();
+		return false;
+	}
+	return true;
 }
 
-void loopback_hook(void*, double* buf, int count, hipStream_t stream)
+void loopback_hook(void* user, double* buf, int count, hipStream_t stream)
 {
+	DevCtx* c = static_cast<DevCtx*>(user);
+	Loopback& lp = *c->red.loop;
+	const int me = c->red.rank;
 	double tmp[kRedMax];
 	SQN_HIP_OK(hipStreamSynchronize(stream));
 	for (int done = 0; done < count; done += kRedMax) {            // Fisher products reduce fisher_size scalars
 		const int k = count - done < kRedMax ? count - done : kRedMax;
 		SQN_HIP_OK(hipMemcpy(tmp, buf + done, (size_t) k * sizeof(double), hipMemcpyDeviceToHost));
-		std::memcpy(&g_loop.slots[(size_t) t_loop_rank * kRedMax], tmp, (size_t) k * sizeof(double));
-		loop_barrier();
+		std::memcpy(&lp.slots[(size_t) me * kRedMax], tmp, (size_t) k * sizeof(double));
+		if (!loop_barrier(lp)) { reducer_failed(user, "a shard did not reach the host-side reduction"); return; }
 		for (int j = 0; j < k; j++) {
 			double s = 0;
-			for (int r = 0; r < g_loop.nranks; r++) s += g_loop.slots[(size_t) r * kRedMax + j];
+			for (int r = 0; r < lp.nranks; r++) s += lp.slots[(size_t) r * kRedMax + j];
 			tmp[j] = s;
 		}
-		loop_barrier();             // nobody overwrites a slot before everybody has read it
+		// nobody overwrites a slot before everybody has read it
+		if (!loop_barrier(lp)) { reducer_failed(user, "a shard did not reach the host-side reduction"); return; }
 		SQN_HIP_OK(hipMemcpy(buf + done, tmp, (size_t) k * sizeof(double), hipMemcpyHostToDevice));
 	}
 }
@@ -181,7 +203,17 @@ void at_exit()
 
 }  // namespace
 
-Options& options() { return g_opt; }
+Options& options()
+{
+	static const bool env_read = [] {            // environment defaults, for callers that cannot reach set_option (R, Python)
+		if (const char* e = std::getenv("STOCHQN_HIP_DEVICES")) g_opt.devices = std::atoi(e);
+		if (const char* e = std::getenv("STOCHQN_HIP_VIRTUAL_DEVICES")) g_opt.virtual_devices = std::atoi(e) != 0;
+		if (const char* e = std::getenv("STOCHQN_HIP_DEVICES_MIN_N")) g_opt.devices_min_n = std::atol(e);
+		return true;
+	}();
+	(void) env_read;
+	return g_opt;
+}
 
 bool device_alloc(void** p, size_t bytes)
 {
@@ -451,25 +483,62 @@ void sync(DevCtx* c)
 	if (c->sc.prof) c->prof.collect();
 }
 
+// The reducer a context created by the calling thread gets: the thread's own binding when one was
+// installed (shard workers of the single-process multi-device mode, loop-back test threads), else
+// the process-wide communicator (one process per GPU), else none.
+Reducer current_reducer()
+{
+	if (t_reducer.kind != Reducer::NONE) return t_reducer;
+	Reducer r;
+	if (g_comm.comm) { r.kind = Reducer::RCCL; r.comm = g_comm.comm; r.rank = g_comm.rank; r.nranks = g_comm.nranks; }
+	else if (g_custom.fn) { r.kind = Reducer::CUSTOM; r.rank = g_custom.rank; r.nranks = g_custom.nranks; }
+	return r;
+}
+
+void set_thread_reducer(const Reducer& r) { t_reducer = r; }
+
 int comm_nranks()
 {
-	if (g_comm.comm) return g_comm.nranks;
-	if (g_custom.fn) return g_custom.nranks;
-	return (g_loop.nranks > 1 && t_loop_rank >= 0) ? g_loop.nranks : 1;
+	const Reducer r = current_reducer();
+	return r.kind == Reducer::NONE ? 1 : r.nranks;
 }
 
 void comm_attach(DevCtx* c)
 {
-	const bool loop = g_loop.nranks > 1 && t_loop_rank >= 0;
-	if (!g_comm.comm && !g_custom.fn && !loop) { c->sc.allreduce = nullptr; c->n_global = (double) c->n; return; }
-	c->sc.allreduce = loop ? loopback_hook : (g_custom.fn ? custom_hook : allreduce_hook);
+	c->red = current_reducer();
+	if (c->red.kind == Reducer::NONE || (c->red.kind == Reducer::LOOP && c->red.nranks <= 1)) {
+		c->red = Reducer{};
+		c->sc.allreduce = nullptr;
+		c->n_global = (double) c->n;
+		return;
+	}
+	c->sc.allreduce = c->red.kind == Reducer::LOOP ? loopback_hook : (c->red.kind == Reducer::CUSTOM ? custom_hook : allreduce_hook);
 	// global problem size for the ||dir|| > 1e3*n guard (reference src/stochqn.c:829)
 	double nn = (double) c->n;
 	SQN_HIP_OK(hipMemcpyAsync(c->sc.red[0], &nn, sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
-	c->sc.allreduce(nullptr, c->sc.red[0], 1, c->sc.stream);
+	c->sc.allreduce(c, c->sc.red[0], 1, c->sc.stream);
 	SQN_HIP_OK(hipMemcpyAsync(&nn, c->sc.red[0], sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
 	SQN_HIP_OK(hipStreamSynchronize(c->sc.stream));
 	c->n_global = nn;
+}
+
+// ---- RCCL communicators for the shards of one process (single-process multi-device mode) --------
+bool comm_init_all(int ndev, const int* devices, void** comms_out)
+{
+	if (!load_rccl()) return false;
+	std::vector<ncclComm_t> comms((size_t) ndev);
+	ncclResult_t r = g_comm.CommInitAll(comms.data(), ndev, devices);
+	if (r != ncclSuccess) {
+		std::fprintf(stderr, "stochqn: ncclCommInitAll over %d devices failed: %s\n", ndev, g_comm.GetErrorString ? g_comm.GetErrorString(r) : "?");
+		return false;
+	}
+	for (int i = 0; i < ndev; i++) comms_out[i] = comms[(size_t) i];
+	return true;
+}
+
+void comm_destroy(void* comm)
+{
+	if (comm && g_comm.CommDestroy) g_comm.CommDestroy((ncclComm_t) comm);
 }
 
 }  // namespace sqn
@@ -485,14 +554,27 @@ int stochqn_hip_available(void) { return device_ready() ? 1 : 0; }
 
 void stochqn_hip_invalidate(const void* s_mem)
 {
-	if (DevCtx* c = lookup(s_mem)) { c->rho_ok.assign(c->m, 0); c->gram_ok.assign(c->m, 0); }
+	if (group_invalidate(s_mem)) return;
+	if (!s_mem) return;
+	for (const void* key : {s_mem, raw_key(s_mem)})
+		if (DevCtx* c = lookup(key)) { c->rho_ok.assign(c->m, 0); c->gram_ok.assign(c->m, 0); }
 }
 
-void stochqn_hip_release(const void* s_mem) { release(s_mem); }
-void stochqn_hip_release_all(void) { release_all(); }
+void stochqn_hip_release(const void* s_mem)
+{
+	if (!s_mem || group_release(s_mem)) return;
+	release(s_mem);
+	release(raw_key(s_mem));
+}
+void stochqn_hip_release_all(void) { group_release_all(); release_all(); }
+
+int stochqn_hip_devices_active(const void* s_mem) { return group_shards(s_mem); }
+int stochqn_hip_devices_reducer(const void* s_mem) { return group_reducer_kind(s_mem); }
 
 int stochqn_hip_export(const void* s_mem)
 {
+	int grc = 0;
+	if (group_export(s_mem, &grc)) return grc;
 	DevCtx* c = lookup(s_mem);
 	if (!c) return -1000;
 	View* vs[] = {&c->S, &c->Y, &c->sbak, &c->ybak, &c->gprev, &c->xsum, &c->xprev, &c->H0, &c->G, &c->F};
@@ -504,6 +586,7 @@ int stochqn_hip_export(const void* s_mem)
 int stochqn_hip_set_option(const char* name, double value)
 {
 	if (!name) return -1;
+	(void) options();                            // environment defaults first, explicit settings win
 	if (!std::strcmp(name, "nontemporal")) g_opt.nontemporal = value != 0;
 	else if (!std::strcmp(name, "grid_cap")) {
 		int g = (int) value;
@@ -525,6 +608,11 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "twopass")) g_opt.twopass = value != 0;
 	else if (!std::strcmp(name, "twopass_h0")) g_opt.twopass_h0 = value != 0;
 	else if (!std::strcmp(name, "strict_grad")) g_opt.strict_grad = value != 0;
+	else if (!std::strcmp(name, "devices")) options().devices = value < 0 ? 0 : (int) value;
+	else if (!std::strcmp(name, "virtual_devices")) options().virtual_devices = value != 0;
+	else if (!std::strcmp(name, "devices_min_n")) options().devices_min_n = (long) value;
+	else if (!std::strcmp(name, "verify_cache")) options().verify_cache = value != 0;
+	else if (!std::strcmp(name, "raw_reuse_cache")) options().raw_reuse_cache = value != 0;
 	else if (!std::strcmp(name, "fail_alloc_after")) g_fail_alloc_after.store((long) value);
 	else if (!std::strcmp(name, "inject_device_fault")) g_inject_device_fault.store(value != 0);
 	else return -1;
@@ -558,6 +646,30 @@ int stochqn_hip_profile_get(int id, long long* launches, double* total_ms)
 	if (launches) *launches = l;
 	if (total_ms) *total_ms = ms;
 	return 0;
+}
+
+// ---- synthetic inputs (measurement helpers; device pointers, enqueued on the null stream) ----------
+int stochqn_hip_synth_uniform(real_t* out, size_t count, unsigned long long first_index, unsigned long long seed,
+                              unsigned long long stream, unsigned long long t, double a, double b)
+{
+	if (!device_ready() || !out || !is_device_pointer(out)) return -1000;
+	if (count) launch_synth_uniform(nullptr, out, count, first_index, synth_key(seed, stream, t), a, b);
+	return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+int stochqn_hip_synth_noisy_grad(real_t* grad, const real_t* d, const real_t* x, size_t count, unsigned long long first_index,
+                                 unsigned long long seed, unsigned long long stream, unsigned long long t, double amp)
+{
+	if (!device_ready() || !grad || !d || !x || !is_device_pointer(grad) || !is_device_pointer(d) || !is_device_pointer(x)) return -1000;
+	if (count) launch_synth_grad(nullptr, grad, d, x, count, first_index, synth_key(seed, stream, t), amp);
+	return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+int stochqn_hip_synth_batch_row(real_t* row, const real_t* d, size_t count, unsigned long long first_index, unsigned k, unsigned bs)
+{
+	if (!device_ready() || !row || !d || bs == 0 || !is_device_pointer(row) || !is_device_pointer(d)) return -1000;
+	if (count) launch_synth_batch_row(nullptr, row, d, count, first_index, k, bs);
+	return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
 int stochqn_hip_comm_unique_id(void* out128)
@@ -604,6 +716,7 @@ int stochqn_hip_loopback_init(int nranks)
 	std::lock_guard<std::mutex> lk(g_loop.mu);
 	g_loop.nranks = nranks;
 	g_loop.arrived = 0;
+	g_loop.broken = false;
 	g_loop.slots.assign((size_t) nranks * kRedMax, 0.0);
 	return 0;
 }
@@ -611,7 +724,9 @@ int stochqn_hip_loopback_init(int nranks)
 int stochqn_hip_loopback_join(int rank)
 {
 	if (rank < 0 || rank >= g_loop.nranks) return -1;
-	t_loop_rank = rank;
+	Reducer r;
+	r.kind = Reducer::LOOP; r.loop = &g_loop; r.rank = rank; r.nranks = g_loop.nranks;
+	set_thread_reducer(r);
 	return 0;
 }
 
@@ -619,7 +734,7 @@ void stochqn_hip_loopback_finalize(void)
 {
 	release_all();
 	g_loop.nranks = 0;
-	t_loop_rank = -1;
+	set_thread_reducer(Reducer{});
 }
 
 void stochqn_hip_comm_finalize(void)

@@ -4,7 +4,9 @@
 #include "sqn_device.hpp"
 #include "stochqn.h"
 
+#include <condition_variable>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 
 namespace sqn {
@@ -34,11 +36,40 @@ struct Options {
 	int h0_per_cu = 0;
 	bool twopass_h0 = true;      // adaQN (diagonal H0) in the two-pass form as well
 	bool strict_grad = true;
+	// single-process multi-device mode (group.cpp): shard n over `devices` GPUs of this process
+	int devices = 0;             // 0 / 1 = off; also STOCHQN_HIP_DEVICES in the environment
+	bool virtual_devices = false;   // shards may share a physical device (host-side reducer): rehearsal on one GPU
+	long devices_min_n = 1 << 20;   // problems smaller than this stay on one device (SURVEY.md 8e "no-shard fallback")
+	bool raw_reuse_cache = false;   // isolated entry points keep their cached s'y / Gram entries between calls (caller vouches for S, Y)
+	bool verify_cache = false;   // debugging aid for device callers: recompute cached dots every call and compare
 };
 int default_grid_cap();
 Options& options();
 
+// Host-side rendezvous reducer: P shards of one problem driven by P host threads of this process,
+// summed in rank order.  Used where RCCL cannot serve: shards that share a physical device (tests,
+// the "virtual_devices" rehearsal of the single-process multi-device mode).
+struct Loopback {
+	int nranks = 0;
+	std::mutex mu;
+	std::condition_variable cv;
+	int arrived = 0;
+	long generation = 0;
+	bool broken = false;            // a shard failed to show up: every later reduction fails immediately
+	int patience_s = 120;           // how long a shard waits for the others before giving up
+	std::vector<double> slots;      // [nranks][kRedMax]
+};
+
+// What a context sums its partial dot products through (fixed when the context is created).
+struct Reducer {
+	enum Kind { NONE = 0, RCCL, CUSTOM, LOOP } kind = NONE;
+	void* comm = nullptr;           // ncclComm_t (RCCL)
+	Loopback* loop = nullptr;       // LOOP
+	int rank = 0, nranks = 1;
+};
+
 struct DevCtx {
+	Reducer red;
 	const void* key = nullptr;
 	int kind = 0;
 	int n = 0;
@@ -82,6 +113,8 @@ bool is_device_pointer(const void* p);
 // Find or create the context of a workspace.  `fresh` tells the caller whether it was created now.
 DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* fresh);
 DevCtx* lookup(const void* key);
+// registry key of the context behind the isolated entry points (stochqn_hip_two_loop / _take_step) for the arrays at `s_mem`
+inline const void* raw_key(const void* s_mem) { return static_cast<const char*>(s_mem) + 1; }
 // remember the caller-visible state on return; true if the context saw a HIP error during the call
 bool note_state(const void* key, size_t niter, int section);
 void release(const void* key);
@@ -109,6 +142,10 @@ struct ApiRange {
 // multi-GPU
 int comm_nranks();
 void comm_attach(DevCtx* c);                           // install the all-reduce hook, compute n_global
+Reducer current_reducer();                             // the calling thread's binding, else the process-wide communicator
+void set_thread_reducer(const Reducer& r);             // contexts created by this thread from now on reduce through `r`
+bool comm_init_all(int ndev, const int* devices, void** comms_out);   // ncclCommInitAll (one process, ndev devices)
+void comm_destroy(void* comm);
 
 #define SQN_HIP_OK(expr)                                                                             \
 	do {                                                                                             \

@@ -234,6 +234,11 @@ void launch_commit(const Scratch& sc, Partials in, double* sy_dst, double* yy_ds
 // totals of (s'y, s's, y'y), accept / reject against min_curvature, commit of s'y and y'y when accepted;
 // out[0..3] = s'y, s's, y'y, rejected flag
 void launch_verdict(const Scratch& sc, Partials in, double min_curvature, double* sy_dst, double* yy_dst, double* out);
+// ---- synthetic inputs for measurement (counter-based, shard-invariant) ------------
+uint64_t synth_key(uint64_t seed, uint64_t stream, uint64_t t);
+void launch_synth_uniform(hipStream_t stream, real* out, size_t count, uint64_t first, uint64_t key, double a, double b);
+void launch_synth_grad(hipStream_t stream, real* g, const real* d, const real* x, size_t count, uint64_t first, uint64_t key, double amp);
+void launch_synth_batch_row(hipStream_t stream, real* row, const real* d, size_t count, uint64_t first, uint32_t k, uint32_t bs);
 // tiny helpers
 void launch_scale(const Scratch& sc, size_t n, real* x, double a);
 

@@ -1,0 +1,216 @@
+"""Single-process multi-device mode (stochqn_amd/csrc/group.cpp) on ONE GPU: option "devices" = P with
+"virtual_devices" = 1 puts P shards -- each with its own host thread, device context and stream -- on the
+one physical device and sums their partial dot products through the host-side rendezvous reducer (RCCL
+refuses two ranks on one device).  Everything else is the code an 8-GPU node runs: the unchanged reference
+ABI called by ONE host process, n cut into contiguous slices, the fan-out of every run_* call, the
+scatter of x / grad / hess_vec and the gather of x / direction / *req / *req_vec, identical decisions on
+all shards.  Bar: the unsharded CPU oracle, integers exactly, vectors to 1e-10."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from harness import OPTIMIZERS, NoisyQuadratic, compare_traces, rel_err, run_trace
+from test_gpu_parity import CONFIGS, FREE_RUN_TOL, TOL
+from test_oracle_known_answers import GOLD, host_view, run_c_rosen
+
+pytestmark = pytest.mark.gpu
+
+LOOP, RCCL = 3, 1           # Reducer::Kind of runtime.hpp
+
+
+def _lib():
+    import stochqn_amd
+    lib = stochqn_amd.cdll()
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    lib.stochqn_hip_devices_active.argtypes = [C.c_void_p]
+    lib.stochqn_hip_devices_reducer.argtypes = [C.c_void_p]
+    lib.stochqn_hip_export.argtypes = [C.c_void_p]
+    lib.stochqn_hip_release.argtypes = [C.c_void_p]
+    return lib
+
+
+@pytest.fixture(params=[2, 3])
+def devices(request, hip_backend):
+    lib = _lib()
+    assert lib.stochqn_hip_set_option(b"virtual_devices", 1.0) == 0
+    assert lib.stochqn_hip_set_option(b"devices_min_n", 1.0) == 0
+    assert lib.stochqn_hip_set_option(b"devices", float(request.param)) == 0
+    yield request.param
+    lib.stochqn_hip_release_all()
+    lib.stochqn_hip_set_option(b"devices", 0.0)
+    lib.stochqn_hip_set_option(b"virtual_devices", 0.0)
+    lib.stochqn_hip_set_option(b"devices_min_n", float(1 << 20))
+
+
+NAMES = ["olbfgs_default", "olbfgs_nocurv_hess_init", "olbfgs_nan_grad", "olbfgs_reject_all", "sqn_hessvec", "sqn_graddiff",
+         "sqn_reject", "sqn_nan", "sqn_nonan_check", "adaqn_fisher_rms", "adaqn_graddiff", "adaqn_func_increased", "adaqn_nan",
+         "adaqn_fisher500", "sqn_ring20", "sqn_ring30"]
+
+
+@pytest.mark.parametrize("n", [3001, 64])
+@pytest.mark.parametrize("name", NAMES)
+def test_host_caller_on_P_devices_equals_unsharded_oracle(name, n, devices, hip_backend, oracle_backend):
+    """Profile B (the R / Cython protocol): numpy arrays, structs rebuilt per call, ONE process.  The
+    trace -- every task, info, counter, which array *req aliases, x, *req and *req_vec after every call --
+    must equal the oracle's on the unsharded problem."""
+    lib = _lib()
+    cfg = [c for c in CONFIGS if c[0] == name][0]
+    _, optname, kw, step, calls, pkw = cfg
+    P = NoisyQuadratic(n, seed=7, **pkw)
+    want = run_trace(OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw), P, P.x0(), step, calls)
+    opt = OPTIMIZERS[optname](backend=hip_backend, space="host", **kw)
+    x = P.x0()
+    got = run_trace(opt, P, x, step, calls)
+    key = C.c_void_p(opt.BFGS_mem.s_mem.ctypes.data)
+    assert lib.stochqn_hip_devices_active(key) == devices
+    assert lib.stochqn_hip_devices_reducer(key) == LOOP
+    compare_traces(got, want, FREE_RUN_TOL.get(name, TOL))
+    opt.release()
+
+
+def test_c_rosen_protocol_on_P_devices(devices, hip_backend):
+    """Profile A: initialize_SQN / run_SQN / dealloc_SQN exactly as reference example/c_rosen.c:100-125 does,
+    the workspace sharded over the devices (n = 4: shards of 1-2 variables), *req and *req_vec read on the host."""
+    k = GOLD["c_rosen"]
+    out = run_c_rosen(hip_backend, np.array(k["x0"]), host_view)
+    for key in ("f_initial", "f_it10", "f_it200", "f_final"):
+        assert out[key].strip() == k[key], (key, out[key])
+    assert out["x_final"] == k["x_final"]
+
+
+@pytest.mark.parametrize("which", ["oLBFGS", "SQN-hessvec", "SQN-graddiff", "adaQN-fisher", "adaQN-graddiff"])
+def test_library_owned_sharded_workspaces(which, devices, hip_backend, oracle_backend):
+    """initialize_* in group mode hands out a workspace whose arrays exist only as device slices; a plain
+    host caller (malloc'ed x / grad, reads *req on the host) must see the oracle's run."""
+    lib = _lib()
+    n = 20011
+    P = NoisyQuadratic(n, seed=4, f_spike_calls=range(30, 36))
+
+    def drive(be):
+        x, g, hv = P.x0(), np.zeros(n), np.zeros(n)
+        req, rv, task, info = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
+        if which == "oLBFGS":
+            w = be.initialize_oLBFGS(n, 4, 0.0, 0.0, 1e-4, 1, 1)
+            run = lambda f: be.run_oLBFGS(0.1, x.ctypes.data, g.ctypes.data, C.byref(req), C.byref(task), w, C.byref(info))
+            free = be.dealloc_oLBFGS
+        elif which.startswith("SQN"):
+            w = be.initialize_SQN(n, 3, 4, 1e-4, int(which.endswith("graddiff")), 0.0, 1, 1)
+            run = lambda f: be.run_SQN(0.1, x.ctypes.data, g.ctypes.data, hv.ctypes.data, C.byref(req), C.byref(rv), C.byref(task), w, C.byref(info))
+            free = be.dealloc_SQN
+        else:
+            w = be.initialize_adaQN(n, 3, 6, 4, 1.01, 1e-4, 1e-4, 0.9, int(which.endswith("graddiff")), 0.0, 1, 1)
+            run = lambda f: be.run_adaQN(0.05, x.ctypes.data, f, g.ctypes.data, C.byref(req), C.byref(task), w, C.byref(info))
+            free = be.dealloc_adaQN
+        assert bool(w), "initialize returned NULL"
+        if be is hip_backend:
+            assert lib.stochqn_hip_devices_active(C.c_void_p(w.contents.bfgs_memory.contents.s_mem)) == devices
+        out, f, last = [], 0.0, 0
+        for call in range(60):
+            rc = run(f)
+            assert rc in (0, 1), rc
+            at = host_view(req.value, n).copy()
+            rec = [rc, task.value, info.value, w.contents.niter, w.contents.section,
+                   w.contents.bfgs_memory.contents.mem_used, w.contents.bfgs_memory.contents.mem_st_ix, x.copy(), at]
+            if task.value in (101, 102, 103):
+                if task.value == 101:
+                    last = call
+                g[:] = P.grad(at, last if task.value == 102 else call)
+            elif task.value == 104:
+                v = host_view(rv.value, n).copy()
+                rec.append(v)
+                hv[:] = P.hess_vec(at, v)
+            elif task.value == 105:
+                f = P.f(at, call)
+            out.append(rec)
+        free(w)
+        return out
+
+    want, got = drive(oracle_backend), drive(hip_backend)
+    for i, (g_, w_) in enumerate(zip(got, want)):
+        assert g_[:7] == w_[:7], (which, i, g_[:7], w_[:7])
+        for a, b in zip(g_[7:], w_[7:]):
+            assert rel_err(a, b) <= TOL, (which, i, rel_err(a, b))
+
+
+@pytest.mark.parametrize("optname,kw", [
+    ("SQN", dict(mem_size=3, bfgs_upd_freq=4)),
+    ("oLBFGS", dict(mem_size=4)),
+    ("adaQN", dict(mem_size=3, fisher_size=6, bfgs_upd_freq=4, rmsprop_weight=0.9)),
+])
+def test_export_and_resume_on_P_devices(optname, kw, devices, hip_backend, oracle_backend):
+    """Checkpoint of a sharded host caller: export gathers every shard's slices back into the caller's host
+    arrays (strided rows of S, Y, F); after the shards are dropped the next call re-imports them."""
+    lib = _lib()
+    n = 777
+    P = NoisyQuadratic(n, seed=5)
+    ref = OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw)
+    opt = OPTIMIZERS[optname](backend=hip_backend, space="host", **kw)
+    x_ref, x = P.x0(), P.x0()
+    compare_traces(run_trace(opt, P, x, 0.05, 41), run_trace(ref, P, x_ref, 0.05, 41), TOL)
+    key = C.c_void_p(opt.BFGS_mem.s_mem.ctypes.data)
+    assert lib.stochqn_hip_devices_active(key) == devices
+    assert lib.stochqn_hip_export(key) == 0
+    for name in ("s_mem", "y_mem"):
+        assert rel_err(getattr(opt.BFGS_mem, name), getattr(ref.BFGS_mem, name)) <= TOL, name
+    for name in ("x_sum", "x_avg_prev", "grad_sum_sq", "grad_prev"):
+        if hasattr(ref, name) and getattr(ref, name).shape[0] == n:
+            assert rel_err(getattr(opt, name), getattr(ref, name)) <= TOL, name
+    if hasattr(ref, "Fisher_mem"):
+        assert rel_err(opt.Fisher_mem.F, ref.Fisher_mem.F) <= TOL
+    lib.stochqn_hip_release(key)
+    assert lib.stochqn_hip_devices_active(key) == 0
+    P2 = NoisyQuadratic(n, seed=6)
+    compare_traces(run_trace(opt, P2, x, 0.05, 40), run_trace(ref, P2, x_ref, 0.05, 40), TOL)
+    assert lib.stochqn_hip_devices_active(key) == devices
+
+
+def test_device_arrays_and_small_problems_stay_on_one_device(hip_backend, oracle_backend):
+    """The mode only takes workspaces it can shard: a caller that keeps its arrays in one device's memory
+    (torch tensors) and problems below devices_min_n run on the single-device path, unchanged."""
+    import torch
+    lib = _lib()
+    assert lib.stochqn_hip_set_option(b"virtual_devices", 1.0) == 0
+    assert lib.stochqn_hip_set_option(b"devices", 3.0) == 0
+    try:
+        cfg = [c for c in CONFIGS if c[0] == "sqn_hessvec"][0]
+        _, optname, kw, step, calls, pkw = cfg
+        P = NoisyQuadratic(1000, seed=7)
+        want = run_trace(OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw), P, P.x0(), step, calls)
+        # below devices_min_n (default 2^20): host arrays, one device
+        opt = OPTIMIZERS[optname](backend=hip_backend, space="host", **kw)
+        compare_traces(run_trace(opt, P, P.x0(), step, calls), want, TOL)
+        assert lib.stochqn_hip_devices_active(C.c_void_p(opt.BFGS_mem.s_mem.ctypes.data)) == 0
+        # device arrays: one device whatever n
+        assert lib.stochqn_hip_set_option(b"devices_min_n", 1.0) == 0
+        opt = OPTIMIZERS[optname](backend=hip_backend, space="device", **kw)
+        x = torch.as_tensor(P.x0(), device="cuda")
+        compare_traces(run_trace(opt, P, x, step, calls), want, TOL)
+        assert lib.stochqn_hip_devices_active(C.c_void_p(opt.BFGS_mem.s_mem.data_ptr())) == 0
+    finally:
+        lib.stochqn_hip_release_all()
+        lib.stochqn_hip_set_option(b"devices", 0.0)
+        lib.stochqn_hip_set_option(b"virtual_devices", 0.0)
+        lib.stochqn_hip_set_option(b"devices_min_n", float(1 << 20))
+
+
+def test_more_devices_than_gpus_without_virtual_devices_falls_back(hip_backend, oracle_backend, capfd):
+    """devices = 4 on a one-GPU box without the rehearsal switch: the library says so and runs on what exists."""
+    import torch
+    lib = _lib()
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a one-GPU box")
+    assert lib.stochqn_hip_set_option(b"devices_min_n", 1.0) == 0
+    assert lib.stochqn_hip_set_option(b"devices", 4.0) == 0
+    try:
+        P = NoisyQuadratic(500, seed=3)
+        kw = dict(mem_size=3, bfgs_upd_freq=3)
+        want = run_trace(OPTIMIZERS["SQN"](backend=oracle_backend, space="host", **kw), P, P.x0(), 0.1, 30)
+        opt = OPTIMIZERS["SQN"](backend=hip_backend, space="host", **kw)
+        compare_traces(run_trace(opt, P, P.x0(), 0.1, 30), want, TOL)
+        assert lib.stochqn_hip_devices_active(C.c_void_p(opt.BFGS_mem.s_mem.ctypes.data)) == 0
+        assert "only 1 device(s) are visible" in capfd.readouterr().err
+    finally:
+        lib.stochqn_hip_release_all()
+        lib.stochqn_hip_set_option(b"devices", 0.0)
+        lib.stochqn_hip_set_option(b"devices_min_n", float(1 << 20))
