@@ -291,6 +291,9 @@ Group* create_group(const Shape& sp, int P, bool owned, bool resumed)
 		}
 		if (!ok) { destroy_group(g.release()); return nullptr; }
 	}
+	if (std::getenv("STOCHQN_HIP_VERBOSE"))
+		std::fprintf(stderr, "stochqn: workspace with n = %d sharded over %d device shards (%s workspace, reducer: %s)\n", sp.n, P,
+		             owned ? "library-owned" : "caller-owned host", g->virt ? "host-side rendezvous (virtual devices)" : "RCCL");
 	for (auto& s : g->sh) {
 		s->rho.assign(m, 0); s->alpha.assign(m, 0); s->fy.assign(fsz ? fsz : 1, 0);
 		s->b.s_mem = s->S; s->b.y_mem = s->Y; s->b.s_bak = s->sbak; s->b.y_bak = s->ybak;

@@ -77,3 +77,19 @@ def test_compiled_callers_match_oracle_on_gpu(tmp_path, source, cxx):
     want = subprocess.check_output([build(tmp_path, os.path.join(SRC, source), cxx, against_oracle=True)]).decode()
     got = subprocess.check_output([build(tmp_path, os.path.join(SRC, source), cxx, against_oracle=False)]).decode()
     compare_outputs(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [2, 3])
+@pytest.mark.parametrize("source,cxx", [("sqn_host_caller.c", False), ("raii_callers.cpp", True)])
+def test_compiled_callers_on_several_device_shards(tmp_path, source, cxx, shards):
+    """The same unmodified programs, one host process each, with STOCHQN_HIP_DEVICES in the environment: the
+    library shards their workspaces (rehearsed on the one GPU of the box: virtual devices) and they must
+    print the oracle's numbers."""
+    want = subprocess.check_output([build(tmp_path, os.path.join(SRC, source), cxx, against_oracle=True)]).decode()
+    env = dict(os.environ, STOCHQN_HIP_DEVICES=str(shards), STOCHQN_HIP_VIRTUAL_DEVICES="1", STOCHQN_HIP_DEVICES_MIN_N="1",
+               STOCHQN_HIP_VERBOSE="1")
+    run = subprocess.run([build(tmp_path, os.path.join(SRC, source), cxx, against_oracle=False)], capture_output=True, env=env, timeout=300)
+    assert run.returncode == 0, run.stderr.decode()[-2000:]
+    assert ("sharded over %d device shards (library-owned" % shards) in run.stderr.decode()
+    compare_outputs(run.stdout.decode(), want)

@@ -201,10 +201,26 @@ def hip_two_loop(lib, g, H0, h0, Y, S, n, m, used, st):
     return rho, alpha
 
 
+TWO_LOOP_SHAPES = [(1, 1, 0), (5, 5, 3), (5, 2, 0), (5, 3, 4), (20, 20, 7), (20, 1, 19)]
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 4096, 1000003])
-@pytest.mark.parametrize("m,used,st", [(1, 1, 0), (5, 5, 3), (5, 2, 0), (5, 3, 4), (20, 20, 7), (20, 1, 19)])
-@pytest.mark.parametrize("mode", ["gamma", "h0", "H0"])
+@pytest.mark.parametrize("m,used,st", TWO_LOOP_SHAPES)
+@pytest.mark.parametrize("mode", ["gamma", "h0"])
 def test_two_loop_matches_oracle(n, m, used, st, mode, form, hip_backend):
+    """Scalar H0 (gamma from the newest pair, or h0 > 0): both forms of the recursion."""
+    check_two_loop(n, m, used, st, mode)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4096, 1000003])
+@pytest.mark.parametrize("m,used,st", TWO_LOOP_SHAPES)
+def test_two_loop_with_a_given_diagonal_matches_oracle(n, m, used, st, hip_backend):
+    """A caller-supplied diagonal H0 always runs as the chain of sweeps (stochqn_hip.h): one form to test.
+    The two-pass kernels with a diagonal H0 are adaQN's, reached through stochqn_hip_take_step (below)."""
+    check_two_loop(n, m, used, st, "H0")
+
+
+def check_two_loop(n, m, used, st, mode):
     import stochqn_amd
     from oracle import oracle
     torch = torch_cuda()
@@ -251,6 +267,134 @@ def test_two_loop_host_pointers(hip_backend):
 
 
 # ---------------------------------------------------------------------------------------------
+# take_step on its own (reference src/stochqn.c:802-840): the entry that reaches adaQN's diagonal-H0
+# kernels of the two-pass form (k_gram_h0 / k_coef_h0 / k_combine<H0V>) with a state of the caller's choice
+# ---------------------------------------------------------------------------------------------
+def take_step_args(lib):
+    from stochqn_amd import _abi
+    lib.stochqn_hip_take_step.restype = C.c_int
+    lib.stochqn_hip_take_step.argtypes = [C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_abi.bfgs_mem), C.c_double,
+                                          C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_int)]
+    return _abi
+
+
+def oracle_take_step(step, x, g, S, Y, m, used, st_ix, w, H0, h0, G, eps, check_nan):
+    """In place on numpy arrays; returns (info, mem_used, rho, alpha)."""
+    from oracle import oracle
+    from stochqn_amd import _abi
+    n = x.shape[0]
+    rho, alpha = np.zeros(m), np.zeros(m)
+    b = _abi.bfgs_mem(S.ctypes.data, Y.ctypes.data, rho.ctypes.data, alpha.ctypes.data, None, None, m, used, st_ix, 1, 0.0, 0.0)
+    info = C.c_int(200)
+    oracle.cdll().oracle_take_step(step, n, x.ctypes.data, g.ctypes.data, C.byref(b), w, None if H0 is None else H0.ctypes.data,
+                                   h0, None if G is None else G.ctypes.data, eps, check_nan, C.byref(info))
+    return info.value, b.mem_used, rho, alpha
+
+
+def hip_take_step(lib, step, x, g, S, Y, m, used, st_ix, w, H0, h0, G, eps, check_nan):
+    """On torch device tensors; returns (info, mem_used, rho, alpha)."""
+    _abi = take_step_args(lib)
+    rho, alpha = np.zeros(m), np.zeros(m)
+    b = _abi.bfgs_mem(S.data_ptr(), Y.data_ptr(), rho.ctypes.data, alpha.ctypes.data, None, None, m, used, st_ix, 1, 0.0, 0.0)
+    info = C.c_int(200)
+    rc = lib.stochqn_hip_take_step(step, x.shape[0], x.data_ptr(), g.data_ptr(), C.byref(b), w, None if H0 is None else H0.data_ptr(),
+                                   h0, None if G is None else G.data_ptr(), eps, check_nan, C.byref(info))
+    assert rc == 0
+    return info.value, b.mem_used, rho, alpha
+
+
+@pytest.mark.parametrize("n", [1, 65, 4096, 1000003])
+@pytest.mark.parametrize("m,used,st_ix", [(5, 5, 3), (5, 2, 2), (20, 20, 7), (20, 20, 0), (3, 0, 0), (1, 1, 0)])
+@pytest.mark.parametrize("mode", ["rmsprop", "adagrad", "gamma", "h0"])
+def test_take_step_matches_oracle(n, m, used, st_ix, mode, form, hip_backend):
+    """Direction, x, G, H0, rho, alpha and the verdict of one isolated step; `form` = twopass really selects
+    k_gram_h0 / k_coef_h0 / k_combine<H0V> for the two diagonal modes (and rows-dot / coef / combine for the
+    scalar ones), `sweeps` the chain of dependent sweeps."""
+    import stochqn_amd
+    torch = torch_cuda()
+    lib = stochqn_amd.cdll()
+    rng = np.random.default_rng(n * 17 + m * 5 + used + len(mode))
+    S, Y = make_pairs(rng, n, m)
+    g = rng.random(n) - 0.5
+    x = 1.0 + rng.random(n)
+    diag = mode in ("rmsprop", "adagrad")
+    G = (0.1 + rng.random(n)) if diag else None
+    H0 = np.zeros(n) if diag else None
+    w = 0.9 if mode == "rmsprop" else 0.0
+    h0 = 0.37 if mode == "h0" else 0.0
+    dev = lambda a: None if a is None else torch.as_tensor(a, device="cuda")
+    dx, dg, dS, dY, dG, dH0 = dev(x), dev(g), dev(S), dev(Y), dev(G), dev(H0)
+    want = oracle_take_step(0.05, x, g, S, Y, m, used, st_ix, w, H0, h0, G, 1e-4, 1)
+    got = hip_take_step(lib, 0.05, dx, dg, dS, dY, m, used, st_ix, w, dH0, h0, dG, 1e-4, 1)
+    lib.stochqn_hip_release(C.c_void_p(dS.data_ptr()))
+    assert got[:2] == want[:2]
+    assert want[0] == 200
+    for name, a, b in (("x", dx, x), ("direction", dg, g), ("G", dG, G), ("H0", dH0, H0 if used > 0 else None)):
+        if b is not None:
+            assert rel_err(a.cpu().numpy(), b) <= TOL, (name, rel_err(a.cpu().numpy(), b))
+    if used > 0:
+        assert np.allclose(got[2][:used], want[2][:used], rtol=TOL, atol=0)
+        assert np.allclose(got[3][:used], want[3][:used], rtol=1e-9, atol=1e-13 * np.abs(want[3][:used]).max())
+
+
+def test_take_step_guard_rejects_like_the_oracle(form, hip_backend):
+    """A non-finite gradient entry: x untouched, memory flushed, search_direction_was_nan -- in both forms."""
+    import stochqn_amd
+    torch = torch_cuda()
+    lib = stochqn_amd.cdll()
+    n, m = 5000, 4
+    rng = np.random.default_rng(3)
+    S, Y = make_pairs(rng, n, m)
+    g = rng.random(n) - 0.5
+    g[n // 3] = np.inf
+    x = 1.0 + rng.random(n)
+    G, H0 = 0.1 + rng.random(n), np.zeros(n)
+    dx, dg, dS, dY, dG, dH0 = (torch.as_tensor(a, device="cuda") for a in (x, g, S, Y, G, H0))
+    want = oracle_take_step(0.05, x.copy(), g, S, Y, m, m, 1, 0.9, H0, 0.0, G, 1e-4, 1)
+    got = hip_take_step(lib, 0.05, dx, dg, dS, dY, m, m, 1, 0.9, dH0, 0.0, dG, 1e-4, 1)
+    lib.stochqn_hip_release(C.c_void_p(dS.data_ptr()))
+    assert got[:2] == want[:2] == (203, 0)
+    assert np.array_equal(dx.cpu().numpy(), x)
+
+
+def test_adaqn_step_matches_the_oracle_at_full_size(hip_backend):
+    """adaQN's step at the headline shape, n = 1e8, m = 20, ring full and wrapped, RMSProp diagonal: direction,
+    x, G and H0 to 1e-10 against the oracle, for the default two-pass kernels (k_gram_h0 36 GB, k_coef_h0,
+    k_combine<H0V>) and for the sweep form.  (BASELINE config 4's per-step path; the oracle needs 32 GB of host
+    memory and a few seconds per call.)"""
+    import stochqn_amd
+    torch = torch_cuda()
+    lib = stochqn_amd.cdll()
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    n, m, st_ix = 100_000_000, 20, 3
+    d, S, Y, gen = device_pairs(torch, n, m, 20240611)
+    g = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) - 0.5
+    x = 1.0 + torch.rand(n, dtype=torch.float64, device="cuda", generator=gen)
+    G = 0.05 + 0.1 * torch.rand(n, dtype=torch.float64, device="cuda", generator=gen)
+    S_h, Y_h = S.cpu().numpy(), Y.cpu().numpy()
+    x_w, g_w, G_w, H0_w = x.cpu().numpy(), g.cpu().numpy(), G.cpu().numpy(), np.zeros(n)
+    want = oracle_take_step(0.01, x_w, g_w, S_h, Y_h, m, m, st_ix, 0.9, H0_w, 0.0, G_w, 1e-4, 1)
+    del S_h, Y_h
+    try:
+        for twopass in (1.0, 0.0):
+            lib.stochqn_hip_set_option(b"twopass", twopass)
+            lib.stochqn_hip_set_option(b"twopass_h0", twopass)
+            xq, gq, Gq, H0q = x.clone(), g.clone(), G.clone(), torch.zeros_like(g)
+            got = hip_take_step(lib, 0.01, xq, gq, S, Y, m, m, st_ix, 0.9, H0q, 0.0, Gq, 1e-4, 1)
+            assert got[:2] == want[:2] == (200, m)
+            for name, a, b in (("direction", gq, g_w), ("x", xq, x_w), ("G", Gq, G_w), ("H0", H0q, H0_w)):
+                e = rel_err(a.cpu().numpy(), b)
+                assert e <= TOL, (name, twopass, e)
+            assert np.allclose(got[2], want[2], rtol=TOL, atol=0)
+            assert np.allclose(got[3], want[3], rtol=1e-9, atol=1e-13 * np.abs(want[3]).max())
+            del xq, gq, Gq, H0q
+    finally:
+        lib.stochqn_hip_set_option(b"twopass", 1.0)
+        lib.stochqn_hip_set_option(b"twopass_h0", 1.0)
+        lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))
+
+
+# ---------------------------------------------------------------------------------------------
 # empirical Fisher product (reference src/stochqn.c:936-952)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 65, 4096, 100001])
@@ -292,6 +436,58 @@ def test_fisher_product_matches_the_oracle_at_full_size(hip_backend):
     t_w, y_w = oracle.fisher_product(dF.cpu().numpy(), fu, ds.cpu().numpy())
     assert rel_err(t, t_w) <= TOL
     assert rel_err(dy.cpu().numpy(), y_w) <= TOL
+
+
+def _chunked_fisher_reference(torch, F, fu, n, s, chunk=4_000_000):
+    """t = F s and y = F't / fu with plain torch fp64 matrix-vector products over column chunks (an independent
+    implementation: rocBLAS gemv, other summation order), F = [fu][n] row-major on the device."""
+    Fm = F.view(-1, n)[:fu]
+    t = torch.zeros(fu, dtype=torch.float64, device=F.device)
+    for a in range(0, n, chunk):
+        t += Fm[:, a:a + chunk] @ s[a:a + chunk]
+    y = torch.empty(n, dtype=torch.float64, device=F.device)
+    for a in range(0, n, chunk):
+        y[a:a + chunk] = (Fm[:, a:a + chunk].t() @ t) / fu
+    return t, y
+
+
+def test_adaqn_at_the_c4_shape_builds_its_pairs_from_all_128_fisher_rows(hip_backend):
+    """BASELINE config 4 as stated: adaQN, n = 1e8, m = 20, fisher_size = 128 (102.4 GB ring), RMSProp H0, L = 20,
+    min_curvature = 1e-4.  141 iterations fill the Fisher ring; the pair built at iteration 140 must be
+    y = F'(F s)/128 over ALL 128 rows -- checked on the device against chunked torch fp64 products -- and satisfy
+    s'y = |F s|^2 / 128.  (The oracle would need the 102 GB ring on the host; the per-step kernels at this size
+    are held to the oracle by test_adaqn_step_matches_the_oracle_at_full_size, the product at 32 rows by
+    test_fisher_product_matches_the_oracle_at_full_size.)"""
+    torch = torch_cuda()
+    n, m, f, L = 100_000_000, 20, 128, 20
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    d = 0.5 + torch.rand(n, dtype=torch.float64, device="cuda", generator=gen)
+    dn = [d * (1 + 0.01 * (2 * torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) - 1)) for _ in range(3)]
+    x = 1 + torch.rand(n, dtype=torch.float64, device="cuda", generator=gen)
+    opt = OPTIMIZERS["adaQN"](backend=hip_backend, space="device", mem_size=m, fisher_size=f, bfgs_upd_freq=L, max_incr=None,
+                              min_curvature=1e-4, rmsprop_weight=0.9, scal_reg=1e-4)
+    t, infos = 0, set()
+    while (opt.niter if opt.initialized else 0) < 141:
+        r = opt.run_optimizer(x, 0.01)
+        infos.add(r["info"]["iteration_info"])
+        assert r["task"] == "calc_grad"
+        torch.mul(dn[t % 3], r["requested_on"], out=opt.gradient)
+        t += 1
+        if opt.niter == 140 and opt.section == 1 and opt.Fisher_mem.mem_used == f:
+            break                                               # right after the call that built the pair of iteration 140
+    assert infos == {"no_problems_encountered"}
+    assert opt.Fisher_mem.mem_used == f and opt.BFGS_mem.mem_used == 6          # pairs at 40, 60, ..., 140
+    row = (opt.BFGS_mem.mem_st_ix - 1) % m
+    s = opt.BFGS_mem.s_mem[row * n:(row + 1) * n]
+    y = opt.BFGS_mem.y_mem[row * n:(row + 1) * n]
+    t_ref, y_ref = _chunked_fisher_reference(torch, opt.Fisher_mem.F, f, n, s)
+    err = float(torch.linalg.norm(y - y_ref) / torch.linalg.norm(y_ref))
+    assert err <= TOL, err
+    assert rel_err(opt.Fisher_mem.buffer_y, t_ref.cpu().numpy()) <= TOL
+    sy, tt = float(torch.dot(s, y)), float(torch.dot(t_ref, t_ref)) / f
+    assert abs(sy - tt) <= 1e-9 * abs(tt), (sy, tt)
+    assert float(torch.linalg.norm(s)) > 0
+    opt.release()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -345,7 +541,8 @@ def test_two_loop_properties_at_baseline_size(n, m, form, hip_backend):
 def test_two_loop_matches_the_oracle_at_full_size(hip_backend):
     """The headline shape itself against the oracle: n = 1e8, m = 20, ring full and wrapped, fp64.  The oracle
     needs the 32 GB of S and Y in host memory and ~4 s per two-loop on the box's 16 CPUs, so this is done once,
-    for both forms of the recursion, plus the diagonal-H0 variant."""
+    for both forms of the recursion; with a caller-supplied diagonal H0 the entry always takes the sweep form
+    (one run).  adaQN's diagonal-H0 two-pass kernels at this size: test_adaqn_step_matches_the_oracle_at_full_size."""
     import stochqn_amd
     from oracle import oracle
     torch = torch_cuda()
@@ -360,7 +557,7 @@ def test_two_loop_matches_the_oracle_at_full_size(hip_backend):
         for H0_d in (None, H0):
             want = g.cpu().numpy().copy()
             rho_w, alpha_w = oracle.two_loop(want, None if H0_d is None else H0_d.cpu().numpy(), 0.0, Y_h, S_h, m, m, st)
-            for twopass in (1.0, 0.0):
+            for twopass in ((1.0, 0.0) if H0_d is None else (0.0,)):
                 lib.stochqn_hip_set_option(b"twopass", twopass)
                 lib.stochqn_hip_set_option(b"twopass_h0", twopass)
                 q = g.clone()
@@ -1210,6 +1407,82 @@ def test_bench_multi_process_control_flow_on_one_gpu(tmp_path):
     assert d["config"]["hess_vec_requests"] >= 1 and d["config"]["rejected_steps"] == 0
     assert d["reference_form"] is not None and d["cpu_baseline"] is None
     assert "REHEARSAL" in d["config"]["parallelism"]
+
+
+def _bench(args, timeout=600):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                         cwd=root, env=env)
+    return out
+
+
+def test_bench_starts_its_own_ranks_and_shards_one_problem(tmp_path):
+    """`python bench.py --gpus 3` with NO launcher: the parent decides before touching torch / HIP, starts 3 fresh
+    ranks (torch.distributed.run child) and relays rank 0's single JSON line (rehearsed on the one GPU of the
+    box, reductions over gloo).  The inputs come from the counter-based generator, so the 3-rank problem IS the
+    1-rank problem: the concatenated x of the ranks must equal the x of a 1-rank run over n = 3 x 3,000,001."""
+    per = 3_000_001
+    common = ["--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--no-reference-form"]
+    out = _bench(["--gpus", "3", "--rehearse", "--vars-per-gpu", str(per), "--dump-x", str(tmp_path / "x3")] + common)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["rccl_nranks"] == 3 and len(d["per_rank_ms_per_step"]) == 3
+    assert d["steps"] == 12 and d["value"] > 0 and d["config"]["hess_vec_requests"] >= 1
+    one = _bench(["--gpus", "1", "--vars-per-gpu", str(3 * per), "--dump-x", str(tmp_path / "x1")] + common)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["rccl_nranks"] == 1
+    x3 = np.concatenate([np.load(str(tmp_path / ("x3.%d.npy" % r))) for r in range(3)])
+    x1 = np.load(str(tmp_path / "x1.0.npy"))
+    assert x3.shape == x1.shape
+    assert rel_err(x3, x1) <= TOL, rel_err(x3, x1)
+    assert abs(d["config"]["f_end"] - d1["config"]["f_end"]) <= 1e-9 * abs(d1["config"]["f_end"])
+    assert d["config"]["calls"] == d1["config"]["calls"]
+
+
+def test_bench_refuses_to_mislabel_a_smaller_job():
+    """--gpus 2 on a box with one GPU and no launcher: exit code != 0, no JSON line (never a 1-GPU run labelled 2)."""
+    if torch_cuda().cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU box")
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], timeout=120)
+    assert out.returncode != 0
+    assert "only 1 device(s) are visible" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_a_failing_reducer_fails_the_call(hip_backend, capfd):
+    """A reduction that fails must not let the step finish on un-reduced local sums (wrong alpha / beta, ranks
+    taking different decisions): the call returns -1000 / invalid_input (fault injected through a custom reducer)."""
+    import stochqn_amd
+    lib = stochqn_amd.cdll()
+    REDUCER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+    state = {"fail": False, "calls": 0}
+
+    def reducer(user, buf, count, stream):
+        state["calls"] += 1
+        return 1 if state["fail"] else 0            # one rank: the sum over ranks is the buffer itself
+
+    keep = REDUCER(reducer)
+    lib.stochqn_hip_comm_init_custom.argtypes = [C.c_int, C.c_int, REDUCER, C.c_void_p]
+    assert lib.stochqn_hip_comm_init_custom(0, 1, keep, None) == 0
+    try:
+        P = NoisyQuadratic(800, seed=5)
+        opt = OPTIMIZERS["SQN"](backend=hip_backend, space="device", mem_size=4, bfgs_upd_freq=3)
+        x = torch_cuda().as_tensor(P.x0(), device="cuda")
+        run_trace(opt, P, x, 0.1, 12)
+        assert state["calls"] > 0
+        state["fail"] = True
+        with pytest.raises(ValueError):
+            for _ in range(3):                       # at the latest the next step with pairs reduces something
+                opt.run_optimizer(x, 0.1)
+        assert "instead of continuing on un-reduced sums" in capfd.readouterr().err
+    finally:
+        lib.stochqn_hip_comm_finalize()
 
 
 def test_device_errors_fail_the_call_loudly(hip_backend, capfd):
