@@ -581,7 +581,7 @@ struct ScaleOp {
 // ------------------------------------------------------------------------------------------------
 // pass 1: blockIdx.y selects a group of kFisherRows rows; each lane keeps one accumulator per row
 // of the group while it strides over its columns, so F is read exactly once and s once per group.
-template <int W, bool NT>
+template <int W, bool NT, int kFisherRows>
 __global__ void __launch_bounds__(kBlock) k_fisher_t(const real* F, size_t ld_, uint32_t n, uint32_t fu,
                                                      const real* s, double* parts)
 {
@@ -688,19 +688,23 @@ struct Probes { const real* p[3]; };
 // Single-probe pass A: one accumulator per row and lane, NG groups of 8 rows; the compiler hoists
 // the row loads of a pack ahead of the arithmetic (one wave per SIMD, up to 512 registers per lane),
 // which measured faster than the row-split form below for a single probe (5.1 vs 5.8 ms, n=1e8, 40 rows).
-template <int W, int NG, bool NT>
-__global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, const real* probe, real* copy_out, uint32_t n, int rev,
+template <int W, int NG, bool NT, int NPR>
+__global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, Probes pr, real* copy_out, uint32_t n, int rev,
                                                          double* parts)
 {
-	__shared__ double sh[NG * 8 * kWaves];
-	double acc[NG * 8];
+	__shared__ double sh[NPR * NG * 8 * kWaves];
+	double acc[NPR][NG * 8];
 	#pragma unroll
-	for (int j = 0; j < NG * 8; j++) acc[j] = 0;
+	for (int q = 0; q < NPR; q++)
+		#pragma unroll
+		for (int j = 0; j < NG * 8; j++) acc[q][j] = 0;
 	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
 	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
 		const uint32_t i = (rev ? last - p : p) * W;
-		const Pack<W> pv = ld<W, false>(probe, i);
-		if (copy_out) st<W>(copy_out, i, pv);
+		Pack<W> pv[NPR];
+		#pragma unroll
+		for (int q = 0; q < NPR; q++) pv[q] = ld<W, false>(pr.p[q], i);
+		if (copy_out) st<W>(copy_out, i, pv[0]);
 		#pragma unroll
 		for (int g = 0; g < NG; g++) {
 			RPack<W> f[8];
@@ -711,35 +715,43 @@ __global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, const real* 
 			for (int u = 0; u < 8; u++)
 				if (g * 8 + u < rs.count) {
 					#pragma unroll
-					for (int k = 0; k < W; k++) acc[g * 8 + u] = fma((double) f[u].v[k], pv.v[k], acc[g * 8 + u]);
+					for (int q = 0; q < NPR; q++)
+						#pragma unroll
+						for (int k = 0; k < W; k++) acc[q][g * 8 + u] = fma((double) f[u].v[k], pv[q].v[k], acc[q][g * 8 + u]);
 				}
 		}
 	}
 	if (W > 1) {
 		const uint32_t i = packs * W + threadIdx.x;
 		if (blockIdx.x == gridDim.x - 1 && i < n) {
-			const double pv = probe[i];
-			if (copy_out) copy_out[i] = pv;
+			if (copy_out) copy_out[i] = pr.p[0][i];
 			#pragma unroll
-			for (int j = 0; j < NG * 8; j++)
-				if (j < rs.count) acc[j] = fma(rs.row[j][i], pv, acc[j]);
+			for (int q = 0; q < NPR; q++) {
+				const double pv = (double) pr.p[q][i];
+				#pragma unroll
+				for (int j = 0; j < NG * 8; j++)
+					if (j < rs.count) acc[q][j] = fma((double) rs.row[j][i], pv, acc[q][j]);
+			}
 		}
 	}
 	// all quantities through the shuffle tree first, then ONE barrier (same tree and wave order as
 	// block_sum, so the same bits; 2 barriers per quantity made this epilogue the whole kernel at small n)
 	#pragma unroll
-	for (int j = 0; j < NG * 8; j++) {
-		if (j < rs.count) {           // uniform
-			const double t = wave_sum(acc[j]);
-			if ((threadIdx.x & 63) == 0) sh[j * kWaves + (threadIdx.x >> 6)] = t;
-		}
-	}
-	__syncthreads();
-	for (int j = threadIdx.x; j < rs.count; j += kBlock) {
-		double t = sh[j * kWaves];
+	for (int q = 0; q < NPR; q++)
 		#pragma unroll
-		for (int w = 1; w < kWaves; w++) t += sh[j * kWaves + w];
-		parts[(size_t) j * kMaxGrid + blockIdx.x] = t;
+		for (int j = 0; j < NG * 8; j++) {
+			if (j < rs.count) {           // uniform
+				const double t = wave_sum(acc[q][j]);
+				if ((threadIdx.x & 63) == 0) sh[(q * NG * 8 + j) * kWaves + (threadIdx.x >> 6)] = t;
+			}
+		}
+	__syncthreads();
+	for (int e = threadIdx.x; e < NPR * rs.count; e += kBlock) {
+		const int q = e / rs.count, j = e % rs.count;
+		double t = sh[(q * NG * 8 + j) * kWaves];
+		#pragma unroll
+		for (int w = 1; w < kWaves; w++) t += sh[(q * NG * 8 + j) * kWaves + w];
+		parts[(size_t) (q * rs.count + j) * kMaxGrid + blockIdx.x] = t;
 	}
 }
 
@@ -1424,11 +1436,18 @@ Partials launch_fisher(const Scratch& sc, int buf, size_t n, const real* F, size
 {
 	const int grid = sweep_grid(sc, n);
 	const bool vec = all_aligned(F, s, y_out);
-	const dim3 g1(grid, (unsigned) ((fu + kFisherRows - 1) / kFisherRows));
+	// rows one workgroup accumulates per pass over its columns: s is re-read once per group of rows (fu = 128:
+	// 16 groups of 8 re-read 12.5 % on top of F, 8 groups of 16 6 %).  Measured at n = 1e8 (r02_ab_rows3_fisher.jsonl):
+	// fu = 128: 17.54 / 17.09 / 23.79 ms for 8 / 16 / 32 rows (32 rows: 64 row packs in flight per lane, the
+	// compiler serialises them); fu = 32: 4.52 / 4.45 / 6.50 ms.  Default 16.
+	const int fr = sc.fisher_rows >= 32 ? 32 : (sc.fisher_rows >= 16 ? 16 : 8);
+	const dim3 g1(grid, (unsigned) ((fu + fr - 1) / fr));
 	{
 		ProfScope ps(sc, K_FISHER_T);
-		if (vec) hipLaunchKernelGGL((k_fisher_t<kVec, true>), g1, dim3(kBlock), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part);
-		else     hipLaunchKernelGGL((k_fisher_t<1, true>), g1, dim3(kBlock), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part);
+		#define SQN_FT(WW, FR) hipLaunchKernelGGL((k_fisher_t<WW, true, FR>), g1, dim3(kBlock), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part)
+		if (vec) { if (fr == 32) SQN_FT(kVec, 32); else if (fr == 16) SQN_FT(kVec, 16); else SQN_FT(kVec, 8); }
+		else     { if (fr == 32) SQN_FT(1, 32); else if (fr == 16) SQN_FT(1, 16); else SQN_FT(1, 8); }
+		#undef SQN_FT
 	}
 	launch_fin(sc, Partials{sc.fisher_part, grid, kMaxGrid}, (int) fu, t_dev);
 	if (sc.allreduce) sc.allreduce(sc.user, t_dev, (int) fu, sc.stream);
@@ -1480,11 +1499,11 @@ static int rows_dot_dispatch(const Scratch& sc, int slot, size_t max_grid, int r
 	return grid;
 }
 
-template <int W>
-static void rows_dot_all_dispatch(const Scratch& sc, int slot, int grid, int ng, const RowSet& rows, const real* probe,
+template <int W, int NPR>
+static void rows_dot_all_dispatch(const Scratch& sc, int slot, int grid, int ng, const RowSet& rows, const Probes& probe,
                                   real* copy_out, uint32_t n, int rev)
 {
-	#define SQN_RA(NG) hipLaunchKernelGGL((k_rows_dot_all<W, NG, true>), dim3(grid), dim3(kBlock), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[slot])
+	#define SQN_RA(NG) hipLaunchKernelGGL((k_rows_dot_all<W, NG, true, NPR>), dim3(grid), dim3(kBlock), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[slot])
 	switch (ng) {
 	case 1: SQN_RA(1); break;
 	case 2: SQN_RA(2); break;
@@ -1499,19 +1518,25 @@ static void rows_dot_all_dispatch(const Scratch& sc, int slot, int grid, int ng,
 Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& rows, const real* probe, real* copy_out,
                          int kernel_id, const real* probe_y, const real* probe_s)
 {
-	if (!probe_y && !sc.rows_split) {      // single probe: every lane keeps all rows
+	// Single probe: every lane keeps all rows.  (The same shape with the three probes of the Gram-row pass --
+	// 3 x 40 accumulators per lane -- measured 12.3 ms against 6.85 ms for the row-split kernel at n = 1e8,
+	// k = 20, and 0.58 against 0.35 ms at n = 1e7, k = 10: profiles/r02_ab_rows3_fisher.jsonl; not instantiated.)
+	if (!probe_y && !sc.rows_split) {
 		const int grid = sweep_grid(sc, n);
 		const bool vec = rows_aligned(rows) && all_aligned(probe, copy_out);
 		const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
+		const Probes pr{{probe, nullptr, nullptr}};
+		const int ng = (rows.count + 7) / 8;
 		{
 			ProfScope ps(sc, kernel_id);
-			if (vec) rows_dot_all_dispatch<kVec>(sc, slot, grid, (rows.count + 7) / 8, rows, probe, copy_out, (uint32_t) n, rev);
-			else     rows_dot_all_dispatch<1>(sc, slot, grid, (rows.count + 7) / 8, rows, probe, copy_out, (uint32_t) n, rev);
+			if (vec) rows_dot_all_dispatch<kVec, 1>(sc, slot, grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
+			else     rows_dot_all_dispatch<1, 1>(sc, slot, grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
 		}
+		const int nq = rows.count;
 		Partials raw{sc.rows_part[slot], grid, kMaxGrid};
 		if (!sc.allreduce) return raw;
-		launch_fin(sc, raw, rows.count, sc.red[slot]);
-		sc.allreduce(sc.user, sc.red[slot], rows.count, sc.stream);
+		launch_fin(sc, raw, nq, sc.red[slot]);
+		sc.allreduce(sc.user, sc.red[slot], nq, sc.stream);
 		return Partials{sc.red[slot], 1, 1};
 	}
 

@@ -119,8 +119,7 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 	if (!bind_bfgs(c, b, fresh && resumed)) { release(b->s_mem); return false; }
 	if (fresh) {
 		comm_attach(c);
-		c->rho_ok.assign(c->m, 0);
-		c->gram_ok.assign(c->m, 0);
+		c->forget_rows();
 	}
 	io.x_caller = x;
 	io.g_caller = grad;
@@ -241,9 +240,52 @@ Partials enqueue_two_loop(DevCtx* c, real* g, size_t used, size_t st, const Firs
 }
 
 // ---- two-pass form (scalar H0): Gram maintenance + rows-dot / coef / combine ----------------------
-bool twopass_ok(const DevCtx* c, size_t used, const real* H0_vec)
+// The fallback rule of the two-pass form.  Expanding the recursion over cached inner products is the same
+// arithmetic as the reference's sequential sweeps associated differently: on every input class probed
+// (tests/test_gpu_adversarial.py: Hessian condition 1e8, nearly collinear pairs, inconsistent and negative
+// curvature, g in the span of Y, |g| ~ 1e+-150) both forms sit within a few ulps of an extended-precision
+// evaluation.  The exception is pairs with s almost orthogonal to y (rho_i = 1/s'y huge): there every form
+// loses digits -- about kappa_i = |s||y|/|s'y| per pair -- and the expanded form loses up to ~16x more than
+// the sequential one.  So the two-pass form is used only while every pair in use has kappa_i <= option
+// "twopass_kappa_max" (default 1e6); beyond, the step runs as the reference's own chain of sweeps.
+// kappa comes from the all-reduced (s'y, s's, y'y) of the pair: identical on every rank.
+bool pairs_tame(DevCtx* c, size_t st, size_t used)
 {
-	return options().twopass && H0_vec == nullptr && used >= 1 && c->m <= (size_t) kPairsMax;
+	const double kmax = options().twopass_kappa_max;
+	if (!(kmax > 0) || std::isinf(kmax)) return true;            // rule switched off
+	const size_t m = c->m;
+	size_t unknown = 0;
+	for (size_t i = 0; i < used; i++) {
+		const size_t r = (st + i) % m;
+		if (c->kappa[r] >= 0) continue;
+		// a pair that did not come through accept_or_reject (imported state, isolated entry points, the bak->slot
+		// quirk): its three dots now, with a read-back (rare path, one synchronisation for all such rows)
+		Partials p = launch_dots3(c->sc, c->next_buf(), N(c), row(c->S, r, c), row(c->Y, r, c));
+		launch_commit(c->sc, p, c->sc.sy + r, c->sc.yy + r);
+		c->rho_ok[r] = 1;
+		launch_fin(c->sc, p, 3, c->kap_dev + 3 * r);
+		unknown++;
+	}
+	if (unknown) {
+		double* land = c->pin + 16 + 2 * m + c->fsize;
+		to_host(c, land, c->kap_dev, 3 * m);
+		sync(c);
+		for (size_t i = 0; i < used; i++) {
+			const size_t r = (st + i) % m;
+			if (c->kappa[r] >= 0) continue;
+			const double sy = land[3 * r], ss = land[3 * r + 1], yy = land[3 * r + 2];
+			const double k = std::sqrt(ss) * std::sqrt(yy) / std::fabs(sy);
+			c->kappa[r] = (k >= 0) ? k : INFINITY;                 // NaN (0/0, non-finite dots) counts as untame
+		}
+	}
+	for (size_t i = 0; i < used; i++)
+		if (!(c->kappa[(st + i) % m] <= kmax)) return false;
+	return true;
+}
+
+bool twopass_ok(DevCtx* c, size_t st, size_t used, const real* H0_vec)
+{
+	return options().twopass && H0_vec == nullptr && used >= 1 && c->m <= (size_t) kPairsMax && pairs_tame(c, st, used);
 }
 
 // Refresh row r and column r of the Gram blocks: s_j'y_r, y_j'y_r, y_j's_r for every ring row j.
@@ -304,12 +346,12 @@ Partials enqueue_two_pass(DevCtx* c, real* g, size_t used, size_t st, double h0,
 
 // adaQN (diagonal H0) in two passes: all inner products incl. the H0-weighted ones + the side effects
 // on the raw gradient in one pass over S and Y, the scalar recursion, the combine pass.
-bool twopass_h0_ok(const DevCtx* c, size_t used, const StepIn& in)
+bool twopass_h0_ok(DevCtx* c, size_t st, size_t used, const StepIn& in)
 {
 	// like twopass_ok: only quantities that are identical on every rank of a sharded run may select
 	// the algorithm (local n, alignment ... merely select kernel variants with the same reductions)
 	return options().twopass && options().twopass_h0 && in.G != nullptr && in.H0 != nullptr && used >= 1 &&
-	       c->m <= (size_t) kPairsMax;
+	       c->m <= (size_t) kPairsMax && pairs_tame(c, st, used);
 }
 
 Partials enqueue_two_pass_h0(DevCtx* c, const StepIn& in, size_t st)
@@ -363,10 +405,10 @@ void enqueue_step(Call& io, const StepIn& in)
 	} else {
 		fa.H0_out = in.H0;                                            // :818
 		const size_t st = (in.st_ix == in.used) ? 0 : in.st_ix;      // :820
-		if (twopass_ok(c, in.used, in.G ? in.H0 : nullptr)) {
+		if (twopass_ok(c, st, in.used, in.G ? in.H0 : nullptr)) {
 			Partials guard = enqueue_two_pass(c, in.g, in.used, st, in.h0, in.gprev_out);
 			launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
-		} else if (twopass_h0_ok(c, in.used, in)) {
+		} else if (twopass_h0_ok(c, st, in.used, in)) {
 			Partials guard = enqueue_two_pass_h0(c, in, st);
 			launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
 		} else {
@@ -429,6 +471,10 @@ void accept_or_reject(DevCtx* c, bfgs_mem* b, Partials p, info_enum* info)
 	}
 	c->rho_ok[st] = 1;
 	c->gram_ok[st] = 0;            // cross products with the other rows: refreshed lazily by ensure_gram
+	{
+		const double k = std::sqrt(c->pin[5]) * std::sqrt(c->pin[6]) / std::fabs(c->pin[4]);   // |s||y| / |s'y|
+		c->kappa[st] = (k >= 0) ? k : INFINITY;
+	}
 	ring_advance(b);
 }
 
@@ -1100,7 +1146,7 @@ static DevCtx* raw_context(real_t s_mem[], real_t y_mem[], int n, size_t mem_siz
 	// library that a caller rewrote S / Y in place (or that an allocator handed the same address to new
 	// arrays): so the caches are dropped on every call unless the caller vouches for the arrays with
 	// option "raw_reuse_cache" = 1 (the two-loop micro-benchmark does).
-	if (!options().raw_reuse_cache || c->S.mirror || c->Y.mirror) { c->rho_ok.assign(c->m, 0); c->gram_ok.assign(c->m, 0); }
+	if (!options().raw_reuse_cache || c->S.mirror || c->Y.mirror) c->forget_rows();
 	if (*fresh) comm_attach(c);
 	return c;
 }
@@ -1120,7 +1166,7 @@ static int two_loop_impl(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 	const bool g_host = !is_device_pointer(grad);
 	real* g = stage_in(c, 1, grad, nn, g_host);
 	if (!g) return -1000;
-	if (twopass_ok(c, mem_used, H0 ? c->H0.dev : nullptr)) {
+	if (twopass_ok(c, mem_st_ix % mem_size, mem_used, H0 ? c->H0.dev : nullptr)) {
 		(void) enqueue_two_pass(c, g, mem_used, mem_st_ix % mem_size, h0, nullptr);
 	} else {
 		FirstArgs fa{};

@@ -260,6 +260,7 @@ void begin_call(DevCtx* c)
 	c->sc.rows_waves = g_opt.rows_waves;
 	c->sc.combine_batch = g_opt.combine_batch;
 	c->sc.h0_per_cu = g_opt.h0_per_cu;
+	c->sc.fisher_rows = g_opt.fisher_rows;
 	c->sc.prof = g_profile ? &c->prof : nullptr;
 	c->sc.phase = &c->phase;
 	c->phase = 1;
@@ -351,8 +352,8 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	// pool layout: part0 | part1 | red0 | red1 | sy | yy | report | rho | alpha | rows_part x2 | gsy | gyy | coef
 	const size_t part = (size_t) kMaxSums * kMaxGrid;
 	const size_t rows_part = (size_t) kRedMax * kMaxGrid;
-	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + 2 * m * m + (2 + 2 * kPairsMax);
-	c->pin_count = 16 + 2 * m + fsize;
+	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + 2 * m * m + (2 + 2 * kPairsMax) + 3 * m;
+	c->pin_count = 16 + 2 * m + fsize + 3 * m;
 	if (!device_alloc((void**) &c->pool, total * sizeof(double)) ||
 	    !pinned_alloc((void**) &c->pin, c->pin_count * sizeof(double)) ||
 	    (fsize > 0 && (!device_alloc((void**) &c->sc.fisher_part, fsize * kMaxGrid * sizeof(double)) ||
@@ -376,9 +377,9 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	c->sc.rows_part[1] = p; p += rows_part;
 	c->sc.gsy = p; p += m * m;
 	c->sc.gyy = p; p += m * m;
-	c->sc.coef = p;
-	c->rho_ok.assign(m, 0);
-	c->gram_ok.assign(m, 0);
+	c->sc.coef = p; p += 2 + 2 * kPairsMax;
+	c->kap_dev = p;
+	c->forget_rows();
 	begin_call(c);
 	c->sc.allreduce = nullptr;
 	c->sc.user = c;
@@ -557,7 +558,7 @@ void stochqn_hip_invalidate(const void* s_mem)
 	if (group_invalidate(s_mem)) return;
 	if (!s_mem) return;
 	for (const void* key : {s_mem, raw_key(s_mem)})
-		if (DevCtx* c = lookup(key)) { c->rho_ok.assign(c->m, 0); c->gram_ok.assign(c->m, 0); }
+		if (DevCtx* c = lookup(key)) c->forget_rows();
 }
 
 void stochqn_hip_release(const void* s_mem)
@@ -604,9 +605,11 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "rows_waves")) g_opt.rows_waves = (int) value;
 	else if (!std::strcmp(name, "combine_batch")) g_opt.combine_batch = (int) value;
 	else if (!std::strcmp(name, "h0_per_cu")) g_opt.h0_per_cu = (int) value;
+	else if (!std::strcmp(name, "fisher_rows")) g_opt.fisher_rows = (int) value;
 	else if (!std::strcmp(name, "reverse")) g_opt.reverse = value != 0;
 	else if (!std::strcmp(name, "twopass")) g_opt.twopass = value != 0;
 	else if (!std::strcmp(name, "twopass_h0")) g_opt.twopass_h0 = value != 0;
+	else if (!std::strcmp(name, "twopass_kappa_max")) g_opt.twopass_kappa_max = value;
 	else if (!std::strcmp(name, "strict_grad")) g_opt.strict_grad = value != 0;
 	else if (!std::strcmp(name, "devices")) options().devices = value < 0 ? 0 : (int) value;
 	else if (!std::strcmp(name, "virtual_devices")) options().virtual_devices = value != 0;

@@ -34,7 +34,9 @@ struct Options {
 	bool reverse = true;
 	bool twopass = true;         // scalar-H0 two-loop in the two-pass (Gram) form when the ring has <= kPairsMax pairs
 	int h0_per_cu = 0;
+	int fisher_rows = 16;        // Fisher rows per workgroup pass (8, 16, 32)
 	bool twopass_h0 = true;      // adaQN (diagonal H0) in the two-pass form as well
+	double twopass_kappa_max = 1e6;   // two-pass form only while every pair in use has |s||y|/|s'y| <= this (else: sweeps)
 	bool strict_grad = true;
 	// single-process multi-device mode (group.cpp): shard n over `devices` GPUs of this process
 	int devices = 0;             // 0 / 1 = off; also STOCHQN_HIP_DEVICES in the environment
@@ -97,7 +99,14 @@ struct DevCtx {
 	int last_section = 0;
 	std::vector<char> rho_ok;          // per physical row: sc.sy / sc.yy hold this row's dots
 	std::vector<char> gram_ok;         // per physical row: its row and column of sc.gsy / sc.gyy are current
-	void touch_row(size_t r) { rho_ok[r] = 0; gram_ok[r] = 0; }   // row r of S or Y was rewritten
+	// per physical row: |s||y| / |s'y| of the pair (1 / cosine of the angle between s and y; < 0 = not known yet).
+	// From all-reduced dots, so identical on every rank of a sharded run.  Pairs that are almost orthogonal
+	// make the recursion amplify rounding errors by about this factor per pair; the two-pass form is only
+	// used while every pair in use stays below option "twopass_kappa_max" (machines.cpp: pairs_tame).
+	std::vector<double> kappa;
+	double* kap_dev = nullptr;         // [3 m] landing zone of (s'y, s's, y'y) for rows whose kappa has to be computed
+	void touch_row(size_t r) { rho_ok[r] = 0; gram_ok[r] = 0; kappa[r] = -1; }   // row r of S or Y was rewritten
+	void forget_rows() { rho_ok.assign(m, 0); gram_ok.assign(m, 0); kappa.assign(m, -1.0); }
 
 	int next_buf() { int b = buf; buf ^= 1; return b; }
 };

@@ -25,7 +25,6 @@ constexpr int kCoefBlock = 1024;  // the one-workgroup coefficient kernels: 16 w
 constexpr int kCoefWaves = kCoefBlock / 64;
 constexpr int kMaxGrid = 2048;    // 256 CUs x 8 resident workgroups; also the partial-sum stride
 constexpr int kMaxSums = 3;       // sums one sweep can produce (s'y, s's, y'y)
-constexpr int kFisherRows = 8;    // Fisher rows one workgroup accumulates per pass-1 sweep
 constexpr int kRowsMax = 48;      // rows one rows-dot launch can take (one accumulator per row and lane)
 constexpr int kPairsMax = 24;     // largest ring the two-pass form handles (2*kPairsMax rows per launch)
 constexpr int kQuantMax = 3 * kPairsMax + kPairsMax * (kPairsMax + 1) / 2;   // 372: quantities of the diagonal-H0 pass A
@@ -107,6 +106,7 @@ struct Scratch {
 	int rows_waves;       // waves per workgroup of the row-split kernel: 4 or 8
 	int combine_batch;    // packs a lane finishes in pass B before storing them (1, 2, 4, 8)
 	int h0_per_cu;        // workgroups per CU of the diagonal-H0 Gram pass (0 = 2)
+	int fisher_rows;      // Fisher rows one workgroup accumulates per pass over its columns: 8, 16 or 32
 	bool nontemporal;     // stream S/Y/F rows with nt loads
 	bool reverse;         // alternate the traversal direction from sweep to sweep (Infinity-Cache reuse of q / r)
 	int* phase;           // sweep counter of the current API call (parity = direction)

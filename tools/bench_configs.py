@@ -24,6 +24,9 @@ from stochqn_amd import oLBFGS_free, SQN_free, adaQN_free
 dev = torch.device("cuda", 0)
 lib = stochqn_amd.cdll()
 lib.stochqn_hip_profile_name.restype = C.c_char_p
+lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+for _name, _val in [kv.split("=") for kv in os.environ.get("SQN_OPTS", "").split(",") if kv]:     # A/B of kernel-shape knobs
+    assert lib.stochqn_hip_set_option(_name.encode(), float(_val)) == 0, _name
 
 
 def kernels():
@@ -120,7 +123,7 @@ def c2():
     x = P.x0.clone()
     opt = oLBFGS_free(mem_size=m, min_curvature=None, check_nan=True, space="device")
     dt, calls = drive(opt, P, x, 0.1, 200, 30)
-    report("C2", "oLBFGS n=1e7 m=10 fp64 check_nan=1, device-resident", n, m, dt, 200, calls, {"f_end": P.f(x), "mem_used": opt.BFGS_mem.mem_used})
+    report("C2", "oLBFGS n=1e7 m=10 fp64 check_nan=1, device-resident, opts=%s" % os.environ.get("SQN_OPTS", ""), n, m, dt, 200, calls, {"f_end": P.f(x), "mem_used": opt.BFGS_mem.mem_used})
 
 
 def c3host():
@@ -145,9 +148,6 @@ def c4():
     nearly parallel gradients are degenerate), which flushes the ring and would understate the cost."""
     n, m, f = 100_000_000, 20, 128
     P = DeviceQuadratic(n)
-    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
-    for name, val in [kv.split("=") for kv in os.environ.get("SQN_OPTS", "").split(",") if kv]:
-        assert lib.stochqn_hip_set_option(name.encode(), float(val)) == 0
     for max_incr in (None,) if os.environ.get("C4_QUICK") else (None, 1.01):
         x = P.x0.clone()
         opt = adaQN_free(mem_size=m, fisher_size=f, bfgs_upd_freq=20, max_incr=max_incr, min_curvature=1e-4,
