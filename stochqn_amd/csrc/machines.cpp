@@ -380,6 +380,64 @@ Partials enqueue_two_pass_h0(DevCtx* c, const StepIn& in, size_t st)
 	return launch_combine(c->sc, c->next_buf(), N(c), ga.y_rows, ga.s_rows, in.g, in.H0);
 }
 
+// Option "verify_cache" (debugging aid for DEVICE callers).  The library caches s'y, y'y and the Gram rows of
+// the pairs in the ring; it learns about changes to S and Y only through its own writes or
+// stochqn_hip_invalidate.  A caller that restores or edits rows in place without saying so gets a direction
+// built from stale inner products and no diagnostic.  With the option on, every step re-derives the cached
+// numbers of ONE pair in use (round robin) from the arrays as they are and compares; a mismatch fails the
+// call (-1000, message on stderr).  Costs a synchronisation and up to (2k+2) n words per step.
+void verify_cache(DevCtx* c, size_t st, size_t used)
+{
+	const size_t m = c->m;
+	const size_t r = (st + (c->verify_turn++ % used)) % m;
+	if (!c->rho_ok[r]) return;                                 // nothing cached for this row yet
+	Partials p = launch_dots3(c->sc, c->next_buf(), N(c), row(c->S, r, c), row(c->Y, r, c));
+	launch_fin(c->sc, p, 3, c->kap_dev);
+	double* land = c->pin + 16 + 2 * m + c->fsize;             // [3 m]: fresh (s'y, s's, y'y) | cached s'y, y'y
+	to_host(c, land, c->kap_dev, 3);
+	to_host(c, land + 3, c->sc.sy + r, 1);
+	to_host(c, land + 4, c->sc.yy + r, 1);
+	std::vector<double> fresh, gsy, gyy;
+	const bool gram = c->gram_ok[r] && m <= (size_t) kPairsMax;
+	if (gram) {
+		RowSet all{};
+		for (size_t j = 0; j < m; j++) { all.row[j] = row(c->S, j, c); all.row[m + j] = row(c->Y, j, c); }
+		all.count = (int) (2 * m);
+		Partials a = launch_rows_dot(c->sc, 0, N(c), all, row(c->Y, r, c), nullptr, K_GRAM);      // s_j'y_r, y_j'y_r
+		fresh.assign(2 * m, 0.0); gsy.assign(m * m, 0.0); gyy.assign(m * m, 0.0);
+		if (a.stride != 1) { launch_fin(c->sc, a, (int) (2 * m), c->sc.red[0]); a = Partials{c->sc.red[0], 1, 1}; }   // totals, contiguous
+		SQN_HIP_OK(hipMemcpyAsync(fresh.data(), a.parts, 2 * m * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
+		SQN_HIP_OK(hipMemcpyAsync(gsy.data(), c->sc.gsy, m * m * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
+		SQN_HIP_OK(hipMemcpyAsync(gyy.data(), c->sc.gyy, m * m * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
+	}
+	sync(c);
+	const double scale = std::sqrt(std::fabs(land[1])) * std::sqrt(std::fabs(land[2]));     // |s_r||y_r|
+	bool stale = !(std::fabs(land[0] - land[3]) <= 1e-8 * scale) || !(std::fabs(land[2] - land[4]) <= 1e-8 * std::fabs(land[2]));
+	if (stale) std::fprintf(stderr, "stochqn: verify_cache: row %zu: s'y now %.17g cached %.17g, y'y now %.17g cached %.17g\n", r, land[0], land[3], land[2], land[4]);
+	if (gram && !stale) {
+		double big = 0;
+		for (size_t j = 0; j < used; j++) {
+			const size_t q = (st + j) % m;
+			if (!c->gram_ok[q]) continue;
+			big = std::fmax(big, std::fmax(std::fabs(fresh[q]), std::fabs(fresh[m + q])));
+		}
+		for (size_t j = 0; j < used && !stale; j++) {
+			const size_t q = (st + j) % m;
+			if (!c->gram_ok[q]) continue;
+			if (!(std::fabs(fresh[q] - gsy[q * m + r]) <= 1e-7 * big) || !(std::fabs(fresh[m + q] - gyy[q * m + r]) <= 1e-7 * big)) {
+				stale = true;
+				std::fprintf(stderr, "stochqn: verify_cache: Gram entries of rows (%zu, %zu): s'y now %.17g cached %.17g, y'y now %.17g cached %.17g\n",
+				             q, r, fresh[q], gsy[q * m + r], fresh[m + q], gyy[q * m + r]);
+			}
+		}
+	}
+	if (stale) {
+		std::fprintf(stderr, "stochqn: verify_cache: the cached inner products of ring row %zu do not match s_mem / y_mem as they are now "
+		                     "(rows changed outside the library without stochqn_hip_invalidate?) -- failing the call\n", r);
+		c->fault = true;
+	}
+}
+
 // take_step (reference src/stochqn.c:802-840) + the caller's follow-up that only depends on the
 // guard (x_sum += x, oLBFGS s-slot).  Enqueues everything and the read-back of the report block.
 void enqueue_step(Call& io, const StepIn& in)
@@ -387,6 +445,7 @@ void enqueue_step(Call& io, const StepIn& in)
 	DevCtx* c = io.c;
 	const Scratch& sc = c->sc;
 	const size_t n = N(c);
+	if (options().verify_cache && in.used > 0) verify_cache(c, (in.st_ix == in.used) ? 0 : in.st_ix, in.used);
 	ApplyArgs ap{in.x, in.x_sum, in.s_slot, in.step};
 	FirstArgs fa{};
 	fa.q = in.g;

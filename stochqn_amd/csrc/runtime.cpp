@@ -353,7 +353,7 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	const size_t part = (size_t) kMaxSums * kMaxGrid;
 	const size_t rows_part = (size_t) kRedMax * kMaxGrid;
 	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + 2 * m * m + (2 + 2 * kPairsMax) + 3 * m;
-	c->pin_count = 16 + 2 * m + fsize + 3 * m;
+	c->pin_count = 16 + 2 * m + fsize + 3 * m + 8;
 	if (!device_alloc((void**) &c->pool, total * sizeof(double)) ||
 	    !pinned_alloc((void**) &c->pin, c->pin_count * sizeof(double)) ||
 	    (fsize > 0 && (!device_alloc((void**) &c->sc.fisher_part, fsize * kMaxGrid * sizeof(double)) ||

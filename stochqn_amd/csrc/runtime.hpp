@@ -104,6 +104,7 @@ struct DevCtx {
 	// make the recursion amplify rounding errors by about this factor per pair; the two-pass form is only
 	// used while every pair in use stays below option "twopass_kappa_max" (machines.cpp: pairs_tame).
 	std::vector<double> kappa;
+	size_t verify_turn = 0;            // option verify_cache: which pair in use is re-derived on the next call
 	double* kap_dev = nullptr;         // [3 m] landing zone of (s'y, s's, y'y) for rows whose kappa has to be computed
 	void touch_row(size_t r) { rho_ok[r] = 0; gram_ok[r] = 0; kappa[r] = -1; }   // row r of S or Y was rewritten
 	void forget_rows() { rho_ok.assign(m, 0); gram_ok.assign(m, 0); kappa.assign(m, -1.0); }

@@ -156,6 +156,45 @@ class _StochQN_free:
         """Hand over the gradient that the last request asked for."""
         self._sp.assign(self.gradient, gradient)
 
+    # -- state that lives behind the ABI ---------------------------------------------------------
+    def export(self):
+        """Bring this object's numpy arrays up to date with the device (host space only).
+
+        The reference's Python objects ARE their state (every array is a numpy array the C code works on
+        in place), so pickling one is a checkpoint.  Here S, Y, F, x_sum, grad_sum_sq ... of a host-space
+        object live in HBM between calls and the numpy arrays go stale; `export` copies them back
+        (stochqn_hip_export).  Called automatically by pickle / copy (`__getstate__`)."""
+        if getattr(self, "initialized", False) and self._sp.name == "host" and hasattr(self._be.lib, "stochqn_hip_export"):
+            rc = self._be.lib.stochqn_hip_export(C.c_void_p(self._sp.ptr(self.BFGS_mem.s_mem)))
+            if rc not in (0, -1000):                 # -1000: no device state exists (nothing ran yet): arrays are current
+                raise RuntimeError("stochqn_hip_export failed")
+
+    def __getstate__(self):
+        if self._sp.name != "host":
+            raise TypeError("only host-space optimizer objects can be pickled (device tensors belong to the caller)")
+        if getattr(self._be, "prefix", ""):
+            raise TypeError("only objects driven by libstochqn itself can be pickled")
+        self.export()
+        state = dict(self.__dict__)
+        state["_be"] = None                          # ctypes handles do not pickle: re-bound on load
+        state["_sp"] = None
+        return state
+
+    def __setstate__(self, state):
+        from . import lib
+        self.__dict__.update(state)
+        self._sp = _space("host", None, self.use_float)
+        self._be = lib(use_float=self.use_float)
+
+    def _order_streams(self):
+        """Device space: the library's stream is ordered after the NULL stream only (stochqn_hip.h).  A caller
+        that produced x / the gradient on another torch stream gets that stream drained first."""
+        if self._sp.name == "device":
+            torch = self._sp.torch
+            cur = torch.cuda.current_stream(self._sp.device)
+            if cur != torch.cuda.default_stream(self._sp.device):
+                cur.synchronize()
+
     def release(self):
         """Free the device context that mirrors this object's arrays (the reference's Python
         objects have no such call; the library also recognises a recycled address by itself)."""
@@ -220,6 +259,7 @@ class oLBFGS_free(_StochQN_free):
 
     def run_optimizer(self, x, step_size):
         self._check_x(x)
+        self._order_streams()
         sp = self._sp
         b = self.BFGS_mem.c_struct(sp, self._be)
         w = self._be.workspace_oLBFGS(C.pointer(b), sp.ptr(self.grad_prev), self.hess_init, self.niter,
@@ -262,6 +302,7 @@ class SQN_free(_StochQN_free):
 
     def run_optimizer(self, x, step_size):
         self._check_x(x)
+        self._order_streams()
         sp = self._sp
         b = self.BFGS_mem.c_struct(sp, self._be)
         w = self._be.workspace_SQN(C.pointer(b), sp.ptr(self.grad_prev), sp.ptr(self.x_sum), sp.ptr(self.x_avg_prev),
@@ -336,6 +377,7 @@ class adaQN_free(_StochQN_free):
 
     def run_optimizer(self, x, step_size):
         self._check_x(x)
+        self._order_streams()
         sp = self._sp
         b = self.BFGS_mem.c_struct(sp, self._be)
         fm = self.Fisher_mem.c_struct(sp, self._be)

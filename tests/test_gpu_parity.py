@@ -719,6 +719,108 @@ def test_export_and_resume_host_state(optname, kw, form, hip_backend, oracle_bac
     compare_traces(got2, want2, TOL)
 
 
+@pytest.mark.parametrize("optname,kw", [
+    ("SQN", dict(mem_size=3, bfgs_upd_freq=4)),
+    ("oLBFGS", dict(mem_size=4)),
+    ("adaQN", dict(mem_size=3, fisher_size=6, bfgs_upd_freq=4, rmsprop_weight=0.9)),
+])
+def test_pickle_round_trip_of_a_running_host_object(optname, kw, form, hip_backend, oracle_backend):
+    """The reference's Python objects pickle correctly because they ARE their state.  Here the arrays of a
+    host-space object live in HBM between calls: __getstate__ exports them first (stochqn_hip_export), and the
+    copy -- new arrays at new addresses, a new device context -- continues exactly like the oracle."""
+    import copy
+    import pickle
+    n = 600
+    P = NoisyQuadratic(n, seed=5)
+    ref = OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw)
+    opt = OPTIMIZERS[optname](backend=hip_backend, space="host", **kw)
+    x_ref, x = P.x0(), P.x0()
+    compare_traces(run_trace(opt, P, x, 0.05, 37), run_trace(ref, P, x_ref, 0.05, 37), TOL)
+    clone = pickle.loads(pickle.dumps(opt))
+    assert rel_err(clone.BFGS_mem.s_mem, ref.BFGS_mem.s_mem) <= TOL and rel_err(clone.BFGS_mem.y_mem, ref.BFGS_mem.y_mem) <= TOL
+    assert (clone.niter, clone.section, clone.BFGS_mem.mem_used) == (ref.niter, ref.section, ref.BFGS_mem.mem_used)
+    twin = copy.deepcopy(opt)
+    P2 = NoisyQuadratic(n, seed=6)
+    want = run_trace(ref, P2, x_ref, 0.05, 30)
+    for obj in (clone, twin, opt):                                   # the original keeps working as well
+        # run_trace fed the last request before it stopped: the gradient / Hessian-vector product / f it stored travels along
+        compare_traces(run_trace(obj, P2, x.copy(), 0.05, 30), want, TOL)
+    dev = OPTIMIZERS[optname](backend=hip_backend, space="device", **kw)
+    dev.run_optimizer(torch_cuda().as_tensor(P.x0(), device="cuda"), 0.05)
+    with pytest.raises(TypeError):
+        pickle.dumps(dev)
+
+
+def test_device_caller_on_a_side_stream_is_ordered(hip_backend, oracle_backend):
+    """The library's stream waits for the NULL stream only; free.py drains the caller's current stream when it
+    is another one, so a gradient produced on a side stream is complete before the step reads it."""
+    torch = torch_cuda()
+    n = 2_000_000
+    P = NoisyQuadratic(n, seed=3)
+    kw = dict(mem_size=3, bfgs_upd_freq=3)
+    want = run_trace(OPTIMIZERS["SQN"](backend=oracle_backend, space="host", **kw), P, P.x0(), 0.05, 25)
+    opt = OPTIMIZERS["SQN"](backend=hip_backend, space="device", **kw)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        x = torch.as_tensor(P.x0(), device="cuda")
+        got = run_trace(opt, P, x, 0.05, 25)                      # update_gradient's H2D copies run on `side`
+    compare_traces(got, want, TOL)
+    opt.release()
+
+
+def _edit_pairs_in_place(opt, n, to_t):
+    """Row 0 of the ring gets a tenth of row 1 added, in S and in Y (stays a valid pair of the quadratic)."""
+    for name in ("s_mem", "y_mem"):
+        a = getattr(opt.BFGS_mem, name)
+        a[0:n] += 0.1 * a[n:2 * n]
+
+
+@pytest.mark.parametrize("invalidate", [True, False])
+def test_in_place_edit_of_the_ring_by_a_device_caller(invalidate, form, hip_backend, oracle_backend, capfd):
+    """The cache contract for device callers: the library learns about changes to S / Y only
+    through its own writes or stochqn_hip_invalidate.  With the call, an in-place edit continues exactly like
+    the oracle on the same edited arrays; without it, option verify_cache turns the silent wrong direction into
+    a failed call."""
+    lib = _lib()
+    n = 1500
+    P = NoisyQuadratic(n, seed=8)
+    kw = dict(mem_size=3, bfgs_upd_freq=2, min_curvature=None)
+    ref = OPTIMIZERS["SQN"](backend=oracle_backend, space="host", **kw)
+    opt = OPTIMIZERS["SQN"](backend=hip_backend, space="device", **kw)
+    x_ref, x = P.x0(), torch_cuda().as_tensor(P.x0(), device="cuda")
+    compare_traces(run_trace(opt, P, x, 0.05, 31), run_trace(ref, P, x_ref, 0.05, 31), TOL)
+    assert ref.BFGS_mem.mem_used == 3
+    _edit_pairs_in_place(ref, n, None)
+    _edit_pairs_in_place(opt, n, None)
+    key = C.c_void_p(opt.BFGS_mem.s_mem.data_ptr())
+    P2 = NoisyQuadratic(n, seed=9)
+    if invalidate:
+        lib.stochqn_hip_invalidate(key)
+        compare_traces(run_trace(opt, P2, x, 0.05, 24), run_trace(ref, P2, x_ref, 0.05, 24), TOL)
+    else:
+        assert lib.stochqn_hip_set_option(b"verify_cache", 1.0) == 0
+        try:
+            with pytest.raises(ValueError):
+                run_trace(opt, P2, x, 0.05, 12)             # round robin over the 3 pairs in use: row 0 within 3 steps
+        finally:
+            lib.stochqn_hip_set_option(b"verify_cache", 0.0)
+        assert "verify_cache: the cached inner products of ring row 0" in capfd.readouterr().err
+    opt.release()
+
+
+def test_verify_cache_is_silent_on_untouched_state(form, hip_backend, oracle_backend):
+    """The debugging option must not change results nor raise false alarms (all three optimisers, ring wrapping)."""
+    lib = _lib()
+    assert lib.stochqn_hip_set_option(b"verify_cache", 1.0) == 0
+    try:
+        for name in ("sqn_hessvec", "olbfgs_default", "adaqn_fisher_rms", "sqn_ring20", "sqn_reject"):
+            cfg = [c for c in CONFIGS if c[0] == name][0]
+            got, want = both_traces(cfg, 1000, "device", hip_backend, oracle_backend)
+            compare_traces(got, want, FREE_RUN_TOL.get(name, TOL))
+    finally:
+        lib.stochqn_hip_set_option(b"verify_cache", 0.0)
+
+
 def test_rejected_pair_with_full_ring_reproduces_bak_quirk(form, hip_backend, oracle_backend):
     """once the ring is full, a rejected pair leaves the bak buffers' contents in
     the slot of the oldest (still counted) pair; with zero bak buffers the next direction is NaN and
