@@ -50,6 +50,17 @@ int stochqn_hip_take_step(real_t step_size, int n, real_t x[], real_t grad[], bf
  * without the curvature check).  F is [fu][n] row-major.  Device or host pointers. */
 int stochqn_hip_fisher_product(real_t F[], size_t fu, int n, real_t s[], real_t buffer_y[], real_t y[]);
 
+/* ---- contract for callers that pass DEVICE pointers ------------------------------------------------
+ * Streams: each context works on its own blocking-flavour HIP stream, ordered after the NULL stream only.
+ *   Inputs must be complete on (or ordered before) the NULL stream when a call is entered; outputs are
+ *   complete when it returns.  Work on hipStreamNonBlocking / per-thread / side streams must be
+ *   synchronised by the caller first.
+ * Caches: s'y, y'y and the Gram rows of the pairs in the ring are cached per (s_mem, ring row).  run_*
+ *   notices a different optimiser at the same address (counters that do not continue) but NOT rows of
+ *   s_mem / y_mem edited or restored in place at the same counters: call stochqn_hip_invalidate(s_mem)
+ *   after such an edit.  Option "verify_cache" = 1 re-derives one pair's cached numbers per step and fails
+ *   the call (-1000) on a mismatch: a debugging aid, costs a synchronisation and up to (2k+2) n words. */
+
 /* ---- device-context management ------------------------------------------------------------------
  * State that mirrors caller-owned HOST arrays lives in a context keyed by the address of
  * `bfgs_mem.s_mem`.  R and Python never call dealloc_*, so contexts are released explicitly, or
@@ -74,6 +85,11 @@ int stochqn_hip_export(const void *s_mem);
  *                            effects on the raw gradient (needs "twopass" = 1 as well)
  * "rows_grid", "rows_split", "combine_batch", "h0_per_cu": kernel-shape knobs, see DESIGN.md 3.2
  * "strict_grad" (default 1)  host callers: copy the search direction back into `grad`
+ * "twopass_kappa_max" (default 1e6)  the two-pass forms are used only while every pair in use has
+ *                            |s||y| / |s'y| <= this (s almost orthogonal to y: every fp64 evaluation loses
+ *                            digits, the expanded form somewhat more); beyond, the chain of sweeps. inf = off
+ * "fisher_rows" (default 16) Fisher rows one workgroup accumulates per pass (8, 16, 32)
+ * "verify_cache" (default 0) see "contract for callers that pass DEVICE pointers"
  * "raw_reuse_cache" (default 0)  stochqn_hip_two_loop / _take_step keep cached inner products between calls
  * "devices", "virtual_devices", "devices_min_n": single-process multi-device mode, see below
  * "fail_alloc_after" (default -1 = off)  fault injection for tests: the (value+1)-th device or

@@ -2,7 +2,13 @@
 a contiguous slice of all n-vectors and of every pair row; each dot product of the recursion is a
 local partial plus one all-reduce(sum) of 1-3 scalars; the guard uses the GLOBAL n and the global
 sum of squares.  The per-rank arithmetic here is numpy (a model of the sweeps in kernels.hip, in
-the same fused order); the unsharded oracle is the reference result."""
+the same fused order); the unsharded oracle is the reference result.
+
+This file checks the ALGEBRA on the CPU (no GPU here, and the product has no CPU path).  The library itself
+runs sharded in the -m gpu tests: world-size-3 over gloo through stochqn_hip_comm_init_custom
+(tests/test_gpu_parity.py::test_bench_starts_its_own_ranks_and_shards_one_problem), P host threads with the
+loop-back reducer (::test_sharded_library_equals_unsharded_oracle) and the single-process multi-device mode
+(tests/test_gpu_devices.py)."""
 import os
 import sys
 
