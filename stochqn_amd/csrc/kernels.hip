@@ -110,6 +110,20 @@ template <int W> __device__ __forceinline__ void st_nt(real* p, uint32_t i, cons
 	} else __builtin_nontemporal_store((real) a.v[0], p + i);
 }
 
+// The single store stream of pass B (1 of 2k+2 streams): agent-scope, non-temporal cache policy on the store
+// (gfx942 / gfx950 "sc1 nt").  Measured on the pass-B micro-benchmark (scratch/tune7.hip,
+// profiles/r02_tune_store_policy.log, n = 1e8, k = 20): 6.01 ms plain, 5.98 ms nt, 5.84 ms sc1, 5.75 ms sc1 nt
+// (no store at all: 4.77 ms).  There is no builtin for the sc bits, hence the one line of assembly.
+template <int W> __device__ __forceinline__ void st_stream(real* p, uint32_t i, const Pack<W>& a)
+{
+	if constexpr (W == kVec) {
+		rvec t;
+		#pragma unroll
+		for (int k = 0; k < W; k++) t[k] = (real) a.v[k];
+		asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p + i), "v"(t) : "memory");
+	} else p[i] = (real) a.v[0];
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 	#pragma unroll
@@ -895,7 +909,7 @@ __global__ void __launch_bounds__(kCoefBlock) k_coef(const double* bparts, int c
 // pass B: r = gamma g + sum_i cy_i y_i + sum_i cs_i s_i  (pairs visited oldest to newest).
 // A lane finishes T packs before it stores any of them: the single store stream (1 of 2k+2) costs
 // disproportionately when it trickles out between the loads, less when it leaves in groups.
-template <int W, bool NT, int T, bool H0V>
+template <int W, bool NT, int T, bool H0V, bool SS>
 __global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const double* coef, real* g, const real* H0,
                                                     uint32_t n, int rev, double* parts)
 {
@@ -970,7 +984,10 @@ __global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const 
 		#pragma unroll
 		for (int t = 0; t < T; t++) {
 			const uint32_t p = p0 + t * stride;
-			if (p < packs) st<W>(g, (rev ? last - p : p) * W, out[t]);
+			if (p < packs) {
+				if constexpr (SS) st_stream<W>(g, (rev ? last - p : p) * W, out[t]);
+				else st<W>(g, (rev ? last - p : p) * W, out[t]);
+			}
 		}
 	}
 	if (W > 1) {
@@ -1591,14 +1608,15 @@ Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, 
 	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
 	{
 		ProfScope ps(sc, K_COMBINE);
-		#define SQN_CB(W, T, HV) hipLaunchKernelGGL((k_combine<W, true, T, HV>), dim3(grid), dim3(kBlock), 0, sc.stream, ys, ss, sc.coef, g, H0, (uint32_t) n, rev, sc.part[buf])
+		#define SQN_CB(W, T, HV) { if (sc.stream_stores) hipLaunchKernelGGL((k_combine<W, true, T, HV, true>), dim3(grid), dim3(kBlock), 0, sc.stream, ys, ss, sc.coef, g, H0, (uint32_t) n, rev, sc.part[buf]); \
+		                           else hipLaunchKernelGGL((k_combine<W, true, T, HV, false>), dim3(grid), dim3(kBlock), 0, sc.stream, ys, ss, sc.coef, g, H0, (uint32_t) n, rev, sc.part[buf]); }
 		const int T = sc.combine_batch;
 		if (H0) {
-			if (vec) { if (T >= 4) SQN_CB(kVec, 4, true); else SQN_CB(kVec, 1, true); }
-			else     { if (T >= 4) SQN_CB(1, 4, true); else SQN_CB(1, 1, true); }
+			if (vec) { if (T >= 4) SQN_CB(kVec, 4, true) else SQN_CB(kVec, 1, true) }
+			else     { if (T >= 4) SQN_CB(1, 4, true) else SQN_CB(1, 1, true) }
 		} else {
-			if (vec) { if (T >= 8) SQN_CB(kVec, 8, false); else if (T >= 4) SQN_CB(kVec, 4, false); else if (T >= 2) SQN_CB(kVec, 2, false); else SQN_CB(kVec, 1, false); }
-			else     { if (T >= 8) SQN_CB(1, 8, false); else if (T >= 4) SQN_CB(1, 4, false); else if (T >= 2) SQN_CB(1, 2, false); else SQN_CB(1, 1, false); }
+			if (vec) { if (T >= 16) SQN_CB(kVec, 16, false) else if (T >= 8) SQN_CB(kVec, 8, false) else if (T >= 4) SQN_CB(kVec, 4, false) else if (T >= 2) SQN_CB(kVec, 2, false) else SQN_CB(kVec, 1, false) }
+			else     { if (T >= 8) SQN_CB(1, 8, false) else if (T >= 4) SQN_CB(1, 4, false) else if (T >= 2) SQN_CB(1, 2, false) else SQN_CB(1, 1, false) }
 		}
 		#undef SQN_CB
 	}

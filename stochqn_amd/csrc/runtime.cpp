@@ -261,6 +261,7 @@ void begin_call(DevCtx* c)
 	c->sc.combine_batch = g_opt.combine_batch;
 	c->sc.h0_per_cu = g_opt.h0_per_cu;
 	c->sc.fisher_rows = g_opt.fisher_rows;
+	c->sc.stream_stores = g_opt.stream_stores;
 	c->sc.prof = g_profile ? &c->prof : nullptr;
 	c->sc.phase = &c->phase;
 	c->phase = 1;
@@ -606,6 +607,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "combine_batch")) g_opt.combine_batch = (int) value;
 	else if (!std::strcmp(name, "h0_per_cu")) g_opt.h0_per_cu = (int) value;
 	else if (!std::strcmp(name, "fisher_rows")) g_opt.fisher_rows = (int) value;
+	else if (!std::strcmp(name, "stream_stores")) g_opt.stream_stores = value != 0;
 	else if (!std::strcmp(name, "reverse")) g_opt.reverse = value != 0;
 	else if (!std::strcmp(name, "twopass")) g_opt.twopass = value != 0;
 	else if (!std::strcmp(name, "twopass_h0")) g_opt.twopass_h0 = value != 0;

@@ -107,6 +107,7 @@ struct Scratch {
 	int combine_batch;    // packs a lane finishes in pass B before storing them (1, 2, 4, 8)
 	int h0_per_cu;        // workgroups per CU of the diagonal-H0 Gram pass (0 = 2)
 	int fisher_rows;      // Fisher rows one workgroup accumulates per pass over its columns: 8, 16 or 32
+	bool stream_stores;   // pass B stores its result with the agent-scope non-temporal policy (sc1 nt)
 	bool nontemporal;     // stream S/Y/F rows with nt loads
 	bool reverse;         // alternate the traversal direction from sweep to sweep (Infinity-Cache reuse of q / r)
 	int* phase;           // sweep counter of the current API call (parity = direction)
