@@ -261,6 +261,9 @@ Group* create_group(const Shape& sp, int P, bool owned, bool resumed)
 		if (ok && sp.need_diag) ok = dalloc(&s.H0, c, false) && dalloc(&s.G, c, true);
 		if (ok && fsz) ok = dalloc(&s.F, fsz * c, false);
 		if (ok && sp.kind == KIND_SQN) ok = dalloc(&s.hv, c, false);
+		// the shard's device context (scratch pool, pinned read-back block, Fisher partials) now, not inside the first
+		// call: a shard that ran out of memory there would leave the others waiting in an all-reduce
+		if (ok) ok = prepare_context(s.S, sp.kind, (int) c, m, fsz);
 		s.ok = ok;
 		if (!ok || owned) return;
 		// profile B: the caller's host arrays are the initial state (fresh R / numpy objects hold zeros

@@ -117,9 +117,10 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 	// a context that could not be completed is dropped again: the next call starts over (and
 	// re-imports host arrays) instead of continuing on half-bound views
 	if (!bind_bfgs(c, b, fresh && resumed)) { release(b->s_mem); return false; }
-	if (fresh) {
+	if (!c->attached) {                  // first call on this context (created now, or ahead of time by a shard group)
 		comm_attach(c);
 		c->forget_rows();
+		c->attached = true;
 	}
 	io.x_caller = x;
 	io.g_caller = grad;
@@ -1206,7 +1207,7 @@ static DevCtx* raw_context(real_t s_mem[], real_t y_mem[], int n, size_t mem_siz
 	// arrays): so the caches are dropped on every call unless the caller vouches for the arrays with
 	// option "raw_reuse_cache" = 1 (the two-loop micro-benchmark does).
 	if (!options().raw_reuse_cache || c->S.mirror || c->Y.mirror) c->forget_rows();
-	if (*fresh) comm_attach(c);
+	if (!c->attached) { comm_attach(c); c->attached = true; }
 	return c;
 }
 
@@ -1308,7 +1309,7 @@ static int fisher_product_impl(real_t F[], size_t fu, int n, real_t s[], real_t 
 	DevCtx* c = acquire(raw_key(F), KIND_RAW, n, 1, fu, &fresh);
 	if (!c) return -1000;
 	const size_t nn = (size_t) n;
-	if (fresh) comm_attach(c);
+	if (!c->attached) { comm_attach(c); c->attached = true; }
 	// F: used in place when on the device, else mirrored (re-uploaded every call: contents may have changed)
 	if (!bind(c, c->F, F, fu * nn, false)) return -1000;
 	if (c->F.mirror) SQN_HIP_OK(hipMemcpyAsync(c->F.dev, F, fu * nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));

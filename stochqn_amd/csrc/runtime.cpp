@@ -394,6 +394,12 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	return c;
 }
 
+bool prepare_context(const void* key, int kind, int n, size_t m, size_t fsize)
+{
+	bool fresh = false;
+	return acquire(key, kind, n, m, fsize, &fresh) != nullptr;
+}
+
 bool note_state(const void* key, size_t niter, int section)
 {
 	std::lock_guard<std::mutex> lk(g_mu);

@@ -94,6 +94,7 @@ struct DevCtx {
 	size_t pin_count = 0;
 	// what the caller's struct looked like when the last call on this context returned; a call that
 	// does not continue from there belongs to a different optimiser object at the same address
+	bool attached = false;             // the reducer was bound and n_global agreed (first call on this context)
 	bool fault = false;                // a launch or the stream reported an error: the call that saw it fails loudly
 	bool has_last = false;
 	size_t last_niter = 0;
@@ -124,6 +125,10 @@ bool is_device_pointer(const void* p);
 // Find or create the context of a workspace.  `fresh` tells the caller whether it was created now.
 DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* fresh);
 DevCtx* lookup(const void* key);
+// Create the context of a workspace ahead of its first call (all its allocations, no collective): the shards of
+// a multi-device group do this together, so that none of them can fail on memory while the others are already
+// waiting in an all-reduce.
+bool prepare_context(const void* key, int kind, int n, size_t m, size_t fsize);
 // registry key of the context behind the isolated entry points (stochqn_hip_two_loop / _take_step) for the arrays at `s_mem`
 inline const void* raw_key(const void* s_mem) { return static_cast<const char*>(s_mem) + 1; }
 // remember the caller-visible state on return; true if the context saw a HIP error during the call

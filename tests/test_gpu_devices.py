@@ -214,3 +214,86 @@ def test_more_devices_than_gpus_without_virtual_devices_falls_back(hip_backend, 
         lib.stochqn_hip_release_all()
         lib.stochqn_hip_set_option(b"devices", 0.0)
         lib.stochqn_hip_set_option(b"devices_min_n", float(1 << 20))
+
+
+@pytest.mark.parametrize("profile", ["host_arrays", "library_owned"])
+def test_allocation_failures_while_sharding_are_refused_cleanly(profile, hip_backend, oracle_backend, capfd):
+    """Every device / pinned allocation of setting a workspace up on 3 shards fails in turn (fault injection): the call
+    that needed it returns -1000 / NULL with a message -- no shard is left waiting in a reduction -- and the next
+    attempt, with memory available again, runs the oracle's trajectory from the start."""
+    lib = _lib()
+    assert lib.stochqn_hip_set_option(b"virtual_devices", 1.0) == 0
+    assert lib.stochqn_hip_set_option(b"devices_min_n", 1.0) == 0
+    assert lib.stochqn_hip_set_option(b"devices", 3.0) == 0
+    n = 1200
+    P = NoisyQuadratic(n, seed=2)
+    kw = dict(mem_size=3, bfgs_upd_freq=3)
+    want = run_trace(OPTIMIZERS["SQN"](backend=oracle_backend, space="host", **kw), P, P.x0(), 0.1, 20)
+    refused = 0
+    try:
+        for k in range(0, 80):
+            lib.stochqn_hip_set_option(b"fail_alloc_after", float(k))
+            if profile == "host_arrays":
+                opt = OPTIMIZERS["SQN"](backend=hip_backend, space="host", **kw)
+                x = P.x0()
+                try:
+                    opt.run_optimizer(x, 0.1)            # section 0: no device work yet
+                    opt.update_gradient(P.grad(x, 0))
+                    opt.run_optimizer(x, 0.1)            # first step: the group is built here
+                    failed = False
+                except ValueError:
+                    failed = True
+                lib.stochqn_hip_set_option(b"fail_alloc_after", -1.0)
+                if failed:
+                    refused += 1
+                    assert np.array_equal(x, P.x0())     # nothing was touched
+                opt.release()
+                fresh = OPTIMIZERS["SQN"](backend=hip_backend, space="host", **kw)
+                compare_traces(run_trace(fresh, P, P.x0(), 0.1, 20), want, TOL)
+                fresh.release()
+            else:
+                w = hip_backend.initialize_SQN(n, 3, 3, 1e-4, 0, 0.0, 1, 1)
+                lib.stochqn_hip_set_option(b"fail_alloc_after", -1.0)
+                failed = not bool(w)
+                if failed:
+                    refused += 1
+                else:
+                    hip_backend.dealloc_SQN(w)
+            if not failed and k > 10:
+                break                                    # the injection point lies beyond the last allocation
+    finally:
+        lib.stochqn_hip_set_option(b"fail_alloc_after", -1.0)
+        lib.stochqn_hip_release_all()
+        lib.stochqn_hip_set_option(b"devices", 0.0)
+        lib.stochqn_hip_set_option(b"virtual_devices", 0.0)
+        lib.stochqn_hip_set_option(b"devices_min_n", float(1 << 20))
+    assert refused >= 10, refused
+    assert "could not allocate" in capfd.readouterr().err.lower()
+
+
+def test_float_abi_on_device_shards(hip_backend):
+    """libstochqn_f32.so in the same mode (the group front-end is compiled for both precisions)."""
+    import stochqn_amd
+    from oracle import oracle
+    from test_gpu_parity import F32_TOL
+    be32 = stochqn_amd.lib(use_float=True)
+    lib32 = stochqn_amd.cdll(use_float=True)
+    lib32.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    lib32.stochqn_hip_devices_active.argtypes = [C.c_void_p]
+    for name, val in ((b"virtual_devices", 1.0), (b"devices_min_n", 1.0), (b"devices", 3.0)):
+        assert lib32.stochqn_hip_set_option(name, val) == 0
+    try:
+        for cfgname in ("sqn_hessvec", "olbfgs_default", "sqn_graddiff"):      # free-running float trajectories: the tamer configurations
+            _, optname, kw, step, calls, pkw = [c for c in CONFIGS if c[0] == cfgname][0]
+            P = NoisyQuadratic(2000, seed=7, **pkw)
+            want = run_trace(OPTIMIZERS[optname](backend=oracle.bound_f32(), space="host", use_float=True, **kw), P, P.x0().astype(np.float32), step, 40)
+            opt = OPTIMIZERS[optname](backend=be32, space="host", use_float=True, **kw)
+            got = run_trace(opt, P, P.x0().astype(np.float32), step, 40)
+            assert lib32.stochqn_hip_devices_active(C.c_void_p(opt.BFGS_mem.s_mem.ctypes.data)) == 3
+            compare_traces(got, want, 3 * F32_TOL)
+            opt.release()
+    finally:
+        lib32.stochqn_hip_release_all()
+        lib32.stochqn_hip_set_option(b"devices", 0.0)
+        lib32.stochqn_hip_set_option(b"virtual_devices", 0.0)
+        lib32.stochqn_hip_set_option(b"devices_min_n", float(1 << 20))
