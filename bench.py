@@ -128,7 +128,11 @@ def main():
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.in_process:
+    if args.in_process:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("--in-process is a single-process mode: do not start it under a launcher")
+        return run_in_process(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     run(args)
 
@@ -147,10 +151,7 @@ def run(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    shards = args.gpus if args.in_process else 1       # shards inside this process
-    if args.in_process:
-        raise SystemExit("--in-process: use tools/bench_devices.py (host caller through the plain ABI, PCIe-inclusive)")
-    if not args.in_process and world != args.gpus:
+    if world != args.gpus:
         raise SystemExit("--gpus (%d) must equal WORLD_SIZE (%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the library has no CPU path)")
@@ -166,11 +167,6 @@ def run(args):
     for kv in args.opt:
         name, val = kv.split("=")
         assert lib.stochqn_hip_set_option(name.encode(), float(val)) == 0, kv
-    if args.in_process:
-        if args.virtual_devices:
-            assert lib.stochqn_hip_set_option(b"virtual_devices", 1.0) == 0
-        assert lib.stochqn_hip_set_option(b"devices", float(shards)) == 0, "this build has no single-process multi-device mode"
-
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -208,7 +204,7 @@ def run(args):
     cpu_or_dev = "cpu" if args.rehearse else dev
 
     n_gpu = args.n if args.n > 0 else CONFIGS[args.config]     # variables per GPU
-    n = n_gpu * shards                                         # variables this process holds
+    n = n_gpu                                                  # variables this process holds
     n_total = n * world
     first = rank * n                                           # global index of this rank's first variable
     m, L, bs = args.mem, args.upd_freq, args.bsize
@@ -292,16 +288,6 @@ def run(args):
             v = float(tv.item())
         return v
 
-    def kernel_table():
-        kern = {}
-        lib.stochqn_hip_profile_name.restype = C.c_char_p
-        for i in range(lib.stochqn_hip_profile_kernels()):
-            cnt, ms = C.c_longlong(), C.c_double()
-            lib.stochqn_hip_profile_get(i, C.byref(cnt), C.byref(ms))
-            if cnt.value:
-                kern[lib.stochqn_hip_profile_name(i).decode()] = (cnt.value, ms.value)
-        return kern
-
     # ---- the measurement: W warm-up steps, then EXACTLY K steps, profiler off -----------------------
     f0 = objective()
     t_idx = 0
@@ -350,7 +336,344 @@ def run(args):
         barrier()
         prof_elapsed = time.perf_counter() - t1
         lib.stochqn_hip_profile_enable(0)
-        kern = kernel_table()
+        kern = kernel_table(lib)
+    detail, roof, two_loop, what = analyse_kernels(kern, n_gpu, m, bs, prof_steps, 1)
+
+    steps_per_s = args.steps / elapsed
+    value = steps_per_s * n_total / 1e8
+
+    # ---- outside the timed region: the same workload in the reference's own dependency structure
+    # (2m+1 dependent fused sweeps, 64*m*n algorithmic bytes) for the roofline the north star names --
+    ref_form = None
+    if "combine" in kern and not args.no_reference_form:
+        lib.stochqn_hip_set_option(b"twopass", 0.0)
+        for _ in range(2):
+            one_step(t_idx)
+            t_idx += 1
+        lib.stochqn_hip_profile_enable(1)
+        lib.stochqn_hip_profile_reset()
+        barrier()
+        t1 = time.perf_counter()
+        extra = 10
+        for _ in range(extra):
+            one_step(t_idx)
+            t_idx += 1
+        barrier()
+        el2 = time.perf_counter() - t1
+        lib.stochqn_hip_profile_enable(0)
+        lib.stochqn_hip_set_option(b"twopass", 1.0)
+        k2 = kernel_table(lib)
+        if "bwd" in k2:
+            cnt, ms = k2["bwd"]
+            ach = 4 * n_gpu * 8 / (ms / cnt * 1e-3) / 1e9
+            tl = sum(k2[k][1] for k in ("first", "bwd", "mid", "fwd", "fwd_last") if k in k2) / extra
+            tr, src = pmc_traffic("bwd", n_gpu, m)
+            ref_form = {"note": "same workload with --opt twopass=0, %d steps after the timed region" % extra,
+                        "steps_per_s": round(extra / el2 * n_total / 1e8, 3),
+                        "two_loop_ms": round(tl, 3), "two_loop_alg_bytes": 64 * m * n_gpu,
+                        "two_loop_alg_GBps": round(64.0 * m * n_gpu / (tl * 1e-3) / 1e9, 1),
+                        "two_loop_frac_of_8TBps": round(64.0 * m * n_gpu / (tl * 1e-3) / 1e9 / PEAK, 4),
+                        "roofline": {"bound": "hbm", "kernel": "bwd (%s)" % what["bwd"], "achieved": round(ach, 1),
+                                     "peak": PEAK, "unit": "GB/s", "frac": round(ach / PEAK, 4), "traffic": tr,
+                                     "traffic_source": src, "alg_bytes_per_launch": 4 * n_gpu * 8,
+                                     "avg_launch_ms": round(ms / cnt, 4)}}
+
+    # ---- the two-loop recursion on its own (SURVEY.md 8d "two-loop micro-benchmark"): the ring as the
+    # run left it (m pairs, oldest in row mem_st_ix), H0 = NULL, h0 = 0; 3 warm-up + 20 timed calls of
+    # stochqn_hip_two_loop per form, median wall clock of the synchronous call --------------------------
+    micro = None
+    if not args.no_reference_form:
+        lib.stochqn_hip_two_loop.restype = C.c_int
+        lib.stochqn_hip_two_loop.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        g0 = uniform(torch.empty(n, dtype=f64, device=dev), 2, 0, -0.5, 1.0)          # g_i = u(i,2,t) - 0.5
+        gq = torch.empty_like(g0)
+        micro = {"note": "stochqn_hip_two_loop alone: mem_used=%d, oldest pair in row %d, H0=NULL, 3 warm-up + 20 calls, median; "
+                         "reference-form bytes = SURVEY 8d's 64*m*n (the sweeps form moves exactly those; the two-pass form moves (4m+3)*n*8)" % (m, b.mem_st_ix)}
+        lib.stochqn_hip_set_option(b"raw_reuse_cache", 1.0)      # S and Y do not change between these calls
+        for form, flag in (("two_pass", 1.0), ("sweeps", 0.0)):
+            lib.stochqn_hip_set_option(b"twopass", flag)
+            ts = []
+            for rep in range(23):
+                gq.copy_(g0)
+                barrier()
+                tq = time.perf_counter()
+                rc = lib.stochqn_hip_two_loop(gq.data_ptr(), n, None, 0.0, Y.data_ptr(), S.data_ptr(), m, m, b.mem_st_ix,
+                                              rho_h.ctypes.data, alpha_h.ctypes.data)
+                assert rc == 0
+                ts.append(time.perf_counter() - tq)
+            med = sorted(ts[3:])[10]
+            if dist is not None:
+                tm = torch.tensor([med], dtype=f64, device=cpu_or_dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                med = float(tm.item())
+            moved = ((4 * m + 3) if form == "two_pass" else 8 * m) * n * 8        # bytes this form has to stream
+            micro[form] = {"median_ms": round(1e3 * med, 3), "bytes_moved": moved,
+                           "GBps_on_bytes_moved": round(moved / med / 1e9, 1),
+                           "frac_of_8TBps_on_bytes_moved": round(moved / med / 1e9 / PEAK, 4),
+                           "GBps_on_reference_form_bytes": round(64.0 * m * n / med / 1e9, 1)}
+        lib.stochqn_hip_set_option(b"twopass", 1.0)
+        lib.stochqn_hip_set_option(b"raw_reuse_cache", 0.0)
+        lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))      # the raw context keyed by S; the optimiser is finished
+        del g0, gq
+
+    # ---- CPU baseline: the oracle on the host cores, the same workload, bounded sample --------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:     # a reported baseline of the N = 1 line only
+        lib.stochqn_hip_release_all()
+        fill_ring()                                          # the state the GPU leg started from
+        uniform(x, ST_X0, 0, 1.0, 1.0)
+        torch.cuda.synchronize()
+        gpu = {"S": S, "Y": Y, "A": A, "d": d, "x": x, "noise": lambda t, out: uniform(out, ST_NOISE, t, 0.99, 0.02)}
+        cpu = cpu_baseline(args, gpu, n, m, L, bs, step_size)
+
+    if rank == 0:
+        par = ("n sharded over %d GPU(s), one process per GPU; one RCCL all-reduce per dot product" % world)
+        if args.rehearse:
+            par = "REHEARSAL: %d ranks sharing one GPU, all-reduce over gloo -- not a measurement" % world
+        out = {
+            "metric": "optimizer steps/sec + achieved HBM GB/s, two-loop at n=10^8 m=20 fp64",
+            "value": round(value, 3),
+            "unit": "steps/s" if n_total == 100_000_000 else "steps/s normalised to n=1e8 (steps/s * n_total/1e8)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "SQN n=%g per GPU (n_total=%g), m=%d, L=%d, Hessian-vector pairs via A'(Av)/%d, "
+                                   "check_nan=1, ring full, fp64" % (n_gpu, n_total, m, L, bs),
+                       "name": args.config if args.n <= 0 else "custom",
+                       "parallelism": par,
+                       "inputs": "counter-based generator (stochqn_hip_synth_*, seed %d): shard-invariant" % SEED,
+                       "calls": timed_counters["calls"], "hess_vec_requests": timed_counters["hv"],
+                       "rejected_steps": timed_counters["bad"], "rejected_pairs": timed_counters["rejected"],
+                       "options": args.opt,
+                       "f_start": f0, "f_end": f1},
+            "rccl_nranks": rccl_nranks,
+            "per_rank_ms_per_step": per_rank_ms,
+            "steps_per_s_unnormalised": round(steps_per_s, 3),
+            "profiled_pass": None if prof_elapsed is None else {"steps": prof_steps, "ms_per_step": round(1e3 * prof_elapsed / prof_steps, 3)},
+            "roofline": roof,
+            "two_loop": two_loop,
+            "two_loop_micro": micro,
+            "reference_form": ref_form,
+            "kernels": detail,
+            "cpu_baseline": cpu,
+        }
+        if args.config == "c5" or n_gpu == CONFIGS["c5"]:
+            out["shard_reference_1gpu"] = shard_reference(world, steps_per_s)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if dist is not None:
+        lib.stochqn_hip_comm_finalize()
+        dist.destroy_process_group()
+    lib.stochqn_hip_release_all()
+
+
+def run_in_process(args):
+    """`--gpus N --in-process`: ONE host process, the library's single-process multi-device mode (group.cpp), a
+    device-resident caller: initialize_SQN(n_total) hands out a workspace sharded over the N devices, the
+    caller keeps x / grad / hess_vec as per-device slices (stochqn_hip_devices_layout / _bind), calls run_SQN
+    once per step and does its own per-shard work -- the synthetic gradient, the Hessian-vector product
+    A'(Av)/bs through stochqn_hip_fisher_product -- on the shards' threads (stochqn_hip_devices_foreach), so
+    that the product's reduction spans the shards.  Same problem as the one-process-per-GPU run (counter-
+    based inputs); the ring is filled by running the optimiser itself (m*L untimed steps) because the arrays
+    of a library-owned sharded workspace are not the caller's to pre-fill."""
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    import numpy as np
+    import torch
+    import stochqn_amd
+    P = args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the library has no CPU path)")
+    if torch.cuda.device_count() < P and not args.virtual_devices:
+        raise SystemExit("bench.py: --gpus %d --in-process asked for but only %d device(s) are visible "
+                         "(--virtual-devices rehearses the mode on fewer)" % (P, torch.cuda.device_count()))
+    lib = stochqn_amd.cdll()
+    be = stochqn_amd.lib()
+    assert lib.stochqn_hip_available() == 1
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    for kv in args.opt:
+        name, val = kv.split("=")
+        assert lib.stochqn_hip_set_option(name.encode(), float(val)) == 0, kv
+    if args.virtual_devices:
+        assert lib.stochqn_hip_set_option(b"virtual_devices", 1.0) == 0
+    assert lib.stochqn_hip_set_option(b"devices_min_n", 1.0) == 0
+    assert lib.stochqn_hip_set_option(b"devices", float(P)) == 0
+
+    n_gpu = args.n if args.n > 0 else CONFIGS[args.config]
+    n_total = n_gpu * P
+    m, L, bs = args.mem, args.upd_freq, args.bsize
+    f64 = torch.float64
+    u64 = C.c_ulonglong
+    vp = C.c_void_p
+    lib.stochqn_hip_synth_uniform.argtypes = [vp, C.c_size_t, u64, u64, u64, u64, C.c_double, C.c_double]
+    lib.stochqn_hip_synth_noisy_grad.argtypes = [vp, vp, vp, C.c_size_t, u64, u64, u64, u64, C.c_double]
+    lib.stochqn_hip_synth_batch_row.argtypes = [vp, vp, C.c_size_t, u64, C.c_uint, C.c_uint]
+    lib.stochqn_hip_fisher_product.argtypes = [vp, C.c_size_t, C.c_int, vp, vp, vp]
+    lib.stochqn_hip_devices_active.argtypes = [vp]
+    lib.stochqn_hip_devices_reducer.argtypes = [vp]
+    lib.stochqn_hip_devices_layout.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.stochqn_hip_devices_bind.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.stochqn_hip_devices_request.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
+    SHARD_FN = C.CFUNCTYPE(None, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t)
+    lib.stochqn_hip_devices_foreach.argtypes = [vp, SHARD_FN, vp]
+
+    w = be.initialize_SQN(n_total, m, L, 0.0, 0, 0.0, 1, 1)
+    assert bool(w), "initialize_SQN(n = %d) on %d device shards failed" % (n_total, P)
+    key = vp(w.contents.bfgs_memory.contents.s_mem)
+    assert lib.stochqn_hip_devices_active(key) == P
+    reducer = {1: "RCCL (ncclCommInitAll)", 3: "host-side rendezvous (virtual devices)"}.get(lib.stochqn_hip_devices_reducer(key), "?")
+
+    shards = []
+    for p in range(P):
+        dv, off, cnt = C.c_int(), C.c_size_t(), C.c_size_t()
+        assert lib.stochqn_hip_devices_layout(key, p, C.byref(dv), C.byref(off), C.byref(cnt)) == 0
+        dev = torch.device("cuda", dv.value)
+        torch.cuda.set_device(dev)                       # the synth kernels go to the current device's null stream
+        k = cnt.value
+        sh = {"dev": dev, "off": off.value, "cnt": k}
+        for name in ("d", "x", "grad", "hv"):
+            sh[name] = torch.empty(k, dtype=f64, device=dev)
+        sh["t"] = np.zeros(bs)
+        assert lib.stochqn_hip_synth_uniform(sh["d"].data_ptr(), k, off.value, SEED, ST_D, 0, 0.5, 1.0) == 0
+        assert lib.stochqn_hip_synth_uniform(sh["x"].data_ptr(), k, off.value, SEED, ST_X0, 0, 1.0, 1.0) == 0
+        sh["A"] = torch.empty(bs * k, dtype=f64, device=dev)
+        for r in range(bs):
+            assert lib.stochqn_hip_synth_batch_row(sh["A"].data_ptr() + 8 * r * k, sh["d"].data_ptr(), k, off.value, r, bs) == 0
+        assert lib.stochqn_hip_devices_bind(key, p, sh["x"].data_ptr(), sh["grad"].data_ptr(), sh["hv"].data_ptr()) == 0
+        shards.append(sh)
+    for sh in shards:
+        torch.cuda.synchronize(sh["dev"])
+    torch.cuda.set_device(shards[0]["dev"])
+
+    req, req_vec, task, info = vp(), vp(), C.c_int(0), C.c_int(200)
+    dummy = np.zeros(1)                                  # run_SQN wants non-NULL x / grad / hess_vec; bound shards never read them
+    cur = {"task": 0, "t": 0}
+    counters = {"calls": 0, "hv": 0, "bad": 0, "rejected": 0}
+    errors = []
+
+    def shard_work(user, p, device, off, cnt):           # on shard p's own thread, its device current, its reducer bound
+        try:
+            sh = shards[p]
+            rq, rqv = vp(), vp()
+            assert lib.stochqn_hip_devices_request(key, p, C.byref(rq), C.byref(rqv)) == 0
+            if cur["task"] == 101:
+                assert lib.stochqn_hip_synth_noisy_grad(sh["grad"].data_ptr(), sh["d"].data_ptr(), rq.value, cnt, off, SEED, ST_NOISE, cur["t"], 0.01) == 0
+            elif cur["task"] == 104:
+                assert lib.stochqn_hip_fisher_product(sh["A"].data_ptr(), bs, cnt, rqv.value, sh["t"].ctypes.data, sh["hv"].data_ptr()) == 0
+        except Exception as e:                           # an exception must not escape into the C thread
+            errors.append(repr(e))
+
+    work_cb = SHARD_FN(shard_work)
+
+    def call():
+        rc = be.run_SQN(0.05, dummy.ctypes.data, dummy.ctypes.data, dummy.ctypes.data, C.byref(req), C.byref(req_vec),
+                        C.byref(task), w, C.byref(info))
+        assert rc in (0, 1), rc
+        counters["calls"] += 1
+        counters["bad"] += info.value == 203
+        counters["rejected"] += info.value == 202
+
+    def one_step(t):
+        target = w.contents.niter + 1
+        while w.contents.niter < target:
+            cur["task"], cur["t"] = task.value, t
+            if task.value == 104:
+                counters["hv"] += 1
+            assert lib.stochqn_hip_devices_foreach(key, work_cb, None) == 0 and not errors, errors
+            call()
+
+    def sync_all():
+        for sh in shards:
+            torch.cuda.synchronize(sh["dev"])
+
+    def objective():
+        return sum(float(0.5 * torch.sum(sh["d"] * sh["x"] * sh["x"])) for sh in shards)
+
+    call()                                               # section 0: "give me a gradient at x"
+    f0 = objective()
+    t_idx = 0
+    fill = m * L + L                                     # the optimiser fills its own ring: m pairs, one every L steps
+    for _ in range(fill + args.warmup):
+        one_step(t_idx)
+        t_idx += 1
+    assert w.contents.bfgs_memory.contents.mem_used == m, "the ring did not fill up"
+    lib.stochqn_hip_profile_enable(0)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(t_idx)
+        t_idx += 1
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    f1 = objective()
+    assert np.isfinite(f1) and f1 < f0, "optimiser diverged on the synthetic quadratic: %r -> %r" % (f0, f1)
+    timed_counters = dict(counters)
+
+    kern, prof_elapsed, prof_steps = {}, None, 0
+    if not args.no_profile:
+        prof_steps = max(L, min(args.steps, 4 * L)) // L * L
+        lib.stochqn_hip_profile_enable(1)
+        lib.stochqn_hip_profile_reset()
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(prof_steps):
+            one_step(t_idx)
+            t_idx += 1
+        sync_all()
+        prof_elapsed = time.perf_counter() - t1
+        lib.stochqn_hip_profile_enable(0)
+        kern = kernel_table(lib)
+    detail, roof, two_loop, _ = analyse_kernels(kern, n_gpu, m, bs, prof_steps, P)
+    steps_per_s = args.steps / elapsed
+    out = {
+        "metric": "optimizer steps/sec + achieved HBM GB/s, two-loop at n=10^8 m=20 fp64",
+        "value": round(steps_per_s * n_total / 1e8, 3),
+        "unit": "steps/s" if n_total == 100_000_000 else "steps/s normalised to n=1e8 (steps/s * n_total/1e8)",
+        "n_gpus": P, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "SQN n=%g per GPU (n_total=%g), m=%d, L=%d, Hessian-vector pairs via A'(Av)/%d, "
+                               "check_nan=1, ring full (filled by %d untimed steps of the run itself), fp64" % (n_gpu, n_total, m, L, bs, fill),
+                   "name": args.config if args.n <= 0 else "custom",
+                   "parallelism": "n sharded over %d device shard(s) inside ONE process behind the plain ABI (option devices=%d), "
+                                  "device-resident caller (stochqn_hip_devices_bind); reducer: %s%s" % (
+                                      P, P, reducer, " -- shards share devices: a rehearsal, not a measurement" if args.virtual_devices else ""),
+                   "inputs": "counter-based generator (stochqn_hip_synth_*, seed %d): shard-invariant" % SEED,
+                   "calls": timed_counters["calls"], "hess_vec_requests": timed_counters["hv"],
+                   "rejected_steps": timed_counters["bad"], "rejected_pairs": timed_counters["rejected"],
+                   "options": args.opt, "f_start": f0, "f_end": f1},
+        "rccl_nranks": P if reducer.startswith("RCCL") else 1,
+        "device_shards": P,
+        "steps_per_s_unnormalised": round(steps_per_s, 3),
+        "profiled_pass": None if prof_elapsed is None else {"steps": prof_steps, "ms_per_step": round(1e3 * prof_elapsed / prof_steps, 3)},
+        "roofline": roof, "two_loop": two_loop, "two_loop_micro": None, "reference_form": None,
+        "kernels": detail, "cpu_baseline": None,
+    }
+    if args.dump_x:
+        np.save("%s.0.npy" % args.dump_x, np.concatenate([sh["x"].cpu().numpy() for sh in shards]))
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    be.dealloc_SQN(w)
+    lib.stochqn_hip_release_all()
+
+
+def kernel_table(lib):
+    """Per-kernel (launches, total ms) of the library's HIP-event profiler."""
+    kern = {}
+    lib.stochqn_hip_profile_name.restype = C.c_char_p
+    for i in range(lib.stochqn_hip_profile_kernels()):
+        cnt, ms = C.c_longlong(), C.c_double()
+        lib.stochqn_hip_profile_get(i, C.byref(cnt), C.byref(ms))
+        if cnt.value:
+            kern[lib.stochqn_hip_profile_name(i).decode()] = (cnt.value, ms.value)
+    return kern
+
+
+def analyse_kernels(kern, n_gpu, m, bs, prof_steps, shards):
+    """Kernel table -> (per-kernel detail, roofline of the dominant kernel, two-loop summary, kernel descriptions).
+    `shards` = device shards whose launches the table aggregates (1 per process except --in-process)."""
     # algorithmic n-words per launch (DESIGN.md section 3)
     words = {"first": 2, "bwd": 4, "mid": 3, "fwd": 4, "fwd_last": 3, "apply": 5,
              "rows_dot": 2 * m + 1, "rows_dot3": 2 * m + 3, "combine": 2 * m + 2,
@@ -392,136 +715,7 @@ def run(args):
                     "reference_form_bytes": 64 * m * n_gpu,
                     "effective_GBps_vs_reference_form": round(64.0 * m * n_gpu / (two_loop_ms * 1e-3) / 1e9, 1)}
 
-    steps_per_s = args.steps / elapsed
-    value = steps_per_s * n_total / 1e8
-
-    # ---- outside the timed region: the same workload in the reference's own dependency structure
-    # (2m+1 dependent fused sweeps, 64*m*n algorithmic bytes) for the roofline the north star names --
-    ref_form = None
-    if "combine" in kern and not args.no_reference_form:
-        lib.stochqn_hip_set_option(b"twopass", 0.0)
-        for _ in range(2):
-            one_step(t_idx)
-            t_idx += 1
-        lib.stochqn_hip_profile_enable(1)
-        lib.stochqn_hip_profile_reset()
-        barrier()
-        t1 = time.perf_counter()
-        extra = 10
-        for _ in range(extra):
-            one_step(t_idx)
-            t_idx += 1
-        barrier()
-        el2 = time.perf_counter() - t1
-        lib.stochqn_hip_profile_enable(0)
-        lib.stochqn_hip_set_option(b"twopass", 1.0)
-        k2 = kernel_table()
-        if "bwd" in k2:
-            cnt, ms = k2["bwd"]
-            ach = 4 * n_gpu * 8 / (ms / cnt * 1e-3) / 1e9
-            tl = sum(k2[k][1] for k in ("first", "bwd", "mid", "fwd", "fwd_last") if k in k2) / (extra * shards)
-            tr, src = pmc_traffic("bwd", n_gpu, m)
-            ref_form = {"note": "same workload with --opt twopass=0, %d steps after the timed region" % extra,
-                        "steps_per_s": round(extra / el2 * n_total / 1e8, 3),
-                        "two_loop_ms": round(tl, 3), "two_loop_alg_bytes": 64 * m * n_gpu,
-                        "two_loop_alg_GBps": round(64.0 * m * n_gpu / (tl * 1e-3) / 1e9, 1),
-                        "two_loop_frac_of_8TBps": round(64.0 * m * n_gpu / (tl * 1e-3) / 1e9 / PEAK, 4),
-                        "roofline": {"bound": "hbm", "kernel": "bwd (%s)" % what["bwd"], "achieved": round(ach, 1),
-                                     "peak": PEAK, "unit": "GB/s", "frac": round(ach / PEAK, 4), "traffic": tr,
-                                     "traffic_source": src, "alg_bytes_per_launch": 4 * n_gpu * 8,
-                                     "avg_launch_ms": round(ms / cnt, 4)}}
-
-    # ---- the two-loop recursion on its own (SURVEY.md 8d "two-loop micro-benchmark"): the ring as the
-    # run left it (m pairs, oldest in row mem_st_ix), H0 = NULL, h0 = 0; 3 warm-up + 20 timed calls of
-    # stochqn_hip_two_loop per form, median wall clock of the synchronous call --------------------------
-    micro = None
-    if not args.no_reference_form and not args.in_process:
-        lib.stochqn_hip_two_loop.restype = C.c_int
-        lib.stochqn_hip_two_loop.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
-                                             C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
-        g0 = uniform(torch.empty(n, dtype=f64, device=dev), 2, 0, -0.5, 1.0)          # g_i = u(i,2,t) - 0.5
-        gq = torch.empty_like(g0)
-        micro = {"note": "stochqn_hip_two_loop alone: mem_used=%d, oldest pair in row %d, H0=NULL, 3 warm-up + 20 calls, median; "
-                         "reference-form bytes = SURVEY 8d's 64*m*n (the sweeps form moves exactly those; the two-pass form moves (4m+3)*n*8)" % (m, b.mem_st_ix)}
-        lib.stochqn_hip_set_option(b"raw_reuse_cache", 1.0)      # S and Y do not change between these calls
-        for form, flag in (("two_pass", 1.0), ("sweeps", 0.0)):
-            lib.stochqn_hip_set_option(b"twopass", flag)
-            ts = []
-            for rep in range(23):
-                gq.copy_(g0)
-                barrier()
-                tq = time.perf_counter()
-                rc = lib.stochqn_hip_two_loop(gq.data_ptr(), n, None, 0.0, Y.data_ptr(), S.data_ptr(), m, m, b.mem_st_ix,
-                                              rho_h.ctypes.data, alpha_h.ctypes.data)
-                assert rc == 0
-                ts.append(time.perf_counter() - tq)
-            med = sorted(ts[3:])[10]
-            if dist is not None:
-                tm = torch.tensor([med], dtype=f64, device=cpu_or_dev)
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                med = float(tm.item())
-            moved = ((4 * m + 3) if form == "two_pass" else 8 * m) * n * 8        # bytes this form has to stream
-            micro[form] = {"median_ms": round(1e3 * med, 3), "bytes_moved": moved,
-                           "GBps_on_bytes_moved": round(moved / med / 1e9, 1),
-                           "frac_of_8TBps_on_bytes_moved": round(moved / med / 1e9 / PEAK, 4),
-                           "GBps_on_reference_form_bytes": round(64.0 * m * n / med / 1e9, 1)}
-        lib.stochqn_hip_set_option(b"twopass", 1.0)
-        lib.stochqn_hip_set_option(b"raw_reuse_cache", 0.0)
-        lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))      # the raw context keyed by S; the optimiser is finished
-        del g0, gq
-
-    # ---- CPU baseline: the oracle on the host cores, the same workload, bounded sample --------------
-    cpu = None
-    if rank == 0 and world == 1 and shards == 1 and not args.no_cpu_baseline:     # a reported baseline of the N = 1 line only
-        lib.stochqn_hip_release_all()
-        fill_ring()                                          # the state the GPU leg started from
-        uniform(x, ST_X0, 0, 1.0, 1.0)
-        torch.cuda.synchronize()
-        gpu = {"S": S, "Y": Y, "A": A, "d": d, "x": x, "noise": lambda t, out: uniform(out, ST_NOISE, t, 0.99, 0.02)}
-        cpu = cpu_baseline(args, gpu, n, m, L, bs, step_size)
-
-    if rank == 0:
-        par = ("n sharded over %d GPU(s), one process per GPU; one RCCL all-reduce per dot product" % world)
-        if args.in_process:
-            par = "n sharded over %d device shard(s) inside ONE process (library option devices=%d%s)" % (
-                shards, shards, ", virtual devices: rehearsal, not a measurement" if args.virtual_devices else "")
-        if args.rehearse:
-            par = "REHEARSAL: %d ranks sharing one GPU, all-reduce over gloo -- not a measurement" % world
-        out = {
-            "metric": "optimizer steps/sec + achieved HBM GB/s, two-loop at n=10^8 m=20 fp64",
-            "value": round(value, 3),
-            "unit": "steps/s" if n_total == 100_000_000 else "steps/s normalised to n=1e8 (steps/s * n_total/1e8)",
-            "n_gpus": world * shards, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "SQN n=%g per GPU (n_total=%g), m=%d, L=%d, Hessian-vector pairs via A'(Av)/%d, "
-                                   "check_nan=1, ring full, fp64" % (n_gpu, n_total, m, L, bs),
-                       "name": args.config if args.n <= 0 else "custom",
-                       "parallelism": par,
-                       "inputs": "counter-based generator (stochqn_hip_synth_*, seed %d): shard-invariant" % SEED,
-                       "calls": timed_counters["calls"], "hess_vec_requests": timed_counters["hv"],
-                       "rejected_steps": timed_counters["bad"], "rejected_pairs": timed_counters["rejected"],
-                       "options": args.opt,
-                       "f_start": f0, "f_end": f1},
-            "rccl_nranks": rccl_nranks,
-            "per_rank_ms_per_step": per_rank_ms,
-            "steps_per_s_unnormalised": round(steps_per_s, 3),
-            "profiled_pass": None if prof_elapsed is None else {"steps": prof_steps, "ms_per_step": round(1e3 * prof_elapsed / prof_steps, 3)},
-            "roofline": roof,
-            "two_loop": two_loop,
-            "two_loop_micro": micro,
-            "reference_form": ref_form,
-            "kernels": detail,
-            "cpu_baseline": cpu,
-        }
-        if args.config == "c5" or n_gpu == CONFIGS["c5"]:
-            out["shard_reference_1gpu"] = shard_reference(world * shards, steps_per_s)
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        lib.stochqn_hip_comm_finalize()
-        dist.destroy_process_group()
-    lib.stochqn_hip_release_all()
+    return detail, roof, two_loop, what
 
 
 def shard_reference(n_gpus, steps_per_s):

@@ -159,6 +159,23 @@ void stochqn_hip_comm_finalize(void);
 int stochqn_hip_devices_active(const void *s_mem);    /* shards this workspace runs on (0: single-device path) */
 int stochqn_hip_devices_reducer(const void *s_mem);   /* 1 = RCCL, 3 = host-side rendezvous (virtual devices), 0 = none */
 
+/* Device-resident callers of the single-process mode (a process that keeps its vectors on the GPUs, e.g. torch
+ * tensors on cuda:0..P-1): no PCIe per step.  For a workspace made by initialize_* while "devices" is on:
+ *   layout   which device shard `shard` lives on and which slice [offset, offset + count) of n it owns;
+ *   bind     shard `shard` uses the caller's own device vectors x / grad / hess_vec (count elements each, on that
+ *            shard's device) in place: nothing is uploaded or downloaded for it any more; run_* is still called once
+ *            per step with non-NULL x / grad arguments (they are not dereferenced for bound shards).  All-NULL unbinds;
+ *   request  the shard-local device pointers behind *req / *req_vec of the last run_* call (x -> the bound x);
+ *   foreach  runs fn(user, shard, device, offset, count) on every shard's own host thread, concurrently, with that
+ *            shard's device current and its reducer bound: the place for the caller's per-shard work (gradient
+ *            kernels; isolated entry points such as stochqn_hip_fisher_product, whose reductions then span the shards).
+ * Return 0, or -1000 when s_mem is not a sharded workspace / arguments are invalid. */
+typedef void (*stochqn_hip_shard_fn)(void *user, int shard, int device, size_t offset, size_t count);
+int stochqn_hip_devices_layout(const void *s_mem, int shard, int *device, size_t *offset, size_t *count);
+int stochqn_hip_devices_bind(const void *s_mem, int shard, real_t *x, real_t *grad, real_t *hess_vec);
+int stochqn_hip_devices_request(const void *s_mem, int shard, real_t **req, real_t **req_vec);
+int stochqn_hip_devices_foreach(const void *s_mem, stochqn_hip_shard_fn fn, void *user);
+
 /* ---- caller-supplied reducer (MPI, gloo, a fabric RCCL does not speak) ------------------------------
  * Same sharding, but every reduction is handed to `fn`: sum device_buf[0..count) over all ranks, in
  * place, identically on every rank (count <= max(384, fisher_size)).  `device_buf` is device memory; `hip_stream` is

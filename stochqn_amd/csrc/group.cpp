@@ -95,6 +95,8 @@ struct Shard {
 	real *S = nullptr, *Y = nullptr, *sbak = nullptr, *ybak = nullptr, *gprev = nullptr, *xsum = nullptr, *xprev = nullptr,
 	     *H0 = nullptr, *G = nullptr, *F = nullptr;
 	real *x = nullptr, *g = nullptr, *hv = nullptr;          // device copies of the caller's per-call vectors
+	real *bx = nullptr, *bg = nullptr, *bhv = nullptr;       // device-resident caller: its own per-shard vectors, used in place
+	bool bound = false;
 	std::vector<real_t> rho, alpha, fy;                      // buffer_rho / buffer_alpha / buffer_y of ranks > 0
 	// outcome of the last call
 	int ret = 0;
@@ -400,7 +402,7 @@ real* landing(Group* g, int slot) { return g->landing[slot]; }      // allocated
 real_t* req_home(Group* g, const Shape& sp, const Shard& s, const real_t* req, real_t* x_caller, bool* is_x)
 {
 	*is_x = false;
-	if (req == s.x) { *is_x = true; return x_caller; }
+	if (req == (s.bound ? s.bx : s.x)) { *is_x = true; return x_caller; }
 	if (g->owned) return landing(g, 0);
 	if (req == s.xsum) return sp.xsum;
 	if (req == s.xprev) return sp.xprev;
@@ -480,6 +482,7 @@ struct Io {                       // the caller's per-call vectors (host memory)
 
 void upload(Shard& s, const Io& io)
 {
+	if (s.bound) return;                                       // the caller's vectors already live on this device
 	const size_t bytes = s.cnt * sizeof(real);
 	if (io.up_x && io.x) SQN_HIP_OK(hipMemcpy(s.x, io.x + s.off, bytes, hipMemcpyDefault));
 	if (io.up_g && io.grad) SQN_HIP_OK(hipMemcpy(s.g, io.grad + s.off, bytes, hipMemcpyDefault));
@@ -489,7 +492,7 @@ void upload(Shard& s, const Io& io)
 void download(Group* g, const Shape& sp, Shard& s, const Io& io)
 {
 	const size_t bytes = s.cnt * sizeof(real);
-	if (s.ret == -1000) return;
+	if (s.ret == -1000 || s.bound) return;                     // bound: *req / *req_vec are fetched per shard (devices_request)
 	if (io.down_x && io.x) SQN_HIP_OK(hipMemcpy(io.x + s.off, s.x, bytes, hipMemcpyDefault));
 	if (io.down_g && io.grad && options().strict_grad) SQN_HIP_OK(hipMemcpy(io.grad + s.off, s.g, bytes, hipMemcpyDefault));
 	bool is_x = false;
@@ -503,6 +506,13 @@ void download(Group* g, const Shape& sp, Shard& s, const Io& io)
 		if (home) SQN_HIP_OK(hipMemcpy(home + s.off, s.req_vec, bytes, hipMemcpyDefault));
 		else s.ok = false;
 	}
+}
+
+// calls the front-end answers by itself ("evaluate the gradient at x"): the shards' requests follow
+void request_x(const void* key)
+{
+	if (Group* g = find_group(key))
+		for (auto& s : g->sh) { s->req = s->bound ? s->bx : s->x; s->req_vec = nullptr; }
 }
 
 void note(Group* g, size_t niter, int section)
@@ -523,6 +533,7 @@ int group_run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, 
 	*req = x;
 	if (w->section == 0) {
 		if (!group_owns(b->s_mem)) drop_group(b->s_mem);        // a brand-new optimiser object at this address
+		request_x(b->s_mem);
 		*task = calc_grad;
 		w->section = 1;
 		return 0;
@@ -542,7 +553,7 @@ int group_run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, 
 		s.wo.section = w->section; s.wo.nthreads = w->nthreads; s.wo.check_nan = w->check_nan; s.wo.n = (int) s.cnt;
 		upload(s, io);
 		s.req = nullptr; s.req_vec = nullptr;
-		s.ret = local_run_oLBFGS(step_size, s.x, s.g, &s.req, &s.task, &s.wo, &s.info);
+		s.ret = local_run_oLBFGS(step_size, s.bound ? s.bx : s.x, s.bound ? s.bg : s.g, &s.req, &s.task, &s.wo, &s.info);
 		download(g, sp, s, io);
 	});
 	if (!agree(g, "run_oLBFGS")) { *task = invalid_input; return -1000; }
@@ -562,6 +573,7 @@ int group_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[]
 	bfgs_mem* b = w->bfgs_memory;
 	if (w->section == 0) {
 		if (!group_owns(b->s_mem)) drop_group(b->s_mem);
+		request_x(b->s_mem);
 		*task = calc_grad;
 		*req = x;
 		w->section = 1;
@@ -587,7 +599,7 @@ int group_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[]
 		if (w->use_grad_diff && !s.gprev) { s.ok = dalloc(&s.gprev, s.cnt, false); s.ws.grad_prev = s.gprev; }
 		upload(s, io);
 		s.req = nullptr; s.req_vec = nullptr;
-		s.ret = local_run_SQN(step_size, s.x, s.g, s.hv, &s.req, &s.req_vec, &s.task, &s.ws, &s.info);
+		s.ret = local_run_SQN(step_size, s.bound ? s.bx : s.x, s.bound ? s.bg : s.g, s.bound ? s.bhv : s.hv, &s.req, &s.req_vec, &s.task, &s.ws, &s.info);
 		if (s.task != calc_hess_vec) s.req_vec = nullptr;
 		download(g, sp, s, io);
 	});
@@ -612,6 +624,7 @@ int group_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
 	fisher_mem* fm = w->use_grad_diff ? nullptr : w->fisher_memory;
 	if (w->section == 0) {
 		if (!group_owns(b->s_mem)) drop_group(b->s_mem);
+		request_x(b->s_mem);
 		*task = calc_grad;
 		*req = x;
 		w->section = 1;
@@ -622,6 +635,7 @@ int group_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
 		w->section = 1;
 		*task = calc_grad;
 		*req = x;
+		request_x(b->s_mem);
 		if (Group* g = find_group(b->s_mem)) note(g, w->niter, w->section);
 		return 0;
 	}
@@ -651,7 +665,7 @@ int group_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
 		if (w->use_grad_diff && !s.gprev) { s.ok = dalloc(&s.gprev, s.cnt, false); s.wa.grad_prev = s.gprev; }
 		upload(s, io);
 		s.req = nullptr; s.req_vec = nullptr;
-		s.ret = local_run_adaQN(step_size, s.x, f, s.g, &s.req, &s.task, &s.wa, &s.info);
+		s.ret = local_run_adaQN(step_size, s.bound ? s.bx : s.x, f, s.bound ? s.bg : s.g, &s.req, &s.task, &s.wa, &s.info);
 		download(g, sp, s, io);
 	});
 	if (!agree(g, "run_adaQN")) { *task = invalid_input; return -1000; }
@@ -667,6 +681,50 @@ int group_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
 	*req = req_home(g, sp, a, a.req, x, &is_x);
 	note(g, w->niter, w->section);
 	return a.ret;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-resident callers of the mode: per-shard vectors used in place, per-shard requests, per-shard work
+// ------------------------------------------------------------------------------------------------
+int group_layout(const void* key, int shard, int* device, size_t* offset, size_t* count)
+{
+	Group* g = find_group(key);
+	if (!g || shard < 0 || shard >= g->P) return -1000;
+	const Shard& s = *g->sh[(size_t) shard];
+	if (device) *device = s.device;
+	if (offset) *offset = s.off;
+	if (count) *count = s.cnt;
+	return 0;
+}
+
+int group_bind(const void* key, int shard, real_t* x, real_t* grad, real_t* hess_vec)
+{
+	Group* g = find_group(key);
+	if (!g || shard < 0 || shard >= g->P) return -1000;
+	Shard& s = *g->sh[(size_t) shard];
+	if (!x && !grad && !hess_vec) { s.bound = false; s.bx = s.bg = s.bhv = nullptr; return 0; }
+	if (!x || !grad || !is_device_pointer(x) || !is_device_pointer(grad) || (hess_vec && !is_device_pointer(hess_vec))) return -1000;
+	s.bx = x; s.bg = grad; s.bhv = hess_vec;
+	s.bound = true;
+	return 0;
+}
+
+int group_request(const void* key, int shard, real_t** req, real_t** req_vec)
+{
+	Group* g = find_group(key);
+	if (!g || shard < 0 || shard >= g->P) return -1000;
+	const Shard& s = *g->sh[(size_t) shard];
+	if (req) *req = s.req;
+	if (req_vec) *req_vec = s.req_vec;
+	return 0;
+}
+
+int group_foreach(const void* key, void (*fn)(void*, int, int, size_t, size_t), void* user)
+{
+	Group* g = find_group(key);
+	if (!g || !fn) return -1000;
+	for_all(g, [&](Shard& s) { fn(user, s.rank, s.device, s.off, s.cnt); });
+	return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -38,6 +38,10 @@ bool group_release(const void* key);
 void group_release_all();
 bool group_invalidate(const void* key);
 bool group_export(const void* key, int* rc);
+int group_layout(const void* key, int shard, int* device, size_t* offset, size_t* count);
+int group_bind(const void* key, int shard, real_t* x, real_t* grad, real_t* hess_vec);
+int group_request(const void* key, int shard, real_t** req, real_t** req_vec);
+int group_foreach(const void* key, void (*fn)(void*, int, int, size_t, size_t), void* user);
 int group_shards(const void* key);                     // 0 = not a group
 int group_reducer_kind(const void* key);               // Reducer::Kind of its shards
 

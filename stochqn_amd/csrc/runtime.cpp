@@ -578,6 +578,22 @@ void stochqn_hip_release_all(void) { group_release_all(); release_all(); }
 
 int stochqn_hip_devices_active(const void* s_mem) { return group_shards(s_mem); }
 int stochqn_hip_devices_reducer(const void* s_mem) { return group_reducer_kind(s_mem); }
+int stochqn_hip_devices_layout(const void* s_mem, int shard, int* device, size_t* offset, size_t* count)
+{
+	return group_layout(s_mem, shard, device, offset, count);
+}
+int stochqn_hip_devices_bind(const void* s_mem, int shard, real_t* x, real_t* grad, real_t* hess_vec)
+{
+	return group_bind(s_mem, shard, x, grad, hess_vec);
+}
+int stochqn_hip_devices_request(const void* s_mem, int shard, real_t** req, real_t** req_vec)
+{
+	return group_request(s_mem, shard, req, req_vec);
+}
+int stochqn_hip_devices_foreach(const void* s_mem, stochqn_hip_shard_fn fn, void* user)
+{
+	return group_foreach(s_mem, fn, user);
+}
 
 int stochqn_hip_export(const void* s_mem)
 {

@@ -297,3 +297,180 @@ def test_float_abi_on_device_shards(hip_backend):
         lib32.stochqn_hip_set_option(b"devices", 0.0)
         lib32.stochqn_hip_set_option(b"virtual_devices", 0.0)
         lib32.stochqn_hip_set_option(b"devices_min_n", float(1 << 20))
+
+
+def _hip_rt():
+    import torch
+    import os
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return hip
+
+
+@pytest.mark.parametrize("which", ["SQN-hessvec", "adaQN-fisher", "oLBFGS"])
+def test_device_resident_caller_binds_its_own_shard_vectors(which, devices, hip_backend, oracle_backend):
+    """A process that keeps x / grad on the devices: stochqn_hip_devices_layout / _bind / _request.  No vector crosses
+    PCIe inside run_*; the requests come back as per-shard device pointers.  Same trajectory as the oracle."""
+    import torch
+    lib = _lib()
+    hip = _hip_rt()
+    lib.stochqn_hip_devices_layout.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.stochqn_hip_devices_bind.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.stochqn_hip_devices_request.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    n = 10007
+    P = NoisyQuadratic(n, seed=4, f_spike_calls=range(30, 36))
+
+    def drive(be, bound):
+        x, g, hv = P.x0(), np.zeros(n), np.zeros(n)
+        req, rv, task, info = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
+        if which == "oLBFGS":
+            w = be.initialize_oLBFGS(n, 4, 0.0, 0.0, 1e-4, 1, 1)
+            run = lambda f: be.run_oLBFGS(0.1, x.ctypes.data, g.ctypes.data, C.byref(req), C.byref(task), w, C.byref(info))
+            free = be.dealloc_oLBFGS
+        elif which.startswith("SQN"):
+            w = be.initialize_SQN(n, 3, 4, 1e-4, 0, 0.0, 1, 1)
+            run = lambda f: be.run_SQN(0.1, x.ctypes.data, g.ctypes.data, hv.ctypes.data, C.byref(req), C.byref(rv), C.byref(task), w, C.byref(info))
+            free = be.dealloc_SQN
+        else:
+            w = be.initialize_adaQN(n, 3, 6, 4, 1.01, 1e-4, 1e-4, 0.9, 0, 0.0, 1, 1)
+            run = lambda f: be.run_adaQN(0.05, x.ctypes.data, f, g.ctypes.data, C.byref(req), C.byref(task), w, C.byref(info))
+            free = be.dealloc_adaQN
+        assert bool(w)
+        shards = []
+        if bound:
+            key = C.c_void_p(w.contents.bfgs_memory.contents.s_mem)
+            assert lib.stochqn_hip_devices_active(key) == devices
+            for p in range(devices):
+                dv, off, cnt = C.c_int(), C.c_size_t(), C.c_size_t()
+                assert lib.stochqn_hip_devices_layout(key, p, C.byref(dv), C.byref(off), C.byref(cnt)) == 0
+                dev = torch.device("cuda", dv.value)
+                xs = torch.as_tensor(x[off.value:off.value + cnt.value].copy(), device=dev)
+                gs = torch.zeros(cnt.value, dtype=torch.float64, device=dev)
+                hs = torch.zeros(cnt.value, dtype=torch.float64, device=dev)
+                assert lib.stochqn_hip_devices_bind(key, p, xs.data_ptr(), gs.data_ptr(), hs.data_ptr()) == 0
+                shards.append((off.value, cnt.value, xs, gs, hs))
+            assert sum(s[1] for s in shards) == n
+            x[:] = -7.0                                     # the host x is not the state any more: must stay untouched
+
+        def fetch(ptr_of):                                  # gather a requested vector from the shards' device pointers
+            out = np.empty(n)
+            for p, (off, cnt, xs, gs, hs) in enumerate(shards):
+                rq, rqv = C.c_void_p(), C.c_void_p()
+                assert lib.stochqn_hip_devices_request(key, p, C.byref(rq), C.byref(rqv)) == 0
+                src = ptr_of(rq.value, rqv.value)
+                if src == xs.data_ptr():
+                    out[off:off + cnt] = xs.cpu().numpy()
+                else:
+                    assert hip.hipMemcpy(out[off:off + cnt].ctypes.data, src, 8 * cnt, 2) == 0
+            return out
+
+        def scatter(vec, idx):
+            for off, cnt, *ts in shards:
+                ts[idx].copy_(torch.as_tensor(vec[off:off + cnt]))
+
+        out, f, last = [], 0.0, 0
+        for call in range(50):
+            rc = run(f)
+            assert rc in (0, 1), rc
+            if bound:
+                at = fetch(lambda a, b: a)
+                xnow = np.concatenate([s[2].cpu().numpy() for s in shards])
+            else:
+                at, xnow = host_view(req.value, n).copy(), x.copy()
+            rec = [rc, task.value, info.value, w.contents.niter, w.contents.section,
+                   w.contents.bfgs_memory.contents.mem_used, w.contents.bfgs_memory.contents.mem_st_ix, xnow, at]
+            if task.value in (101, 102, 103):
+                if task.value == 101:
+                    last = call
+                gv = P.grad(at, last if task.value == 102 else call)
+                if bound:
+                    scatter(gv, 1)
+                else:
+                    g[:] = gv
+            elif task.value == 104:
+                v = fetch(lambda a, b: b) if bound else host_view(rv.value, n).copy()
+                rec.append(v)
+                if bound:
+                    scatter(P.hess_vec(at, v), 2)
+                else:
+                    hv[:] = P.hess_vec(at, v)
+            elif task.value == 105:
+                f = P.f(at, call)
+            out.append(rec)
+        if bound:
+            assert np.all(x == -7.0)
+        free(w)
+        return out
+
+    want, got = drive(oracle_backend, False), drive(hip_backend, True)
+    for i, (g_, w_) in enumerate(zip(got, want)):
+        assert g_[:7] == w_[:7], (which, i, g_[:7], w_[:7])
+        for a, b in zip(g_[7:], w_[7:]):
+            assert rel_err(a, b) <= TOL, (which, i, rel_err(a, b))
+
+
+def test_foreach_runs_the_callers_shard_work_under_the_groups_reducer(devices, hip_backend):
+    """stochqn_hip_devices_foreach: the callback runs on every shard's own thread, with the shard's device current and
+    its reducer bound -- so an isolated entry point called from it reduces over ALL shards: the sharded
+    Fisher product t = F s, y = F't / fu equals the oracle's product on the whole matrix."""
+    import threading
+    import torch
+    from oracle import oracle
+    lib = _lib()
+    SHARD_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t)
+    lib.stochqn_hip_devices_foreach.argtypes = [C.c_void_p, SHARD_FN, C.c_void_p]
+    lib.stochqn_hip_fisher_product.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    n, fu = 50021, 9
+    rng = np.random.default_rng(1)
+    F, s = rng.standard_normal((fu, n)), rng.standard_normal(n)
+    t_w, y_w = oracle.fisher_product(F.reshape(-1).copy(), fu, s)
+    w = hip_backend.initialize_SQN(n, 3, 4, 0.0, 0, 0.0, 1, 1)
+    key = C.c_void_p(w.contents.bfgs_memory.contents.s_mem)
+    seen, results, errors = {}, {}, []
+
+    def work(user, shard, device, off, cnt):
+        try:
+            seen[shard] = (device, off, cnt, threading.get_ident())
+            dev = torch.device("cuda", device)
+            Fp = torch.as_tensor(np.ascontiguousarray(F[:, off:off + cnt]).reshape(-1), device=dev)
+            sp = torch.as_tensor(s[off:off + cnt].copy(), device=dev)
+            yp = torch.zeros(cnt, dtype=torch.float64, device=dev)
+            t = np.zeros(fu)
+            rc = lib.stochqn_hip_fisher_product(Fp.data_ptr(), fu, cnt, sp.data_ptr(), t.ctypes.data, yp.data_ptr())
+            lib.stochqn_hip_release(C.c_void_p(Fp.data_ptr()))
+            results[shard] = (rc, t, yp.cpu().numpy(), off, cnt)
+        except Exception as e:                               # pragma: no cover
+            errors.append(repr(e))
+
+    keep = SHARD_FN(work)
+    assert lib.stochqn_hip_devices_foreach(key, keep, None) == 0
+    hip_backend.dealloc_SQN(w)
+    assert not errors, errors
+    assert sorted(seen) == list(range(devices))
+    assert len({v[3] for v in seen.values()}) == devices            # one host thread per shard
+    assert sum(v[2] for v in seen.values()) == n
+    y = np.empty(n)
+    for rc, t, yp, off, cnt in results.values():
+        assert rc == 0
+        assert rel_err(t, t_w) <= TOL                                # every shard holds the GLOBAL t
+        y[off:off + cnt] = yp
+    assert rel_err(y, y_w) <= TOL
+
+
+def test_bench_in_process_mode_is_shard_invariant(tmp_path):
+    """bench.py --in-process (one process, device-resident caller of the multi-device mode, rehearsed on one GPU): the
+    same n_total cut into 2 and into 3 shards must give the same x (counter-based inputs, identical decisions)."""
+    import json
+    from test_gpu_parity import _bench
+    common = ["--in-process", "--virtual-devices", "--mem", "4", "--upd-freq", "3", "--steps", "9", "--warmup", "2", "--no-cpu-baseline"]
+    outs = {}
+    for P, per in ((2, 1_500_000), (3, 1_000_000)):
+        r = _bench(["--gpus", str(P), "--vars-per-gpu", str(per), "--dump-x", str(tmp_path / ("x%d" % P))] + common)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        assert d["n_gpus"] == P and d["device_shards"] == P and d["config"]["hess_vec_requests"] >= 2
+        assert d["config"]["rejected_steps"] == 0 and d["config"]["f_end"] < d["config"]["f_start"]
+        outs[P] = (d, np.load(str(tmp_path / ("x%d.0.npy" % P))))
+    assert outs[2][1].shape == outs[3][1].shape == (3_000_000,)
+    assert rel_err(outs[2][1], outs[3][1]) <= TOL
+    assert outs[2][0]["config"]["calls"] == outs[3][0]["config"]["calls"]
