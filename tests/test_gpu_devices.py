@@ -474,3 +474,18 @@ def test_bench_in_process_mode_is_shard_invariant(tmp_path):
     assert outs[2][1].shape == outs[3][1].shape == (3_000_000,)
     assert rel_err(outs[2][1], outs[3][1]) <= TOL
     assert outs[2][0]["config"]["calls"] == outs[3][0]["config"]["calls"]
+
+
+def test_c5_shard_size_through_the_single_process_mode():
+    """BASELINE config 5's per-GPU shard (n = 1.25e8, m = 20: 40 GB of S and Y per shard) through the single-process
+    multi-device mode: two such shards (n_total = 2.5e8) rehearsed on the one GPU -- initialize_SQN on shards, the ring
+    filled by the run itself, the 32-row Hessian product reduced over the shards, full-size kernels."""
+    import json
+    from test_gpu_parity import _bench
+    r = _bench(["--gpus", "2", "--in-process", "--virtual-devices", "--config", "c5", "--steps", "10", "--warmup", "2"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["device_shards"] == 2 and "n_total=2.5e+08" in d["config"]["workload"]
+    assert d["config"]["hess_vec_requests"] == 1 and d["config"]["rejected_steps"] == 0 and d["config"]["rejected_pairs"] == 0
+    assert d["config"]["f_end"] < d["config"]["f_start"]
+    assert d["roofline"]["alg_bytes_per_launch"] == 42 * 125_000_000 * 8

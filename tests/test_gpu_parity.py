@@ -506,7 +506,7 @@ def device_pairs(torch, n, m, seed):
     return d, S, Y, gen
 
 
-@pytest.mark.parametrize("n,m", [(10_000_000, 10), (100_000_000, 20)])
+@pytest.mark.parametrize("n,m", [(10_000_000, 10), (100_000_000, 20), (125_000_000, 20)])      # C2, C3 / C4, C5's per-GPU shard
 def test_two_loop_properties_at_baseline_size(n, m, form, hip_backend):
     """(i) secant equation: the L-BFGS inverse maps the newest y onto the newest s exactly;
     (ii) linearity in the gradient; (iii) bit-reproducibility of a repeated call."""
@@ -1545,6 +1545,30 @@ def test_bench_starts_its_own_ranks_and_shards_one_problem(tmp_path):
     assert rel_err(x3, x1) <= TOL, rel_err(x3, x1)
     assert abs(d["config"]["f_end"] - d1["config"]["f_end"]) <= 1e-9 * abs(d1["config"]["f_end"])
     assert d["config"]["calls"] == d1["config"]["calls"]
+
+
+@pytest.mark.parametrize("config,n", [("c3", 100_000_000), ("c5", 125_000_000)])
+def test_bench_headline_workload_runs_clean(config, n):
+    """bench.py's own workload under pytest: BASELINE config 3 exactly as measured (SQN n = 1e8, m = 20, L = 10, pairs from
+    the 32-row Hessian mini-batch A'(Av)/32, check_nan = 1) and config 5's per-GPU shard (n = 1.25e8): pairs are built and
+    accepted, no step is rejected, the objective falls, and the JSON line carries what the driver reads."""
+    out = _bench(["--config", config, "--steps", "20", "--warmup", "3", "--no-cpu-baseline"], timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 3 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert ("n=%g per GPU" % n) in d["config"]["workload"] and d["config"]["name"] == config
+    assert d["config"]["hess_vec_requests"] == 2 and d["config"]["rejected_steps"] == 0 and d["config"]["rejected_pairs"] == 0
+    assert d["config"]["f_end"] < d["config"]["f_start"]
+    assert abs(d["value"] - d["steps_per_s_unnormalised"] * n / 1e8) <= 1e-2 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.5 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["alg_bytes_per_launch"] == (2 * 20 + 2) * n * 8 and r["kernel"].startswith("combine")
+    assert d["reference_form"]["two_loop_alg_bytes"] == 64 * 20 * n and d["reference_form"]["two_loop_frac_of_8TBps"] > 0.6
+    assert d["two_loop_micro"]["two_pass"]["median_ms"] < d["two_loop_micro"]["sweeps"]["median_ms"]
+    if config == "c5":
+        assert d["shard_reference_1gpu"]["source"] == "this run"
 
 
 def test_bench_refuses_to_mislabel_a_smaller_job():
