@@ -1272,11 +1272,25 @@ __global__ void __launch_bounds__(kBlock) k_synth_uniform(real* out, size_t coun
 		out[j] = (real) (a + b * synth_u(key, first + j));
 }
 
-// g_j = d_j x_j (1 + amp (2 u(first + j) - 1)): the noisy gradient of f = 1/2 sum d x^2 (3 n words)
+// g_j = d_j x_j (1 + amp (2 u(first + j) - 1)): the noisy gradient of f = 1/2 sum d x^2 (3 n words), one 16-byte
+// pack per lane and step like the sweeps
 __global__ void __launch_bounds__(kBlock) k_synth_grad(real* g, const real* d, const real* x, size_t count, uint64_t first,
                                                       uint64_t key, double amp)
 {
-	for (size_t j = blockIdx.x * (size_t) kBlock + threadIdx.x; j < count; j += (size_t) gridDim.x * kBlock) {
+	const size_t packs = count / kVec;
+	for (size_t p = blockIdx.x * (size_t) kBlock + threadIdx.x; p < packs; p += (size_t) gridDim.x * kBlock) {
+		const size_t j = p * kVec;
+		const rvec dv = *reinterpret_cast<const rvec_u*>(d + j), xv = *reinterpret_cast<const rvec_u*>(x + j);
+		rvec gv;
+		#pragma unroll
+		for (int k = 0; k < kVec; k++) {
+			const double noise = 1.0 + amp * (2.0 * synth_u(key, first + j + k) - 1.0);
+			gv[k] = (real) (((double) dv[k] * (double) xv[k]) * noise);
+		}
+		*reinterpret_cast<rvec_u*>(g + j) = gv;
+	}
+	const size_t j = packs * kVec + threadIdx.x;                  // tail (count not a multiple of the pack)
+	if (blockIdx.x == 0 && j < count) {
 		const double noise = 1.0 + amp * (2.0 * synth_u(key, first + j) - 1.0);
 		g[j] = (real) (((double) d[j] * (double) x[j]) * noise);
 	}
@@ -1706,7 +1720,10 @@ void launch_synth_uniform(hipStream_t stream, real* out, size_t count, uint64_t 
 
 void launch_synth_grad(hipStream_t stream, real* g, const real* d, const real* x, size_t count, uint64_t first, uint64_t key, double amp)
 {
-	hipLaunchKernelGGL(k_synth_grad, dim3(synth_grid(count)), dim3(kBlock), 0, stream, g, d, x, count, first, key, amp);
+	size_t blocks = (count / kVec + kBlock - 1) / kBlock;
+	if (blocks < 1) blocks = 1;
+	if (blocks > 1024) blocks = 1024;
+	hipLaunchKernelGGL(k_synth_grad, dim3((unsigned) blocks), dim3(kBlock), 0, stream, g, d, x, count, first, key, amp);
 }
 
 void launch_synth_batch_row(hipStream_t stream, real* row, const real* d, size_t count, uint64_t first, uint32_t k, uint32_t bs)

@@ -1641,3 +1641,47 @@ def test_device_errors_fail_the_call_loudly(hip_backend, capfd):
     assert lib.stochqn_hip_two_loop(dg.data_ptr(), 300, None, 0.0, dY.data_ptr(), dS.data_ptr(), 3, 3, 0,
                                     rho.ctypes.data, alpha.ctypes.data) == 0
     lib.stochqn_hip_release(C.c_void_p(dS.data_ptr()))
+
+
+def synth_u(i, seed, stream, t):
+    """numpy restatement of the counter-based generator of include/stochqn_hip.h (uint64 arithmetic mod 2^64)."""
+    M = np.uint64
+    with np.errstate(over="ignore"):
+        key = M(seed) ^ (M(stream) * M(0x9E3779B97F4A7C15)) ^ (M(t) * M(0xD1B54A32D192ED03))
+        z = key + i.astype(np.uint64) * M(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> M(30))) * M(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> M(27))) * M(0x94D049BB133111EB)
+        z = z ^ (z >> M(31))
+    return (z >> M(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+@pytest.mark.parametrize("count,first", [(1, 0), (7, 5), (1000, 123456789012), (100003, 3)])
+def test_counter_based_inputs_match_their_definition(count, first, hip_backend):
+    """The synthetic-input kernels against the formula in the header, bit for bit; and a slice generated on its own
+    equals the same slice of a longer vector (what makes the inputs shard-invariant)."""
+    import stochqn_amd
+    torch = torch_cuda()
+    lib = stochqn_amd.cdll()
+    u64 = C.c_ulonglong
+    lib.stochqn_hip_synth_uniform.argtypes = [C.c_void_p, C.c_size_t, u64, u64, u64, u64, C.c_double, C.c_double]
+    lib.stochqn_hip_synth_noisy_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64, u64, u64, u64, C.c_double]
+    lib.stochqn_hip_synth_batch_row.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, u64, C.c_uint, C.c_uint]
+    seed = 20240611
+    idx = np.arange(first, first + count, dtype=np.uint64)
+    out = torch.empty(count, dtype=torch.float64, device="cuda")
+    assert lib.stochqn_hip_synth_uniform(out.data_ptr(), count, first, seed, 3, 7, 0.5, 2.0) == 0
+    assert np.array_equal(out.cpu().numpy(), 0.5 + 2.0 * synth_u(idx, seed, 3, 7))
+    d = torch.as_tensor(0.5 + synth_u(idx, seed, 0, 0), device="cuda")
+    x = torch.as_tensor(1.0 + synth_u(idx, seed, 3, 0), device="cuda")
+    g = torch.empty(count, dtype=torch.float64, device="cuda")
+    assert lib.stochqn_hip_synth_noisy_grad(g.data_ptr(), d.data_ptr(), x.data_ptr(), count, first, seed, 4, 11, 0.01) == 0
+    want = (d.cpu().numpy() * x.cpu().numpy()) * (1.0 + 0.01 * (2.0 * synth_u(idx, seed, 4, 11) - 1.0))
+    assert np.array_equal(g.cpu().numpy(), want)
+    row = torch.empty(count, dtype=torch.float64, device="cuda")
+    assert lib.stochqn_hip_synth_batch_row(row.data_ptr(), d.data_ptr(), count, first, 3, 32) == 0
+    want = np.where((idx % np.uint64(32)) == 3, np.sqrt(32.0 * d.cpu().numpy()), 0.0)
+    assert np.array_equal(row.cpu().numpy(), want)
+    if count > 10:                                              # a slice on its own = the slice of the whole
+        part = torch.empty(count - 5, dtype=torch.float64, device="cuda")
+        assert lib.stochqn_hip_synth_uniform(part.data_ptr(), count - 5, first + 5, seed, 3, 7, 0.5, 2.0) == 0
+        assert torch.equal(part, out[5:])
