@@ -345,7 +345,7 @@ def run(args):
     # ---- outside the timed region: the same workload in the reference's own dependency structure
     # (2m+1 dependent fused sweeps, 64*m*n algorithmic bytes) for the roofline the north star names --
     ref_form = None
-    if "combine" in kern and not args.no_reference_form:
+    if ("combine" in kern or "sadd" in kern) and not args.no_reference_form:
         lib.stochqn_hip_set_option(b"twopass", 0.0)
         for _ in range(2):
             one_step(t_idx)
@@ -389,10 +389,12 @@ def run(args):
         g0 = uniform(torch.empty(n, dtype=f64, device=dev), 2, 0, -0.5, 1.0)          # g_i = u(i,2,t) - 0.5
         gq = torch.empty_like(g0)
         micro = {"note": "stochqn_hip_two_loop alone: mem_used=%d, oldest pair in row %d, H0=NULL, 3 warm-up + 20 calls, median; "
-                         "reference-form bytes = SURVEY 8d's 64*m*n (the sweeps form moves exactly those; the two-pass form moves (4m+3)*n*8)" % (m, b.mem_st_ix)}
+                         "reference-form bytes = SURVEY 8d's 64*m*n (the sweeps form moves exactly those; the three-pass form moves "
+                         "(3m+5)*n*8, the two-pass form (4m+3)*n*8)" % (m, b.mem_st_ix)}
         lib.stochqn_hip_set_option(b"raw_reuse_cache", 1.0)      # S and Y do not change between these calls
-        for form, flag in (("two_pass", 1.0), ("sweeps", 0.0)):
+        for form, flag, three in (("three_pass", 1.0, 1.0), ("two_pass", 1.0, 0.0), ("sweeps", 0.0, 1.0)):
             lib.stochqn_hip_set_option(b"twopass", flag)
+            lib.stochqn_hip_set_option(b"threepass", three)
             ts = []
             for rep in range(23):
                 gq.copy_(g0)
@@ -407,12 +409,13 @@ def run(args):
                 tm = torch.tensor([med], dtype=f64, device=cpu_or_dev)
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 med = float(tm.item())
-            moved = ((4 * m + 3) if form == "two_pass" else 8 * m) * n * 8        # bytes this form has to stream
+            moved = {"three_pass": 3 * m + 5, "two_pass": 4 * m + 3, "sweeps": 8 * m}[form] * n * 8        # bytes this form has to stream
             micro[form] = {"median_ms": round(1e3 * med, 3), "bytes_moved": moved,
                            "GBps_on_bytes_moved": round(moved / med / 1e9, 1),
                            "frac_of_8TBps_on_bytes_moved": round(moved / med / 1e9 / PEAK, 4),
                            "GBps_on_reference_form_bytes": round(64.0 * m * n / med / 1e9, 1)}
         lib.stochqn_hip_set_option(b"twopass", 1.0)
+        lib.stochqn_hip_set_option(b"threepass", 1.0)
         lib.stochqn_hip_set_option(b"raw_reuse_cache", 0.0)
         lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))      # the raw context keyed by S; the optimiser is finished
         del g0, gq
@@ -679,11 +682,15 @@ def analyse_kernels(kern, n_gpu, m, bs, prof_steps, shards):
     # algorithmic n-words per launch
     words = {"first": 2, "bwd": 4, "mid": 3, "fwd": 4, "fwd_last": 3, "apply": 5,
              "rows_dot": 2 * m + 1, "rows_dot3": 2 * m + 3, "combine": 2 * m + 2,
+             "sdot": m + 1, "sdot2": m + 2, "qdot": m + 2, "sadd": m + 2,
              "fisher_t": bs + 1, "fisher_y": bs + 2, "pair_s": 4, "pair_y_hv": 6}
     what = {"bwd": "fused backward sweep: read y_i, q, s_{i-1}; write q",
             "fwd": "fused forward sweep: read s_i, r, y_{i+1}; write r",
             "combine": "two-pass form, pass B: read g and the %d rows of S and Y; write r" % (2 * m),
-            "rows_dot": "two-pass form, pass A: read g and the %d rows of S and Y" % (2 * m)}
+            "rows_dot": "two-pass form, pass A: read g and the %d rows of S and Y" % (2 * m),
+            "sdot": "three-pass form, pass 1: read g and the %d rows of S" % m,
+            "qdot": "three-pass form, pass 2: read g and the %d rows of Y; write r0" % m,
+            "sadd": "three-pass form, pass 3: read r0 and the %d rows of S; write r" % m}
     detail = {}
     for name, (cnt, ms) in kern.items():
         avg = ms / cnt
@@ -705,12 +712,12 @@ def analyse_kernels(kern, n_gpu, m, bs, prof_steps, shards):
                 "alg_bytes_per_launch": alg, "avg_launch_ms": round(ms / cnt, 4),
                 "measured": "HIP events on the library's stream, %d steps of the same workload right after the timed "
                             "region (the timed region itself runs with the event profiler off)" % prof_steps}
-    chain = ("first", "bwd", "mid", "fwd", "fwd_last", "rows_dot", "rows_dot3", "coef", "combine")
+    chain = ("first", "bwd", "mid", "fwd", "fwd_last", "rows_dot", "rows_dot3", "coef", "combine", "sdot", "sdot2", "qdot", "sadd")
     two_loop_ms = sum(kern[k][1] for k in chain if k in kern) / max(prof_steps * shards, 1)
     two_loop = None
     if two_loop_ms > 0:
-        form = "two-pass" if "combine" in kern else "sweeps"
-        own = (4 * m + 3) if form == "two-pass" else 8 * m           # n-words this form has to move
+        form = "three-pass" if "sadd" in kern else ("two-pass" if "combine" in kern else "sweeps")
+        own = {"three-pass": 3 * m + 5, "two-pass": 4 * m + 3, "sweeps": 8 * m}[form]      # n-words this form has to move
         two_loop = {"form": form, "ms": round(two_loop_ms, 3),
                     "bytes_moved": own * n_gpu * 8, "GBps_on_bytes_moved": round(own * n_gpu * 8 / (two_loop_ms * 1e-3) / 1e9, 1),
                     "frac_of_8TBps_on_bytes_moved": round(own * n_gpu * 8 / (two_loop_ms * 1e-3) / 1e9 / PEAK, 4),
@@ -743,7 +750,8 @@ def pmc_traffic(kernel, n, m):
     gfx950 + WRITE_SIZE, separate passes; profiles/summarise.py).  The counters were taken at
     n = 1e8, m = 20; the kernels are pure streams, so bytes scale with n."""
     import glob
-    key = {"bwd": "BwdOp", "fwd": "FwdOp<true, false, false>", "combine": "k_combine<2", "rows_dot": "k_rows_dot_all<2, 5"}[kernel]
+    key = {"bwd": "BwdOp", "fwd": "FwdOp<true, false, false>", "combine": "k_combine<2", "rows_dot": "k_rows_dot_all<2, 5",
+           "sdot": "k_rows_dot_all<2, 3, true, 1", "qdot": "k_qdot<2, 3", "sadd": "k_sadd<2"}[kernel]
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         d = json.load(open(f))
         for k, v in d.items():
@@ -751,7 +759,7 @@ def pmc_traffic(kernel, n, m):
                 raw = v["raw"]
                 # rows_dot: the same kernel also runs Gram maintenance with the probe among the rows
                 # (one stream fewer); pass A is the largest dispatch
-                stat = "max_KiB" if kernel == "rows_dot" else "median_KiB"
+                stat = "max_KiB" if kernel in ("rows_dot", "sdot") else "median_KiB"
                 b = raw.get("FETCH_SIZE", {}).get(stat, 0.0) * 1024 * 2 + raw.get("WRITE_SIZE", {}).get(stat, 0.0) * 1024
                 return int(round(b * n / 1e8)), os.path.relpath(f, ROOT) + " (measured at n=1e8, m=20)"
     return None, None

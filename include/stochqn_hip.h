@@ -27,8 +27,9 @@ int stochqn_hip_available(void);
  * are (a pure function of its arguments).  A caller that calls repeatedly on UNCHANGED s_mem / y_mem may
  * set option "raw_reuse_cache" = 1: s'y, y'y and the Gram blocks of the two-pass form are then kept per
  * (s_mem, row) between calls (stochqn_hip_invalidate(s_mem) after changing rows).  With a caller-supplied
- * diagonal H0 the recursion always runs as the chain of dependent sweeps (the two-pass form needs the
- * H0-weighted Gram entries, which it can only fuse when it builds H0 itself: stochqn_hip_take_step).
+ * diagonal H0 the three-pass form scales q0 by it in its second pass (the two-pass form has no kernel for a
+ * GIVEN diagonal).  Without "raw_reuse_cache" an isolated call runs as the chain of sweeps: when every inner
+ * product has to be rebuilt for one call that is the cheapest way to evaluate it.
  * The state behind these isolated entries is separate from any optimiser's using the same arrays and
  * is freed by stochqn_hip_release(s_mem) / stochqn_hip_release_all().
  * Returns 0 on success, -1000 on invalid input / no device. */
@@ -41,8 +42,7 @@ int stochqn_hip_two_loop(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
  * search_direction_was_nan, x untouched) -> x -= step_size * dir.  grad is overwritten with the direction;
  * bfgs_memory->mem_used / mem_st_ix are the caller's counters (mem_st_ix as stored in the struct, reference
  * :820), buffer_rho / buffer_alpha are filled.  grad_sum_sq == NULL: oLBFGS / SQN step (h0 as in two_loop, H0
- * ignored); else adaQN's step -- the diagonal-H0 kernels of the two-pass form when the "twopass" options
- * are on.  Device or host pointers.  Cache policy as for stochqn_hip_two_loop.  Returns 0 or -1000. */
+ * ignored); else adaQN's step (H0 built and applied inside the cached forms' own passes when they are on).  Device or host pointers.  Cache policy as for stochqn_hip_two_loop.  Returns 0 or -1000. */
 int stochqn_hip_take_step(real_t step_size, int n, real_t x[], real_t grad[], bfgs_mem *bfgs_memory, real_t rmsprop_weight,
 	real_t H0[], real_t h0, real_t grad_sum_sq[], real_t scal_reg, int check_nan, info_enum *iter_info);
 
@@ -76,13 +76,16 @@ int stochqn_hip_export(const void *s_mem);
  * "nontemporal" (default 1)  stream pair / Fisher rows with non-temporal loads
  * "grid_cap"    (default 0 = one workgroup per compute unit) maximum workgroups per sweep
  * "reverse"     (default 1)  alternate the traversal direction of consecutive sweeps
- * "twopass"     (default 1)  scalar-H0 two-loop (oLBFGS, SQN) in the two-pass form: inner products
- *                            of g with all stored pairs, O(m^2) scalar recursion over cached Gram
- *                            blocks, one combine pass -- (4m+3)n words instead of 8mn; 0 = the
- *                            chain of 2m+1 dependent sweeps (always used for m > 24)
- * "twopass_h0"  (default 1)  the same for adaQN's diagonal H0: the H0-weighted inner products are
- *                            recomputed every step in the pass that also applies adaQN's side
- *                            effects on the raw gradient (needs "twopass" = 1 as well)
+ * "twopass"     (default 1)  the two-loop recursion from cached inner products between the stored pairs
+ *                            instead of the chain of 2m+1 dependent sweeps (8mn words; always used for
+ *                            m > 24, for ill-conditioned pairs and with 0 here)
+ * "threepass"   (default 1)  which cached form: 1 = three passes -- S'g, then q0 / r0 / Y'r0 with Y held in
+ *                            registers, then r0 + S'c: S is read twice, Y once, (3m+5)n words; 0 = round 1's
+ *                            two passes -- [S;Y]g, O(m^2) scalar recursion over the Gram blocks, one
+ *                            combine pass: (4m+3)n words
+ * "twopass_h0"  (default 1)  two-pass form only: adaQN's diagonal H0 as well (the H0-weighted inner products
+ *                            are recomputed every step in the pass that also applies adaQN's side effects
+ *                            on the raw gradient); the three-pass form needs no such entries
  * "rows_grid", "rows_split", "combine_batch", "h0_per_cu": kernel-shape knobs, see DESIGN.md 3.2
  * "strict_grad" (default 1)  host callers: copy the search direction back into `grad`
  * "twopass_kappa_max" (default 1e6)  the two-pass forms are used only while every pair in use has

@@ -843,6 +843,16 @@ __global__ void __launch_bounds__(kBlock) k_gram_store(const double* a, int a_co
 	}
 }
 
+// three-pass form, rebuild of one column: gsy[rows[i]][col] = total of partial i (= s_i'y_col), i < k
+__global__ void __launch_bounds__(kBlock) k_store_column(const double* a, int a_count, int a_stride, CoefArgs ca, int col_row, double* gsy)
+{
+	__shared__ double sh[kWaves];
+	for (int i = 0; i < ca.k; i++) {
+		const double t = total_of(a + (size_t) i * a_stride, a_count, sh);
+		if (threadIdx.x == 0) gsy[(size_t) ca.rows[i] * ca.m + col_row] = t;
+	}
+}
+
 // The scalar part of the recursion (reference src/stochqn.c:671-707 with every inner product
 // expanded over the cached Gram blocks).  One workgroup of 16 waves; one wave runs the recursion from LDS.
 // `fresh_row` >= 0: pass A was the 3-probe form over the k pairs in use (rows 0..k-1 = S, k..2k-1 = Y,
@@ -1217,6 +1227,240 @@ __global__ void __launch_bounds__(kCoefBlock) k_coef_h0(const double* bparts, in
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// three-pass form: S is streamed twice, Y ONCE -- (3k+5) n words per two-loop instead of (4k+3) n.
+//   pass 1  b_i = s_i'g                      (k rows of S + g; after a new pair: + the probe y_new -> s_i'y_new)
+//   coef a  backward recursion:  alpha_i = rho_i (b_i - sum_{j>i} alpha_j s_i'y_j)          (cached s_old'y_new)
+//   pass 2  q0 = g - sum_j alpha_j y_j (newest first, element by element exactly as the reference's sweeps);
+//           r0 = gamma q0 | h0 q0 | H0 .* q0 (adaQN: with its side effects on the raw gradient);
+//           v_i = y_i'r0 for every i -- the k rows of Y are held in registers for both uses; r0 replaces g
+//   coef b  forward recursion:   beta_i = rho_i (v_i + sum_{j<i} c_j s_j'y_i),  c_i = alpha_i - beta_i
+//   pass 3  r = r0 + sum_j c_j s_j (oldest first, as the sweeps), guard sums
+// The only cached inner products are s_a'y_b for pairs a older than b (+ the diagonal): when pair b enters the
+// ring as the newest, one extra probe in the next pass 1 yields its column.  Compared with the two-pass form
+// the inner products with Y (y_i'g, y_i'y_j, the H0-weighted W_ij of adaQN) disappear: y_i'r0 is a direct dot
+// with the vector it belongs to.  Reference: src/stochqn.c:663-708.
+// ------------------------------------------------------------------------------------------------
+struct DiagArgs {               // how pass 2 scales q0
+	const real* H0_in;          // caller-supplied diagonal (isolated two-loop), or NULL
+	real* G;                    // adaQN: grad_sum_sq in/out (then H0_out receives g/sqrt(G+eps)), or NULL
+	real* H0_out;
+	real* frow_out;             // adaQN: Fisher row <- raw gradient (nullable)
+	double w_old, w_new, scal_reg;
+	bool rms;
+};
+
+template <int W, int NG, bool NT, int MODE /*0 scalar, 1 given diagonal, 2 adaQN*/, bool SS>
+__global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, const double* coef, real* g, DiagArgs dg, uint32_t n, int rev, double* parts)
+{
+	__shared__ double sh[NG * 8 * kWaves];
+	__shared__ double cf[1 + kPairsMax];
+	const int k = ys.count;
+	for (int e = threadIdx.x; e < 1 + k; e += kBlock) cf[e] = coef[e];
+	__syncthreads();
+	double acc[NG * 8];
+	#pragma unroll
+	for (int j = 0; j < NG * 8; j++) acc[j] = 0;
+	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
+	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
+		const uint32_t i = (rev ? last - p : p) * W;
+		const Pack<W> gv = ld<W, false>(g, i);
+		RPack<W> f[NG * 8];
+		#pragma unroll
+		for (int j = 0; j < NG * 8; j++)
+			if (j < k) f[j] = ldr<W, NT>(ys.row[j], i);
+		Pack<W> h;
+		if constexpr (MODE == 1) h = ld<W, false>(dg.H0_in, i);
+		if constexpr (MODE == 2) {
+			const Pack<W> Gv = ld<W, false>(dg.G, i);
+			Pack<W> Gn;
+			#pragma unroll
+			for (int e = 0; e < W; e++) {
+				const double x = gv.v[e];
+				Gn.v[e] = dg.rms ? (dg.w_old * Gv.v[e] + dg.w_new * (x * x)) : (Gv.v[e] + x * x);     // reference :738 / :745
+				h.v[e] = x / sqrt(Gn.v[e] + dg.scal_reg);                                            // :781
+			}
+			st<W>(dg.G, i, Gn);
+			st<W>(dg.H0_out, i, h);
+			if (dg.frow_out) st_nt<W>(dg.frow_out, i, gv);
+		}
+		Pack<W> q = gv;
+		#pragma unroll
+		for (int j = NG * 8 - 1; j >= 0; j--)                     // newest pair first (:671-679)
+			if (j < k) {
+				#pragma unroll
+				for (int e = 0; e < W; e++) q.v[e] = fma(-cf[1 + j], (double) f[j].v[e], q.v[e]);
+			}
+		#pragma unroll
+		for (int e = 0; e < W; e++) q.v[e] = (MODE == 0) ? cf[0] * q.v[e] : q.v[e] * h.v[e];      // :688 / :698 / :695
+		#pragma unroll
+		for (int j = 0; j < NG * 8; j++)
+			if (j < k) {
+				#pragma unroll
+				for (int e = 0; e < W; e++) acc[j] = fma((double) f[j].v[e], q.v[e], acc[j]);
+			}
+		if constexpr (SS) st_stream<W>(g, i, q); else st<W>(g, i, q);
+	}
+	if (W > 1) {
+		const uint32_t i = packs * W + threadIdx.x;
+		if (blockIdx.x == gridDim.x - 1 && i < n) {
+			const double x = (double) g[i];
+			double h = 0;
+			if (MODE == 1) h = (double) dg.H0_in[i];
+			if (MODE == 2) {
+				const double Gv = (double) dg.G[i];
+				const double Gn = dg.rms ? (dg.w_old * Gv + dg.w_new * (x * x)) : (Gv + x * x);
+				h = x / sqrt(Gn + dg.scal_reg);
+				dg.G[i] = (real) Gn;
+				dg.H0_out[i] = (real) h;
+				if (dg.frow_out) dg.frow_out[i] = (real) x;
+			}
+			double q = x;
+			for (int j = k - 1; j >= 0; j--) q = fma(-cf[1 + j], (double) ys.row[j][i], q);
+			q = (MODE == 0) ? cf[0] * q : q * h;
+			#pragma unroll
+			for (int j = 0; j < NG * 8; j++)
+				if (j < k) acc[j] = fma((double) ys.row[j][i], q, acc[j]);
+			g[i] = (real) q;
+		}
+	}
+	#pragma unroll
+	for (int j = 0; j < NG * 8; j++)
+		if (j < k) {
+			const double t = wave_sum(acc[j]);
+			if ((threadIdx.x & 63) == 0) sh[j * kWaves + (threadIdx.x >> 6)] = t;
+		}
+	__syncthreads();
+	for (int j = threadIdx.x; j < k; j += kBlock) {
+		double t = sh[j * kWaves];
+		#pragma unroll
+		for (int w = 1; w < kWaves; w++) t += sh[j * kWaves + w];
+		parts[(size_t) j * kMaxGrid + blockIdx.x] = t;
+	}
+}
+
+// pass 3: r = r0 + sum_j c_j s_j, oldest pair first (:702-707); guard sums (sum r^2, #non-finite)
+template <int W, bool NT, int T, bool SS>
+__global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, real* r, uint32_t n, int rev, double* parts)
+{
+	__shared__ double sh[kWaves];
+	__shared__ double cf[kPairsMax];
+	const int k = ss.count;
+	for (int e = threadIdx.x; e < k; e += kBlock) cf[e] = coef[e];
+	__syncthreads();
+	double acc0 = 0, acc1 = 0;
+	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
+	for (uint32_t p0 = blockIdx.x * kBlock + threadIdx.x; p0 < packs; p0 += T * stride) {
+		Pack<W> out[T];
+		#pragma unroll
+		for (int t = 0; t < T; t++) {
+			const uint32_t p = p0 + t * stride;
+			if (p < packs) {
+				const uint32_t i = (rev ? last - p : p) * W;
+				Pack<W> v = ld<W, false>(r, i);
+				for (int j0 = 0; j0 < k; j0 += 8) {
+					RPack<W> fs[8];
+					#pragma unroll
+					for (int u = 0; u < 8; u++)
+						if (j0 + u < k) fs[u] = ldr<W, NT>(ss.row[j0 + u], i);
+					#pragma unroll
+					for (int u = 0; u < 8; u++)
+						if (j0 + u < k) {
+							#pragma unroll
+							for (int e = 0; e < W; e++) v.v[e] = fma(cf[j0 + u], (double) fs[u].v[e], v.v[e]);
+						}
+				}
+				#pragma unroll
+				for (int e = 0; e < W; e++) { acc0 = fma(v.v[e], v.v[e], acc0); acc1 += (isfinite(v.v[e]) ? 0.0 : 1.0); }
+				out[t] = v;
+			}
+		}
+		#pragma unroll
+		for (int t = 0; t < T; t++) {
+			const uint32_t p = p0 + t * stride;
+			if (p < packs) {
+				if constexpr (SS) st_stream<W>(r, (rev ? last - p : p) * W, out[t]);
+				else st<W>(r, (rev ? last - p : p) * W, out[t]);
+			}
+		}
+	}
+	if (W > 1) {
+		const uint32_t i = packs * W + threadIdx.x;
+		if (blockIdx.x == gridDim.x - 1 && i < n) {
+			double v = (double) r[i];
+			for (int j = 0; j < k; j++) v = fma(cf[j], (double) ss.row[j][i], v);
+			acc0 = fma(v, v, acc0); acc1 += (isfinite(v) ? 0.0 : 1.0);
+			r[i] = (real) v;
+		}
+	}
+	const double t0 = block_sum(acc0, sh), t1 = block_sum(acc1, sh);
+	if (threadIdx.x == 0) { parts[blockIdx.x] = t0; parts[kMaxGrid + blockIdx.x] = t1; }
+}
+
+// coef a: totals of pass 1, the new pair's column of the cached s_old'y_new block (fresh_row >= 0: quantities
+// k..2k-1 are s_i'y_fresh), the backward recursion.  sy / yy: s'y and y'y of every physical row (rho, gamma).
+__global__ void __launch_bounds__(kCoefBlock) k_coef3a(const double* bparts, int count, int stride, CoefArgs a, int fresh_row,
+                                                       double* gsy, const double* sy, const double* yy, double* alpha_out, double* rho_out, double* coef)
+{
+	__shared__ double SY[kPairsMax * kPairsMax], bS[kPairsMax];
+	const int k = a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	if (fresh_row >= 0) {
+		for (int i = wave; i < k; i += kCoefWaves) {
+			const double t = wave_total_of(bparts + (size_t) (k + i) * stride, count);          // s_i'y_fresh
+			if (lane == 0) gsy[(size_t) a.rows[i] * a.m + fresh_row] = t;
+		}
+		__threadfence_block();
+		__syncthreads();
+	}
+	for (int e = threadIdx.x; e < k * k; e += kCoefBlock) {
+		const int i = e / k, j = e % k;
+		SY[e] = (i == j) ? sy[a.rows[i]] : gsy[(size_t) a.rows[i] * a.m + a.rows[j]];               // used for i <= j only
+	}
+	for (int q = wave; q < k; q += kCoefWaves) {
+		const double t = wave_total_of(bparts + (size_t) q * stride, count);
+		if (lane == 0) bS[q] = t;
+	}
+	__syncthreads();
+	if (wave != 0) return;
+	const bool mine = lane < k;
+	double al = 0;
+	for (int i = k - 1; i >= 0; i--) {                       // alpha_i = rho_i s_i'q_{i+1}  (:676-677)
+		const double t = (mine && lane > i) ? al * SY[i * k + lane] : 0.0;
+		const double sq = bS[i] - wave_sum_all(t);
+		const double rho_i = 1.0 / SY[i * k + i];
+		if (lane == i) { al = rho_i * sq; alpha_out[i] = al; rho_out[i] = rho_i; }
+	}
+	if (lane == 0) coef[0] = (a.h0 > 0) ? a.h0 : SY[(k - 1) * k + (k - 1)] / yy[a.rows[k - 1]];   // :683-689 / :698
+	if (mine) coef[1 + lane] = al;
+}
+
+// coef b: totals of pass 2 (v_i = y_i'r0), the forward recursion; c_i -> coef[1 + kPairsMax + i]
+__global__ void __launch_bounds__(kCoefBlock) k_coef3b(const double* vparts, int count, int stride, CoefArgs a, const double* gsy,
+                                                       const double* sy, const double* alpha, double* coef)
+{
+	__shared__ double SY[kPairsMax * kPairsMax], V[kPairsMax];
+	const int k = a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	for (int e = threadIdx.x; e < k * k; e += kCoefBlock) {
+		const int i = e / k, j = e % k;
+		SY[e] = (i == j) ? sy[a.rows[i]] : gsy[(size_t) a.rows[i] * a.m + a.rows[j]];
+	}
+	for (int q = wave; q < k; q += kCoefWaves) {
+		const double t = wave_total_of(vparts + (size_t) q * stride, count);
+		if (lane == 0) V[q] = t;
+	}
+	__syncthreads();
+	if (wave != 0) return;
+	const bool mine = lane < k;
+	const double al = mine ? alpha[lane] : 0.0;
+	double c = 0;
+	for (int i = 0; i < k; i++) {                            // beta_i = rho_i y_i'r_i, r_i = r0 + sum_{j<i} c_j s_j  (:705-706)
+		const double t = (lane < i) ? c * SY[lane * k + i] : 0.0;
+		const double yr = V[i] + wave_sum_all(t);
+		if (lane == i) c = al - (1.0 / SY[i * k + i]) * yr;
+	}
+	if (mine) coef[1 + kPairsMax + lane] = c;
+}
+
 // out[j] = sum of partial array j (one workgroup per quantity)
 __global__ void __launch_bounds__(kBlock) k_fin(const double* parts, int count, int stride, double* out)
 {
@@ -1344,7 +1588,8 @@ const char* kernel_name(int id)
 {
 	static const char* names[K_COUNT] = {
 		"first", "bwd", "mid", "fwd", "fwd_last", "apply", "pair_s", "pair_y_diff", "pair_y_hv",
-		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy", "rows_dot", "coef", "combine", "gram", "rows_dot3", "gram_h0"};
+		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy", "rows_dot", "coef", "combine", "gram", "rows_dot3", "gram_h0",
+		"sdot", "sdot2", "qdot", "sadd"};
 	return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
@@ -1635,6 +1880,98 @@ Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, 
 		#undef SQN_CB
 	}
 	return finish(sc, buf, 2, grid);
+}
+
+// ---- three-pass form ---------------------------------------------------------------------------------
+// pass 1: the single-probe / two-probe all-rows rows-dot over the k rows of S
+Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows, const real* g, real* copy_out, const real* probe_y)
+{
+	// the two-probe variant (2 x k accumulators, 145 VGPRs: three waves per SIMD) wants three workgroups per CU: 2.78 ms
+	// against 5.12 ms with one and 3.01 ms for the row-split shape (n = 1e8, k = 20; profiles/r02_ab_threepass_shapes.jsonl)
+	const int grid = sweep_grid(sc, n, probe_y ? (sc.sdot2_per_cu > 0 ? sc.sdot2_per_cu : 3) : 1);
+	const bool vec = rows_aligned(s_rows) && all_aligned(g, copy_out, probe_y);
+	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
+	const Probes pr{{g, probe_y, nullptr}};
+	const int ng = (s_rows.count + 7) / 8;
+	{
+		ProfScope ps(sc, probe_y ? K_SDOT2 : K_SDOT);
+		if (probe_y) {
+			if (vec) rows_dot_all_dispatch<kVec, 2>(sc, 0, grid, ng, s_rows, pr, copy_out, (uint32_t) n, rev);
+			else     rows_dot_all_dispatch<1, 2>(sc, 0, grid, ng, s_rows, pr, copy_out, (uint32_t) n, rev);
+		} else {
+			if (vec) rows_dot_all_dispatch<kVec, 1>(sc, 0, grid, ng, s_rows, pr, copy_out, (uint32_t) n, rev);
+			else     rows_dot_all_dispatch<1, 1>(sc, 0, grid, ng, s_rows, pr, copy_out, (uint32_t) n, rev);
+		}
+	}
+	const int nq = (probe_y ? 2 : 1) * s_rows.count;
+	Partials raw{sc.rows_part[0], grid, kMaxGrid};
+	if (!sc.allreduce) return raw;
+	launch_fin(sc, raw, nq, sc.red[0]);
+	sc.allreduce(sc.user, sc.red[0], nq, sc.stream);
+	return Partials{sc.red[0], 1, 1};
+}
+
+void launch_coef3a(const Scratch& sc, Partials b, const CoefArgs& a, int fresh_row)
+{
+	ProfScope ps(sc, K_COEF);
+	hipLaunchKernelGGL(k_coef3a, dim3(1), dim3(kCoefBlock), 0, sc.stream, b.parts, b.count, b.stride, a, fresh_row, sc.gsy, sc.sy, sc.yy,
+	                   sc.alpha, sc.rho, sc.coef);
+}
+
+Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g, const QdotScale& q)
+{
+	const int grid = sweep_grid(sc, n, sc.qdot_per_cu > 0 ? sc.qdot_per_cu : 1);
+	const bool vec = rows_aligned(y_rows) && all_aligned(g, q.H0_in, q.G, q.H0_out, q.frow_out);
+	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
+	const int ng = (y_rows.count + 7) / 8;
+	const int mode = q.G ? 2 : (q.H0_in ? 1 : 0);
+	DiagArgs dg{q.H0_in, q.G, q.H0_out, q.frow_out, q.rmsprop_weight, 1 - q.rmsprop_weight, q.scal_reg, q.rmsprop_weight > 0 && q.rmsprop_weight < 1};
+	{
+		ProfScope ps(sc, K_QDOT);
+		#define SQN_QD3(WW, NG, MODE) { if (sc.stream_stores) hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, true>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, sc.coef, g, dg, (uint32_t) n, rev, sc.rows_part[1]); \
+		                                else hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, false>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, sc.coef, g, dg, (uint32_t) n, rev, sc.rows_part[1]); }
+		#define SQN_QD2(WW, NG) { if (mode == 2) SQN_QD3(WW, NG, 2) else if (mode == 1) SQN_QD3(WW, NG, 1) else SQN_QD3(WW, NG, 0) }
+		#define SQN_QD1(WW) { if (ng <= 1) SQN_QD2(WW, 1) else if (ng == 2) SQN_QD2(WW, 2) else SQN_QD2(WW, 3) }
+		if (vec) SQN_QD1(kVec) else SQN_QD1(1)
+		#undef SQN_QD1
+		#undef SQN_QD2
+		#undef SQN_QD3
+	}
+	Partials raw{sc.rows_part[1], grid, kMaxGrid};
+	if (!sc.allreduce) return raw;
+	launch_fin(sc, raw, y_rows.count, sc.red[1]);
+	sc.allreduce(sc.user, sc.red[1], y_rows.count, sc.stream);
+	return Partials{sc.red[1], 1, 1};
+}
+
+void launch_coef3b(const Scratch& sc, Partials v, const CoefArgs& a)
+{
+	ProfScope ps(sc, K_COEF);
+	hipLaunchKernelGGL(k_coef3b, dim3(1), dim3(kCoefBlock), 0, sc.stream, v.parts, v.count, v.stride, a, sc.gsy, sc.sy, sc.alpha, sc.coef);
+}
+
+Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r)
+{
+	const int grid = sweep_grid(sc, n, sc.sadd_per_cu > 0 ? sc.sadd_per_cu : 2);
+	const bool vec = rows_aligned(s_rows) && all_aligned(r);
+	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
+	{
+		ProfScope ps(sc, K_SADD);
+		#define SQN_SA(WW, T) { if (sc.stream_stores) hipLaunchKernelGGL((k_sadd<WW, true, T, true>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, sc.coef + 1 + kPairsMax, r, (uint32_t) n, rev, sc.part[buf]); \
+		                        else hipLaunchKernelGGL((k_sadd<WW, true, T, false>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, sc.coef + 1 + kPairsMax, r, (uint32_t) n, rev, sc.part[buf]); }
+		const int T = sc.combine_batch;
+		if (vec) { if (T >= 8) SQN_SA(kVec, 8) else if (T >= 4) SQN_SA(kVec, 4) else SQN_SA(kVec, 1) }
+		else     { if (T >= 4) SQN_SA(1, 4) else SQN_SA(1, 1) }
+		#undef SQN_SA
+	}
+	return finish(sc, buf, 2, grid);
+}
+
+// one column of the cached block outside the normal path (imported state, isolated entries): out[j] = total of partial j
+void launch_store_column(const Scratch& sc, Partials in, const CoefArgs& a, int col_row)
+{
+	ProfScope ps(sc, K_SMALL);
+	hipLaunchKernelGGL(k_store_column, dim3(1), dim3(kBlock), 0, sc.stream, in.parts, in.count, in.stride, a, col_row, sc.gsy);
 }
 
 template <int KT>

@@ -345,6 +345,62 @@ Partials enqueue_two_pass(DevCtx* c, real* g, size_t used, size_t st, double h0,
 	return launch_combine(c->sc, c->next_buf(), N(c), ys, ss, g);
 }
 
+// ---- three-pass form: S twice, Y once (kernels.hip "three-pass form") ------------------------------------------
+// The cached block holds s_a'y_b for pairs a older than b.  Column b is computed when pair b is the newest: in
+// the normal course exactly one column is missing on the step after a pair was accepted, and it comes out of
+// that step's pass 1 (one extra probe).  Anything else -- imported state, invalidate, the bak->slot quirk --
+// rebuilds the missing columns with one stand-alone pass over S each (rare path).  Returns the ring row whose
+// column pass 1 has to produce, or -1.
+int ensure_sy_columns(DevCtx* c, size_t st, size_t used, const RowSet& s_rows, const CoefArgs& a)
+{
+	const size_t m = c->m;
+	size_t stale = 0;
+	for (size_t i = 0; i < used; i++) stale += !c->sy_ok[(st + i) % m];
+	const size_t newest = (st + used - 1) % m;
+	if (stale == 0) return -1;
+	if (stale == 1 && !c->sy_ok[newest]) return (int) newest;
+	for (size_t i = 0; i < used; i++) {
+		const size_t b = (st + i) % m;
+		if (c->sy_ok[b]) continue;
+		Partials col = launch_sdot(c->sc, N(c), s_rows, row(c->Y, b, c), nullptr, nullptr);      // s_j'y_b for every pair j in use
+		launch_store_column(c->sc, col, a, (int) b);
+		c->sy_ok[b] = 1;
+	}
+	return -1;
+}
+
+bool threepass_ok(DevCtx* c, size_t st, size_t used)
+{
+	return options().twopass && options().threepass && used >= 1 && c->m <= (size_t) kPairsMax && pairs_tame(c, st, used);
+}
+
+// Returns the guard partials (sum r^2, nonfinite); the direction replaces g.  `qs` says how q0 is scaled:
+// all-NULL = scalar (gamma of the newest pair, or h0 > 0), H0_in = a given diagonal, G = adaQN's step.
+Partials enqueue_three_pass(DevCtx* c, real* g, size_t used, size_t st, double h0, real* gprev_out, const QdotScale& qs)
+{
+	const size_t m = c->m, k = used;
+	RowSet ss{}, ys{};
+	CoefArgs a{};
+	a.k = (int) k;
+	a.m = (int) m;
+	a.h0 = h0;
+	for (size_t i = 0; i < k; i++) {
+		const size_t r = (st + i) % m;
+		a.rows[i] = (int) r;
+		ss.row[i] = row(c->S, r, c);
+		ys.row[i] = row(c->Y, r, c);
+	}
+	ss.count = ys.count = (int) k;
+	ensure_rho(c, st, k);                                     // s'y, y'y of every pair in use (rho_i, gamma)
+	const int fresh = ensure_sy_columns(c, st, k, ss, a);
+	Partials b = launch_sdot(c->sc, N(c), ss, g, gprev_out, fresh >= 0 ? row(c->Y, (size_t) fresh, c) : nullptr);
+	if (fresh >= 0) c->sy_ok[(size_t) fresh] = 1;             // stored by the coefficient kernel, ahead of the recursion
+	launch_coef3a(c->sc, b, a, fresh);
+	Partials v = launch_qdot(c->sc, N(c), ys, g, qs);
+	launch_coef3b(c->sc, v, a);
+	return launch_sadd(c->sc, c->next_buf(), N(c), ss, g);
+}
+
 // adaQN (diagonal H0) in two passes: all inner products incl. the H0-weighted ones + the side effects
 // on the raw gradient in one pass over S and Y, the scalar recursion, the combine pass.
 bool twopass_h0_ok(DevCtx* c, size_t st, size_t used, const StepIn& in)
@@ -411,6 +467,21 @@ void verify_cache(DevCtx* c, size_t st, size_t used)
 		SQN_HIP_OK(hipMemcpyAsync(gsy.data(), c->sc.gsy, m * m * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
 		SQN_HIP_OK(hipMemcpyAsync(gyy.data(), c->sc.gyy, m * m * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
 	}
+	// three-pass form: the cached column s_q'y_r of every pair q in use that is older than r
+	std::vector<double> col;
+	size_t r_logical = used;
+	for (size_t i = 0; i < used; i++) if ((st + i) % m == r) r_logical = i;
+	const bool column = c->sy_ok[r] && m <= (size_t) kPairsMax && r_logical < used;
+	if (column) {
+		RowSet ss{};
+		for (size_t i = 0; i < used; i++) ss.row[i] = row(c->S, (st + i) % m, c);
+		ss.count = (int) used;
+		Partials a = launch_sdot(c->sc, N(c), ss, row(c->Y, r, c), nullptr, nullptr);                  // s_i'y_r, logical order
+		if (a.stride != 1) { launch_fin(c->sc, a, (int) used, c->sc.red[1]); a = Partials{c->sc.red[1], 1, 1}; }
+		col.assign(used, 0.0);
+		if (gsy.empty()) { gsy.assign(m * m, 0.0); SQN_HIP_OK(hipMemcpyAsync(gsy.data(), c->sc.gsy, m * m * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream)); }
+		SQN_HIP_OK(hipMemcpyAsync(col.data(), a.parts, used * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
+	}
 	sync(c);
 	const double scale = std::sqrt(std::fabs(land[1])) * std::sqrt(std::fabs(land[2]));     // |s_r||y_r|
 	bool stale = !(std::fabs(land[0] - land[3]) <= 1e-8 * scale) || !(std::fabs(land[2] - land[4]) <= 1e-8 * std::fabs(land[2]));
@@ -429,6 +500,18 @@ void verify_cache(DevCtx* c, size_t st, size_t used)
 				stale = true;
 				std::fprintf(stderr, "stochqn: verify_cache: Gram entries of rows (%zu, %zu): s'y now %.17g cached %.17g, y'y now %.17g cached %.17g\n",
 				             q, r, fresh[q], gsy[q * m + r], fresh[m + q], gyy[q * m + r]);
+			}
+		}
+	}
+	if (column && !stale) {
+		double big = 0;
+		for (size_t i = 0; i < r_logical; i++) big = std::fmax(big, std::fabs(col[i]));
+		big = std::fmax(big, scale);
+		for (size_t i = 0; i < r_logical && !stale; i++) {
+			const size_t q = (st + i) % m;
+			if (!(std::fabs(col[i] - gsy[q * m + r]) <= 1e-7 * big)) {
+				stale = true;
+				std::fprintf(stderr, "stochqn: verify_cache: s'y of rows (%zu, %zu): now %.17g cached %.17g\n", q, r, col[i], gsy[q * m + r]);
 			}
 		}
 	}
@@ -465,10 +548,16 @@ void enqueue_step(Call& io, const StepIn& in)
 	} else {
 		fa.H0_out = in.H0;                                            // :818
 		const size_t st = (in.st_ix == in.used) ? 0 : in.st_ix;      // :820
-		if (twopass_ok(c, st, in.used, in.G ? in.H0 : nullptr)) {
+		const bool raw_cold = c->kind == KIND_RAW && !options().raw_reuse_cache;   // nothing cached survives the call: sweeps are cheapest
+		if (!raw_cold && (!in.G || in.H0) && threepass_ok(c, st, in.used)) {
+			QdotScale qs{};
+			if (in.G) { qs.G = in.G; qs.H0_out = in.H0; qs.frow_out = in.frow_out; qs.rmsprop_weight = in.w; qs.scal_reg = in.eps; }
+			Partials guard = enqueue_three_pass(c, in.g, in.used, st, in.h0, in.gprev_out, qs);
+			launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
+		} else if (!raw_cold && twopass_ok(c, st, in.used, in.G ? in.H0 : nullptr)) {
 			Partials guard = enqueue_two_pass(c, in.g, in.used, st, in.h0, in.gprev_out);
 			launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
-		} else if (twopass_h0_ok(c, st, in.used, in)) {
+		} else if (!raw_cold && twopass_h0_ok(c, st, in.used, in)) {
 			Partials guard = enqueue_two_pass_h0(c, in, st);
 			launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
 		} else {
@@ -526,6 +615,7 @@ void accept_or_reject(DevCtx* c, bfgs_mem* b, Partials p, info_enum* info)
 		d2d(c, row(c->S, st, c), c->sbak.dev, N(c));                    // "rollback" = bak -> slot (:597-604)
 		d2d(c, row(c->Y, st, c), c->ybak.dev, N(c));
 		c->touch_row(st);
+		c->sy_ok.assign(c->m, 0);                                    // row st may still be in use (full ring): its products with every newer pair are gone
 		*info = curvature_too_small;
 		return;
 	}
@@ -1226,7 +1316,12 @@ static int two_loop_impl(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 	const bool g_host = !is_device_pointer(grad);
 	real* g = stage_in(c, 1, grad, nn, g_host);
 	if (!g) return -1000;
-	if (twopass_ok(c, mem_st_ix % mem_size, mem_used, H0 ? c->H0.dev : nullptr)) {
+	const bool cold = !options().raw_reuse_cache;             // every inner product would be rebuilt for this one call: sweeps are cheapest
+	if (!cold && threepass_ok(c, mem_st_ix % mem_size, mem_used)) {
+		QdotScale qs{};
+		qs.H0_in = H0 ? c->H0.dev : nullptr;
+		(void) enqueue_three_pass(c, g, mem_used, mem_st_ix % mem_size, h0, nullptr, qs);
+	} else if (!cold && twopass_ok(c, mem_st_ix % mem_size, mem_used, H0 ? c->H0.dev : nullptr)) {
 		(void) enqueue_two_pass(c, g, mem_used, mem_st_ix % mem_size, h0, nullptr);
 	} else {
 		FirstArgs fa{};

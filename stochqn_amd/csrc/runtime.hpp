@@ -32,9 +32,11 @@ struct Options {
 	int rows_waves = 0;          // waves per workgroup of the row-split rows-dot kernel (0 = 8 for one probe, 4 for three)
 	int combine_batch = 8;       // packs a lane finishes in pass B before it stores them
 	bool reverse = true;
-	bool twopass = true;         // scalar-H0 two-loop in the two-pass (Gram) form when the ring has <= kPairsMax pairs
+	bool threepass = true;       // the three-pass form (S twice, Y once: (3k+5) n words) instead of the two-pass form, when "twopass" is on
+	bool twopass = true;         // 0: the reference's chain of dependent sweeps; 1: a cached-inner-product form when the ring has <= kPairsMax pairs
 	int h0_per_cu = 0;
 	int fisher_rows = 16;        // Fisher rows per workgroup pass (8, 16, 32)
+	int qdot_per_cu = 0, sadd_per_cu = 0, sdot2_per_cu = 0;
 	bool stream_stores = true;   // pass B: sc1 nt stores (kernels.hip: st_stream)
 	bool twopass_h0 = true;      // adaQN (diagonal H0) in the two-pass form as well
 	double twopass_kappa_max = 1e6;   // two-pass form only while every pair in use has |s||y|/|s'y| <= this (else: sweeps)
@@ -105,11 +107,12 @@ struct DevCtx {
 	// From all-reduced dots, so identical on every rank of a sharded run.  Pairs that are almost orthogonal
 	// make the recursion amplify rounding errors by about this factor per pair; the two-pass form is only
 	// used while every pair in use stays below option "twopass_kappa_max" (machines.cpp: pairs_tame).
+	std::vector<char> sy_ok;           // per physical row r: the cached s_i'y_r of every pair i in use (three-pass form) are current
 	std::vector<double> kappa;
 	size_t verify_turn = 0;            // option verify_cache: which pair in use is re-derived on the next call
 	double* kap_dev = nullptr;         // [3 m] landing zone of (s'y, s's, y'y) for rows whose kappa has to be computed
-	void touch_row(size_t r) { rho_ok[r] = 0; gram_ok[r] = 0; kappa[r] = -1; }   // row r of S or Y was rewritten
-	void forget_rows() { rho_ok.assign(m, 0); gram_ok.assign(m, 0); kappa.assign(m, -1.0); }
+	void touch_row(size_t r) { rho_ok[r] = 0; gram_ok[r] = 0; sy_ok[r] = 0; kappa[r] = -1; }   // row r of S or Y was rewritten
+	void forget_rows() { rho_ok.assign(m, 0); gram_ok.assign(m, 0); sy_ok.assign(m, 0); kappa.assign(m, -1.0); }
 
 	int next_buf() { int b = buf; buf ^= 1; return b; }
 };

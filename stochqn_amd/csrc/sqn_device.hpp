@@ -33,7 +33,8 @@ constexpr int kRedMax = 384;      // doubles per all-reduce landing zone (>= kQu
 // Kernel ids for the built-in HIP-event profiler (stochqn_hip_profile_*).
 enum KernelId {
 	K_FIRST = 0, K_BWD, K_MID, K_FWD, K_FWD_LAST, K_APPLY, K_PAIR_S, K_PAIR_Y_DIFF, K_PAIR_Y_HV,
-	K_DOTS3, K_FISHER_T, K_FISHER_Y, K_FIN, K_SMALL, K_COPY, K_ROWS_DOT, K_COEF, K_COMBINE, K_GRAM, K_ROWS_DOT3, K_GRAM_H0, K_COUNT
+	K_DOTS3, K_FISHER_T, K_FISHER_Y, K_FIN, K_SMALL, K_COPY, K_ROWS_DOT, K_COEF, K_COMBINE, K_GRAM, K_ROWS_DOT3, K_GRAM_H0,
+	K_SDOT, K_SDOT2, K_QDOT, K_SADD, K_COUNT
 };
 const char* kernel_name(int id);
 
@@ -107,6 +108,7 @@ struct Scratch {
 	int combine_batch;    // packs a lane finishes in pass B before storing them (1, 2, 4, 8)
 	int h0_per_cu;        // workgroups per CU of the diagonal-H0 Gram pass (0 = 2)
 	int fisher_rows;      // Fisher rows one workgroup accumulates per pass over its columns: 8, 16 or 32
+	int qdot_per_cu, sadd_per_cu, sdot2_per_cu;   // workgroups per CU of the three-pass kernels (0 = default)
 	bool stream_stores;   // pass B stores its result with the agent-scope non-temporal policy (sc1 nt)
 	bool nontemporal;     // stream S/Y/F rows with nt loads
 	bool reverse;         // alternate the traversal direction from sweep to sweep (Infinity-Cache reuse of q / r)
@@ -210,6 +212,25 @@ void launch_coef(const Scratch& sc, Partials b /*2k: s_i'g then y_i'g, logical o
 // r = H0 .* (g + sum cy_j y_j) + sum cs_j s_j, else r = coef[0] g + sum cy_j y_j + sum cs_j s_j.
 Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& y_rows, const RowSet& s_rows, real* g,
                         const real* H0 = nullptr);
+
+// ---- three-pass form: S twice, Y once -- (3k+5) n words (kernels.hip "three-pass form") -----------------------
+// pass 1: quantities [0,k) s_i'g, and with probe_y (the pair that just entered, ring row r) [k,2k) s_i'y_r
+Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows /*logical order*/, const real* g, real* copy_out, const real* probe_y);
+// totals, (fresh_row >= 0) the new column of the cached s_old'y_new block, backward recursion -> alpha (coef[1..k]), scale (coef[0])
+void launch_coef3a(const Scratch& sc, Partials b, const CoefArgs& a, int fresh_row);
+struct QdotScale {
+	const real* H0_in;      // caller-supplied diagonal, or NULL
+	real* G;                // adaQN: grad_sum_sq (in/out), or NULL
+	real* H0_out;           // adaQN: receives g/sqrt(G+eps)
+	real* frow_out;         // adaQN: Fisher row <- raw gradient, nullable
+	double rmsprop_weight, scal_reg;
+};
+// pass 2: q0, r0 (replaces g), v_i = y_i'r0 -> quantities [0,k)
+Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows /*logical order*/, real* g, const QdotScale& q);
+void launch_coef3b(const Scratch& sc, Partials v, const CoefArgs& a);
+// pass 3: r = r0 + sum c_j s_j; returns the guard partials (sum r^2, nonfinite)
+Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r);
+void launch_store_column(const Scratch& sc, Partials in /*k: s_i'y_col*/, const CoefArgs& a, int col_row);
 
 // ---- two-pass form with the diagonal H0 of adaQN -----------------------------------------------------
 // r_0 = H0 .* q_0 makes the forward loop need H0-weighted inner products: u_i = sum y_i H0 g and

@@ -115,11 +115,12 @@ def launches(lib):
     return out
 
 
-def gpu_two_loop(lib, g, S, Y, m, used, st, twopass, kappa_max=None, h0=0.0):
+def gpu_two_loop(lib, g, S, Y, m, used, st, form, kappa_max=None, h0=0.0):
+    from test_gpu_parity import reset_form, set_form
     torch = torch_cuda()
     n = g.shape[0]
     dS, dY, dg = (torch.as_tensor(a.reshape(-1), device="cuda") for a in (S, Y, g))
-    lib.stochqn_hip_set_option(b"twopass", float(twopass))
+    set_form(lib, form)
     if kappa_max is not None:
         lib.stochqn_hip_set_option(b"twopass_kappa_max", kappa_max)
     lib.stochqn_hip_profile_enable(1)
@@ -129,10 +130,13 @@ def gpu_two_loop(lib, g, S, Y, m, used, st, twopass, kappa_max=None, h0=0.0):
         ran = launches(lib)
     finally:
         lib.stochqn_hip_profile_enable(0)
-        lib.stochqn_hip_set_option(b"twopass", 1.0)
+        reset_form(lib)
         lib.stochqn_hip_set_option(b"twopass_kappa_max", 1e6)
         lib.stochqn_hip_release(C.c_void_p(dS.data_ptr()))
     return dg.cpu().numpy(), ran
+
+
+RAN = {"threepass": "sadd", "twopass": "combine", "sweeps": "mid"}        # the kernel that only this form launches
 
 
 ACCURATE = ["benign", "hessian_cond_1e8", "collinear_1e-8", "collinear_1e-4", "inconsistent_curvature", "negative_curvature",
@@ -151,12 +155,12 @@ def test_both_forms_are_as_accurate_as_fp64_allows(name, n, k, st, hip_backend):
     oracle.two_loop(want, None, 0.0, Y.reshape(-1), S.reshape(-1), k, k, st)
     e_oracle = err(want, truth)
     assert e_oracle <= 1e-12, e_oracle                       # the class is one fp64 handles
-    for twopass in (1, 0):
-        got, ran = gpu_two_loop(lib, g, S, Y, k, k, st, twopass)
-        assert ("combine" in ran) == bool(twopass), ran      # the form asked for is the form that ran
+    for form in ("threepass", "twopass", "sweeps"):
+        got, ran = gpu_two_loop(lib, g, S, Y, k, k, st, form)
+        assert [f for f in RAN if RAN[f] in ran] == [form], ran      # the form asked for is the form that ran
         e_gpu = err(got, truth)
-        assert e_gpu <= max(1e-13, 20 * e_oracle), (name, twopass, e_gpu, e_oracle)
-        assert rel_err(got, want) <= TOL, (name, twopass, rel_err(got, want))
+        assert e_gpu <= max(1e-13, 20 * e_oracle), (name, form, e_gpu, e_oracle)
+        assert rel_err(got, want) <= TOL, (name, form, rel_err(got, want))
 
 
 @pytest.mark.parametrize("eps", [1e-8, 1e-10, 1e-12])
@@ -173,18 +177,21 @@ def test_nearly_orthogonal_pairs_take_the_sweep_form(eps, hip_backend):
     want = g.copy()
     oracle.two_loop(want, None, 0.0, Y.reshape(-1), S.reshape(-1), k, k, st)
     e_oracle = err(want, truth)
-    got, ran = gpu_two_loop(lib, g, S, Y, k, k, st, twopass=1)           # default rule
-    assert "combine" not in ran and "mid" in ran, ran
+    got, ran = gpu_two_loop(lib, g, S, Y, k, k, st, "threepass")         # default rule: falls back to the sweeps
+    assert "sadd" not in ran and "combine" not in ran and "mid" in ran, ran
     e_default = err(got, truth)
     assert e_default <= 50 * e_oracle + 1e-13, (e_default, e_oracle)
-    forced, ran = gpu_two_loop(lib, g, S, Y, k, k, st, twopass=1, kappa_max=float("inf"))
-    assert "combine" in ran
-    e_forced = err(forced, truth)
-    print("eps %g: oracle %.2e  sweeps (default) %.2e  two-pass (forced) %.2e" % (eps, e_oracle, e_default, e_forced))
-    assert e_forced <= 1e4 * e_oracle + 1e-13
+    report = "eps %g: oracle %.2e  sweeps (default) %.2e" % (eps, e_oracle, e_default)
+    for form in ("threepass", "twopass"):
+        forced, ran = gpu_two_loop(lib, g, S, Y, k, k, st, form, kappa_max=float("inf"))
+        assert RAN[form] in ran
+        e_forced = err(forced, truth)
+        report += "  %s (forced) %.2e" % (form, e_forced)
+        assert e_forced <= 1e4 * e_oracle + 1e-13
+    print(report)
 
 
-@pytest.mark.parametrize("twopass", [1, 0])
+@pytest.mark.parametrize("twopass", ["threepass", "twopass", "sweeps"])
 @pytest.mark.parametrize("check_nan", [1, 0])
 def test_zero_curvature_pair_is_rejected_like_the_oracle(twopass, check_nan, hip_backend):
     """s'y == 0 exactly (disjoint supports): rho = inf, the direction is non-finite.  With the guard: flagged,
@@ -203,11 +210,12 @@ def test_zero_curvature_pair_is_rejected_like_the_oracle(twopass, check_nan, hip
     xw, gw = x.copy(), g.copy()
     want = oracle_take_step(0.05, xw, gw, S.reshape(-1), Y.reshape(-1), m, m, 0, 0.0, None, 0.0, None, 0.0, check_nan)
     dx, dg, dS, dY = (torch.as_tensor(a.reshape(-1), device="cuda") for a in (x, g, S, Y))
-    lib.stochqn_hip_set_option(b"twopass", float(twopass))
+    from test_gpu_parity import reset_form, set_form
+    set_form(lib, twopass)
     try:
         got = hip_take_step(lib, 0.05, dx, dg, dS, dY, m, m, 0, 0.0, None, 0.0, None, 0.0, check_nan)
     finally:
-        lib.stochqn_hip_set_option(b"twopass", 1.0)
+        reset_form(lib)
         lib.stochqn_hip_release(C.c_void_p(dS.data_ptr()))
     assert got[:2] == want[:2]
     if check_nan:
@@ -217,7 +225,7 @@ def test_zero_curvature_pair_is_rejected_like_the_oracle(twopass, check_nan, hip
         assert not np.isfinite(xw).any() and not np.isfinite(dx.cpu().numpy()).any()
 
 
-@pytest.mark.parametrize("twopass", [1, 0])
+@pytest.mark.parametrize("twopass", ["threepass", "twopass", "sweeps"])
 @pytest.mark.parametrize("scale", [1e150, 1e-150])
 def test_extreme_gradient_scales_get_the_oracles_verdict(scale, twopass, hip_backend):
     """|g| ~ 1e150: sum r^2 overflows where the reference's dnrm2 does not -- the verdict (norm > 1e3 n: rejected)
@@ -233,11 +241,12 @@ def test_extreme_gradient_scales_get_the_oracles_verdict(scale, twopass, hip_bac
     xw, gw = x.copy(), g.copy()
     want = oracle_take_step(0.05, xw, gw, S.reshape(-1), Y.reshape(-1), m, m, 2, 0.0, None, 0.0, None, 0.0, 1)
     dx, dg, dS, dY = (torch.as_tensor(a.reshape(-1), device="cuda") for a in (x, g, S, Y))
-    lib.stochqn_hip_set_option(b"twopass", float(twopass))
+    from test_gpu_parity import reset_form, set_form
+    set_form(lib, twopass)
     try:
         got = hip_take_step(lib, 0.05, dx, dg, dS, dY, m, m, 2, 0.0, None, 0.0, None, 0.0, 1)
     finally:
-        lib.stochqn_hip_set_option(b"twopass", 1.0)
+        reset_form(lib)
         lib.stochqn_hip_release(C.c_void_p(dS.data_ptr()))
     assert got[:2] == want[:2]
     assert want[0] == (203 if scale > 1 else 200)

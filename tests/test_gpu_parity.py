@@ -16,19 +16,44 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-@pytest.fixture(params=["twopass", "sweeps"])
+FORMS = {"threepass": (1.0, 1.0), "twopass": (1.0, 0.0), "sweeps": (0.0, 1.0)}      # name -> options (twopass, threepass)
+
+
+def set_form(lib, name):
+    """Select the implementation of the two-loop recursion: the three-pass form (default: S twice, Y once), the
+    two-pass (Gram) form, or the reference's chain of dependent sweeps.  The isolated entry points only use a cached
+    form when the caller vouches for the arrays (raw_reuse_cache); the tests release their contexts after every call."""
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    tw, th = FORMS[name]
+    assert lib.stochqn_hip_set_option(b"twopass", tw) == 0
+    assert lib.stochqn_hip_set_option(b"twopass_h0", tw) == 0
+    assert lib.stochqn_hip_set_option(b"threepass", th) == 0
+    assert lib.stochqn_hip_set_option(b"raw_reuse_cache", 1.0 if tw else 0.0) == 0
+
+
+def reset_form(lib):
+    set_form(lib, "threepass")
+    lib.stochqn_hip_set_option(b"raw_reuse_cache", 0.0)
+
+
+@pytest.fixture(params=["threepass", "sweeps"])
 def form(request, hip_backend):
-    """Run a test once per implementation of the two-loop: the two-pass (Gram) form -- for the
-    scalar H0 of oLBFGS / SQN and for adaQN's diagonal H0 -- and the chain of dependent sweeps."""
+    """Run a test once per implementation of the two-loop: the default three-pass form and the chain of sweeps."""
     import stochqn_amd
     lib = stochqn_amd.cdll()
-    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
-    on = 1.0 if request.param == "twopass" else 0.0
-    assert lib.stochqn_hip_set_option(b"twopass", on) == 0
-    assert lib.stochqn_hip_set_option(b"twopass_h0", on) == 0
+    set_form(lib, request.param)
     yield request.param
-    lib.stochqn_hip_set_option(b"twopass", 1.0)
-    lib.stochqn_hip_set_option(b"twopass_h0", 1.0)
+    reset_form(lib)
+
+
+@pytest.fixture(params=["threepass", "twopass", "sweeps"])
+def form3(request, hip_backend):
+    """All three implementations (the two-pass form stays selectable with option threepass = 0)."""
+    import stochqn_amd
+    lib = stochqn_amd.cdll()
+    set_form(lib, request.param)
+    yield request.param
+    reset_form(lib)
 
 
 def torch_cuda():
@@ -42,7 +67,7 @@ def torch_cuda():
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("space", ["host", "device"])
 @pytest.mark.parametrize("case", ["oLBFGS_rosen2d", "SQN_rosen2d", "adaQN_rosen2d"])
-def test_known_answers(case, space, form, hip_backend):
+def test_known_answers(case, space, form3, hip_backend):
     # chaotic Rosenbrock trajectories amplify last-bit differences; 1e3 x the oracle's own pin
     check_known_answer(case, hip_backend, space=space, tol_scale=1e3)
 
@@ -140,7 +165,7 @@ def test_lockstep_parity(cfg, n, form, hip_backend, oracle_backend):
 
 
 @pytest.mark.parametrize("cfgname", ["sqn_ring20", "adaqn_ring20", "olbfgs_default"])
-def test_lockstep_parity_full_grids(cfgname, form, hip_backend, oracle_backend):
+def test_lockstep_parity_full_grids(cfgname, form3, hip_backend, oracle_backend):
     """The same lock-step comparison at a size where every kernel runs its full launch shape: one
     workgroup per CU in the sweeps, 768 workgroups in the row-split pass A, whole LDS tiles plus a ragged
     last one in the diagonal-H0 Gram kernel, and -- n odd -- every other ring row off the 16-byte grid."""
@@ -165,7 +190,7 @@ def test_trace_parity_host_arrays(cfg, n, form, hip_backend, oracle_backend):
     compare_traces(got, want, FREE_RUN_TOL.get(cfg[0], TOL))
 
 
-def test_golden_traces(form, hip_backend):
+def test_golden_traces(form3, hip_backend):
     """Committed regression vectors (tests/golden/traces.json, made by tests/golden/make_traces.py)."""
     path = os.path.join(os.path.dirname(__file__), "golden", "traces.json")
     gold = json.load(open(path))
@@ -207,16 +232,16 @@ TWO_LOOP_SHAPES = [(1, 1, 0), (5, 5, 3), (5, 2, 0), (5, 3, 4), (20, 20, 7), (20,
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 4096, 1000003])
 @pytest.mark.parametrize("m,used,st", TWO_LOOP_SHAPES)
 @pytest.mark.parametrize("mode", ["gamma", "h0"])
-def test_two_loop_matches_oracle(n, m, used, st, mode, form, hip_backend):
+def test_two_loop_matches_oracle(n, m, used, st, mode, form3, hip_backend):
     """Scalar H0 (gamma from the newest pair, or h0 > 0): both forms of the recursion."""
     check_two_loop(n, m, used, st, mode)
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 4096, 1000003])
 @pytest.mark.parametrize("m,used,st", TWO_LOOP_SHAPES)
-def test_two_loop_with_a_given_diagonal_matches_oracle(n, m, used, st, hip_backend):
-    """A caller-supplied diagonal H0 always runs as the chain of sweeps (stochqn_hip.h): one form to test.
-    The two-pass kernels with a diagonal H0 are adaQN's, reached through stochqn_hip_take_step (below)."""
+def test_two_loop_with_a_given_diagonal_matches_oracle(n, m, used, st, form, hip_backend):
+    """A caller-supplied diagonal H0: the three-pass form scales q0 by it in pass 2; the two-pass form has no kernel for
+    a GIVEN diagonal (its H0-weighted Gram entries are fused with building H0: adaQN's step, stochqn_hip_take_step)."""
     check_two_loop(n, m, used, st, "H0")
 
 
@@ -306,7 +331,7 @@ def hip_take_step(lib, step, x, g, S, Y, m, used, st_ix, w, H0, h0, G, eps, chec
 @pytest.mark.parametrize("n", [1, 65, 4096, 1000003])
 @pytest.mark.parametrize("m,used,st_ix", [(5, 5, 3), (5, 2, 2), (20, 20, 7), (20, 20, 0), (3, 0, 0), (1, 1, 0)])
 @pytest.mark.parametrize("mode", ["rmsprop", "adagrad", "gamma", "h0"])
-def test_take_step_matches_oracle(n, m, used, st_ix, mode, form, hip_backend):
+def test_take_step_matches_oracle(n, m, used, st_ix, mode, form3, hip_backend):
     """Direction, x, G, H0, rho, alpha and the verdict of one isolated step; `form` = twopass really selects
     k_gram_h0 / k_coef_h0 / k_combine<H0V> for the two diagonal modes (and rows-dot / coef / combine for the
     scalar ones), `sweeps` the chain of dependent sweeps."""
@@ -337,7 +362,7 @@ def test_take_step_matches_oracle(n, m, used, st_ix, mode, form, hip_backend):
         assert np.allclose(got[3][:used], want[3][:used], rtol=1e-9, atol=1e-13 * np.abs(want[3][:used]).max())
 
 
-def test_take_step_guard_rejects_like_the_oracle(form, hip_backend):
+def test_take_step_guard_rejects_like_the_oracle(form3, hip_backend):
     """A non-finite gradient entry: x untouched, memory flushed, search_direction_was_nan -- in both forms."""
     import stochqn_amd
     torch = torch_cuda()
@@ -359,8 +384,8 @@ def test_take_step_guard_rejects_like_the_oracle(form, hip_backend):
 
 def test_adaqn_step_matches_the_oracle_at_full_size(hip_backend):
     """adaQN's step at the headline shape, n = 1e8, m = 20, ring full and wrapped, RMSProp diagonal: direction,
-    x, G and H0 to 1e-10 against the oracle, for the default two-pass kernels (k_gram_h0 36 GB, k_coef_h0,
-    k_combine<H0V>) and for the sweep form.  (BASELINE config 4's per-step path; the oracle needs 32 GB of host
+    x, G and H0 to 1e-10 against the oracle, for the default three-pass kernels (pass 2 builds H0 and applies the
+    side effects), the two-pass kernels (k_gram_h0, k_coef_h0, k_combine<H0V>) and the sweep form.  (BASELINE config 4's per-step path; the oracle needs 32 GB of host
     memory and a few seconds per call.)"""
     import stochqn_amd
     torch = torch_cuda()
@@ -376,9 +401,8 @@ def test_adaqn_step_matches_the_oracle_at_full_size(hip_backend):
     want = oracle_take_step(0.01, x_w, g_w, S_h, Y_h, m, m, st_ix, 0.9, H0_w, 0.0, G_w, 1e-4, 1)
     del S_h, Y_h
     try:
-        for twopass in (1.0, 0.0):
-            lib.stochqn_hip_set_option(b"twopass", twopass)
-            lib.stochqn_hip_set_option(b"twopass_h0", twopass)
+        for twopass in ("threepass", "twopass", "sweeps"):
+            set_form(lib, twopass)
             xq, gq, Gq, H0q = x.clone(), g.clone(), G.clone(), torch.zeros_like(g)
             got = hip_take_step(lib, 0.01, xq, gq, S, Y, m, m, st_ix, 0.9, H0q, 0.0, Gq, 1e-4, 1)
             assert got[:2] == want[:2] == (200, m)
@@ -389,8 +413,7 @@ def test_adaqn_step_matches_the_oracle_at_full_size(hip_backend):
             assert np.allclose(got[3], want[3], rtol=1e-9, atol=1e-13 * np.abs(want[3]).max())
             del xq, gq, Gq, H0q
     finally:
-        lib.stochqn_hip_set_option(b"twopass", 1.0)
-        lib.stochqn_hip_set_option(b"twopass_h0", 1.0)
+        reset_form(lib)
         lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))
 
 
@@ -541,8 +564,9 @@ def test_two_loop_properties_at_baseline_size(n, m, form, hip_backend):
 def test_two_loop_matches_the_oracle_at_full_size(hip_backend):
     """The headline shape itself against the oracle: n = 1e8, m = 20, ring full and wrapped, fp64.  The oracle
     needs the 32 GB of S and Y in host memory and ~4 s per two-loop on the box's 16 CPUs, so this is done once,
-    for both forms of the recursion; with a caller-supplied diagonal H0 the entry always takes the sweep form
-    (one run).  adaQN's diagonal-H0 two-pass kernels at this size: test_adaqn_step_matches_the_oracle_at_full_size."""
+    for all three forms of the recursion with the scalar H0; with a caller-supplied diagonal for the three-pass and
+    the sweep form (the two-pass form has no kernel for a GIVEN diagonal).  adaQN's step at this size:
+    test_adaqn_step_matches_the_oracle_at_full_size."""
     import stochqn_amd
     from oracle import oracle
     torch = torch_cuda()
@@ -557,9 +581,8 @@ def test_two_loop_matches_the_oracle_at_full_size(hip_backend):
         for H0_d in (None, H0):
             want = g.cpu().numpy().copy()
             rho_w, alpha_w = oracle.two_loop(want, None if H0_d is None else H0_d.cpu().numpy(), 0.0, Y_h, S_h, m, m, st)
-            for twopass in ((1.0, 0.0) if H0_d is None else (0.0,)):
-                lib.stochqn_hip_set_option(b"twopass", twopass)
-                lib.stochqn_hip_set_option(b"twopass_h0", twopass)
+            for twopass in (("threepass", "twopass", "sweeps") if H0_d is None else ("threepass", "sweeps")):
+                set_form(lib, twopass)
                 q = g.clone()
                 rho, alpha = hip_two_loop(lib, q, H0_d, 0.0, Y, S, n, m, m, st)
                 got = q.cpu().numpy()
@@ -568,8 +591,7 @@ def test_two_loop_matches_the_oracle_at_full_size(hip_backend):
                 assert np.allclose(alpha, alpha_w, rtol=1e-9, atol=1e-13 * np.abs(alpha_w).max())
                 del q, got
     finally:
-        lib.stochqn_hip_set_option(b"twopass", 1.0)
-        lib.stochqn_hip_set_option(b"twopass_h0", 1.0)
+        reset_form(lib)
         lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))
 
 
@@ -639,8 +661,7 @@ def test_full_size_steps_agree_between_the_two_forms(optname, kw, iters, step, t
     x0 = 1 + torch.rand(n, dtype=torch.float64, device="cuda", generator=gen)
 
     def run(twopass):
-        lib.stochqn_hip_set_option(b"twopass", float(twopass))
-        lib.stochqn_hip_set_option(b"twopass_h0", float(twopass))
+        set_form(lib, twopass)
         opt = OPTIMIZERS[optname](backend=hip_backend, space="device", **kw)
         x = x0.clone()
         log = []
@@ -658,11 +679,10 @@ def test_full_size_steps_agree_between_the_two_forms(optname, kw, iters, step, t
         return x, log
 
     try:
-        xa, la = run(1)
-        xb, lb = run(0)
+        xa, la = run("threepass")
+        xb, lb = run("sweeps")
     finally:
-        lib.stochqn_hip_set_option(b"twopass", 1.0)
-        lib.stochqn_hip_set_option(b"twopass_h0", 1.0)
+        reset_form(lib)
     assert la == lb
     assert la[-1][3] == 20                                     # the ring did fill up
     err = float(torch.linalg.norm(xa - xb) / torch.linalg.norm(xb))
@@ -1089,17 +1109,13 @@ def hip_backend_f32():
     return be
 
 
-@pytest.fixture(params=["twopass", "sweeps"])
+@pytest.fixture(params=["threepass", "twopass", "sweeps"])
 def form_f32(request, hip_backend_f32):
     import stochqn_amd
     lib = stochqn_amd.cdll(use_float=True)
-    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
-    on = 1.0 if request.param == "twopass" else 0.0
-    lib.stochqn_hip_set_option(b"twopass", on)
-    lib.stochqn_hip_set_option(b"twopass_h0", on)
+    set_form(lib, request.param)
     yield request.param
-    lib.stochqn_hip_set_option(b"twopass", 1.0)
-    lib.stochqn_hip_set_option(b"twopass_h0", 1.0)
+    reset_form(lib)
 
 
 @pytest.mark.parametrize("n", [5, 64, 1000, 4099])
