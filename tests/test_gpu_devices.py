@@ -488,4 +488,4 @@ def test_c5_shard_size_through_the_single_process_mode():
     assert d["n_gpus"] == 2 and d["device_shards"] == 2 and "n_total=2.5e+08" in d["config"]["workload"]
     assert d["config"]["hess_vec_requests"] == 1 and d["config"]["rejected_steps"] == 0 and d["config"]["rejected_pairs"] == 0
     assert d["config"]["f_end"] < d["config"]["f_start"]
-    assert d["roofline"]["alg_bytes_per_launch"] == 42 * 125_000_000 * 8
+    assert d["roofline"]["alg_bytes_per_launch"] in (21 * 125_000_000 * 8, 22 * 125_000_000 * 8)      # a pass of the three-pass form
