@@ -1886,6 +1886,7 @@ Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, 
 // pass 1: the single-probe / two-probe all-rows rows-dot over the k rows of S
 Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows, const real* g, real* copy_out, const real* probe_y)
 {
+	if (!probe_y && sc.rows_split) return launch_rows_dot(sc, 0, n, s_rows, g, copy_out, K_SDOT);      // float build: the row-split kernel
 	// the two-probe variant (2 x k accumulators, 145 VGPRs: three waves per SIMD) wants three workgroups per CU: 2.78 ms
 	// against 5.12 ms with one and 3.01 ms for the row-split shape (n = 1e8, k = 20; profiles/r02_ab_threepass_shapes.jsonl)
 	const int grid = sweep_grid(sc, n, probe_y ? (sc.sdot2_per_cu > 0 ? sc.sdot2_per_cu : 3) : 1);
@@ -1928,7 +1929,7 @@ Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g,
 	DiagArgs dg{q.H0_in, q.G, q.H0_out, q.frow_out, q.rmsprop_weight, 1 - q.rmsprop_weight, q.scal_reg, q.rmsprop_weight > 0 && q.rmsprop_weight < 1};
 	{
 		ProfScope ps(sc, K_QDOT);
-		#define SQN_QD3(WW, NG, MODE) { if (sc.stream_stores) hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, true>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, sc.coef, g, dg, (uint32_t) n, rev, sc.rows_part[1]); \
+		#define SQN_QD3(WW, NG, MODE) { if (sc.stream_stores && sc.qdot_stream) hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, true>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, sc.coef, g, dg, (uint32_t) n, rev, sc.rows_part[1]); \
 		                                else hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, false>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, sc.coef, g, dg, (uint32_t) n, rev, sc.rows_part[1]); }
 		#define SQN_QD2(WW, NG) { if (mode == 2) SQN_QD3(WW, NG, 2) else if (mode == 1) SQN_QD3(WW, NG, 1) else SQN_QD3(WW, NG, 0) }
 		#define SQN_QD1(WW) { if (ng <= 1) SQN_QD2(WW, 1) else if (ng == 2) SQN_QD2(WW, 2) else SQN_QD2(WW, 3) }

@@ -262,6 +262,7 @@ void begin_call(DevCtx* c)
 	c->sc.h0_per_cu = g_opt.h0_per_cu;
 	c->sc.fisher_rows = g_opt.fisher_rows;
 	c->sc.stream_stores = g_opt.stream_stores;
+	c->sc.qdot_stream = g_opt.qdot_stream;
 	c->sc.qdot_per_cu = g_opt.qdot_per_cu; c->sc.sadd_per_cu = g_opt.sadd_per_cu; c->sc.sdot2_per_cu = g_opt.sdot2_per_cu;
 	c->sc.prof = g_profile ? &c->prof : nullptr;
 	c->sc.phase = &c->phase;
@@ -631,6 +632,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "h0_per_cu")) g_opt.h0_per_cu = (int) value;
 	else if (!std::strcmp(name, "fisher_rows")) g_opt.fisher_rows = (int) value;
 	else if (!std::strcmp(name, "stream_stores")) g_opt.stream_stores = value != 0;
+	else if (!std::strcmp(name, "qdot_stream")) g_opt.qdot_stream = value != 0;
 	else if (!std::strcmp(name, "qdot_per_cu")) g_opt.qdot_per_cu = (int) value;
 	else if (!std::strcmp(name, "sadd_per_cu")) g_opt.sadd_per_cu = (int) value;
 	else if (!std::strcmp(name, "sdot2_per_cu")) g_opt.sdot2_per_cu = (int) value;

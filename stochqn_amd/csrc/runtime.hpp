@@ -37,6 +37,7 @@ struct Options {
 	int h0_per_cu = 0;
 	int fisher_rows = 16;        // Fisher rows per workgroup pass (8, 16, 32)
 	int qdot_per_cu = 0, sadd_per_cu = 0, sdot2_per_cu = 0;
+	bool qdot_stream = true;
 	bool stream_stores = true;   // pass B: sc1 nt stores (kernels.hip: st_stream)
 	bool twopass_h0 = true;      // adaQN (diagonal H0) in the two-pass form as well
 	double twopass_kappa_max = 1e6;   // two-pass form only while every pair in use has |s||y|/|s'y| <= this (else: sweeps)
