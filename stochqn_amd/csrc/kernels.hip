@@ -1889,7 +1889,7 @@ Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows, const re
 	if (!probe_y && sc.rows_split) return launch_rows_dot(sc, 0, n, s_rows, g, copy_out, K_SDOT);      // float build: the row-split kernel
 	// the two-probe variant (2 x k accumulators, 145 VGPRs: three waves per SIMD) wants three workgroups per CU: 2.78 ms
 	// against 5.12 ms with one and 3.01 ms for the row-split shape (n = 1e8, k = 20; profiles/r02_ab_threepass_shapes.jsonl)
-	const int grid = sweep_grid(sc, n, probe_y ? (sc.sdot2_per_cu > 0 ? sc.sdot2_per_cu : 3) : 1);
+	const int grid = sweep_grid(sc, n, probe_y ? (sc.sdot2_per_cu > 0 ? sc.sdot2_per_cu : 3) : (sc.sdot_per_cu > 0 ? sc.sdot_per_cu : 1));
 	const bool vec = rows_aligned(s_rows) && all_aligned(g, copy_out, probe_y);
 	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
 	const Probes pr{{g, probe_y, nullptr}};

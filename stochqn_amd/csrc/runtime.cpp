@@ -263,7 +263,7 @@ void begin_call(DevCtx* c)
 	c->sc.fisher_rows = g_opt.fisher_rows;
 	c->sc.stream_stores = g_opt.stream_stores;
 	c->sc.qdot_stream = g_opt.qdot_stream;
-	c->sc.qdot_per_cu = g_opt.qdot_per_cu; c->sc.sadd_per_cu = g_opt.sadd_per_cu; c->sc.sdot2_per_cu = g_opt.sdot2_per_cu;
+	c->sc.qdot_per_cu = g_opt.qdot_per_cu; c->sc.sadd_per_cu = g_opt.sadd_per_cu; c->sc.sdot2_per_cu = g_opt.sdot2_per_cu; c->sc.sdot_per_cu = g_opt.sdot_per_cu;
 	c->sc.prof = g_profile ? &c->prof : nullptr;
 	c->sc.phase = &c->phase;
 	c->phase = 1;
@@ -636,6 +636,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "qdot_per_cu")) g_opt.qdot_per_cu = (int) value;
 	else if (!std::strcmp(name, "sadd_per_cu")) g_opt.sadd_per_cu = (int) value;
 	else if (!std::strcmp(name, "sdot2_per_cu")) g_opt.sdot2_per_cu = (int) value;
+	else if (!std::strcmp(name, "sdot_per_cu")) g_opt.sdot_per_cu = (int) value;
 	else if (!std::strcmp(name, "reverse")) g_opt.reverse = value != 0;
 	else if (!std::strcmp(name, "twopass")) g_opt.twopass = value != 0;
 	else if (!std::strcmp(name, "twopass_h0")) g_opt.twopass_h0 = value != 0;

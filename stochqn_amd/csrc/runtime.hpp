@@ -36,7 +36,7 @@ struct Options {
 	bool twopass = true;         // 0: the reference's chain of dependent sweeps; 1: a cached-inner-product form when the ring has <= kPairsMax pairs
 	int h0_per_cu = 0;
 	int fisher_rows = 16;        // Fisher rows per workgroup pass (8, 16, 32)
-	int qdot_per_cu = 0, sadd_per_cu = 0, sdot2_per_cu = 0;
+	int qdot_per_cu = 0, sadd_per_cu = 0, sdot2_per_cu = 0, sdot_per_cu = 0;
 	bool qdot_stream = true;
 	bool stream_stores = true;   // pass B: sc1 nt stores (kernels.hip: st_stream)
 	bool twopass_h0 = true;      // adaQN (diagonal H0) in the two-pass form as well

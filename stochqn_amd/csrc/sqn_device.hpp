@@ -108,7 +108,7 @@ struct Scratch {
 	int combine_batch;    // packs a lane finishes in pass B before storing them (1, 2, 4, 8)
 	int h0_per_cu;        // workgroups per CU of the diagonal-H0 Gram pass (0 = 2)
 	int fisher_rows;      // Fisher rows one workgroup accumulates per pass over its columns: 8, 16 or 32
-	int qdot_per_cu, sadd_per_cu, sdot2_per_cu;   // workgroups per CU of the three-pass kernels (0 = default)
+	int qdot_per_cu, sadd_per_cu, sdot2_per_cu, sdot_per_cu;   // workgroups per CU of the three-pass kernels (0 = default)
 	bool qdot_stream;     // pass 2 of the three-pass form stores r0 with the streaming policy too
 	bool stream_stores;   // pass B stores its result with the agent-scope non-temporal policy (sc1 nt)
 	bool nontemporal;     // stream S/Y/F rows with nt loads
