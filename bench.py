@@ -48,7 +48,7 @@ ST_D, ST_S, ST_X0, ST_NOISE = 0, 1, 3, 4
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=160, help="timed steps (default: about 2 s of device time)")
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default: about 2.2 s of device time)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3",
                     help="c3: n = 1e8 per GPU (the headline configuration); c5: n = 1.25e8 per GPU (n_total = 1e9 on 8 GPUs)")
