@@ -29,6 +29,7 @@ int main(int argc, char** argv)
 	CK(hipMemcpy(d, hd.data(), n * 8.0, hipMemcpyHostToDevice)); CK(hipMemcpy(x, hx.data(), n * 8.0, hipMemcpyHostToDevice));
 	double* req = nullptr; double* req_vec = nullptr; task_enum task; info_enum info;
 	const bool sqn = kind[0] == 's';
+	if (argc > 6) stochqn_hip_set_option("threepass", atof(argv[6]));      // 0: the two-pass form (A/B of the per-call cost)
 	workspace_oLBFGS* wo = sqn ? nullptr : initialize_oLBFGS(n, m, 0, 0, 0, 1, 1);
 	workspace_SQN* ws = sqn ? initialize_SQN(n, m, 10, 0, 0, 0, 1, 1) : nullptr;
 	auto iter = [&](long& calls) {
