@@ -807,6 +807,18 @@ def cpu_baseline(args, gpu, n, m, L, bs, step_size):
     builds a pair), composed into a cycle -- a 1-thread step at n = 1e8 takes ~10 s."""
     import numpy as np
     import torch
+    # BASELINE.md section 4: the timed CPU path is built for THIS host (-O3 -march=native -fopenmp); the prebuilt
+    # liboracle.so (-O2, generic x86-64: it has to run wherever the tests run) is the fallback when no compiler is around
+    flags = "gcc -O2 -fopenmp (prebuilt, generic x86-64)"
+    native = os.path.join(os.environ.get("TMPDIR", "/tmp"), "liboracle_native_%d.so" % os.getpid())
+    try:
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-std=c99", "-fPIC", "-fopenmp", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                               "-shared", "-o", native, os.path.join(ROOT, "oracle", "stochqn_oracle.c"), "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        os.environ["ORACLE_SO"] = native
+        flags = "gcc -O3 -march=native -fopenmp, built on this host"
+    except (OSError, subprocess.SubprocessError):
+        pass
     from oracle import oracle
     from stochqn_amd import _abi
     model, avail, quota = host_facts()
@@ -883,12 +895,17 @@ def cpu_baseline(args, gpu, n, m, L, bs, step_size):
            "host_mem_available_GB": None if avail is None else round(avail / 1e9, 1),
            "allcores_cycle_s": round(t_cycle, 3), "one_thread_ordinary_step_s": round(t1_ord, 3),
            "one_thread_pair_step_s": round(t1_pair, 3),
-           "sample": "oracle/liboracle.so (CPU restatement of the reference, gcc -O2 -fopenmp, own BLAS-1 loops, no BLAS library), "
+           "build": flags,
+           "sample": "oracle/stochqn_oracle.c (CPU restatement of the reference; " + flags + "; own BLAS-1 loops, no BLAS library), "
                      "SQN m=%d L=%d bsize=%d at n=%g, the GPU leg's own inputs copied to the host (%.1f s); seconds inside "
                      "run_SQN + the Hessian-vector product A'(Av)/%d (oracle_fisher_product), caller's gradient excluded. "
                      "All usable cores (%d threads): one whole L-cycle = %d steps incl. one pair (%.2f s; %d earlier steps: %.2f s). "
                      "One thread: one ordinary step (%.2f s) and one pair-building step (%.2f s), composed into a cycle."
                      % (m, L, bs, nc, t_copy, bs, threads, L, t_cycle, max(L - 3, 0), t_pre, t1_ord, t1_pair)}
+    try:
+        os.unlink(native)                                  # the mapping stays valid; nothing is left behind in TMPDIR
+    except OSError:
+        pass
     return out
 
 
