@@ -54,6 +54,8 @@ def parse():
                     help="c3: n = 1e8 per GPU (the headline configuration); c5: n = 1.25e8 per GPU (n_total = 1e9 on 8 GPUs)")
     ap.add_argument("--n", "--vars-per-gpu", dest="n", type=int, default=0,
                     help="variables per GPU, overrides --config (--vars-per-gpu under torch.distributed.run, whose parser takes --n for itself)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the configuration's n is the TOTAL problem, split evenly over the GPUs (default: weak, n per GPU)")
     ap.add_argument("--mem", type=int, default=20)
     ap.add_argument("--upd-freq", type=int, default=10)
     ap.add_argument("--bsize", type=int, default=32)
@@ -204,6 +206,8 @@ def run(args):
     cpu_or_dev = "cpu" if args.rehearse else dev
 
     n_gpu = args.n if args.n > 0 else CONFIGS[args.config]     # variables per GPU
+    if args.strong:
+        n_gpu = n_gpu // world                                 # the same total problem over 1 / 2 / 4 / 8 GPUs
     n = n_gpu                                                  # variables this process holds
     n_total = n * world
     first = rank * n                                           # global index of this rank's first variable
@@ -440,7 +444,7 @@ def run(args):
             "unit": "steps/s" if n_total == 100_000_000 else "steps/s normalised to n=1e8 (steps/s * n_total/1e8)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "SQN n=%g per GPU (n_total=%g), m=%d, L=%d, Hessian-vector pairs via A'(Av)/%d, "
                                    "check_nan=1, ring full, fp64" % (n_gpu, n_total, m, L, bs),
