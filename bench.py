@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0, help="CPU baseline: problem size (0 = n when host memory allows, else the largest that fits)")
     ap.add_argument("--no-profile", action="store_true", help="skip the second, HIP-event-profiled pass (no roofline object)")
+    ap.add_argument("--sustain-seconds", type=float, default=6.0,
+                    help="after the K timed steps: the same workload for about this long (whole steps, profiler off), reported as "
+                         "`sustained` -- the rate over seconds instead of a fraction of one; 0 = skip")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, RCCL communicator) even with one rank")
     ap.add_argument("--rehearse", action="store_true",
@@ -325,6 +328,25 @@ def run(args):
     if args.dump_x:
         np.save("%s.%d.npy" % (args.dump_x, rank), x.cpu().numpy())
 
+    # ---- the same workload over seconds (K is the driver's choice and may last a quarter of a second): every rank
+    # derives the same number of steps from the max-over-ranks time of the K steps above ---------------------------------
+    sustained = None
+    if args.sustain_seconds > 0:
+        extra = max(L, int(args.sustain_seconds / (elapsed / args.steps)) // L * L)
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(extra):
+            one_step(t_idx)
+            t_idx += 1
+        barrier()
+        dt = time.perf_counter() - ts
+        if dist is not None:
+            td = torch.tensor([dt], dtype=f64, device=cpu_or_dev)
+            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+            dt = float(td.item())
+        sustained = {"steps": extra, "seconds": round(dt, 3), "ms_per_step": round(1e3 * dt / extra, 3),
+                     "value": round(extra / dt * n_total / 1e8, 3)}
+
     # ---- second pass, same workload, every launch bracketed by HIP events on the library's stream:
     # per-kernel durations -> roofline of the dominant kernel --------------------------------------
     kern, prof_elapsed, prof_steps = {}, None, 0
@@ -459,6 +481,7 @@ def run(args):
             "per_rank_ms_per_step": per_rank_ms,
             "steps_per_s_unnormalised": round(steps_per_s, 3),
             "profiled_pass": None if prof_elapsed is None else {"steps": prof_steps, "ms_per_step": round(1e3 * prof_elapsed / prof_steps, 3)},
+            "sustained": sustained,
             "roofline": roof,
             "two_loop": two_loop,
             "two_loop_micro": micro,

@@ -1514,7 +1514,7 @@ def test_bench_multi_process_control_flow_on_one_gpu(tmp_path):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "3", "--rehearse", "--vars-per-gpu", "3000001",
-           "--steps", "12", "--warmup", "3", "--no-cpu-baseline"]
+           "--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--sustain-seconds", "0.5"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -1524,6 +1524,7 @@ def test_bench_multi_process_control_flow_on_one_gpu(tmp_path):
     assert d["value"] > 0 and d["config"]["f_end"] < d["config"]["f_start"]
     assert d["config"]["hess_vec_requests"] >= 1 and d["config"]["rejected_steps"] == 0
     assert d["reference_form"] is not None and d["cpu_baseline"] is None
+    assert d["sustained"]["steps"] >= 10                            # every rank derived the same number of extra steps
     assert "REHEARSAL" in d["config"]["parallelism"]
 
 
@@ -1532,6 +1533,8 @@ def _bench(args, timeout=600):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if "--sustain-seconds" not in args and "--in-process" not in args:
+        args = args + ["--sustain-seconds", "0"]               # the tests that want the sustained leg ask for it
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
                          cwd=root, env=env)
     return out
@@ -1568,7 +1571,7 @@ def test_bench_headline_workload_runs_clean(config, n):
     """bench.py's own workload under pytest: BASELINE config 3 exactly as measured (SQN n = 1e8, m = 20, L = 10, pairs from
     the 32-row Hessian mini-batch A'(Av)/32, check_nan = 1) and config 5's per-GPU shard (n = 1.25e8): pairs are built and
     accepted, no step is rejected, the objective falls, and the JSON line carries what the driver reads."""
-    out = _bench(["--config", config, "--steps", "20", "--warmup", "3", "--no-cpu-baseline"], timeout=600)
+    out = _bench(["--config", config, "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--sustain-seconds", "1"], timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -1586,6 +1589,8 @@ def test_bench_headline_workload_runs_clean(config, n):
     assert d["reference_form"]["two_loop_alg_bytes"] == 64 * 20 * n and d["reference_form"]["two_loop_frac_of_8TBps"] > 0.6
     micro = d["two_loop_micro"]
     assert micro["three_pass"]["median_ms"] < micro["two_pass"]["median_ms"] < micro["sweeps"]["median_ms"]
+    assert d["sustained"]["steps"] % 10 == 0 and d["sustained"]["seconds"] > 0.5
+    assert abs(d["sustained"]["value"] / d["value"] - 1) < 0.15          # the K = 20 steps are representative of a second of the same
     if config == "c5":
         assert d["shard_reference_1gpu"]["source"] == "this run"
 
