@@ -489,3 +489,49 @@ def test_c5_shard_size_through_the_single_process_mode():
     assert d["config"]["hess_vec_requests"] == 1 and d["config"]["rejected_steps"] == 0 and d["config"]["rejected_pairs"] == 0
     assert d["config"]["f_end"] < d["config"]["f_start"]
     assert d["roofline"]["alg_bytes_per_launch"] in (21 * 125_000_000 * 8, 22 * 125_000_000 * 8)      # a pass of the three-pass form
+
+
+def test_shard_groups_do_not_leak_device_memory_or_threads(hip_backend):
+    """Sixty sharded workspaces -- host-array ones dropped by release / a new optimiser at the same address, library-owned
+    ones by dealloc_* -- must leave the device's free memory and the process's thread count where they were (every group
+    owns P worker threads, P device contexts and the slices of every array)."""
+    import threading
+    import torch
+    lib = _lib()
+    for name, val in ((b"virtual_devices", 1.0), (b"devices_min_n", 1.0), (b"devices", 3.0)):
+        assert lib.stochqn_hip_set_option(name, val) == 0
+    n = 40_000
+    P = NoisyQuadratic(n, seed=3)
+
+    def cycle():
+        for optname, kw in (("SQN", dict(mem_size=6, bfgs_upd_freq=3)), ("adaQN", dict(mem_size=5, fisher_size=9, bfgs_upd_freq=3, max_incr=None)),
+                            ("oLBFGS", dict(mem_size=6))):
+            opt = OPTIMIZERS[optname](backend=hip_backend, space="host", **kw)
+            run_trace(opt, P, P.x0(), 0.05, 10)
+            opt.release()
+        w = hip_backend.initialize_SQN(n, 5, 3, 1e-4, 0, 0.0, 1, 1)
+        assert bool(w)
+        hip_backend.dealloc_SQN(w)
+
+    def threads():
+        import os
+        return len(os.listdir("/proc/self/task"))
+
+    try:
+        cycle()
+        lib.stochqn_hip_release_all()
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        t0 = threads()
+        for _ in range(15):
+            cycle()
+        lib.stochqn_hip_release_all()
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free0 - free1 < 2 * 6 * n * 8, "device memory shrank by %d bytes over 60 sharded workspaces" % (free0 - free1)
+        assert threads() <= t0 + 2, (t0, threads())
+    finally:
+        lib.stochqn_hip_release_all()
+        lib.stochqn_hip_set_option(b"devices", 0.0)
+        lib.stochqn_hip_set_option(b"virtual_devices", 0.0)
+        lib.stochqn_hip_set_option(b"devices_min_n", float(1 << 20))
