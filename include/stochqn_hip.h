@@ -78,7 +78,7 @@ int stochqn_hip_export(const void *s_mem);
  * "reverse"     (default 1)  alternate the traversal direction of consecutive sweeps
  * "twopass"     (default 1)  the two-loop recursion from cached inner products between the stored pairs
  *                            instead of the chain of 2m+1 dependent sweeps (8mn words; always used for
- *                            m > 24, for ill-conditioned pairs and with 0 here)
+ *                            m > 48 -- m > 24 with "threepass" = 0 --, for ill-conditioned pairs and with 0 here)
  * "threepass"   (default 1)  which cached form: 1 = three passes -- S'g, then q0 / r0 / Y'r0 with Y held in
  *                            registers, then r0 + S'c: S is read twice, Y once, (3m+5)n words; 0 = round 1's
  *                            two passes -- [S;Y]g, O(m^2) scalar recursion over the Gram blocks, one

@@ -1254,7 +1254,7 @@ template <int W, int NG, bool NT, int MODE /*0 scalar, 1 given diagonal, 2 adaQN
 __global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, const double* coef, real* g, DiagArgs dg, uint32_t n, int rev, double* parts)
 {
 	__shared__ double sh[NG * 8 * kWaves];
-	__shared__ double cf[1 + kPairsMax];
+	__shared__ double cf[1 + kPairsMax3];
 	const int k = ys.count;
 	for (int e = threadIdx.x; e < 1 + k; e += kBlock) cf[e] = coef[e];
 	__syncthreads();
@@ -1344,7 +1344,7 @@ template <int W, bool NT, int T, bool SS>
 __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, real* r, uint32_t n, int rev, double* parts)
 {
 	__shared__ double sh[kWaves];
-	__shared__ double cf[kPairsMax];
+	__shared__ double cf[kPairsMax3];
 	const int k = ss.count;
 	for (int e = threadIdx.x; e < k; e += kBlock) cf[e] = coef[e];
 	__syncthreads();
@@ -1402,7 +1402,7 @@ __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, 
 __global__ void __launch_bounds__(kCoefBlock) k_coef3a(const double* bparts, int count, int stride, CoefArgs a, int fresh_row,
                                                        double* gsy, const double* sy, const double* yy, double* alpha_out, double* rho_out, double* coef)
 {
-	__shared__ double SY[kPairsMax * kPairsMax], bS[kPairsMax];
+	__shared__ double SY[kPairsMax3 * kPairsMax3], bS[kPairsMax3];
 	const int k = a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	if (fresh_row >= 0) {
 		for (int i = wave; i < k; i += kCoefWaves) {
@@ -1434,11 +1434,11 @@ __global__ void __launch_bounds__(kCoefBlock) k_coef3a(const double* bparts, int
 	if (mine) coef[1 + lane] = al;
 }
 
-// coef b: totals of pass 2 (v_i = y_i'r0), the forward recursion; c_i -> coef[1 + kPairsMax + i]
+// coef b: totals of pass 2 (v_i = y_i'r0), the forward recursion; c_i -> coef[1 + kPairsMax3 + i]
 __global__ void __launch_bounds__(kCoefBlock) k_coef3b(const double* vparts, int count, int stride, CoefArgs a, const double* gsy,
                                                        const double* sy, const double* alpha, double* coef)
 {
-	__shared__ double SY[kPairsMax * kPairsMax], V[kPairsMax];
+	__shared__ double SY[kPairsMax3 * kPairsMax3], V[kPairsMax3];
 	const int k = a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	for (int e = threadIdx.x; e < k * k; e += kCoefBlock) {
 		const int i = e / k, j = e % k;
@@ -1458,7 +1458,7 @@ __global__ void __launch_bounds__(kCoefBlock) k_coef3b(const double* vparts, int
 		const double yr = V[i] + wave_sum_all(t);
 		if (lane == i) c = al - (1.0 / SY[i * k + i]) * yr;
 	}
-	if (mine) coef[1 + kPairsMax + lane] = c;
+	if (mine) coef[1 + kPairsMax3 + lane] = c;
 }
 
 // out[j] = sum of partial array j (one workgroup per quantity)
@@ -1932,7 +1932,7 @@ Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g,
 		#define SQN_QD3(WW, NG, MODE) { if (sc.stream_stores && sc.qdot_stream) hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, true>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, sc.coef, g, dg, (uint32_t) n, rev, sc.rows_part[1]); \
 		                                else hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, false>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, sc.coef, g, dg, (uint32_t) n, rev, sc.rows_part[1]); }
 		#define SQN_QD2(WW, NG) { if (mode == 2) SQN_QD3(WW, NG, 2) else if (mode == 1) SQN_QD3(WW, NG, 1) else SQN_QD3(WW, NG, 0) }
-		#define SQN_QD1(WW) { if (ng <= 1) SQN_QD2(WW, 1) else if (ng == 2) SQN_QD2(WW, 2) else SQN_QD2(WW, 3) }
+		#define SQN_QD1(WW) { if (ng <= 1) SQN_QD2(WW, 1) else if (ng == 2) SQN_QD2(WW, 2) else if (ng == 3) SQN_QD2(WW, 3) else if (ng == 4) SQN_QD2(WW, 4) else if (ng == 5) SQN_QD2(WW, 5) else SQN_QD2(WW, 6) }
 		if (vec) SQN_QD1(kVec) else SQN_QD1(1)
 		#undef SQN_QD1
 		#undef SQN_QD2
@@ -1958,8 +1958,8 @@ Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows,
 	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
 	{
 		ProfScope ps(sc, K_SADD);
-		#define SQN_SA(WW, T) { if (sc.stream_stores) hipLaunchKernelGGL((k_sadd<WW, true, T, true>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, sc.coef + 1 + kPairsMax, r, (uint32_t) n, rev, sc.part[buf]); \
-		                        else hipLaunchKernelGGL((k_sadd<WW, true, T, false>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, sc.coef + 1 + kPairsMax, r, (uint32_t) n, rev, sc.part[buf]); }
+		#define SQN_SA(WW, T) { if (sc.stream_stores) hipLaunchKernelGGL((k_sadd<WW, true, T, true>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, sc.coef + 1 + kPairsMax3, r, (uint32_t) n, rev, sc.part[buf]); \
+		                        else hipLaunchKernelGGL((k_sadd<WW, true, T, false>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, sc.coef + 1 + kPairsMax3, r, (uint32_t) n, rev, sc.part[buf]); }
 		const int T = sc.combine_batch;
 		if (vec) { if (T >= 8) SQN_SA(kVec, 8) else if (T >= 4) SQN_SA(kVec, 4) else SQN_SA(kVec, 1) }
 		else     { if (T >= 4) SQN_SA(1, 4) else SQN_SA(1, 1) }

@@ -371,7 +371,7 @@ int ensure_sy_columns(DevCtx* c, size_t st, size_t used, const RowSet& s_rows, c
 
 bool threepass_ok(DevCtx* c, size_t st, size_t used)
 {
-	return options().twopass && options().threepass && used >= 1 && c->m <= (size_t) kPairsMax && pairs_tame(c, st, used);
+	return options().twopass && options().threepass && used >= 1 && c->m <= (size_t) kPairsMax3 && pairs_tame(c, st, used);
 }
 
 // Returns the guard partials (sum r^2, nonfinite); the direction replaces g.  `qs` says how q0 is scaled:
@@ -471,7 +471,7 @@ void verify_cache(DevCtx* c, size_t st, size_t used)
 	std::vector<double> col;
 	size_t r_logical = used;
 	for (size_t i = 0; i < used; i++) if ((st + i) % m == r) r_logical = i;
-	const bool column = c->sy_ok[r] && m <= (size_t) kPairsMax && r_logical < used;
+	const bool column = c->sy_ok[r] && m <= (size_t) kPairsMax3 && r_logical < used;
 	if (column) {
 		RowSet ss{};
 		for (size_t i = 0; i < used; i++) ss.row[i] = row(c->S, (st + i) % m, c);

@@ -355,7 +355,7 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	// pool layout: part0 | part1 | red0 | red1 | sy | yy | report | rho | alpha | rows_part x2 | gsy | gyy | coef
 	const size_t part = (size_t) kMaxSums * kMaxGrid;
 	const size_t rows_part = (size_t) kRedMax * kMaxGrid;
-	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + 2 * m * m + (2 + 2 * kPairsMax) + 3 * m;
+	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + 2 * m * m + (2 + 2 * kPairsMax3) + 3 * m;
 	c->pin_count = 16 + 2 * m + fsize + 3 * m + 8;
 	if (!device_alloc((void**) &c->pool, total * sizeof(double)) ||
 	    !pinned_alloc((void**) &c->pin, c->pin_count * sizeof(double)) ||
@@ -380,7 +380,7 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	c->sc.rows_part[1] = p; p += rows_part;
 	c->sc.gsy = p; p += m * m;
 	c->sc.gyy = p; p += m * m;
-	c->sc.coef = p; p += 2 + 2 * kPairsMax;
+	c->sc.coef = p; p += 2 + 2 * kPairsMax3;
 	c->kap_dev = p;
 	c->forget_rows();
 	begin_call(c);

@@ -27,6 +27,7 @@ constexpr int kMaxGrid = 2048;    // 256 CUs x 8 resident workgroups; also the p
 constexpr int kMaxSums = 3;       // sums one sweep can produce (s'y, s's, y'y)
 constexpr int kRowsMax = 48;      // rows one rows-dot launch can take (one accumulator per row and lane)
 constexpr int kPairsMax = 24;     // largest ring the two-pass form handles (2*kPairsMax rows per launch)
+constexpr int kPairsMax3 = 48;    // largest ring the three-pass form handles (its passes take k rows each; one lane per pair in the recursion)
 constexpr int kQuantMax = 3 * kPairsMax + kPairsMax * (kPairsMax + 1) / 2;   // 372: quantities of the diagonal-H0 pass A
 constexpr int kRedMax = 384;      // doubles per all-reduce landing zone (>= kQuantMax, >= 3*kRowsMax)
 
@@ -100,7 +101,7 @@ struct Scratch {
 	double* rows_part[2]; // two [kRedMax][kMaxGrid] partial buffers of rows-dot / Gram passes
 	double* gsy;          // [m][m] Gram block  gsy[i*m+j] = s_i'y_j   (physical rows)
 	double* gyy;          // [m][m] Gram block  gyy[i*m+j] = y_i'y_j
-	double* coef;         // [1 + 2*kPairsMax]: gamma, then the y- and s-coefficients of the combine pass
+	double* coef;         // [1 + 2*kPairsMax3]: gamma, then the y- and s-coefficients of the combine pass (three-pass: alpha, then c at 1 + kPairsMax3)
 	int grid_cap;         // max workgroups per sweep (<= kMaxGrid); default = one per CU
 	int rows_grid;        // workgroups of a row-split rows-dot pass; 0 = CUs x resident workgroups per CU
 	bool rows_split;      // use the row-split rows-dot kernel for single-probe passes too
@@ -204,7 +205,7 @@ void launch_gram_store(const Scratch& sc, Partials sy_yy /*2m: s_j'y_r then y_j'
 struct CoefArgs {
 	int k;                    // pairs in use
 	int m;                    // ring size (Gram leading dimension)
-	int rows[kPairsMax];      // physical row of logical pair i (oldest first)
+	int rows[kPairsMax3];     // physical row of logical pair i (oldest first)
 	double h0;                // > 0: scalar H0, else gamma from the newest pair
 };
 // fresh_row >= 0: b comes from a 3-probe pass A; ring row fresh_row's Gram row / column is stored first

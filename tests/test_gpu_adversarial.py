@@ -143,7 +143,7 @@ ACCURATE = ["benign", "hessian_cond_1e8", "collinear_1e-8", "collinear_1e-4", "i
             "g_1e+150", "g_1e-150", "g_in_span_of_Y", "y_reg", "trajectory_like", "orthogonal_1e-3"]
 
 
-@pytest.mark.parametrize("n,k,st", [(4001, 10, 3), (200003, 20, 7)])
+@pytest.mark.parametrize("n,k,st", [(4001, 10, 3), (200003, 20, 7), (30011, 48, 11)])
 @pytest.mark.parametrize("name", ACCURATE)
 def test_both_forms_are_as_accurate_as_fp64_allows(name, n, k, st, hip_backend):
     from oracle import oracle
@@ -154,8 +154,10 @@ def test_both_forms_are_as_accurate_as_fp64_allows(name, n, k, st, hip_backend):
     want = g.copy()
     oracle.two_loop(want, None, 0.0, Y.reshape(-1), S.reshape(-1), k, k, st)
     e_oracle = err(want, truth)
+    if name == "orthogonal_1e-3" and k > 24 and e_oracle > 1e-12:
+        pytest.skip("48 pairs at kappa = 1e3 each: the oracle itself is %.1e from the yardstick, not an accurate class any more" % e_oracle)
     assert e_oracle <= 1e-12, e_oracle                       # the class is one fp64 handles
-    for form in ("threepass", "twopass", "sweeps"):
+    for form in (("threepass", "twopass", "sweeps") if k <= 24 else ("threepass", "sweeps")):      # the two-pass form stops at 24 pairs
         got, ran = gpu_two_loop(lib, g, S, Y, k, k, st, form)
         assert [f for f in RAN if RAN[f] in ran] == [form], ran      # the form asked for is the form that ran
         e_gpu = err(got, truth)

@@ -45,7 +45,7 @@ def devices(request, hip_backend):
 
 NAMES = ["olbfgs_default", "olbfgs_nocurv_hess_init", "olbfgs_nan_grad", "olbfgs_reject_all", "sqn_hessvec", "sqn_graddiff",
          "sqn_reject", "sqn_nan", "sqn_nonan_check", "adaqn_fisher_rms", "adaqn_graddiff", "adaqn_func_increased", "adaqn_nan",
-         "adaqn_fisher500", "sqn_ring20", "sqn_ring30"]
+         "adaqn_fisher500", "sqn_ring20", "sqn_ring30", "sqn_ring50"]
 
 
 @pytest.mark.parametrize("n", [3001, 64])

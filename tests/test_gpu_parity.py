@@ -106,11 +106,14 @@ CONFIGS = [
     ("adaqn_nonan_check", "adaQN", dict(mem_size=3, fisher_size=6, bfgs_upd_freq=4, check_nan=False), 0.05, 70, {}),
     # a Fisher ring larger than any fixed-size scalar buffer in the library (and never full in this run)
     ("adaqn_fisher500", "adaQN", dict(mem_size=3, fisher_size=500, bfgs_upd_freq=4, max_incr=None), 0.05, 40, {}),
-    # rings beyond the 24 pairs the two-pass form handles fall back to the sweep form.  (The adaQN ring
+    # rings of 25 .. 48 pairs: the three-pass form still applies (the two-pass form stops at 24 and falls back to the
+    # sweeps); beyond 48 every form does (sqn_ring50).  (The adaQN ring
     # configs stop after ~30 calls: later the iterates jitter around the optimum, s = x_avg - x_avg_prev
     # has mixed signs and F s cancels to ~1e-6 of its terms, so ANY two summation orders differ by
     # ~1e-10 in y -- a property of the instance, not of the kernel.)
     ("sqn_ring30", "SQN", dict(mem_size=30, bfgs_upd_freq=1, min_curvature=None), 0.05, 80, {}),
+    ("sqn_ring48", "SQN", dict(mem_size=48, bfgs_upd_freq=1, min_curvature=None), 0.05, 110, {}),
+    ("sqn_ring50", "SQN", dict(mem_size=50, bfgs_upd_freq=1, min_curvature=None), 0.05, 110, {}),
     ("olbfgs_ring26", "oLBFGS", dict(mem_size=26, min_curvature=None), 0.05, 70, {}),
     ("adaqn_ring25", "adaQN", dict(mem_size=25, fisher_size=8, bfgs_upd_freq=1, max_incr=None, min_curvature=None), 0.002, 31, {}),
     # a full 20-pair ring (the BASELINE shape) at test size
