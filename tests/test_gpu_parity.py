@@ -168,7 +168,7 @@ def test_lockstep_parity(cfg, n, form, hip_backend, oracle_backend):
 
 
 @pytest.mark.parametrize("cfgname", ["sqn_ring20", "adaqn_ring20", "olbfgs_default"])
-def test_lockstep_parity_full_grids(cfgname, form3, hip_backend, oracle_backend):
+def test_lockstep_parity_full_grids(cfgname, form, hip_backend, oracle_backend):
     """The same lock-step comparison at a size where every kernel runs its full launch shape: one
     workgroup per CU in the sweeps, 768 workgroups in the row-split pass A, whole LDS tiles plus a ragged
     last one in the diagonal-H0 Gram kernel, and -- n odd -- every other ring row off the 16-byte grid."""
@@ -183,6 +183,18 @@ def test_lockstep_parity_full_grids(cfgname, form3, hip_backend, oracle_backend)
     lib = stochqn_amd.cdll()
     inval = lambda o: lib.stochqn_hip_invalidate(C.c_void_p(o._sp.ptr(o.BFGS_mem.s_mem)))
     run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 30), TOL, on_sync=inval)
+
+
+def test_lockstep_parity_full_grids_two_pass_form(hip_backend, oracle_backend):
+    """The two-pass form (option threepass = 0) at the same size: the 20-pair ring of SQN (its adaQN kernels at full
+    launch shape are covered by test_adaqn_step_matches_the_oracle_at_full_size)."""
+    import stochqn_amd
+    lib = stochqn_amd.cdll()
+    set_form(lib, "twopass")
+    try:
+        test_lockstep_parity_full_grids("sqn_ring20", "twopass", hip_backend, oracle_backend)
+    finally:
+        reset_form(lib)
 
 
 @pytest.mark.parametrize("n", [2, 65, 1000])
