@@ -528,7 +528,8 @@ int group_run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, 
                      info_enum* iter_info)
 {
 	*iter_info = no_problems_encountered;
-	if (!w || !w->bfgs_memory || w->section < 0 || w->section > 2 || !x || !grad) return fail(task, "oLBFGS", "got an invalid workspace as input.");
+	if (!w || !w->bfgs_memory || w->section < 0 || w->section > 2) return fail(task, "oLBFGS", "got an invalid workspace as input.");
+	if (w->section != 0 && (!x || !grad)) return fail(task, "oLBFGS", "got an invalid workspace as input.");      // the first call only asks for a gradient
 	bfgs_mem* b = w->bfgs_memory;
 	*req = x;
 	if (w->section == 0) {
@@ -569,7 +570,8 @@ int group_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[]
                   task_enum* task, workspace_SQN* w, info_enum* iter_info)
 {
 	*iter_info = no_problems_encountered;
-	if (!w || !w->bfgs_memory || w->section < 0 || w->section > 4 || !x || !grad) return fail(task, "SQN", "got an invalid workspace as input.");
+	if (!w || !w->bfgs_memory || w->section < 0 || w->section > 4) return fail(task, "SQN", "got an invalid workspace as input.");
+	if (w->section != 0 && (!x || !grad)) return fail(task, "SQN", "got an invalid workspace as input.");
 	bfgs_mem* b = w->bfgs_memory;
 	if (w->section == 0) {
 		if (!group_owns(b->s_mem)) drop_group(b->s_mem);
@@ -619,7 +621,8 @@ int group_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
                     info_enum* iter_info)
 {
 	*iter_info = no_problems_encountered;
-	if (!w || !w->bfgs_memory || w->section < 0 || w->section > 5 || !x || !grad) return fail(task, "adaQN", "got an invalid workspace as input.");
+	if (!w || !w->bfgs_memory || w->section < 0 || w->section > 5) return fail(task, "adaQN", "got an invalid workspace as input.");
+	if (w->section != 0 && w->section != 3 && (!x || !grad)) return fail(task, "adaQN", "got an invalid workspace as input.");
 	bfgs_mem* b = w->bfgs_memory;
 	fisher_mem* fm = w->use_grad_diff ? nullptr : w->fisher_memory;
 	if (w->section == 0) {
