@@ -397,6 +397,36 @@ def test_take_step_guard_rejects_like_the_oracle(form3, hip_backend):
     assert np.array_equal(dx.cpu().numpy(), x)
 
 
+@pytest.mark.parametrize("mode", ["rmsprop", "gamma"])
+def test_take_step_host_pointers(mode, form, hip_backend):
+    """The same entry fed with plain numpy memory: everything is staged / mirrored behind the ABI and x, the direction,
+    G and H0 come back into the caller's arrays."""
+    import stochqn_amd
+    from stochqn_amd import _abi
+    lib = stochqn_amd.cdll()
+    take_step_args(lib)
+    n, m, used, st_ix = 3001, 5, 5, 2
+    rng = np.random.default_rng(12)
+    S, Y = make_pairs(rng, n, m)
+    g, x = rng.random(n) - 0.5, 1.0 + rng.random(n)
+    diag = mode == "rmsprop"
+    G = (0.1 + rng.random(n)) if diag else None
+    H0 = np.zeros(n) if diag else None
+    xw, gw, Gw, H0w = x.copy(), g.copy(), None if G is None else G.copy(), None if H0 is None else H0.copy()
+    want = oracle_take_step(0.05, xw, gw, S.copy(), Y.copy(), m, used, st_ix, 0.9 if diag else 0.0, H0w, 0.0, Gw, 1e-4, 1)
+    rho, alpha = np.zeros(m), np.zeros(m)
+    b = _abi.bfgs_mem(S.ctypes.data, Y.ctypes.data, rho.ctypes.data, alpha.ctypes.data, None, None, m, used, st_ix, 1, 0.0, 0.0)
+    info = C.c_int(0)
+    rc = lib.stochqn_hip_take_step(0.05, n, x.ctypes.data, g.ctypes.data, C.byref(b), 0.9 if diag else 0.0,
+                                   None if H0 is None else H0.ctypes.data, 0.0, None if G is None else G.ctypes.data, 1e-4, 1, C.byref(info))
+    lib.stochqn_hip_release(C.c_void_p(S.ctypes.data))
+    assert rc == 0 and (info.value, b.mem_used) == want[:2]
+    for name, a, w in (("x", x, xw), ("direction", g, gw), ("G", G, Gw), ("H0", H0, H0w)):
+        if w is not None:
+            assert rel_err(a, w) <= TOL, (name, rel_err(a, w))
+    assert np.allclose(rho[:used], want[2][:used], rtol=TOL, atol=0)
+
+
 def test_adaqn_step_matches_the_oracle_at_full_size(hip_backend):
     """adaQN's step at the headline shape, n = 1e8, m = 20, ring full and wrapped, RMSProp diagonal: direction,
     x, G and H0 to 1e-10 against the oracle, for the default three-pass kernels (pass 2 builds H0 and applies the
