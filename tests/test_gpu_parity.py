@@ -157,6 +157,8 @@ def test_lockstep_parity(cfg, n, form, hip_backend, oracle_backend):
     name, optname, kw, step, calls, pkw = cfg
     if name == "adaqn_fisher500" and n > 5000:
         pytest.skip("500 Fisher rows x 70001 copied back and forth every call: 12 s for no new code path")
+    if kw.get("mem_size", 0) >= 25 and n > 5000:
+        pytest.skip("rings of 25-50 pairs x 70001 copied back and forth every call: the same kernels as at n = 4097")
     P = NoisyQuadratic(n, seed=11, **pkw)
     ref = OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw)
     opt = OPTIMIZERS[optname](backend=hip_backend, space="device", **kw)
@@ -182,7 +184,7 @@ def test_lockstep_parity_full_grids(cfgname, form, hip_backend, oracle_backend):
     x_dev = torch_cuda().as_tensor(P.x0(), device="cuda")
     lib = stochqn_amd.cdll()
     inval = lambda o: lib.stochqn_hip_invalidate(C.c_void_p(o._sp.ptr(o.BFGS_mem.s_mem)))
-    run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 30), TOL, on_sync=inval)
+    run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 20), TOL, on_sync=inval)
 
 
 def test_lockstep_parity_full_grids_two_pass_form(hip_backend, oracle_backend):
@@ -1198,7 +1200,7 @@ def test_float_lockstep_parity_full_grids(name, hip_backend_f32):
     x_dev = torch_cuda().as_tensor(x_ref.copy(), device="cuda")
     lib = stochqn_amd.cdll(use_float=True)
     inval = lambda o: lib.stochqn_hip_invalidate(C.c_void_p(o._sp.ptr(o.BFGS_mem.s_mem)))
-    run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 26), F32_TOL, on_sync=inval)
+    run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 18), F32_TOL, on_sync=inval)
 
 
 @pytest.mark.parametrize("space", ["host", "device"])
