@@ -535,3 +535,32 @@ def test_shard_groups_do_not_leak_device_memory_or_threads(hip_backend):
         lib.stochqn_hip_set_option(b"devices", 0.0)
         lib.stochqn_hip_set_option(b"virtual_devices", 0.0)
         lib.stochqn_hip_set_option(b"devices_min_n", float(1 << 20))
+
+
+def test_process_exit_with_live_shard_groups_is_clean(tmp_path):
+    """An R session (or a script) that just quits: sharded workspaces never released nor deallocated, their worker threads
+    idle on their condition variables.  The process must still end normally."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "quit.py"
+    script.write_text('''
+import ctypes as C, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import stochqn_amd
+from harness import NoisyQuadratic, run_trace, OPTIMIZERS
+lib = stochqn_amd.cdll(); lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+for k, v in ((b"virtual_devices", 1.0), (b"devices_min_n", 1.0), (b"devices", 3.0)):
+    assert lib.stochqn_hip_set_option(k, v) == 0
+P = NoisyQuadratic(5000, seed=1)
+opt = OPTIMIZERS["SQN"](backend=stochqn_amd.lib(), space="host", mem_size=4, bfgs_upd_freq=3)
+run_trace(opt, P, P.x0(), 0.1, 20)
+opt.release = lambda: None                                  # no release from __del__ either
+w = stochqn_amd.lib().initialize_SQN(5000, 3, 3, 0.0, 0, 0.0, 1, 1)
+assert bool(w)
+print("leaving", flush=True)
+''' % (root, os.path.join(root, "tests")))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "leaving" in out.stdout
