@@ -144,6 +144,25 @@ int stochqn_hip_comm_unique_id(void *out128);
 int stochqn_hip_comm_init(int rank, int nranks, const void *unique_id128);
 int stochqn_hip_comm_nranks(void);
 void stochqn_hip_comm_finalize(void);
+/* Latency of one reduction as the kernel chain pays it: `reps` in-place sums of `count` (<= 384) doubles through the
+ * reducer of the calling thread (the RCCL communicator, a caller-supplied reducer, the loop-back), each followed by a
+ * stream synchronisation.  Collective -- every rank (every shard thread under stochqn_hip_devices_foreach) calls it
+ * alike.  Median and minimum in microseconds.  0, -1 when no reducer is installed, -1000 on failure. */
+int stochqn_hip_comm_allreduce_probe(int count, int reps, double *median_us, double *min_us);
+
+/* ---- event counters ---------------------------------------------------------------------------------
+ * Process-wide counts since start (or the last reset).  Names:
+ *   "steps_three_pass", "steps_two_pass", "steps_two_pass_h0", "steps_sweeps"  take_step calls with pairs in memory, by the
+ *                               form of the two-loop recursion that ran; "steps_plain": no pairs yet (reference :808-812);
+ *   "steps_kappa_fallback"      of the sweeps: steps a cached form was configured for but a pair with
+ *                               |s||y|/|s'y| > "twopass_kappa_max" sent to the reference's chain of sweeps;
+ *   "allreduces", "allreduce_doubles"   reductions issued by this process (per shard context) and doubles summed;
+ *   "contexts_created", "contexts_reclaimed"   device contexts made / exported-and-dropped under memory pressure;
+ *   "x_uploads", "x_uploads_skipped", "host_ranges_registered"   host-caller path;
+ *   "graph_launches"            steps replayed from a captured HIP graph (option "graphs").
+ * Returns the count, or -1 for an unknown name. */
+long long stochqn_hip_stat(const char *name);
+void stochqn_hip_stats_reset(void);
 
 /* ---- sharding n across the GPUs of ONE process (single-process multi-device mode) -------------------------
  * What a caller of the plain reference ABI gets -- an R session through .Call (reference src/Rwrapper.c:98-125),

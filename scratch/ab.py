@@ -22,8 +22,8 @@ def setup(kind, n, m, L):
     d = 0.5 + torch.rand(n, dtype=torch.float64, device=dev, generator=g)
     dn = d * (1 + 0.01 * (2 * torch.rand(n, dtype=torch.float64, device=dev, generator=g) - 1))
     x = 1 + torch.rand(n, dtype=torch.float64, device=dev, generator=g)
-    if kind == "sqn":
-        opt = SQN_free(mem_size=m, bfgs_upd_freq=1, min_curvature=None, space="device")
+    if kind in ("sqn", "sqn0"):
+        opt = SQN_free(mem_size=m, bfgs_upd_freq=1, min_curvature=None, space="device", check_nan=(kind == "sqn"))
     elif kind == "adaqn":
         opt = adaQN_free(mem_size=m, fisher_size=16, bfgs_upd_freq=2, max_incr=None, min_curvature=None, scal_reg=1e-4,
                          rmsprop_weight=0.9, space="device")
@@ -56,10 +56,10 @@ if __name__ == "__main__":
     print("after fill: niter", opt.niter, "mem_used", opt.BFGS_mem.mem_used, INFOS, flush=True)
     if kind == "adaqn":
         opt.BFGS_mem.upd_freq = opt.bfgs_upd_freq = 1000000      # no more pair updates: time the step path only
-    if kind == "sqn":
+    if kind in ("sqn", "sqn0"):
         opt.BFGS_mem.upd_freq = opt.bfgs_upd_freq = 10
         opt.niter = 10 * ((opt.niter + 9) // 10)
-    base = {"grid_cap": 0, "rows_grid": 0, "rows_split": 0, "reverse": 1, "twopass": 1, "nontemporal": 1, "combine_batch": 8, "twopass_h0": 1, "h0_per_cu": 0, "rows_waves": 0}
+    base = {"grid_cap": 0, "rows_grid": 0, "rows_split": 0, "reverse": 1, "twopass": 1, "nontemporal": 1, "combine_batch": 8, "twopass_h0": 1, "h0_per_cu": 0, "rows_waves": 0, "fold_coef": 1, "keep_tail": 0, "fuse_apply": 1}
     for rep in range(2):
         for v in variants:
             o = dict(base); o.update(v)

@@ -1241,6 +1241,100 @@ __global__ void __launch_bounds__(kCoefBlock) k_coef_h0(const double* bparts, in
 // the inner products with Y (y_i'g, y_i'y_j, the H0-weighted W_ij of adaQN) disappear: y_i'r0 is a direct dot
 // with the vector it belongs to.  Reference: src/stochqn.c:663-708.
 // ------------------------------------------------------------------------------------------------
+// The scalar recursions of the three-pass form inside the prologues of pass 2 and pass 3 (option "fold_coef"): every
+// workgroup totals the previous pass's partials and runs the recursion itself -- the same functions in the same order as
+// k_coef3a / k_coef3b below, so the same bits -- instead of waiting for a one-workgroup kernel between the passes (two
+// launches and two dependent kernel boundaries less per step).  Workgroup 0 also stores what later kernels / the host
+// read: the new column of the cached block, alpha, rho, the coefficients.
+struct Fold3 {
+	const double* parts;        // previous pass's partials (NULL: coefficients come from k_coef3a / k_coef3b through `coef`)
+	int count, stride;
+	CoefArgs a;
+	int fresh_row;              // pass 2 only: ring row whose column s_i'y_fresh the previous pass produced (quantities k..2k-1), or -1
+	double* gsy;
+	const double* sy;
+	const double* yy;
+	double* alpha;              // [k] logical order: written by pass 2, read by pass 3
+	double* rho_out;
+};
+
+// SY[i*k+j] = s_i'y_j for i <= j in logical order (diagonal from `sy`); a column that pass 1 has only just produced
+// comes from `col` (LDS) because workgroup 0's store to the cached block is not visible to the other workgroups yet
+__device__ __forceinline__ void fold_load_sy(const Fold3& f, const double* col, double* SY)
+{
+	const int k = f.a.k;
+	for (int e = threadIdx.x; e < k * k; e += kBlock) {
+		const int i = e / k, j = e % k;
+		double v;
+		if (i == j) v = f.sy[f.a.rows[i]];
+		else if (col != nullptr && f.a.rows[j] == f.fresh_row) v = col[i];
+		else v = f.gsy[(size_t) f.a.rows[i] * f.a.m + f.a.rows[j]];
+		SY[e] = v;
+	}
+}
+
+// pass 2's prologue = k_coef3a: cf[0] = scale, cf[1 + i] = alpha_i
+__device__ __forceinline__ void fold_backward(const Fold3& f, double* SY, double* bS, double* col, double* cf)
+{
+	const int k = f.a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	if (f.fresh_row >= 0) {
+		for (int i = wave; i < k; i += kWaves) {
+			const double t = wave_total_of(f.parts + (size_t) (k + i) * f.stride, f.count);      // s_i'y_fresh
+			if (lane == 0) {
+				col[i] = t;
+				if (blockIdx.x == 0) f.gsy[(size_t) f.a.rows[i] * f.a.m + f.fresh_row] = t;
+			}
+		}
+		__syncthreads();
+	}
+	fold_load_sy(f, f.fresh_row >= 0 ? col : nullptr, SY);
+	for (int q = wave; q < k; q += kWaves) {
+		const double t = wave_total_of(f.parts + (size_t) q * f.stride, f.count);
+		if (lane == 0) bS[q] = t;
+	}
+	__syncthreads();
+	if (wave == 0) {
+		const bool mine = lane < k;
+		double al = 0;
+		for (int i = k - 1; i >= 0; i--) {                       // alpha_i = rho_i s_i'q_{i+1}  (:676-677)
+			const double t = (mine && lane > i) ? al * SY[i * k + lane] : 0.0;
+			const double sq = bS[i] - wave_sum_all(t);
+			const double rho_i = 1.0 / SY[i * k + i];
+			if (lane == i) {
+				al = rho_i * sq;
+				if (blockIdx.x == 0) { f.alpha[i] = al; f.rho_out[i] = rho_i; }
+			}
+		}
+		if (lane == 0) cf[0] = (f.a.h0 > 0) ? f.a.h0 : SY[(k - 1) * k + (k - 1)] / f.yy[f.a.rows[k - 1]];   // :683-689 / :698
+		if (mine) cf[1 + lane] = al;
+	}
+	__syncthreads();
+}
+
+// pass 3's prologue = k_coef3b: cf[i] = c_i = alpha_i - beta_i
+__device__ __forceinline__ void fold_forward(const Fold3& f, double* SY, double* V, double* cf)
+{
+	const int k = f.a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	fold_load_sy(f, nullptr, SY);
+	for (int q = wave; q < k; q += kWaves) {
+		const double t = wave_total_of(f.parts + (size_t) q * f.stride, f.count);
+		if (lane == 0) V[q] = t;
+	}
+	__syncthreads();
+	if (wave == 0) {
+		const bool mine = lane < k;
+		const double al = mine ? f.alpha[lane] : 0.0;
+		double c = 0;
+		for (int i = 0; i < k; i++) {                            // beta_i = rho_i y_i'r_i, r_i = r0 + sum_{j<i} c_j s_j  (:705-706)
+			const double t = (lane < i) ? c * SY[lane * k + i] : 0.0;
+			const double yr = V[i] + wave_sum_all(t);
+			if (lane == i) c = al - (1.0 / SY[i * k + i]) * yr;
+		}
+		if (mine) cf[lane] = c;
+	}
+	__syncthreads();
+}
+
 struct DiagArgs {               // how pass 2 scales q0
 	const real* H0_in;          // caller-supplied diagonal (isolated two-loop), or NULL
 	real* G;                    // adaQN: grad_sum_sq in/out (then H0_out receives g/sqrt(G+eps)), or NULL
@@ -1251,13 +1345,19 @@ struct DiagArgs {               // how pass 2 scales q0
 };
 
 template <int W, int NG, bool NT, int MODE /*0 scalar, 1 given diagonal, 2 adaQN*/, bool SS>
-__global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, const double* coef, real* g, DiagArgs dg, uint32_t n, int rev, double* parts)
+__global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, const double* coef, Fold3 fo, real* g, DiagArgs dg, uint32_t n, int rev,
+                                                 uint32_t keep_from, double* parts)
 {
 	__shared__ double sh[NG * 8 * kWaves];
 	__shared__ double cf[1 + kPairsMax3];
 	const int k = ys.count;
-	for (int e = threadIdx.x; e < 1 + k; e += kBlock) cf[e] = coef[e];
-	__syncthreads();
+	if (fo.parts != nullptr) {
+		__shared__ double SY[kPairsMax3 * kPairsMax3], bS[kPairsMax3], col[kPairsMax3];
+		fold_backward(fo, SY, bS, col, cf);
+	} else {
+		for (int e = threadIdx.x; e < 1 + k; e += kBlock) cf[e] = coef[e];
+		__syncthreads();
+	}
 	double acc[NG * 8];
 	#pragma unroll
 	for (int j = 0; j < NG * 8; j++) acc[j] = 0;
@@ -1299,7 +1399,10 @@ __global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, const double* coef, 
 				#pragma unroll
 				for (int e = 0; e < W; e++) acc[j] = fma((double) f[j].v[e], q.v[e], acc[j]);
 			}
-		if constexpr (SS) st_stream<W>(g, i, q); else st<W>(g, i, q);
+		// the part of r0 this pass writes last is what pass 3 (opposite direction) reads first: those packs are stored with
+		// the default policy so that they may still sit in the Infinity Cache, the rest streams past it (keep_from)
+		if constexpr (SS) { if (p >= keep_from) st<W>(g, i, q); else st_stream<W>(g, i, q); }
+		else st<W>(g, i, q);
 	}
 	if (W > 1) {
 		const uint32_t i = packs * W + threadIdx.x;
@@ -1339,25 +1442,38 @@ __global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, const double* coef, 
 	}
 }
 
-// pass 3: r = r0 + sum_j c_j s_j, oldest pair first (:702-707); guard sums (sum r^2, #non-finite)
-template <int W, bool NT, int T, bool SS>
-__global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, real* r, uint32_t n, int rev, double* parts)
+// pass 3: r = r0 + sum_j c_j s_j, oldest pair first (:702-707); guard sums (sum r^2, #non-finite).
+// FUSE (check_nan == 0: the update does not wait for a verdict, reference :825-838): x -= step r, x_sum += x and
+// oLBFGS's s-slot / grad <- -step r in the same pass, as the sweep form's last forward sweep does -- no guard sums, no apply pass.
+template <int W, bool NT, int T, bool SS, bool FUSE>
+__global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, Fold3 fo, real* r, ApplyArgs ap, uint32_t n, int rev,
+                                                 uint32_t keep_from, double* parts)
 {
 	__shared__ double sh[kWaves];
 	__shared__ double cf[kPairsMax3];
 	const int k = ss.count;
-	for (int e = threadIdx.x; e < k; e += kBlock) cf[e] = coef[e];
-	__syncthreads();
+	if (fo.parts != nullptr) {
+		__shared__ double SY[kPairsMax3 * kPairsMax3], V[kPairsMax3];
+		fold_forward(fo, SY, V, cf);
+	} else {
+		for (int e = threadIdx.x; e < k; e += kBlock) cf[e] = coef[e];
+		__syncthreads();
+	}
 	double acc0 = 0, acc1 = 0;
 	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
 	for (uint32_t p0 = blockIdx.x * kBlock + threadIdx.x; p0 < packs; p0 += T * stride) {
-		Pack<W> out[T];
+		Pack<W> out[T], xo[T], xso[T];
 		#pragma unroll
 		for (int t = 0; t < T; t++) {
 			const uint32_t p = p0 + t * stride;
 			if (p < packs) {
 				const uint32_t i = (rev ? last - p : p) * W;
 				Pack<W> v = ld<W, false>(r, i);
+				Pack<W> xv, xs;
+				if constexpr (FUSE) {
+					xv = ld<W, false>(ap.x, i);
+					if (ap.x_sum) xs = ld<W, false>(ap.x_sum, i);
+				}
 				for (int j0 = 0; j0 < k; j0 += 8) {
 					RPack<W> fs[8];
 					#pragma unroll
@@ -1370,8 +1486,17 @@ __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, 
 							for (int e = 0; e < W; e++) v.v[e] = fma(cf[j0 + u], (double) fs[u].v[e], v.v[e]);
 						}
 				}
-				#pragma unroll
-				for (int e = 0; e < W; e++) { acc0 = fma(v.v[e], v.v[e], acc0); acc1 += (isfinite(v.v[e]) ? 0.0 : 1.0); }
+				if constexpr (FUSE) {
+					#pragma unroll
+					for (int e = 0; e < W; e++) {
+						xo[t].v[e] = fma(-ap.step, v.v[e], xv.v[e]);                  // :838
+						if (ap.x_sum) xso[t].v[e] = xs.v[e] + xo[t].v[e];             // :283
+						if (ap.s_slot) v.v[e] = (-ap.step) * v.v[e];                  // :1006: grad <- -step r (and the s-slot)
+					}
+				} else {
+					#pragma unroll
+					for (int e = 0; e < W; e++) { acc0 = fma(v.v[e], v.v[e], acc0); acc1 += (isfinite(v.v[e]) ? 0.0 : 1.0); }
+				}
 				out[t] = v;
 			}
 		}
@@ -1379,8 +1504,15 @@ __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, 
 		for (int t = 0; t < T; t++) {
 			const uint32_t p = p0 + t * stride;
 			if (p < packs) {
-				if constexpr (SS) st_stream<W>(r, (rev ? last - p : p) * W, out[t]);
-				else st<W>(r, (rev ? last - p : p) * W, out[t]);
+				const uint32_t i = (rev ? last - p : p) * W;
+				if constexpr (FUSE) {
+					st<W>(ap.x, i, xo[t]);
+					if (ap.x_sum) st<W>(ap.x_sum, i, xso[t]);
+					if (ap.s_slot) st_nt<W>(ap.s_slot, i, out[t]);
+					st<W>(r, i, out[t]);
+				} else if constexpr (SS) {
+					if (p >= keep_from) st<W>(r, i, out[t]); else st_stream<W>(r, i, out[t]);     // see k_qdot: the tail stays cacheable for the apply pass
+				} else st<W>(r, i, out[t]);
 			}
 		}
 	}
@@ -1389,12 +1521,19 @@ __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, 
 		if (blockIdx.x == gridDim.x - 1 && i < n) {
 			double v = (double) r[i];
 			for (int j = 0; j < k; j++) v = fma(cf[j], (double) ss.row[j][i], v);
-			acc0 = fma(v, v, acc0); acc1 += (isfinite(v) ? 0.0 : 1.0);
+			if constexpr (FUSE) {
+				const double xn = fma(-ap.step, v, (double) ap.x[i]);
+				ap.x[i] = (real) xn;
+				if (ap.x_sum) ap.x_sum[i] = (real) ((double) ap.x_sum[i] + xn);
+				if (ap.s_slot) { v = (-ap.step) * v; ap.s_slot[i] = (real) v; }
+			} else { acc0 = fma(v, v, acc0); acc1 += (isfinite(v) ? 0.0 : 1.0); }
 			r[i] = (real) v;
 		}
 	}
-	const double t0 = block_sum(acc0, sh), t1 = block_sum(acc1, sh);
-	if (threadIdx.x == 0) { parts[blockIdx.x] = t0; parts[kMaxGrid + blockIdx.x] = t1; }
+	if constexpr (!FUSE) {
+		const double t0 = block_sum(acc0, sh), t1 = block_sum(acc1, sh);
+		if (threadIdx.x == 0) { parts[blockIdx.x] = t0; parts[kMaxGrid + blockIdx.x] = t1; }
+	}
 }
 
 // coef a: totals of pass 1, the new pair's column of the cached s_old'y_new block (fresh_row >= 0: quantities
@@ -1919,7 +2058,29 @@ void launch_coef3a(const Scratch& sc, Partials b, const CoefArgs& a, int fresh_r
 	                   sc.alpha, sc.rho, sc.coef);
 }
 
-Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g, const QdotScale& q)
+static uint32_t keep_from_pack(const Scratch& sc, size_t n, bool vec)
+{
+	// first pack (in traversal order) that is stored with the default cache policy; the packs before it stream past the caches
+	const double f = sc.keep_tail;
+	if (!(f > 0)) return 0xFFFFFFFFu;
+	const size_t packs = n / (vec ? kVec : 1);
+	if (f >= 1) return 0;
+	return (uint32_t) (packs - (size_t) ((double) packs * f));
+}
+
+static Fold3 fold_args(const Scratch& sc, const Partials* in, const CoefArgs* a, int fresh_row)
+{
+	Fold3 f{};
+	if (!in || !a) return f;                                   // parts == NULL: coefficients come from the coef kernels
+	f.parts = in->parts; f.count = in->count; f.stride = in->stride;
+	f.a = *a;
+	f.fresh_row = fresh_row;
+	f.gsy = sc.gsy; f.sy = sc.sy; f.yy = sc.yy; f.alpha = sc.alpha; f.rho_out = sc.rho;
+	return f;
+}
+
+Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g, const QdotScale& q, const Partials* fold_in,
+                     const CoefArgs* fold_a, int fresh_row)
 {
 	const int grid = sweep_grid(sc, n, sc.qdot_per_cu > 0 ? sc.qdot_per_cu : 1);
 	const bool vec = rows_aligned(y_rows) && all_aligned(g, q.H0_in, q.G, q.H0_out, q.frow_out);
@@ -1927,10 +2088,12 @@ Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g,
 	const int ng = (y_rows.count + 7) / 8;
 	const int mode = q.G ? 2 : (q.H0_in ? 1 : 0);
 	DiagArgs dg{q.H0_in, q.G, q.H0_out, q.frow_out, q.rmsprop_weight, 1 - q.rmsprop_weight, q.scal_reg, q.rmsprop_weight > 0 && q.rmsprop_weight < 1};
+	const Fold3 fo = fold_args(sc, fold_in, fold_a, fresh_row);
+	const uint32_t keep = keep_from_pack(sc, n, vec);
 	{
 		ProfScope ps(sc, K_QDOT);
-		#define SQN_QD3(WW, NG, MODE) { if (sc.stream_stores && sc.qdot_stream) hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, true>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, sc.coef, g, dg, (uint32_t) n, rev, sc.rows_part[1]); \
-		                                else hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, false>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, sc.coef, g, dg, (uint32_t) n, rev, sc.rows_part[1]); }
+		#define SQN_QD3(WW, NG, MODE) { if (sc.stream_stores && sc.qdot_stream) hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, true>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, sc.coef, fo, g, dg, (uint32_t) n, rev, keep, sc.rows_part[1]); \
+		                                else hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, false>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, sc.coef, fo, g, dg, (uint32_t) n, rev, keep, sc.rows_part[1]); }
 		#define SQN_QD2(WW, NG) { if (mode == 2) SQN_QD3(WW, NG, 2) else if (mode == 1) SQN_QD3(WW, NG, 1) else SQN_QD3(WW, NG, 0) }
 		#define SQN_QD1(WW) { if (ng <= 1) SQN_QD2(WW, 1) else if (ng == 2) SQN_QD2(WW, 2) else if (ng == 3) SQN_QD2(WW, 3) else if (ng == 4) SQN_QD2(WW, 4) else if (ng == 5) SQN_QD2(WW, 5) else SQN_QD2(WW, 6) }
 		if (vec) SQN_QD1(kVec) else SQN_QD1(1)
@@ -1951,20 +2114,27 @@ void launch_coef3b(const Scratch& sc, Partials v, const CoefArgs& a)
 	hipLaunchKernelGGL(k_coef3b, dim3(1), dim3(kCoefBlock), 0, sc.stream, v.parts, v.count, v.stride, a, sc.gsy, sc.sy, sc.alpha, sc.coef);
 }
 
-Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r)
+Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r, const Partials* fold_in, const CoefArgs* fold_a,
+                     const ApplyArgs* fuse)
 {
 	const int grid = sweep_grid(sc, n, sc.sadd_per_cu > 0 ? sc.sadd_per_cu : 2);
-	const bool vec = rows_aligned(s_rows) && all_aligned(r);
+	const bool vec = rows_aligned(s_rows) && all_aligned(r) && (!fuse || all_aligned(fuse->x, fuse->x_sum, fuse->s_slot));
 	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
+	const Fold3 fo = fold_args(sc, fold_in, fold_a, -1);
+	const uint32_t keep = keep_from_pack(sc, n, vec);
+	const ApplyArgs ap = fuse ? *fuse : ApplyArgs{};
+	const double* cf = sc.coef + 1 + kPairsMax3;
 	{
 		ProfScope ps(sc, K_SADD);
-		#define SQN_SA(WW, T) { if (sc.stream_stores) hipLaunchKernelGGL((k_sadd<WW, true, T, true>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, sc.coef + 1 + kPairsMax3, r, (uint32_t) n, rev, sc.part[buf]); \
-		                        else hipLaunchKernelGGL((k_sadd<WW, true, T, false>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, sc.coef + 1 + kPairsMax3, r, (uint32_t) n, rev, sc.part[buf]); }
+		#define SQN_SA2(WW, T, SS, FU) hipLaunchKernelGGL((k_sadd<WW, true, T, SS, FU>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, cf, fo, r, ap, (uint32_t) n, rev, keep, sc.part[buf])
+		#define SQN_SA(WW, T) { if (fuse) SQN_SA2(WW, (T > 4 ? 4 : T), false, true); else if (sc.stream_stores) SQN_SA2(WW, T, true, false); else SQN_SA2(WW, T, false, false); }
 		const int T = sc.combine_batch;
 		if (vec) { if (T >= 8) SQN_SA(kVec, 8) else if (T >= 4) SQN_SA(kVec, 4) else SQN_SA(kVec, 1) }
 		else     { if (T >= 4) SQN_SA(1, 4) else SQN_SA(1, 1) }
 		#undef SQN_SA
+		#undef SQN_SA2
 	}
+	if (fuse) return Partials{nullptr, 0, 0};
 	return finish(sc, buf, 2, grid);
 }
 

@@ -43,6 +43,7 @@ struct Call {
 	real* g = nullptr;
 	bool g_host = false;
 	bool fresh = false;             // the device context was created by this call
+	bool x_down = false, g_down = false;   // the update pass already sent x / the direction to the host, slice by slice
 };
 
 inline size_t N(const DevCtx* c) { return (size_t) c->n; }
@@ -114,6 +115,7 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 	}
 	io.c = c;
 	io.fresh = fresh;
+	if (fresh) attach_spill(c, niter, section);      // reclaimed while idle?  then its state comes back from the library's host copy
 	// a context that could not be completed is dropped again: the next call starts over (and
 	// re-imports host arrays) instead of continuing on half-bound views
 	if (!bind_bfgs(c, b, fresh && resumed)) { release(b->s_mem); return false; }
@@ -137,7 +139,7 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 void stage_xg(Call& io, bool need_x, bool need_g)
 {
 	DevCtx* c = io.c;
-	if (need_x) io.x = stage_in(c, 0, io.x_caller, N(c), io.host_caller);
+	if (need_x) io.x = io.host_caller ? stage_x(c, io.x_caller, N(c)) : io.x_caller;
 	if (need_g) io.g = stage_in(c, 1, io.g_caller, N(c), io.g_host);
 }
 
@@ -149,6 +151,7 @@ real* publish(Call& io, View& v, size_t offset, int slot)
 	if (!io.host_caller) return dev;
 	if (v.mirror) {                       // caller's own host array: refresh it, hand it back
 		real* host = (real*) const_cast<void*>(v.caller) + offset;
+		if (v.count == N(c)) (void) ensure_registered(c, host, N(c) * sizeof(real));      // x_sum / x_avg_prev: one array, requested every L steps
 		vec_to_host(c, host, dev, N(c));
 		return host;
 	}
@@ -165,9 +168,48 @@ real* publish(Call& io, View& v, size_t offset, int slot)
 void close_call(Call& io, bool x_changed, bool g_changed)
 {
 	DevCtx* c = io.c;
-	if (x_changed && io.host_caller && io.x) vec_to_host(c, io.x_caller, io.x, N(c));
-	if (g_changed && io.g_host && io.g && options().strict_grad) vec_to_host(c, io.g_caller, io.g, N(c));
+	if (x_changed && io.host_caller && io.x && !io.x_down) vec_to_host(c, io.x_caller, io.x, N(c));
+	if (g_changed && io.g_host && io.g && options().strict_grad && !io.g_down) vec_to_host(c, io.g_caller, io.g, N(c));
 	sync(c);
+	if (io.host_caller && io.x) x_handed_back(c, io.x_caller, N(c));      // device and host copies of x agree from here on
+}
+
+// The guarded update for a HOST caller of a large problem: the pass is element-wise, so it runs slice by slice (bit-identical
+// to one launch) and each finished slice of x -- and of the direction when the caller wants it back -- starts its way over
+// PCIe on a side stream while the next slice is still being updated.
+void apply_step(Call& io, Partials guard, const real* r_in, real* grad_out, const ApplyArgs& ap, bool guarded)
+{
+	DevCtx* c = io.c;
+	const Scratch& sc = c->sc;
+	const size_t n = N(c);
+	const bool want_x = io.host_caller && io.x == ap.x, want_g = io.g_host && options().strict_grad && io.g == grad_out;
+	const int chunks = options().apply_chunks;
+	const size_t min_chunk = (size_t) 1 << 20;               // elements: below this a slice is all launch overhead
+	if ((!want_x && !want_g) || chunks < 2 || n < 2 * min_chunk || !ensure_copy_stream(c, chunks)) {
+		launch_apply(sc, n, c->n_global, guard, r_in, grad_out, ap, guarded);
+		return;
+	}
+	(void) ensure_registered(c, io.x_caller, n * sizeof(real));
+	if (want_g) (void) ensure_registered(c, io.g_caller, n * sizeof(real));
+	size_t per = (n + (size_t) chunks - 1) / (size_t) chunks;
+	if (per < min_chunk) per = min_chunk;
+	per = (per + 2 * kVec - 1) / (2 * kVec) * (2 * kVec);   // whole packs: every slice keeps the alignment of the vector
+	int j = 0;
+	for (size_t off = 0; off < n; off += per, j++) {
+		const size_t cnt = n - off < per ? n - off : per;
+		ApplyArgs a = ap;
+		a.x = ap.x + off;
+		if (ap.x_sum) a.x_sum = ap.x_sum + off;
+		if (ap.s_slot) a.s_slot = ap.s_slot + off;
+		launch_apply(sc, cnt, c->n_global, guard, r_in + off, grad_out + off, a, guarded);
+		SQN_HIP_OK(hipEventRecord(c->chunk_ev[(size_t) j], sc.stream));
+		SQN_HIP_OK(hipStreamWaitEvent(c->copy_stream, c->chunk_ev[(size_t) j], 0));
+		if (want_x) SQN_HIP_OK(hipMemcpyAsync(io.x_caller + off, ap.x + off, cnt * sizeof(real), hipMemcpyDeviceToHost, c->copy_stream));
+		if (want_g) SQN_HIP_OK(hipMemcpyAsync(io.g_caller + off, grad_out + off, cnt * sizeof(real), hipMemcpyDeviceToHost, c->copy_stream));
+	}
+	c->copy_busy = true;
+	io.x_down = want_x;
+	io.g_down = want_g;
 }
 
 // ---- ring bookkeeping (reference src/stochqn.c:554-579) ----------------------------------------
@@ -196,6 +238,13 @@ void ensure_rho(DevCtx* c, size_t st, size_t used)
 		c->rho_ok[r] = 1;
 	}
 }
+
+// the isolated entry points hold their context for the duration of one call
+struct InUse {
+	DevCtx* c;
+	explicit InUse(DevCtx* c_) : c(c_) {}
+	~InUse() { end_use(c); }
+};
 
 struct StepIn {
 	double step = 0;
@@ -376,7 +425,8 @@ bool threepass_ok(DevCtx* c, size_t st, size_t used)
 
 // Returns the guard partials (sum r^2, nonfinite); the direction replaces g.  `qs` says how q0 is scaled:
 // all-NULL = scalar (gamma of the newest pair, or h0 > 0), H0_in = a given diagonal, G = adaQN's step.
-Partials enqueue_three_pass(DevCtx* c, real* g, size_t used, size_t st, double h0, real* gprev_out, const QdotScale& qs)
+Partials enqueue_three_pass(DevCtx* c, real* g, size_t used, size_t st, double h0, real* gprev_out, const QdotScale& qs,
+                            const ApplyArgs* fuse = nullptr)
 {
 	const size_t m = c->m, k = used;
 	RowSet ss{}, ys{};
@@ -395,10 +445,14 @@ Partials enqueue_three_pass(DevCtx* c, real* g, size_t used, size_t st, double h
 	const int fresh = ensure_sy_columns(c, st, k, ss, a);
 	Partials b = launch_sdot(c->sc, N(c), ss, g, gprev_out, fresh >= 0 ? row(c->Y, (size_t) fresh, c) : nullptr);
 	if (fresh >= 0) c->sy_ok[(size_t) fresh] = 1;             // stored by the coefficient kernel, ahead of the recursion
+	if (c->sc.fold_coef) {                                    // the recursions in the prologues of the passes themselves
+		Partials v = launch_qdot(c->sc, N(c), ys, g, qs, &b, &a, fresh);
+		return launch_sadd(c->sc, c->next_buf(), N(c), ss, g, &v, &a, fuse);
+	}
 	launch_coef3a(c->sc, b, a, fresh);
 	Partials v = launch_qdot(c->sc, N(c), ys, g, qs);
 	launch_coef3b(c->sc, v, a);
-	return launch_sadd(c->sc, c->next_buf(), N(c), ss, g);
+	return launch_sadd(c->sc, c->next_buf(), N(c), ss, g, nullptr, nullptr, fuse);
 }
 
 // adaQN (diagonal H0) in two passes: all inner products incl. the H0-weighted ones + the side effects
@@ -544,7 +598,8 @@ void enqueue_step(Call& io, const StepIn& in)
 		const bool need_first = in.check_nan || fa.gprev_out || fa.frow_out || fa.G;
 		Partials guard{nullptr, 0, 0};
 		if (need_first) guard = launch_first(sc, c->next_buf(), n, fa);
-		launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
+		apply_step(io, guard, in.g, in.g, ap, in.check_nan != 0);
+		stat_add(ST_STEP_PLAIN);
 	} else {
 		fa.H0_out = in.H0;                                            // :818
 		const size_t st = (in.st_ix == in.used) ? 0 : in.st_ix;      // :820
@@ -552,18 +607,28 @@ void enqueue_step(Call& io, const StepIn& in)
 		if (!raw_cold && (!in.G || in.H0) && threepass_ok(c, st, in.used)) {
 			QdotScale qs{};
 			if (in.G) { qs.G = in.G; qs.H0_out = in.H0; qs.frow_out = in.frow_out; qs.rmsprop_weight = in.w; qs.scal_reg = in.eps; }
-			Partials guard = enqueue_three_pass(c, in.g, in.used, st, in.h0, in.gprev_out, qs);
-			launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
+			// check_nan == 0: nothing waits for a verdict, the update rides in pass 3 (as in the sweep form below, reference :825-838)
+			const bool fuse = !in.check_nan && options().fuse_apply;
+			Partials guard = enqueue_three_pass(c, in.g, in.used, st, in.h0, in.gprev_out, qs, fuse ? &ap : nullptr);
+			if (!fuse) apply_step(io, guard, in.g, in.g, ap, in.check_nan != 0);
+			stat_add(ST_STEP_THREE_PASS);
 		} else if (!raw_cold && twopass_ok(c, st, in.used, in.G ? in.H0 : nullptr)) {
 			Partials guard = enqueue_two_pass(c, in.g, in.used, st, in.h0, in.gprev_out);
-			launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
+			apply_step(io, guard, in.g, in.g, ap, in.check_nan != 0);
+			stat_add(ST_STEP_TWO_PASS);
 		} else if (!raw_cold && twopass_h0_ok(c, st, in.used, in)) {
 			Partials guard = enqueue_two_pass_h0(c, in, st);
-			launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
+			apply_step(io, guard, in.g, in.g, ap, in.check_nan != 0);
+			stat_add(ST_STEP_TWO_PASS_H0);
 		} else {
+			stat_add(ST_STEP_SWEEPS);
+			// was a cached form configured for this ring, and only the kappa rule said no?  (kappa is cached per row: no extra work)
+			if (!raw_cold && options().twopass && (!in.G || in.H0) &&
+			    c->m <= (size_t) (options().threepass ? kPairsMax3 : kPairsMax) && !pairs_tame(c, st, in.used))
+				stat_add(ST_KAPPA_FALLBACK);
 			Partials guard = enqueue_two_loop(c, in.g, in.used, st, fa, in.h0, in.G ? in.H0 : nullptr,
 			                                  in.check_nan ? nullptr : &ap);
-			if (in.check_nan) launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, true);
+			if (in.check_nan) apply_step(io, guard, in.g, in.g, ap, true);
 		}
 	}
 	// one read-back per step: report (bad flag, sum r^2, #nonfinite) | rho | alpha, contiguous in the pool
@@ -676,9 +741,9 @@ template <class W> void before_call(W* w)
 {
 	if (w && w->bfgs_memory && w->section == 0) release(w->bfgs_memory->s_mem);
 }
-template <class W> int after_call(W* w, int rc, task_enum* task)
+template <class W> int after_call(W* w, int rc, task_enum* task, bool req_is_x)
 {
-	if (w && w->bfgs_memory && note_state(w->bfgs_memory->s_mem, w->niter, w->section)) {
+	if (w && w->bfgs_memory && note_state(w->bfgs_memory->s_mem, w->niter, w->section, req_is_x)) {
 		*task = invalid_input;                    // a HIP error surfaced during this call
 		return -1000;
 	}
@@ -1010,7 +1075,7 @@ int local_run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, 
 		ApiRange range("run_oLBFGS", w ? w->section : -1);
 		before_call(w);
 		const int rc = run_oLBFGS_impl(step_size, x, grad, req, task, w, iter_info);
-		return after_call(w, rc, task);
+		return after_call(w, rc, task, req && *req == x);
 	});
 }
 
@@ -1021,7 +1086,7 @@ int local_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[]
 		ApiRange range("run_SQN", w ? w->section : -1);
 		before_call(w);
 		const int rc = run_SQN_impl(step_size, x, grad, hess_vec, req, req_vec, task, w, iter_info);
-		return after_call(w, rc, task);
+		return after_call(w, rc, task, req && *req == x);
 	});
 }
 
@@ -1032,7 +1097,7 @@ int local_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
 		ApiRange range("run_adaQN", w ? w->section : -1);
 		before_call(w);
 		const int rc = run_adaQN_impl(step_size, x, f, grad, req, task, w, iter_info);
-		return after_call(w, rc, task);
+		return after_call(w, rc, task, req && *req == x);
 	});
 }
 }  // namespace sqn
@@ -1287,7 +1352,7 @@ static DevCtx* raw_context(real_t s_mem[], real_t y_mem[], int n, size_t mem_siz
 	DevCtx* c = acquire(raw_key(s_mem), KIND_RAW, n, mem_size, 0, fresh);
 	if (!c) return nullptr;
 	const size_t nn = (size_t) n;
-	if (!bind(c, c->S, s_mem, mem_size * nn, true) || !bind(c, c->Y, y_mem, mem_size * nn, true)) return nullptr;
+	if (!bind(c, c->S, s_mem, mem_size * nn, true) || !bind(c, c->Y, y_mem, mem_size * nn, true)) { end_use(c); return nullptr; }
 	// host arrays may have changed since the last call: refresh the mirrors
 	if (c->S.mirror && !*fresh) SQN_HIP_OK(hipMemcpyAsync(c->S.dev, s_mem, mem_size * nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
 	if (c->Y.mirror && !*fresh) SQN_HIP_OK(hipMemcpyAsync(c->Y.dev, y_mem, mem_size * nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
@@ -1310,6 +1375,7 @@ static int two_loop_impl(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 	bool fresh = false;
 	DevCtx* c = raw_context(s_mem, y_mem, n, mem_size, &fresh);
 	if (!c) return -1000;
+	InUse hold(c);
 	const size_t nn = (size_t) n;
 	if (!bind(c, c->H0, H0, H0 ? nn : 0, true)) return -1000;
 	if (c->H0.mirror) SQN_HIP_OK(hipMemcpyAsync(c->H0.dev, H0, nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
@@ -1358,6 +1424,7 @@ static int take_step_impl(real_t step_size, int n, real_t x[], real_t grad[], bf
 	bool fresh = false;
 	DevCtx* c = raw_context(b->s_mem, b->y_mem, n, b->mem_size, &fresh);
 	if (!c) return -1000;
+	InUse hold(c);
 	const size_t nn = (size_t) n;
 	real_t* H0_used = grad_sum_sq ? H0 : nullptr;          // a caller-supplied diagonal is approx_inv_hess_grad's business (two_loop)
 	if (!bind(c, c->H0, H0_used, H0_used ? nn : 0, false) || !bind(c, c->G, grad_sum_sq, grad_sum_sq ? nn : 0, true)) return -1000;
@@ -1403,6 +1470,7 @@ static int fisher_product_impl(real_t F[], size_t fu, int n, real_t s[], real_t 
 	bool fresh = false;
 	DevCtx* c = acquire(raw_key(F), KIND_RAW, n, 1, fu, &fresh);
 	if (!c) return -1000;
+	InUse hold(c);
 	const size_t nn = (size_t) n;
 	if (!c->attached) { comm_attach(c); c->attached = true; }
 	// F: used in place when on the device, else mirrored (re-uploaded every call: contents may have changed)

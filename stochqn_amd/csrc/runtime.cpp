@@ -5,11 +5,13 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -18,11 +20,36 @@ namespace sqn {
 
 namespace {
 
-std::mutex g_mu;
+std::recursive_mutex g_mu;          // recursive: an allocation made under the lock may reclaim another context (reclaim_one)
 std::unordered_map<const void*, DevCtx*> g_ctx;
 Options g_opt;
+unsigned long long g_clock = 0;                 // registry clock: DevCtx::last_use
+
+// ---- contexts reclaimed under memory pressure ---------------------------------------------------
+// R and Python never call dealloc_*: an optimiser object that was dropped leaves its device context (the mirrors of its
+// host arrays: S, Y, F ... tens of GB at the BASELINE shapes) behind until the process ends.  When device memory runs out
+// -- or the mirrors exceed option "max_mirror_bytes" -- the least recently used context that is not inside a call is
+// *spilled*: its mirrors are copied to host memory owned by the library and the context is destroyed.  Not into the
+// caller's arrays: the object may be long gone and its arrays freed.  If the object does come back (same address, counters
+// that continue where the spilled context stopped) the first call re-creates the context from the spill; if something
+// else turns up at that address the spill is dropped.
+struct SpillPiece { const void* caller = nullptr; size_t count = 0; real* data = nullptr; };
+struct Spill {
+	int kind = 0, n = 0;
+	size_t m = 0, fsize = 0, niter = 0, bytes = 0;
+	int section = 0;
+	std::vector<SpillPiece> pieces;
+	~Spill() { for (auto& p : pieces) std::free(p.data); }
+};
+std::unordered_map<const void*, Spill*> g_spill;
 std::atomic<long> g_fail_alloc_after{-1};       // fault injection: < 0 off, else allocations left before one fails
 std::atomic<int> g_inject_device_fault{0};      // fault injection: the next stream synchronisation reports a failure
+
+std::atomic<long long> g_stats[ST_COUNT];
+const char* const kStatNames[ST_COUNT] = {
+	"steps_three_pass", "steps_two_pass", "steps_two_pass_h0", "steps_sweeps", "steps_plain", "steps_kappa_fallback",
+	"allreduces", "allreduce_doubles", "contexts_created", "contexts_reclaimed", "x_uploads", "x_uploads_skipped",
+	"host_ranges_registered", "graph_launches"};
 
 bool alloc_should_fail()
 {
@@ -86,6 +113,7 @@ void reducer_failed(void* user, const char* what)
 void allreduce_hook(void* user, double* buf, int count, hipStream_t stream)
 {
 	DevCtx* c = static_cast<DevCtx*>(user);
+	stat_add(ST_ALLREDUCE); stat_add(ST_ALLREDUCE_DOUBLES, count);
 	ncclResult_t r = g_comm.AllReduce(buf, buf, (size_t) count, ncclDouble, ncclSum, (ncclComm_t) c->red.comm, stream);
 	if (r != ncclSuccess) {
 		std::fprintf(stderr, "stochqn: ncclAllReduce: %s\n", g_comm.GetErrorString ? g_comm.GetErrorString(r) : "?");
@@ -102,6 +130,7 @@ struct Custom {
 
 void custom_hook(void* user, double* buf, int count, hipStream_t stream)
 {
+	stat_add(ST_ALLREDUCE); stat_add(ST_ALLREDUCE_DOUBLES, count);
 	if (g_custom.fn(g_custom.user, buf, count, (void*) stream) != 0)
 		reducer_failed(user, "the caller-supplied all-reduce reported a failure");
 }
@@ -139,6 +168,7 @@ void loopback_hook(void* user, double* buf, int count, hipStream_t stream)
 	Loopback& lp = *c->red.loop;
 	const int me = c->red.rank;
 	double tmp[kRedMax];
+	stat_add(ST_ALLREDUCE); stat_add(ST_ALLREDUCE_DOUBLES, count);       // per shard of this process, like the RCCL hook
 	SQN_HIP_OK(hipStreamSynchronize(stream));
 	for (int done = 0; done < count; done += kRedMax) {            // Fisher products reduce fisher_size scalars
 		const int k = count - done < kRedMax ? count - done : kRedMax;
@@ -165,6 +195,8 @@ void free_view(View& v)
 void destroy(DevCtx* c)
 {
 	if (c->sc.stream) SQN_HIP_OK(hipStreamSynchronize(c->sc.stream));
+	delete static_cast<Spill*>(c->spill);
+	c->spill = nullptr;
 	c->prof.collect();
 	for (int i = 0; i < K_COUNT; i++) { g_retired_ms[i] += c->prof.total_ms[i]; g_retired_launches[i] += c->prof.launches[i]; }
 	for (auto& p : c->prof.pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
@@ -180,6 +212,11 @@ void destroy(DevCtx* c)
 		else std::free(c->host_stage[i]);
 	}
 	if (c->pin) SQN_HIP_OK(hipHostFree(c->pin));
+	if (c->copy_stream) { (void) hipStreamSynchronize(c->copy_stream); (void) hipStreamDestroy(c->copy_stream); }
+	for (hipEvent_t e : c->chunk_ev) (void) hipEventDestroy(e);
+	if (c->copy_done) (void) hipEventDestroy(c->copy_done);
+	for (auto& r : c->regs)
+		if (r.p) { if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError(); }   // the caller may have freed it already
 	if (c->sc.stream) SQN_HIP_OK(hipStreamDestroy(c->sc.stream));
 	delete c;
 }
@@ -203,6 +240,99 @@ void at_exit()
 
 }  // namespace
 
+void stat_add(int id, long long v) { g_stats[id].fetch_add(v, std::memory_order_relaxed); }
+
+namespace {
+
+void views_of(DevCtx* c, View** out)
+{
+	View* vs[] = {&c->S, &c->Y, &c->sbak, &c->ybak, &c->gprev, &c->xsum, &c->xprev, &c->H0, &c->G, &c->F};
+	for (int i = 0; i < 10; i++) out[i] = vs[i];
+}
+
+size_t mirror_bytes(DevCtx* c)
+{
+	View* vs[10];
+	views_of(c, vs);
+	size_t b = 0;
+	for (View* v : vs) if (v->mirror && v->dev) b += v->count * sizeof(real);
+	return b;
+}
+
+void drop_spill(const void* key)
+{
+	auto it = g_spill.find(key);
+	if (it == g_spill.end()) return;
+	delete it->second;
+	g_spill.erase(it);
+}
+
+void destroy(DevCtx* c);
+
+// Spill and destroy the least recently used idle context that holds mirrors.  g_mu held.  false: nothing to reclaim.
+bool reclaim_one()
+{
+	for (;;) {
+		DevCtx* victim = nullptr;
+		for (auto& kv : g_ctx) {
+			DevCtx* c = kv.second;
+			if (c->in_call || c->no_spill || mirror_bytes(c) == 0) continue;
+			if (!victim || c->last_use < victim->last_use) victim = c;
+		}
+		if (!victim) return false;
+		const void* key = victim->key;
+		// a context that never completed a call holds nothing the caller's own arrays do not; raw contexts re-upload every call
+		if (victim->has_last && victim->kind != KIND_RAW) {
+			std::unique_ptr<Spill> sp(new Spill());
+			sp->kind = victim->kind; sp->n = victim->n; sp->m = victim->m; sp->fsize = victim->fsize;
+			sp->niter = victim->last_niter; sp->section = victim->last_section;
+			if (victim->sc.stream) SQN_HIP_OK(hipStreamSynchronize(victim->sc.stream));
+			View* vs[10];
+			views_of(victim, vs);
+			bool ok = true;
+			for (View* v : vs) {
+				if (!v->mirror || !v->dev || v->count == 0) continue;
+				SpillPiece pc;
+				pc.caller = v->caller; pc.count = v->count;
+				pc.data = (real*) std::malloc(v->count * sizeof(real));
+				if (!pc.data || hipMemcpy(pc.data, v->dev, v->count * sizeof(real), hipMemcpyDeviceToHost) != hipSuccess) {
+					(void) hipGetLastError();
+					std::free(pc.data);
+					ok = false;
+					break;
+				}
+				sp->bytes += v->count * sizeof(real);
+				sp->pieces.push_back(pc);
+			}
+			if (!ok) { victim->no_spill = true; continue; }     // no host memory for it: leave it alone, look for another
+			drop_spill(key);
+			g_spill[key] = sp.release();
+		}
+		if (std::getenv("STOCHQN_HIP_VERBOSE"))
+			std::fprintf(stderr, "stochqn: device memory is short: the idle context of the workspace at %p (%zu MB of mirrors) was moved to host memory\n",
+			             key, mirror_bytes(victim) >> 20);
+		g_ctx.erase(key);
+		destroy(victim);
+		stat_add(ST_CTX_RECLAIMED);
+		return true;
+	}
+}
+
+}  // namespace
+
+// Option "max_mirror_bytes": keep the mirrors of idle contexts under the cap (the context inside a call is never touched).
+void enforce_mirror_cap()
+{
+	const long cap = options().max_mirror_bytes;
+	if (cap <= 0) return;
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
+	for (;;) {
+		size_t total = 0;
+		for (auto& kv : g_ctx) total += mirror_bytes(kv.second);
+		if (total <= (size_t) cap || !reclaim_one()) return;
+	}
+}
+
 Options& options()
 {
 	static const bool env_read = [] {            // environment defaults, for callers that cannot reach set_option (R, Python)
@@ -217,14 +347,21 @@ Options& options()
 
 bool device_alloc(void** p, size_t bytes)
 {
-	*p = nullptr;
-	if (alloc_should_fail() || hipMalloc(p, bytes ? bytes : 1) != hipSuccess) {
+	for (;;) {
+		*p = nullptr;
+		if (!alloc_should_fail() && hipMalloc(p, bytes ? bytes : 1) == hipSuccess) return true;
 		(void) hipGetLastError();
 		*p = nullptr;
+		// out of device memory: give up the mirrors of an optimiser nobody has called for the longest time, try again
+		bool freed;
+		{
+			std::lock_guard<std::recursive_mutex> lk(g_mu);
+			freed = reclaim_one();
+		}
+		if (freed) continue;
 		std::fprintf(stderr, "stochqn: could not allocate %zu bytes of device memory\n", bytes);
 		return false;
 	}
-	return true;
 }
 
 bool pinned_alloc(void** p, size_t bytes)
@@ -263,6 +400,8 @@ void begin_call(DevCtx* c)
 	c->sc.fisher_rows = g_opt.fisher_rows;
 	c->sc.stream_stores = g_opt.stream_stores;
 	c->sc.qdot_stream = g_opt.qdot_stream;
+	c->sc.fold_coef = g_opt.fold_coef;
+	c->sc.keep_tail = g_opt.keep_tail;
 	c->sc.qdot_per_cu = g_opt.qdot_per_cu; c->sc.sadd_per_cu = g_opt.sadd_per_cu; c->sc.sdot2_per_cu = g_opt.sdot2_per_cu; c->sc.sdot_per_cu = g_opt.sdot_per_cu;
 	c->sc.prof = g_profile ? &c->prof : nullptr;
 	c->sc.phase = &c->phase;
@@ -329,20 +468,22 @@ bool is_device_pointer(const void* p)
 
 DevCtx* lookup(const void* key)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
 	auto it = g_ctx.find(key);
 	return it == g_ctx.end() ? nullptr : it->second;
 }
 
 DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* fresh)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
 	*fresh = false;
 	auto it = g_ctx.find(key);
 	if (it != g_ctx.end()) {
 		DevCtx* c = it->second;
 		if (c->kind == kind && c->n == n && c->m == m && c->fsize == fsize) {
 			begin_call(c);
+			c->last_use = ++g_clock;
+			c->in_call = true;
 			return c;
 		}
 		destroy(c);              // same address, different problem: the old owner is gone
@@ -351,6 +492,8 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	DevCtx* c = new DevCtx();
 	c->key = key; c->kind = kind; c->n = n; c->m = m; c->fsize = fsize;
 	c->n_global = (double) n;
+	c->last_use = ++g_clock;
+	c->in_call = true;
 	SQN_HIP_OK(hipStreamCreate(&c->sc.stream));   // blocking flavour: ordered after the null stream
 	// pool layout: part0 | part1 | red0 | red1 | sy | yy | report | rho | alpha | rows_part x2 | gsy | gyy | coef
 	const size_t part = (size_t) kMaxSums * kMaxGrid;
@@ -387,6 +530,7 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	c->sc.allreduce = nullptr;
 	c->sc.user = c;
 	g_ctx[key] = c;
+	stat_add(ST_CTX_CREATED);
 	if (!g_atexit) {
 		g_atexit = true;
 		std::atexit(at_exit);
@@ -399,14 +543,49 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 bool prepare_context(const void* key, int kind, int n, size_t m, size_t fsize)
 {
 	bool fresh = false;
-	return acquire(key, kind, n, m, fsize, &fresh) != nullptr;
+	DevCtx* c = acquire(key, kind, n, m, fsize, &fresh);
+	if (c) c->in_call = false;
+	return c != nullptr;
 }
 
-bool note_state(const void* key, size_t niter, int section)
+void end_use(DevCtx* c) { if (c) c->in_call = false; }
+
+// The state a reclaimed context left in host memory, if it is this object's: same shape, and the counters continue where
+// that context stopped.  Anything else at this address is a different object: the spill is dropped.
+void attach_spill(DevCtx* c, size_t niter, int section)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
+	auto it = g_spill.find(c->key);
+	if (it == g_spill.end()) return;
+	Spill* sp = it->second;
+	g_spill.erase(it);
+	if (sp->kind == c->kind && sp->n == c->n && sp->m == c->m && sp->fsize == c->fsize && sp->niter == niter && sp->section == section)
+		c->spill = sp;
+	else delete sp;
+}
+
+void detach_spill(DevCtx* c)
+{
+	delete static_cast<Spill*>(c->spill);
+	c->spill = nullptr;
+}
+
+bool has_spill(const void* key)
+{
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
+	return g_spill.count(key) != 0;
+}
+
+bool note_state(const void* key, size_t niter, int section, bool req_is_x)
+{
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
 	auto it = g_ctx.find(key);
 	if (it == g_ctx.end()) return false;
+	it->second->in_call = false;
+	detach_spill(it->second);                        // whatever the first call after a reclaim did not pick up is not this object's
+	// x is only known to be untouched until the next call while it is what *req designates ("do NOT modify", reference
+	// include/stochqn.h:364-366); a request at x_avg leaves the caller free to edit x
+	if (!req_is_x) it->second->x_valid = false;
 	it->second->has_last = true;
 	it->second->last_niter = niter;
 	it->second->last_section = section;
@@ -417,7 +596,8 @@ bool note_state(const void* key, size_t niter, int section)
 
 void release(const void* key)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
+	drop_spill(key);
 	auto it = g_ctx.find(key);
 	if (it == g_ctx.end()) return;
 	destroy(it->second);
@@ -426,14 +606,15 @@ void release(const void* key)
 
 void release_all()
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
 	for (auto& kv : g_ctx) destroy(kv.second);
 	g_ctx.clear();
+	for (auto& kv : g_spill) delete kv.second;
+	g_spill.clear();
 }
 
 bool bind(DevCtx* c, View& v, real* caller, size_t count, bool import)
 {
-	(void) c;
 	if (caller == v.caller && count == v.count && (v.dev || count == 0)) return true;
 	free_view(v);
 	v.caller = caller;
@@ -446,8 +627,32 @@ bool bind(DevCtx* c, View& v, real* caller, size_t count, bool import)
 		return false;
 	}
 	v.mirror = true;
+	// a context that was reclaimed while idle comes back from the library's own host copy, not from the caller's (stale) arrays
+	if (Spill* sp = static_cast<Spill*>(c->spill)) {
+		for (auto& pc : sp->pieces)
+			if (pc.caller == caller && pc.count == count && pc.data) {
+				SQN_HIP_OK(hipMemcpy(v.dev, pc.data, count * sizeof(real), hipMemcpyHostToDevice));
+				std::free(pc.data);
+				pc.data = nullptr;
+				enforce_mirror_cap();
+				return true;
+			}
+	}
 	// without `import` the mirror starts with indeterminate contents, like the reference's malloc
 	if (import) SQN_HIP_OK(hipMemcpy(v.dev, caller, count * sizeof(real), hipMemcpyHostToDevice));
+	enforce_mirror_cap();
+	return true;
+}
+
+// stochqn_hip_export of a workspace whose context was reclaimed: the caller asks for its arrays to be brought up to date,
+// so they are alive -- copy the spilled state into them (the spill stays: the object may still be called again)
+bool export_spill(const void* key)
+{
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
+	auto it = g_spill.find(key);
+	if (it == g_spill.end()) return false;
+	for (auto& pc : it->second->pieces)
+		if (pc.data && pc.caller) std::memcpy(const_cast<void*>(pc.caller), pc.data, pc.count * sizeof(real));
 	return true;
 }
 
@@ -471,19 +676,97 @@ real* host_landing(DevCtx* c, int slot)
 	return c->host_stage[slot];
 }
 
+bool ensure_registered(DevCtx* c, const void* p, size_t bytes)
+{
+	const Options& o = options();
+	if (!o.register_host || !p || (long) bytes < o.register_min_bytes) return false;
+	for (auto& r : c->regs)
+		if (r.p == p) {
+			if (r.bytes >= bytes) return true;
+			if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError();
+			r = DevCtx::HostRange{};
+		}
+	// pinned already by somebody else (hipHostMalloc, a caller's own hipHostRegister)?  then it is as fast as it gets
+	hipPointerAttribute_t a;
+	if (hipPointerGetAttributes(&a, p) == hipSuccess) { if (a.type == hipMemoryTypeHost) return true; }
+	else (void) hipGetLastError();
+	DevCtx::HostRange& slot = c->regs[c->reg_turn++ % (int) (sizeof(c->regs) / sizeof(c->regs[0]))];
+	if (slot.p) { if (hipHostUnregister(const_cast<void*>(slot.p)) != hipSuccess) (void) hipGetLastError(); slot = DevCtx::HostRange{}; }
+	if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
+		(void) hipGetLastError();                        // not fatal: the runtime's staged copies still work
+		return false;
+	}
+	slot.p = p;
+	slot.bytes = bytes;
+	stat_add(ST_HOST_REGISTERED);
+	return true;
+}
+
 real* stage_in(DevCtx* c, int which, real* caller, size_t count, bool host)
 {
 	if (!host) return caller;
 	if (!ensure_stage(c, which)) return nullptr;
+	(void) ensure_registered(c, caller, count * sizeof(real));
 	SQN_HIP_OK(hipMemcpyAsync(c->stage[which], caller, count * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
 	return c->stage[which];
+}
+
+static inline size_t probe_index(int j, size_t count)
+{
+	return count <= 1 ? 0 : (size_t) (((unsigned __int128) j * (count - 1)) / (DevCtx::kProbe - 1));
+}
+
+real* stage_x(DevCtx* c, real* caller, size_t count)
+{
+	if (!ensure_stage(c, 0)) return nullptr;
+	bool current = options().x_upload == 0 && c->kind != KIND_RAW && c->x_valid && c->x_host == caller;
+	if (current) {
+		// belt and braces: the values at kProbe spread-out positions must still be the ones handed back (a caller that
+		// rescales, projects or resets x between calls is caught here and simply gets its x uploaded)
+		for (int j = 0; j < DevCtx::kProbe && current; j++) {
+			const double v = (double) caller[probe_index(j, count)];
+			current = std::memcmp(&v, &c->x_probe[j], sizeof v) == 0;
+		}
+	}
+	if (current) { stat_add(ST_X_UPLOAD_SKIPPED); return c->stage[0]; }
+	c->x_valid = false;
+	stat_add(ST_X_UPLOAD);
+	(void) ensure_registered(c, caller, count * sizeof(real));
+	SQN_HIP_OK(hipMemcpyAsync(c->stage[0], caller, count * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
+	return c->stage[0];
+}
+
+void x_handed_back(DevCtx* c, const real* caller, size_t count)
+{
+	c->x_host = caller;
+	c->x_valid = !c->fault;
+	for (int j = 0; j < DevCtx::kProbe; j++) c->x_probe[j] = (double) caller[probe_index(j, count)];
+}
+
+bool ensure_copy_stream(DevCtx* c, int chunks)
+{
+	if (!c->copy_stream) {
+		if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); c->copy_stream = nullptr; return false; }
+		if (hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); c->copy_done = nullptr; return false; }
+	}
+	while ((int) c->chunk_ev.size() < chunks) {
+		hipEvent_t e;
+		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); return false; }
+		c->chunk_ev.push_back(e);
+	}
+	return c->copy_done != nullptr;
 }
 
 void sync(DevCtx* c)
 {
 	// a kernel that could not be launched (or failed) leaves its outputs stale: never hand that back
 	// as a result -- the call reports invalid_input / -1000 instead (machines.cpp: after_call)
-	const hipError_t e = hipStreamSynchronize(c->sc.stream);
+	hipError_t e = hipStreamSynchronize(c->sc.stream);
+	if (c->copy_busy) {                                  // slices of x still on their way to the host
+		const hipError_t e2 = hipStreamSynchronize(c->copy_stream);
+		if (e == hipSuccess) e = e2;
+		c->copy_busy = false;
+	}
 	hipError_t l = hipGetLastError();
 	if (g_inject_device_fault.exchange(0)) l = hipErrorLaunchFailure;
 	if (e != hipSuccess || l != hipSuccess) {
@@ -602,7 +885,7 @@ int stochqn_hip_export(const void* s_mem)
 	int grc = 0;
 	if (group_export(s_mem, &grc)) return grc;
 	DevCtx* c = lookup(s_mem);
-	if (!c) return -1000;
+	if (!c) return export_spill(s_mem) ? 0 : -1000;      // reclaimed while idle: its state sits in host memory
 	View* vs[] = {&c->S, &c->Y, &c->sbak, &c->ybak, &c->gprev, &c->xsum, &c->xprev, &c->H0, &c->G, &c->F};
 	for (View* v : vs) export_view(c, *v);
 	sync(c);
@@ -633,6 +916,9 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "fisher_rows")) g_opt.fisher_rows = (int) value;
 	else if (!std::strcmp(name, "stream_stores")) g_opt.stream_stores = value != 0;
 	else if (!std::strcmp(name, "qdot_stream")) g_opt.qdot_stream = value != 0;
+	else if (!std::strcmp(name, "fold_coef")) g_opt.fold_coef = value != 0;
+	else if (!std::strcmp(name, "fuse_apply")) g_opt.fuse_apply = value != 0;
+	else if (!std::strcmp(name, "keep_tail")) g_opt.keep_tail = value < 0 ? 0 : (value > 1 ? 1 : value);
 	else if (!std::strcmp(name, "qdot_per_cu")) g_opt.qdot_per_cu = (int) value;
 	else if (!std::strcmp(name, "sadd_per_cu")) g_opt.sadd_per_cu = (int) value;
 	else if (!std::strcmp(name, "sdot2_per_cu")) g_opt.sdot2_per_cu = (int) value;
@@ -643,6 +929,11 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "threepass")) g_opt.threepass = value != 0;
 	else if (!std::strcmp(name, "twopass_kappa_max")) g_opt.twopass_kappa_max = value;
 	else if (!std::strcmp(name, "strict_grad")) g_opt.strict_grad = value != 0;
+	else if (!std::strcmp(name, "register_host")) g_opt.register_host = value != 0;
+	else if (!std::strcmp(name, "register_min_bytes")) g_opt.register_min_bytes = value < 0 ? 0 : (long) value;
+	else if (!std::strcmp(name, "x_upload")) g_opt.x_upload = (int) value;
+	else if (!std::strcmp(name, "apply_chunks")) g_opt.apply_chunks = value < 1 ? 1 : (value > 64 ? 64 : (int) value);
+	else if (!std::strcmp(name, "max_mirror_bytes")) g_opt.max_mirror_bytes = value < 0 ? 0 : (long) value;
 	else if (!std::strcmp(name, "devices")) options().devices = value < 0 ? 0 : (int) value;
 	else if (!std::strcmp(name, "virtual_devices")) options().virtual_devices = value != 0;
 	else if (!std::strcmp(name, "devices_min_n")) options().devices_min_n = (long) value;
@@ -656,14 +947,14 @@ int stochqn_hip_set_option(const char* name, double value)
 
 void stochqn_hip_profile_enable(int on)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
 	g_profile = on != 0;
 	for (auto& kv : g_ctx) kv.second->sc.prof = g_profile ? &kv.second->prof : nullptr;
 }
 
 void stochqn_hip_profile_reset(void)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
 	for (auto& kv : g_ctx) kv.second->prof.reset();
 	for (int i = 0; i < K_COUNT; i++) { g_retired_ms[i] = 0; g_retired_launches[i] = 0; }
 }
@@ -674,7 +965,7 @@ const char* stochqn_hip_profile_name(int id) { return kernel_name(id); }
 int stochqn_hip_profile_get(int id, long long* launches, double* total_ms)
 {
 	if (id < 0 || id >= K_COUNT) return -1;
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
 	long long l = g_retired_launches[id];
 	double ms = g_retired_ms[id];
 	for (auto& kv : g_ctx) { l += kv.second->prof.launches[id]; ms += kv.second->prof.total_ms[id]; }
@@ -744,6 +1035,52 @@ int stochqn_hip_comm_init_custom(int rank, int nranks, stochqn_hip_allreduce_fn 
 }
 
 int stochqn_hip_comm_nranks(void) { return comm_nranks(); }
+
+// Latency of one reduction as the kernel chain pays it: `reps` in-place sums of `count` doubles through the reducer the
+// calling thread's contexts use (RCCL communicator, caller-supplied reducer, loop-back), each followed by a stream
+// synchronisation; median and minimum in microseconds.  Collective: every rank / shard thread calls it alike.
+int stochqn_hip_comm_allreduce_probe(int count, int reps, double* median_us, double* min_us)
+{
+	if (!device_ready() || count < 1 || count > kRedMax || reps < 1) return -1000;
+	DevCtx c;
+	c.red = current_reducer();
+	if (c.red.kind == Reducer::NONE) return -1;
+	void (*hook)(void*, double*, int, hipStream_t) =
+		c.red.kind == Reducer::LOOP ? loopback_hook : (c.red.kind == Reducer::CUSTOM ? custom_hook : allreduce_hook);
+	double* buf = nullptr;
+	hipStream_t st = nullptr;
+	if (!device_alloc((void**) &buf, (size_t) count * sizeof(double))) return -1000;
+	if (hipStreamCreate(&st) != hipSuccess) { (void) hipFree(buf); return -1000; }
+	SQN_HIP_OK(hipMemsetAsync(buf, 0, (size_t) count * sizeof(double), st));
+	std::vector<double> us((size_t) reps);
+	for (int w = 0; w < 5 && !c.fault; w++) { hook(&c, buf, count, st); SQN_HIP_OK(hipStreamSynchronize(st)); }
+	for (int r = 0; r < reps && !c.fault; r++) {
+		const auto t0 = std::chrono::steady_clock::now();
+		hook(&c, buf, count, st);
+		SQN_HIP_OK(hipStreamSynchronize(st));
+		us[(size_t) r] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+	}
+	(void) hipStreamDestroy(st);
+	(void) hipFree(buf);
+	if (c.fault) return -1000;
+	std::sort(us.begin(), us.end());
+	if (median_us) *median_us = us[(size_t) reps / 2];
+	if (min_us) *min_us = us[0];
+	return 0;
+}
+
+long long stochqn_hip_stat(const char* name)
+{
+	if (!name) return -1;
+	for (int i = 0; i < ST_COUNT; i++)
+		if (!std::strcmp(name, kStatNames[i])) return g_stats[i].load(std::memory_order_relaxed);
+	return -1;
+}
+
+void stochqn_hip_stats_reset(void)
+{
+	for (int i = 0; i < ST_COUNT; i++) g_stats[i].store(0, std::memory_order_relaxed);
+}
 
 int stochqn_hip_loopback_init(int nranks)
 {

@@ -38,14 +38,32 @@ struct Options {
 	int fisher_rows = 16;        // Fisher rows per workgroup pass (8, 16, 32)
 	int qdot_per_cu = 0, sadd_per_cu = 0, sdot2_per_cu = 0, sdot_per_cu = 0;
 	bool qdot_stream = true;
+	bool fold_coef = true;       // three-pass form: coefficient recursions inside the prologues of pass 2 / pass 3 (two launches less per step)
+	// three-pass form with check_nan = 0: the position update inside pass 3 (no apply pass).  Measured at n = 1e8, k = 20
+	// (profiles/r03_ab_fuse_apply.jsonl): 3.68 ms fused against 2.79 + 0.73 ms -- two more store streams among 21 read
+	// streams cost more than the pass they save, as for the guarded case in round 2.  Off.
+	bool fuse_apply = false;
+	// three-pass form: fraction of r0 / r stored with the default (cacheable) policy -- the part the next pass, which walks
+	// the other way, reads first; the rest leaves with sc1 nt.  0.25-0.5 measured 1 % ahead of 0 and of 1 (profiles/r03_ab_fold_tail.jsonl)
+	double keep_tail = 0.35;
 	bool stream_stores = true;   // pass B: sc1 nt stores (kernels.hip: st_stream)
 	bool twopass_h0 = true;      // adaQN (diagonal H0) in the two-pass form as well
 	double twopass_kappa_max = 1e6;   // two-pass form only while every pair in use has |s||y|/|s'y| <= this (else: sweeps)
-	bool strict_grad = true;
+	// host callers: copy the search direction back into `grad` (n words over PCIe).  The reference documents `grad` as an
+	// input that "will be modified in-place" (include/stochqn.h:356-358), not as an output, and no shipped caller reads it
+	// afterwards (Rwrapper.c, pywrapper.pxi, c_rosen.c): off by default, on for callers that do.
+	bool strict_grad = false;
 	// single-process multi-device mode (group.cpp): shard n over `devices` GPUs of this process
 	int devices = 0;             // 0 / 1 = off; also STOCHQN_HIP_DEVICES in the environment
 	bool virtual_devices = false;   // shards may share a physical device (host-side reducer): rehearsal on one GPU
 	long devices_min_n = 1 << 20;   // problems smaller than this stay on one device (SURVEY.md 8e "no-shard fallback")
+	// host callers (R / numpy / malloc arrays crossing the ABI): PCIe is what a step costs, so
+	int register_host = 1;          // pin the caller's x / grad / hess_vec in place (hipHostRegister, once per array) so that their copies are DMA at link speed
+	long register_min_bytes = 4l << 20;   // ... for arrays of at least this many bytes (below, the runtime's staged copy is as fast)
+	int x_upload = 0;               // 0: x is not uploaded when the device copy is what the library handed back and the caller kept its hands off
+	                                //    (reference include/stochqn.h:364-366: "*req ... do NOT modify"); 1: always upload
+	int apply_chunks = 8;           // host callers: the update pass runs in this many slices so that the download of x overlaps it
+	long max_mirror_bytes = 0;      // > 0: cap on the device memory held by mirrors of host arrays (least recently used contexts are exported and dropped)
 	bool raw_reuse_cache = false;   // isolated entry points keep their cached s'y / Gram entries between calls (caller vouches for S, Y)
 	bool verify_cache = false;   // debugging aid for device callers: recompute cached dots every call and compare
 };
@@ -91,6 +109,23 @@ struct DevCtx {
 	double* pool = nullptr;            // one allocation behind sc.part/red/sy/yy/alpha/rho/report
 	double* fisher_t = nullptr;        // [fsize] F*s on device
 	real* stage[3] = {nullptr, nullptr, nullptr};     // device staging for host x / grad / hess_vec
+	// host-caller path: the caller's arrays pinned in place, the side stream the download of x runs on while the
+	// update pass is still working on later slices, and what is known about the device copy of x
+	struct HostRange { const void* p = nullptr; size_t bytes = 0; };
+	HostRange regs[6];
+	int reg_turn = 0;
+	hipStream_t copy_stream = nullptr;
+	std::vector<hipEvent_t> chunk_ev;
+	hipEvent_t copy_done = nullptr;
+	bool copy_busy = false;            // work was enqueued on copy_stream during this call
+	const void* x_host = nullptr;      // the host array stage[0] mirrors
+	bool x_valid = false;              // stage[0] holds the caller's current x (the library wrote both; *req == x went back)
+	static constexpr int kProbe = 256;
+	double x_probe[kProbe];            // the caller's x at kProbe spread-out positions when it was last handed back
+	unsigned long long last_use = 0;   // registry clock at the last call (least-recently-used reclaim)
+	bool in_call = false;              // between acquire() and the end of the API call: never reclaimed
+	bool no_spill = false;             // host memory for a spill of this context could not be had: leave it on the device
+	void* spill = nullptr;             // the state a reclaimed predecessor of this context left in host memory (runtime.cpp: Spill)
 	real* host_stage[2] = {nullptr, nullptr};         // host landing zones for *req / *req_vec
 	bool host_stage_pinned[2] = {false, false};       // (pageable when pinned memory ran out)
 	double* pin = nullptr;             // pinned host read-back block
@@ -118,6 +153,15 @@ struct DevCtx {
 	int next_buf() { int b = buf; buf ^= 1; return b; }
 };
 
+// Event counters behind stochqn_hip_stat(): which form of the recursion each step took, how many reductions crossed
+// the shards, what the context manager did.  Process-wide, relaxed atomics; stochqn_hip_stats_reset() zeroes them.
+enum StatId {
+	ST_STEP_THREE_PASS = 0, ST_STEP_TWO_PASS, ST_STEP_TWO_PASS_H0, ST_STEP_SWEEPS, ST_STEP_PLAIN, ST_KAPPA_FALLBACK,
+	ST_ALLREDUCE, ST_ALLREDUCE_DOUBLES, ST_CTX_CREATED, ST_CTX_RECLAIMED, ST_X_UPLOAD, ST_X_UPLOAD_SKIPPED,
+	ST_HOST_REGISTERED, ST_GRAPH_LAUNCH, ST_COUNT
+};
+void stat_add(int id, long long v = 1);
+
 bool device_ready();                                   // a HIP device exists and is usable
 // Every device / pinned-host allocation of the library goes through these two: they report failure
 // instead of printing and carrying on, and honour the fault-injection option "fail_alloc_after"
@@ -136,7 +180,13 @@ bool prepare_context(const void* key, int kind, int n, size_t m, size_t fsize);
 // registry key of the context behind the isolated entry points (stochqn_hip_two_loop / _take_step) for the arrays at `s_mem`
 inline const void* raw_key(const void* s_mem) { return static_cast<const char*>(s_mem) + 1; }
 // remember the caller-visible state on return; true if the context saw a HIP error during the call
-bool note_state(const void* key, size_t niter, int section);
+void end_use(DevCtx* c);                                // the API call that acquired `c` is over (isolated entry points)
+void attach_spill(DevCtx* c, size_t niter, int section);   // a freshly created context picks up what its reclaimed predecessor left
+void detach_spill(DevCtx* c);
+bool has_spill(const void* key);
+bool export_spill(const void* key);
+void enforce_mirror_cap();
+bool note_state(const void* key, size_t niter, int section, bool req_is_x = true);
 void release(const void* key);
 void release_all();
 
@@ -145,6 +195,13 @@ void release_all();
 bool bind(DevCtx* c, View& v, real* caller, size_t count, bool import);
 void export_view(DevCtx* c, View& v);                  // mirror -> caller's host array
 
+// Pin [p, p + bytes) of the caller's host memory in place (option "register_host"); false = not pinned (too small,
+// refused by the runtime, switched off): copies from / to it then go through the runtime's staging path as before.
+bool ensure_registered(DevCtx* c, const void* p, size_t bytes);
+// x of a host caller: upload unless the device copy is known to be current (option "x_upload"); stage[0] on return
+real* stage_x(DevCtx* c, real* caller, size_t count);
+void x_handed_back(DevCtx* c, const real* caller, size_t count);     // after the download of x has completed
+bool ensure_copy_stream(DevCtx* c, int chunks);
 bool ensure_stage(DevCtx* c, int which);               // device staging vector `which` exists
 real* stage_in(DevCtx* c, int which, real* caller, size_t count, bool host);       // H2D if host; nullptr = out of memory
 real* host_landing(DevCtx* c, int slot);               // host landing zone for *req / *req_vec (pinned if possible)

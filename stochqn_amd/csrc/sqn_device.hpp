@@ -110,6 +110,8 @@ struct Scratch {
 	int h0_per_cu;        // workgroups per CU of the diagonal-H0 Gram pass (0 = 2)
 	int fisher_rows;      // Fisher rows one workgroup accumulates per pass over its columns: 8, 16 or 32
 	int qdot_per_cu, sadd_per_cu, sdot2_per_cu, sdot_per_cu;   // workgroups per CU of the three-pass kernels (0 = default)
+	bool fold_coef;       // three-pass form: the scalar recursions run in the prologues of pass 2 / pass 3 instead of in kernels of their own
+	double keep_tail;     // three-pass form: fraction of r0 / r (the part written last) stored with the default policy instead of sc1 nt
 	bool qdot_stream;     // pass 2 of the three-pass form stores r0 with the streaming policy too
 	bool stream_stores;   // pass B stores its result with the agent-scope non-temporal policy (sc1 nt)
 	bool nontemporal;     // stream S/Y/F rows with nt loads
@@ -228,10 +230,15 @@ struct QdotScale {
 	double rmsprop_weight, scal_reg;
 };
 // pass 2: q0, r0 (replaces g), v_i = y_i'r0 -> quantities [0,k)
-Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows /*logical order*/, real* g, const QdotScale& q);
+// With fold_in / fold_a the backward recursion of coef3a runs in the pass's own prologue (every workgroup; option "fold_coef")
+// on the partials of pass 1 -- fresh_row as for launch_coef3a -- and launch_coef3a is not called.
+Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows /*logical order*/, real* g, const QdotScale& q,
+                     const Partials* fold_in = nullptr, const CoefArgs* fold_a = nullptr, int fresh_row = -1);
 void launch_coef3b(const Scratch& sc, Partials v, const CoefArgs& a);
-// pass 3: r = r0 + sum c_j s_j; returns the guard partials (sum r^2, nonfinite)
-Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r);
+// pass 3: r = r0 + sum c_j s_j; returns the guard partials (sum r^2, nonfinite).  fold_in / fold_a: the forward recursion of
+// coef3b in the prologue, on the partials of pass 2.  `fuse` (check_nan == 0): the position update in the same pass, no partials.
+Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r, const Partials* fold_in = nullptr,
+                     const CoefArgs* fold_a = nullptr, const ApplyArgs* fuse = nullptr);
 void launch_store_column(const Scratch& sc, Partials in /*k: s_i'y_col*/, const CoefArgs& a, int col_row);
 
 // ---- two-pass form with the diagonal H0 of adaQN -----------------------------------------------------
