@@ -1,0 +1,255 @@
+"""Host callers (R / numpy arrays crossing the ABI: reference src/Rwrapper.c:98-196, stochqn/pywrapper.pxi:161-207):
+the PCIe-side machinery behind the unchanged ABI -- pinned caller arrays, x not re-uploaded when the device copy
+is current, the update pass in slices with the download of x overlapping it -- must not change a single bit of
+what a device-resident caller gets; and idle contexts that were moved to host memory under device-memory pressure
+must come back as if nothing had happened."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from harness import NoisyQuadratic, OPTIMIZERS, compare_traces, rel_err, run_trace, to_np
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def _lib():
+    import stochqn_amd
+    lib = stochqn_amd.cdll()
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    lib.stochqn_hip_stat.argtypes = [C.c_char_p]
+    lib.stochqn_hip_stat.restype = C.c_longlong
+    lib.stochqn_hip_export.argtypes = [C.c_void_p]
+    return lib
+
+
+def stat(lib, name):
+    v = lib.stochqn_hip_stat(name.encode())
+    assert v >= 0, name
+    return v
+
+
+KW = {
+    "oLBFGS": dict(mem_size=4, min_curvature=1e-4),
+    "SQN": dict(mem_size=4, bfgs_upd_freq=3),
+    "adaQN": dict(mem_size=4, fisher_size=5, bfgs_upd_freq=3, max_incr=1.01, rmsprop_weight=0.9),
+}
+
+
+@pytest.mark.parametrize("kind", ["oLBFGS", "SQN", "adaQN"])
+@pytest.mark.parametrize("n", [1000, 2_500_001])
+def test_host_and_device_callers_agree_bit_for_bit(kind, n, hip_backend):
+    """The same calls with the same inputs through numpy arrays and through torch tensors: every x, every request,
+    every counter identical to the last bit.  n = 2,500,001 is past the thresholds of both host-side mechanisms (arrays of
+    20 MB are pinned in place; the update pass runs in slices) and odd, so every second ring row is off the 16-byte grid."""
+    import torch
+    lib = _lib()
+    lib.stochqn_hip_stats_reset()
+    P = NoisyQuadratic(n, seed=5)
+    calls = 26
+    host = run_trace(OPTIMIZERS[kind](backend=hip_backend, space="host", **KW[kind]), P, P.x0(), 0.05, calls)
+    skipped, uploads, pinned = stat(lib, "x_uploads_skipped"), stat(lib, "x_uploads"), stat(lib, "host_ranges_registered")
+    x = torch.as_tensor(P.x0(), device="cuda:0")
+    dev = run_trace(OPTIMIZERS[kind](backend=hip_backend, space="device", device="cuda:0", **KW[kind]), P, x, 0.05, calls)
+    for i, (h, d) in enumerate(zip(host, dev)):
+        for k in ("task", "info", "changed", "niter", "section", "mem_used", "mem_st_ix", "req_id"):
+            assert h[k] == d[k], (i, k)
+        for k in ("x", "req", "req_vec"):
+            if k in h:
+                assert np.array_equal(h[k], d[k]), "call %d: %s differs between the host and the device caller" % (i, k)
+    # x goes up on the first step and again only after a request that was not at x (x_avg every L steps: the caller may
+    # legally have touched x meanwhile); every other step reuses the device copy
+    assert uploads >= 1 and skipped >= 5, (uploads, skipped)
+    if kind == "oLBFGS":
+        assert uploads == 1, uploads             # every request of oLBFGS is at x
+    if n > 1_000_000:
+        assert pinned >= 2                       # x and grad (at least) were pinned in place
+    else:
+        assert pinned == 0                       # small arrays: not worth pinning
+    lib.stochqn_hip_release_all()
+
+
+def test_x_edited_by_the_caller_between_calls_is_seen(hip_backend, oracle_backend):
+    """The skipped upload must not turn x into the library's private variable: a caller that rescales / projects x between
+    two calls gets its x used.  (The reference forbids touching *req -- include/stochqn.h:364-366 -- which is x after an
+    ordinary step; the library still checks a spread of positions and uploads when anything moved.)"""
+    lib = _lib()
+    n = 50_000
+    P = NoisyQuadratic(n, seed=9)
+    kw = dict(mem_size=3, bfgs_upd_freq=4)
+
+    def drive(backend):
+        opt = OPTIMIZERS["SQN"](backend=backend, space="host", **kw)
+        x = P.x0()
+        xs = []
+        for call in range(30):
+            r = opt.run_optimizer(x, 0.05)
+            xs.append(x.copy())
+            if r["task"] == "calc_hess_vec":
+                rx, rv = r["requested_on"]
+                opt.update_hess_vec(P.hess_vec(to_np(rx), to_np(rv)))
+            else:
+                if call in (7, 16):
+                    x *= 0.5                                     # the caller's own move, between two calls
+                opt.update_gradient(P.grad(to_np(x if call in (7, 16) else r["requested_on"]), call))
+        return xs
+
+    lib.stochqn_hip_stats_reset()
+    got, want = drive(hip_backend), drive(oracle_backend)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert rel_err(g, w) <= TOL, i
+    assert stat(lib, "x_uploads") >= 3                           # the first step and the two edits
+    lib.stochqn_hip_release_all()
+
+
+def test_x_upload_option_always(hip_backend):
+    lib = _lib()
+    P = NoisyQuadratic(3000, seed=1)
+    try:
+        assert lib.stochqn_hip_set_option(b"x_upload", 1.0) == 0
+        lib.stochqn_hip_stats_reset()
+        run_trace(OPTIMIZERS["oLBFGS"](backend=hip_backend, space="host", mem_size=3), P, P.x0(), 0.05, 12)
+        assert stat(lib, "x_uploads_skipped") == 0 and stat(lib, "x_uploads") >= 5
+    finally:
+        lib.stochqn_hip_set_option(b"x_upload", 0.0)
+        lib.stochqn_hip_release_all()
+
+
+def test_sliced_update_equals_one_launch(hip_backend):
+    """apply_chunks = 1 (one launch, download afterwards) against the default slices: same bits."""
+    lib = _lib()
+    n = 2_200_003
+    P = NoisyQuadratic(n, seed=3)
+    out = []
+    try:
+        for chunks in (1.0, 8.0, 3.0):
+            assert lib.stochqn_hip_set_option(b"apply_chunks", chunks) == 0
+            out.append(run_trace(OPTIMIZERS["SQN"](backend=hip_backend, space="host", mem_size=3, bfgs_upd_freq=2), P, P.x0(), 0.05, 14))
+            lib.stochqn_hip_release_all()
+    finally:
+        lib.stochqn_hip_set_option(b"apply_chunks", 8.0)
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert np.array_equal(a["x"], b["x"]) and a["task"] == b["task"]
+
+
+def test_step_counters_name_the_form_that_ran(hip_backend):
+    """stochqn_hip_stat: which form of the recursion each step took."""
+    import torch
+    lib = _lib()
+    P = NoisyQuadratic(4000, seed=2)
+    lib.stochqn_hip_stats_reset()
+    x = torch.as_tensor(P.x0(), device="cuda:0")
+    run_trace(OPTIMIZERS["oLBFGS"](backend=hip_backend, space="device", device="cuda:0", mem_size=3), P, x, 0.05, 21)
+    plain, three = stat(lib, "steps_plain"), stat(lib, "steps_three_pass")
+    assert plain == 1 and three == 9 and stat(lib, "steps_sweeps") == 0, (plain, three)
+    try:
+        lib.stochqn_hip_set_option(b"twopass", 0.0)
+        lib.stochqn_hip_stats_reset()
+        x = torch.as_tensor(P.x0(), device="cuda:0")
+        run_trace(OPTIMIZERS["oLBFGS"](backend=hip_backend, space="device", device="cuda:0", mem_size=3), P, x, 0.05, 21)
+        assert stat(lib, "steps_sweeps") == 9 and stat(lib, "steps_three_pass") == 0 and stat(lib, "steps_kappa_fallback") == 0
+    finally:
+        lib.stochqn_hip_set_option(b"twopass", 1.0)
+    assert lib.stochqn_hip_stat(b"no_such_counter") == -1
+    lib.stochqn_hip_release_all()
+
+
+# ------------------------------------------------------------------------------------------------
+# idle contexts under device-memory pressure
+# ------------------------------------------------------------------------------------------------
+def _advance(opt, P, x, ncalls, first_call):
+    last = getattr(opt, "_last_grad_call", 999983)           # a same-batch request reuses the noise of the calc_grad before it
+    for call in range(first_call, first_call + ncalls):
+        r = opt.run_optimizer(x, 0.05)
+        if r["task"] == "calc_hess_vec":
+            rx, rv = r["requested_on"]
+            opt.update_hess_vec(P.hess_vec(to_np(rx), to_np(rv)))
+        elif r["task"] == "calc_fun_val_batch":
+            opt.update_function(P.f(to_np(r["requested_on"]), call))
+        else:
+            if r["task"] == "calc_grad":
+                last = opt._last_grad_call = call
+            opt.update_gradient(P.grad(to_np(r["requested_on"]), last if r["task"] == "calc_grad_same_batch" else call))
+
+
+@pytest.mark.parametrize("kind", ["oLBFGS", "SQN", "adaQN"])
+def test_abandoned_host_optimisers_are_reclaimed_and_a_survivor_resumes(kind, hip_backend, oracle_backend):
+    """R and Python never call dealloc_*.  With the mirrors capped (option max_mirror_bytes) a stream of host-array optimisers
+    that are used for a few steps and dropped keeps running: the least recently used idle contexts are moved to host
+    memory.  One object is kept alive and left idle meanwhile; when it is called again it continues from the library's
+    own copy of its state -- its own numpy arrays have been stale since its first call -- exactly like an oracle run
+    that was never interrupted."""
+    lib = _lib()
+    n = 40_000
+    P = NoisyQuadratic(n, seed=11)
+    kw = KW[kind]
+    ref = OPTIMIZERS[kind](backend=oracle_backend, space="host", **kw)
+    x_ref = P.x0()
+    _advance(ref, P, x_ref, 40, 0)
+
+    try:
+        per_ctx = (2 * kw["mem_size"] + 8) * n * 8
+        assert lib.stochqn_hip_set_option(b"max_mirror_bytes", float(3 * per_ctx)) == 0
+        lib.stochqn_hip_stats_reset()
+        keep = OPTIMIZERS[kind](backend=hip_backend, space="host", **kw)
+        x = P.x0()
+        _advance(keep, P, x, 17, 0)
+        idle = []
+        for j in range(12):                                  # used for a few steps, then never again, never released: what a
+            other = OPTIMIZERS[kind](backend=hip_backend, space="host", **kw)     # long R session leaves behind
+            xo = P.x0()
+            _advance(other, P, xo, 9, 0)
+            idle.append((other, xo))                         # (kept referenced so that every object has arrays -- a key -- of its own)
+        reclaimed = stat(lib, "contexts_reclaimed")
+        assert reclaimed >= 8, reclaimed
+        _advance(keep, P, x, 23, 17)                         # comes back from the spill
+        assert keep.niter == ref.niter and keep.BFGS_mem.mem_used == ref.BFGS_mem.mem_used
+        assert rel_err(x, x_ref) <= 1e-9
+        # checkpoint of an object whose context is spilled: export brings its own arrays up to date
+        more = OPTIMIZERS[kind](backend=hip_backend, space="host", **kw)
+        xm = P.x0()
+        _advance(more, P, xm, 9, 0)
+        for j in range(4):
+            o2 = OPTIMIZERS[kind](backend=hip_backend, space="host", **kw)
+            xo = P.x0()
+            _advance(o2, P, xo, 9, 0)
+            idle.append((o2, xo))
+        assert lib.stochqn_hip_export(C.c_void_p(more.BFGS_mem.s_mem.ctypes.data)) == 0
+        assert np.any(more.BFGS_mem.s_mem != 0)
+    finally:
+        lib.stochqn_hip_set_option(b"max_mirror_bytes", 0.0)
+        lib.stochqn_hip_release_all()
+
+
+def test_running_out_of_device_memory_reclaims_instead_of_failing(hip_backend, oracle_backend):
+    """The real thing: hipMalloc fails because the device is full; the idle context goes to host memory and the call succeeds."""
+    import torch
+    lib = _lib()
+    n, m = 6_000_000, 8                                      # S + Y mirrors: 2 * 8 * 6e6 * 8 = 768 MB per optimiser
+    P = NoisyQuadratic(n, seed=4)
+    kw = dict(mem_size=m, bfgs_upd_freq=2)
+    ref = OPTIMIZERS["SQN"](backend=oracle_backend, space="host", **kw)
+    x_ref = P.x0()
+    _advance(ref, P, x_ref, 12, 0)
+    lib.stochqn_hip_stats_reset()
+    a = OPTIMIZERS["SQN"](backend=hip_backend, space="host", **kw)
+    xa = P.x0()
+    _advance(a, P, xa, 6, 0)
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    ballast = torch.empty(free - (700 << 20), dtype=torch.uint8, device="cuda:0")     # leaves less than a second optimiser needs
+    try:
+        b = OPTIMIZERS["SQN"](backend=hip_backend, space="host", **kw)
+        xb = P.x0()
+        _advance(b, P, xb, 6, 0)                             # its mirrors only fit once a's have been moved out
+        assert stat(lib, "contexts_reclaimed") >= 1
+        _advance(a, P, xa, 6, 6)                             # and a comes back (b is idle now and makes room in turn)
+        assert stat(lib, "contexts_reclaimed") >= 2
+        assert a.niter == ref.niter and rel_err(xa, x_ref) <= 1e-9
+    finally:
+        del ballast
+        torch.cuda.empty_cache()
+        lib.stochqn_hip_release_all()

@@ -1593,7 +1593,7 @@ def test_bench_starts_its_own_ranks_and_shards_one_problem(tmp_path):
     box, reductions over gloo).  The inputs come from the counter-based generator, so the 3-rank problem IS the
     1-rank problem: the concatenated x of the ranks must equal the x of a 1-rank run over n = 3 x 3,000,001."""
     per = 3_000_001
-    common = ["--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--no-reference-form"]
+    common = ["--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--no-host-caller", "--no-reference-form"]
     out = _bench(["--gpus", "3", "--rehearse", "--vars-per-gpu", str(per), "--dump-x", str(tmp_path / "x3")] + common)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -1613,12 +1613,44 @@ def test_bench_starts_its_own_ranks_and_shards_one_problem(tmp_path):
     assert d["config"]["calls"] == d1["config"]["calls"]
 
 
+def test_bench_default_multi_gpu_run_carries_every_leg():
+    """`python bench.py --gpus 3 --rehearse` and NOTHING else -- the shape of the driver's command for N > 1: after the
+    primary weak-scaling leg the same JSON line must carry BASELINE config 5's weak-scaling point (`c5`), the strong-scaling
+    split of config 3 (`strong`), the latency of one reduction on the library's communicator with the number of reductions a
+    step issues (`allreduce_us`) and the one-process / N-devices mode as a fresh child process (`in_process`).  Rehearsed
+    with 3 ranks on the one GPU (every n divided by 50, reductions over gloo): the control flow is the N-GPU run's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rehearse"], capture_output=True, text=True,
+                         timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["rccl_nranks"] == 3 and d["scaling"] == "weak" and d["config"]["name"] == "c3"
+    assert d["legs_failed"] == [], d["legs"]
+    legs = d["legs"]
+    assert set(legs) == {"c5", "strong", "allreduce_us", "in_process"}
+    assert legs["c5"]["n_per_gpu"] == 125_000_000 // 50 and legs["c5"]["steps"] >= 20 and legs["c5"]["objective_fell"]
+    assert legs["c5"]["hess_vec_requests"] >= 2 and legs["c5"]["rejected_steps"] == 0 and legs["c5"]["steps_per_s"] > 0
+    assert legs["strong"]["n_total"] == 3 * (100_000_000 // 50 // 3) and legs["strong"]["objective_fell"]
+    assert legs["allreduce_us"]["median_us"] > 0 and legs["allreduce_us"]["min_us"] <= legs["allreduce_us"]["median_us"]
+    assert 3.0 <= legs["allreduce_us"]["allreduces_per_step"] <= 4.5        # three per step in the three-pass form + the pair work every L
+    assert abs(legs["c5"]["allreduces_per_step"] - legs["allreduce_us"]["allreduces_per_step"]) < 0.5
+    ip = legs["in_process"]
+    assert ip["device_shards"] == 3 and ip["n_per_gpu"] == 100_000_000 // 50 and ip["steps_per_s"] > 0 and ip["rejected_steps"] == 0
+    assert 3.0 <= ip["allreduces_per_step"] <= 4.5 and ip["allreduce_us"]["median_us"] > 0
+    assert d["forms"]["three_pass"] == d["steps"] and d["forms"]["sweeps"] == 0
+
+
 @pytest.mark.parametrize("config,n", [("c3", 100_000_000), ("c5", 125_000_000)])
 def test_bench_headline_workload_runs_clean(config, n):
     """bench.py's own workload under pytest: BASELINE config 3 exactly as measured (SQN n = 1e8, m = 20, L = 10, pairs from
     the 32-row Hessian mini-batch A'(Av)/32, check_nan = 1) and config 5's per-GPU shard (n = 1.25e8): pairs are built and
     accepted, no step is rejected, the objective falls, and the JSON line carries what the driver reads."""
-    out = _bench(["--config", config, "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--sustain-seconds", "1"], timeout=600)
+    out = _bench(["--config", config, "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-host-caller", "--sustain-seconds", "1"], timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -1636,6 +1668,7 @@ def test_bench_headline_workload_runs_clean(config, n):
     assert d["reference_form"]["two_loop_alg_bytes"] == 64 * 20 * n and d["reference_form"]["two_loop_frac_of_8TBps"] > 0.6
     micro = d["two_loop_micro"]
     assert micro["three_pass"]["median_ms"] < micro["two_pass"]["median_ms"] < micro["sweeps"]["median_ms"]
+    assert d["forms"] == dict(d["forms"], three_pass=20, two_pass=0, sweeps=0, sweeps_because_of_kappa=0) and d["allreduces_per_step"] == 0
     assert d["sustained"]["steps"] % 10 == 0 and d["sustained"]["seconds"] > 0.5
     assert abs(d["sustained"]["value"] / d["value"] - 1) < 0.15          # the K = 20 steps are representative of a second of the same
     if config == "c5":
