@@ -147,10 +147,6 @@ def main():
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    # the CPU baseline's thread team stays where it is put (0.56 vs 1.42 steps/s on the same CPU model
-    # with floating threads); read by libgomp when the oracle is first loaded
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
     if args.in_process:
         if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
             raise SystemExit("--in-process is a single-process mode: do not start it under a launcher")
@@ -1167,26 +1163,25 @@ def host_caller_leg(args, lib, be, hostc, gpu, n, m, L, step_size, two_loop):
         t_first = time.perf_counter()
         one_step()                                  # first call: S and Y (2 m n words) are mirrored, the caller's arrays are pinned
         t_first = time.perf_counter() - t_first
-        one_step()
-        ordinary = []
-        for _ in range(L - 3):                      # niter L+2 .. 2L-2: ordinary steps
+        for _ in range(L - 1):                      # up to niter = 2L: the rest of the first cycle, with its pair
+            one_step()
+        per = []
+        for _ in range(L):                          # niter 2L+1 .. 3L, one whole cycle, every step on the clock
             clock["lib"] = 0.0
             one_step()
-            ordinary.append(clock["lib"])
-        clock["lib"] = 0.0
-        one_step()                                  # niter 2L-1
-        ordinary.append(clock["lib"])
-        clock["lib"] = 0.0
-        one_step()                                  # niter 2L: builds a pair (x_avg and the s-slot go down, the product comes up)
-        pair = clock["lib"]
-        ord_ms = 1e3 * sorted(ordinary)[len(ordinary) // 2]
-        cycle_ms = (L - 1) * ord_ms + 1e3 * pair
-        up = 8 * nc * (1 + (lib.stochqn_hip_stat(b"x_uploads") > 2))          # grad (+ x when it is uploaded every step)
+            per.append(1e3 * clock["lib"])
+        after_pair, pair = per[0], per[-1]          # the step after a request at x_avg uploads x again; the last one builds the pair
+        ordinary = sorted(per[1:-1])
+        ord_ms = ordinary[len(ordinary) // 2]
+        cycle_ms = sum(per)
+        x_every_step = lib.stochqn_hip_stat(b"x_uploads") > 4
+        up = 8 * nc * (1 + x_every_step)            # grad (+ x when it is uploaded every step)
         down = 8 * nc * (1 + strict)
         dev_ms = two_loop["ms"] + 0.75 if two_loop else None
         res["strict_grad_%d" % strict] = {
-            "ordinary_step_ms": round(ord_ms, 2), "pair_step_ms": round(1e3 * pair, 2),
             "ms_per_step": round(cycle_ms / L, 2), "steps_per_s": round(1e3 * L / cycle_ms * nc / 1e8, 3),
+            "ordinary_step_ms": round(ord_ms, 2), "step_after_a_pair_ms": round(after_pair, 2), "pair_step_ms": round(pair, 2),
+            "per_step_ms": [round(v, 2) for v in per],
             "bytes_up_per_ordinary_step": up, "bytes_down_per_ordinary_step": down,
             "link_GBps_per_ordinary_step": None if not dev_ms or ord_ms <= dev_ms else round((up + down) / ((ord_ms - dev_ms) * 1e-3) / 1e9, 1),
             "first_call_s": round(t_first, 2),
@@ -1195,8 +1190,10 @@ def host_caller_leg(args, lib, be, hostc, gpu, n, m, L, step_size, two_loop):
     lib.stochqn_hip_set_option(b"strict_grad", 0.0)
     lib.stochqn_hip_release_all()
     res["note"] = ("strict_grad = 0 is the library's default (the reference documents `grad` as an input that is clobbered, no shipped caller "
-                   "reads it back); link_GBps = (bytes up + down) / (step time - the device-resident step's kernels). Round 2 measured "
-                   "91.6 ms per step on this path (pageable copies, x uploaded every call).")
+                   "reads it back); ms_per_step = one whole L-cycle on the clock (the pair-building step and the step after it, "
+                   "which uploads x again because the request in between was at x_avg, included); link_GBps = (bytes up + down) / "
+                   "(ordinary step - the device-resident step's kernels). Round 2 measured 91.6 ms per step on this path (pageable "
+                   "copies, x and the direction moved on every call).")
     return res
 
 
@@ -1204,7 +1201,7 @@ def cpu_baseline(args, gpu, hostc, n, m, L, bs, step_size):
     """The same SQN workload (same inputs, copied from the GPU; Hessian-vector product A'(Av)/bs through
     oracle_fisher_product) on the CPU oracle (kind 'port'), at n itself when host memory allows.  Timed:
     the seconds spent inside the oracle (run_SQN + the Hessian-vector product), not the caller's gradient.
-    All usable cores, threads bound (OMP_PROC_BIND=close, OMP_PLACES=cores), state first touched by the same team:
+    All usable cores, every thread of the team pinned to a CPU of its own, state first touched by the same team:
     three whole L-cycles, minimum and median.  One thread: one ordinary step and one L-th step (the one that builds a
     pair), composed into a cycle -- a 1-thread step at n = 1e8 takes seconds."""
     import numpy as np
@@ -1220,13 +1217,15 @@ def cpu_baseline(args, gpu, hostc, n, m, L, bs, step_size):
     S, Y, A, d = hostc.S, hostc.Y, hostc.A, hostc.d
     t_copy = hostc.seconds
     oracle.set_threads(threads)
+    # the team stays where it is put (0.56 vs 1.42 steps/s on the same CPU model with floating threads)
+    bound = olib.oracle_bind_threads() if hasattr(olib, "oracle_bind_threads") else 0
 
     def team_array(src=None):
         """An n-vector whose pages are first touched by the thread team that will stream it (static schedule, like every
         loop of the oracle), then filled."""
         a = np.empty(nc)
         if hasattr(olib, "oracle_first_touch"):
-            olib.oracle_first_touch(a.ctypes.data, C.c_size_t(nc))
+            olib.oracle_first_touch(a.ctypes.data, nc)
         else:
             a[:] = 0.0
         if src is not None:
@@ -1293,16 +1292,18 @@ def cpu_baseline(args, gpu, hostc, n, m, L, bs, step_size):
            "host_mem_available_GB": None if avail is None else round(avail / 1e9, 1),
            "allcores_cycles_s": [round(c, 3) for c in cycles], "allcores_cycle_s": round(c_med, 3),
            "one_thread_ordinary_step_s": round(t1_ord, 3), "one_thread_pair_step_s": round(t1_pair, 3),
-           "omp": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"),
+           "omp": {"threads_pinned": bound, "how": "thread t of the team on the t-th allowed CPU (sched_setaffinity, oracle_bind_threads)",
                    "first_touch": "thread team" if hasattr(olib, "oracle_first_touch") else "one thread"},
            "build": flags,
            "sample": "oracle/stochqn_oracle.c (CPU restatement of the reference; " + flags + "; own BLAS-1 loops, no BLAS library), "
                      "SQN m=%d L=%d bsize=%d at n=%g, the GPU leg's own inputs copied to the host (%.1f s); seconds inside "
                      "run_SQN + the Hessian-vector product A'(Av)/%d (oracle_fisher_product), caller's gradient excluded. "
-                     "All usable cores (%d threads, bound): three whole L-cycles of %d steps incl. one pair each (%s s; value = median, "
+                     "All usable cores (%d threads, pinned): three whole L-cycles of %d steps incl. one pair each (%s s; value = median, "
                      "value_allcores_best = minimum). One thread: one ordinary step (%.2f s) and one pair-building step (%.2f s), "
                      "composed into a cycle."
                      % (m, L, bs, nc, t_copy, bs, threads, L, " / ".join("%.2f" % c for c in cycles), t1_ord, t1_pair)}
+    if hasattr(olib, "oracle_unbind_threads"):
+        olib.oracle_unbind_threads()
     if native:
         try:
             os.unlink(native)                                  # the mapping stays valid; nothing is left behind in TMPDIR

@@ -53,6 +53,12 @@ def cdll():
         _lib.oracle_fisher_product.argtypes = [vp, sz, i, vp, vp, vp]
         _lib.oracle_take_step.restype = None
         _lib.oracle_take_step.argtypes = [d, i, vp, vp, C.POINTER(_abi.bfgs_mem), d, vp, d, vp, d, i, C.POINTER(i)]
+        if hasattr(_lib, "oracle_bind_threads"):
+            _lib.oracle_bind_threads.restype = i
+            _lib.oracle_unbind_threads.restype = None
+        if hasattr(_lib, "oracle_first_touch"):
+            _lib.oracle_first_touch.restype = None
+            _lib.oracle_first_touch.argtypes = [vp, sz]
         _lib.oracle_set_threads(usable_cpus())
     return _lib
 

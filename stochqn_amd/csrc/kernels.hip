@@ -642,7 +642,9 @@ __global__ void __launch_bounds__(kBlock) k_fisher_y(const real* F, size_t ld_, 
 {
 	extern __shared__ double t_sh[];   // fu doubles
 	__shared__ double sh[kWaves];
-	for (uint32_t k = threadIdx.x; k < fu; k += kBlock) t_sh[k] = t[k];
+	// t passes through a real_t buffer between the two products in the reference (buffer_y, src/stochqn.c:946-949): in the
+	// float build it is rounded to float on the way, and y = F't/fu -- which can cancel to 1e-4 of its terms -- follows that rounding
+	for (uint32_t k = threadIdx.x; k < fu; k += kBlock) t_sh[k] = (double) (real) t[k];
 	__syncthreads();
 	double acc[3] = {0, 0, 0};
 	const uint32_t packs = n / W;

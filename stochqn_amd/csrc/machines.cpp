@@ -65,6 +65,7 @@ void zero(DevCtx* c, real* dst, size_t count)
 
 void to_host(DevCtx* c, void* dst, const double* src, size_t count)      // scalars of the recursion
 {
+	if (c->async_call) return;               // stream-ordered call: nothing is read back (and nothing that would have been is used)
 	SQN_HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
 }
 
@@ -98,7 +99,7 @@ bool bind_bfgs(DevCtx* c, bfgs_mem* b, bool import_rows)
 
 // Start a call: find the context, bind every struct array, classify and stage x / grad.
 bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resumed, real* x, real* grad,
-               size_t niter, int section)
+               size_t niter, int section, int check_nan)
 {
 	if (!b || !b->s_mem || !b->y_mem || n <= 0 || b->mem_size == 0) return false;
 	(void) hipGetLastError();        // errors other code left behind on this thread are not ours (see sync())
@@ -128,6 +129,10 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 	io.g_caller = grad;
 	io.host_caller = !is_device_pointer(x);
 	io.g_host = !is_device_pointer(grad);
+	// option "async_device": a device-resident caller of a configuration where nothing can be rejected gets its call back
+	// as soon as the kernels are enqueued (sync() then only looks for launch errors)
+	c->async_call = options().async_device && !io.host_caller && !io.g_host && !c->S.mirror && !c->Y.mirror && check_nan == 0 &&
+	                !(b->min_curvature > 0) && !options().verify_cache && c->sc.allreduce == nullptr;
 	// staging vectors for host x / grad exist before anything is enqueued: stage_xg cannot fail later
 	if ((io.host_caller && !ensure_stage(c, 0)) || (io.g_host && !ensure_stage(c, 1))) {
 		if (fresh) release(b->s_mem);
@@ -308,6 +313,7 @@ bool pairs_tame(DevCtx* c, size_t st, size_t used)
 	for (size_t i = 0; i < used; i++) {
 		const size_t r = (st + i) % m;
 		if (c->kappa[r] >= 0) continue;
+		if (c->async_call) { c->kappa[r] = 0; continue; }
 		// a pair that did not come through accept_or_reject (imported state, isolated entry points, the bak->slot
 		// quirk): its three dots now, with a read-back (rare path, one synchronisation for all such rows)
 		Partials p = launch_dots3(c->sc, c->next_buf(), N(c), row(c->S, r, c), row(c->Y, r, c));
@@ -639,7 +645,7 @@ void enqueue_step(Call& io, const StepIn& in)
 bool step_was_bad(Call& io, bfgs_mem* b, size_t used_before, int check_nan)
 {
 	DevCtx* c = io.c;
-	if (used_before > 0) {                            // pinned block: report[8] | rho[m] | alpha[m]
+	if (used_before > 0 && !c->async_call) {          // pinned block: report[8] | rho[m] | alpha[m]
 		hand_back(b->buffer_rho, c->pin + 8, used_before);
 		hand_back(b->buffer_alpha, c->pin + 8 + c->m, used_before);
 	}
@@ -674,6 +680,13 @@ void accept_or_reject(DevCtx* c, bfgs_mem* b, Partials p, info_enum* info)
 	// only needs the verdict for its bookkeeping (and for the rare rollback)
 	double* verdict = c->sc.report + 4;                                // report[4..7] <-> pin[4..7]
 	launch_verdict(c->sc, p, (double) b->min_curvature, c->sc.sy + st, c->sc.yy + st, verdict);
+	if (c->async_call) {                 // min_curvature == 0: the pair is accepted whatever its dots are (:893); no read-back
+		c->rho_ok[st] = 1;
+		c->gram_ok[st] = 0;
+		c->kappa[st] = 0;                // the kappa rule needs the dots on the host: off in stream-ordered calls (documented)
+		ring_advance(b);
+		return;
+	}
 	to_host(c, c->pin + 4, verdict, 4);
 	sync(c);
 	if (c->pin[7] != 0.0) {
@@ -790,7 +803,7 @@ static int run_oLBFGS_impl(real_t step_size, real_t x[], real_t grad[], real_t**
 	}
 
 	Call io;
-	if (!open_call(io, KIND_OLBFGS, w->n, b, 0, w->niter > 0 || b->mem_used > 0, x, grad, w->niter, w->section)) return invalid(task, "oLBFGS");
+	if (!open_call(io, KIND_OLBFGS, w->n, b, 0, w->niter > 0 || b->mem_used > 0, x, grad, w->niter, w->section, w->check_nan)) return invalid(task, "oLBFGS");
 	DevCtx* c = io.c;
 	if (!bind(c, c->gprev, w->grad_prev, N(c), true)) return abandon(io, b, task, "oLBFGS");
 
@@ -846,7 +859,7 @@ static int run_SQN_impl(real_t step_size, real_t x[], real_t grad[], real_t hess
 
 	if (w->section != 0) {
 		Call io;
-		if (!open_call(io, KIND_SQN, w->n, b, 0, w->niter > 0 || b->mem_used > 0, x, grad, w->niter, w->section)) return invalid(task, "SQN");
+		if (!open_call(io, KIND_SQN, w->n, b, 0, w->niter > 0 || b->mem_used > 0, x, grad, w->niter, w->section, w->check_nan)) return invalid(task, "SQN");
 		DevCtx* c = io.c;
 		const size_t n = N(c);
 		if (!bind(c, c->gprev, w->grad_prev, w->use_grad_diff ? n : 0, true) ||
@@ -946,7 +959,7 @@ static int run_adaQN_impl(real_t step_size, real_t x[], real_t f, real_t grad[],
 		Call io;
 		const size_t fsize = fm ? fm->mem_size : 0;
 		const bool resumed = w->niter > 0 || b->mem_used > 0;
-		if (!open_call(io, KIND_ADAQN, w->n, b, fsize, resumed, x, grad, w->niter, w->section)) return invalid(task, "adaQN");
+		if (!open_call(io, KIND_ADAQN, w->n, b, fsize, resumed, x, grad, w->niter, w->section, w->check_nan)) return invalid(task, "adaQN");
 		DevCtx* c = io.c;
 		const size_t n = N(c);
 		if (!bind(c, c->gprev, w->grad_prev, w->use_grad_diff ? n : 0, true) ||
@@ -1051,7 +1064,7 @@ static int run_adaQN_impl(real_t step_size, real_t x[], real_t f, real_t grad[],
 			Partials p = launch_fisher(c->sc, c->next_buf(), n, c->F.dev, fm->mem_used, row(c->S, st, c), c->fisher_t, row(c->Y, st, c));
 			if (fm->buffer_y) to_host(c, c->pin + 8 + 2 * c->m, c->fisher_t, fm->mem_used);
 			accept_or_reject(c, b, p, iter_info);
-			hand_back(fm->buffer_y, c->pin + 8 + 2 * c->m, fm->mem_used);
+			if (!c->async_call) hand_back(fm->buffer_y, c->pin + 8 + 2 * c->m, fm->mem_used);
 			if (*iter_info == no_problems_encountered) d2d(c, c->xprev.dev, c->xsum.dev, n);
 			zero(c, c->xsum.dev, n);
 			sync(c);

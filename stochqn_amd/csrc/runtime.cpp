@@ -761,6 +761,12 @@ void sync(DevCtx* c)
 {
 	// a kernel that could not be launched (or failed) leaves its outputs stale: never hand that back
 	// as a result -- the call reports invalid_input / -1000 instead (machines.cpp: after_call)
+	if (c->async_call && !c->copy_busy && !c->sc.prof && mirror_bytes(c) == 0) {
+		// stream-ordered call (option "async_device"): only what can be known without waiting
+		const hipError_t l0 = hipGetLastError();
+		if (l0 != hipSuccess) { std::fprintf(stderr, "stochqn: device work failed: %s\n", hipGetErrorString(l0)); c->fault = true; }
+		return;
+	}
 	hipError_t e = hipStreamSynchronize(c->sc.stream);
 	if (c->copy_busy) {                                  // slices of x still on their way to the host
 		const hipError_t e2 = hipStreamSynchronize(c->copy_stream);
@@ -939,6 +945,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "devices_min_n")) options().devices_min_n = (long) value;
 	else if (!std::strcmp(name, "verify_cache")) options().verify_cache = value != 0;
 	else if (!std::strcmp(name, "raw_reuse_cache")) options().raw_reuse_cache = value != 0;
+	else if (!std::strcmp(name, "async_device")) options().async_device = value != 0;
 	else if (!std::strcmp(name, "fail_alloc_after")) g_fail_alloc_after.store((long) value);
 	else if (!std::strcmp(name, "inject_device_fault")) g_inject_device_fault.store(value != 0);
 	else return -1;

@@ -64,6 +64,12 @@ struct Options {
 	                                //    (reference include/stochqn.h:364-366: "*req ... do NOT modify"); 1: always upload
 	int apply_chunks = 8;           // host callers: the update pass runs in this many slices so that the download of x overlaps it
 	long max_mirror_bytes = 0;      // > 0: cap on the device memory held by mirrors of host arrays (least recently used contexts are exported and dropped)
+	// Device-resident callers of configurations in which no decision depends on device data (check_nan = 0 and
+	// min_curvature = 0: no step and no pair can be rejected): run_* returns as soon as its kernels are enqueued.  The
+	// context's stream is a blocking one, so the caller's next kernel on the null stream is ordered after them; nothing is
+	// read back (buffer_rho / buffer_alpha / buffer_y stay untouched, the kappa rule is off), a device fault surfaces at
+	// the caller's next synchronisation.  What is left per call is launch cost: DESIGN.md 4.1.
+	bool async_device = false;
 	bool raw_reuse_cache = false;   // isolated entry points keep their cached s'y / Gram entries between calls (caller vouches for S, Y)
 	bool verify_cache = false;   // debugging aid for device callers: recompute cached dots every call and compare
 };
@@ -124,6 +130,7 @@ struct DevCtx {
 	double x_probe[kProbe];            // the caller's x at kProbe spread-out positions when it was last handed back
 	unsigned long long last_use = 0;   // registry clock at the last call (least-recently-used reclaim)
 	bool in_call = false;              // between acquire() and the end of the API call: never reclaimed
+	bool async_call = false;           // this call returns without synchronising (option "async_device"; set by open_call)
 	bool no_spill = false;             // host memory for a spill of this context could not be had: leave it on the device
 	void* spill = nullptr;             // the state a reclaimed predecessor of this context left in host memory (runtime.cpp: Spill)
 	real* host_stage[2] = {nullptr, nullptr};         // host landing zones for *req / *req_vec

@@ -381,7 +381,7 @@ def test_kappa_threshold_follows_from_the_kernels_own_error(k, hip_backend):
             got, ran = gpu_two_loop(lib, g, S, Y, k, k, st, form, kappa_max=float("inf"))
             assert RAN[form] in ran
             row[form] = err(got, truth)
-            row[form + "_vs_oracle"] = rel_err(got, want)
+            row[form + "_vs_oracle"] = err(got, want)
         table.append(row)
         if kappa <= 1e6:
             floor = max(row["oracle"], row["sweeps"], 1e-15)

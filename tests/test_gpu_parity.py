@@ -1183,9 +1183,11 @@ def test_float_lockstep_parity(name, n, form_f32, hip_backend_f32):
     run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 50), F32_TOL, on_sync=inval)
 
 
-# (adaqn_ring20 is left out here: its Fisher pairs cancel to ~1e-6 of their terms, and at n = 1e6 the float
-# oracle's own float accumulation of y = F't/fu is then 3e-4 away from the library's double accumulation)
-@pytest.mark.parametrize("name", ["sqn_ring20", "adaqn_fisher_rms"])
+# adaqn_ring20: its Fisher pairs y = F'(F s)/fu cancel to ~1e-4 of their terms at n = 1e6.  Both the reference and the oracle
+# accumulate in double but pass t = F s through the real_t array buffer_y between the two products (reference
+# src/stochqn.c:946-949), i.e. round it to float in this build; the library used to keep t in double and landed 3.1e-4 away
+# (round 2: case dropped).  It now rounds t the same way (k_fisher_y) and the case is back at the common tolerance.
+@pytest.mark.parametrize("name", ["sqn_ring20", "adaqn_fisher_rms", "adaqn_ring20"])
 def test_float_lockstep_parity_full_grids(name, hip_backend_f32):
     """Single precision at full launch shapes: n = 1,000,003 puts three ring rows in four off the 16-byte grid
     (float4 packs read at 4-byte alignment), the row-split pass A runs its whole-rounds grid."""

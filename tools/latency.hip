@@ -30,8 +30,13 @@ int main(int argc, char** argv)
 	double* req = nullptr; double* req_vec = nullptr; task_enum task; info_enum info;
 	const bool sqn = kind[0] == 's';
 	if (argc > 6) stochqn_hip_set_option("threepass", atof(argv[6]));      // 0: the two-pass form (A/B of the per-call cost)
-	workspace_oLBFGS* wo = sqn ? nullptr : initialize_oLBFGS(n, m, 0, 0, 0, 1, 1);
-	workspace_SQN* ws = sqn ? initialize_SQN(n, m, 10, 0, 0, 0, 1, 1) : nullptr;
+	// argv[7]: 0 = the synchronous ABI with the guard (default); 1 = check_nan = 0, still synchronous; 2 = check_nan = 0 and
+	// option "async_device" (stream-ordered calls: nothing can be rejected, so nothing is waited for)
+	const int mode = argc > 7 ? atoi(argv[7]) : 0;
+	if (mode == 2) stochqn_hip_set_option("async_device", 1);
+	const int check_nan = mode == 0 ? 1 : 0;
+	workspace_oLBFGS* wo = sqn ? nullptr : initialize_oLBFGS(n, m, 0, 0, 0, check_nan, 1);
+	workspace_SQN* ws = sqn ? initialize_SQN(n, m, 10, 0, 0, 0, check_nan, 1) : nullptr;
 	auto iter = [&](long& calls) {
 		const size_t target = (sqn ? ws->niter : wo->niter) + 1;
 		while ((sqn ? ws->niter : wo->niter) < target) {
@@ -53,7 +58,7 @@ int main(int argc, char** argv)
 	const double dt = now() - t0;
 	stochqn_hip_profile_enable(0);
 	double ksum = 0;
-	printf("%s n=%d m=%d: %.1f us/step, %.2f calls/step;", kind, n, m, 1e6 * dt / steps, (double) calls / steps);
+	printf("%s n=%d m=%d mode=%d: %.1f us/step, %.2f calls/step;", kind, n, m, mode, 1e6 * dt / steps, (double) calls / steps);
 	for (int i = 0; i < stochqn_hip_profile_kernels(); i++) {
 		long long cnt; double ms;
 		stochqn_hip_profile_get(i, &cnt, &ms);
