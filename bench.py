@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-caller", action="store_true",
                     help="skip the host-caller leg (N = 1): the same step with every array in pageable host memory, PCIe included")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="N = 1: take roofline.traffic from the committed profiles/ instead of counting it now (two rocprofv3 --pmc "
+                         "passes over a 5-step child run of this workload, about a minute)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="N > 1: only the primary weak-scaling leg (default: also config 5's n = 1.25e8 per GPU, the strong-scaling "
                          "split of n = 1e8, the all-reduce latency and the one-process / N-devices mode, all in the same JSON line)")
@@ -627,6 +630,18 @@ def run(args):
             legs["in_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
             legs_failed.append("in_process")
 
+    # ---- N = 1: the dominant kernel's HBM traffic counted now (PMC), not looked up ------------------------------
+    if world == 1 and roof and not args.no_live_pmc and not args.rehearse:
+        dom = roof["kernel"].split()[0]
+        live = live_pmc(args, dom)
+        if live:
+            roof["traffic"] = live["bytes"]
+            roof["traffic_source"] = live["source"]
+            roof["traffic_read_bytes"], roof["traffic_write_bytes"], roof["traffic_dispatches"] = live["read_bytes"], live["write_bytes"], live["dispatches"]
+            roof["traffic_over_algorithmic"] = round(live["bytes"] / roof["alg_bytes_per_launch"], 4)
+        else:
+            roof["traffic_note"] = "live PMC passes unavailable here: committed profile quoted"
+
     par = ("n sharded over %d GPU(s), one process per GPU; one RCCL all-reduce per dot product" % world)
     if args.rehearse:
         par = "REHEARSAL: %d ranks sharing one GPU, all-reduce over gloo -- not a measurement" % world
@@ -995,13 +1010,67 @@ def shard_reference(n_gpus, steps_per_s):
     return None
 
 
+PMC_KEYS = {"bwd": "BwdOp", "fwd": "FwdOp<true, false, false>", "combine": "k_combine<2", "rows_dot": "k_rows_dot_all<2, 5",
+            "sdot": "k_rows_dot_all<2, 3, true, 1", "qdot": "k_qdot<2, 3", "sadd": "k_sadd<2"}
+
+
+def live_pmc(args, kernel):
+    """HBM bytes per launch of `kernel` counted NOW: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE, separate runs
+    with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short child run of this very workload; FETCH_SIZE is
+    doubled (gfx950 counts wide streaming reads at half their size).  None when rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or kernel not in PMC_KEYS:
+        return None
+    key = PMC_KEYS[kernel]
+    tmp = tempfile.mkdtemp(prefix="sqn_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--config", args.config, "--mem", str(args.mem),
+             "--upd-freq", str(args.upd_freq), "--bsize", str(args.bsize), "--no-profile", "--no-cpu-baseline", "--no-host-caller",
+             "--no-reference-form", "--sustain-seconds", "0", "--no-live-pmc"]
+    if args.n > 0:
+        child += ["--vars-per-gpu", str(args.n)]
+    for kv in args.opt:
+        child += ["--opt", kv]
+    got = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--"] + child
+            env = dict(os.environ, TMPDIR="/tmp")
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=300)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                return None
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if rc != 0 or not files:
+                return None
+            vals = sorted(float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                          if r.get("Counter_Name") == ctr and key in r.get("Kernel_Name", "").replace("sqn::(anonymous namespace)::", ""))
+            if not vals:
+                return None
+            got[ctr] = (vals[-1] if kernel in ("rows_dot", "sdot") else vals[len(vals) // 2], len(vals))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    b = got["FETCH_SIZE"][0] * 1024 * 2 + got["WRITE_SIZE"][0] * 1024
+    return {"bytes": int(round(b)), "read_bytes": int(round(got["FETCH_SIZE"][0] * 2048)), "write_bytes": int(round(got["WRITE_SIZE"][0] * 1024)),
+            "dispatches": got["FETCH_SIZE"][1],
+            "source": "counted in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over a 5-step "
+                      "child run of this workload; FETCH_SIZE x 2 (gfx950 half-count of wide streaming reads)"}
+
+
 def pmc_traffic(kernel, n, m):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
     gfx950 + WRITE_SIZE, separate passes; profiles/summarise.py).  The counters were taken at
     n = 1e8, m = 20; the kernels are pure streams, so bytes scale with n."""
     import glob
-    key = {"bwd": "BwdOp", "fwd": "FwdOp<true, false, false>", "combine": "k_combine<2", "rows_dot": "k_rows_dot_all<2, 5",
-           "sdot": "k_rows_dot_all<2, 3, true, 1", "qdot": "k_qdot<2, 3", "sadd": "k_sadd<2"}[kernel]
+    key = PMC_KEYS[kernel]
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         d = json.load(open(f))
         for k, v in d.items():

@@ -87,7 +87,41 @@ int stochqn_hip_export(const void *s_mem);
  *                            are recomputed every step in the pass that also applies adaQN's side effects
  *                            on the raw gradient); the three-pass form needs no such entries
  * "rows_grid", "rows_split", "combine_batch", "h0_per_cu": kernel-shape knobs, see DESIGN.md 3.2
- * "strict_grad" (default 1)  host callers: copy the search direction back into `grad`
+ * "strict_grad" (default 0)  host callers: copy the search direction back into `grad` (n words over PCIe per step).  The
+ *                            reference documents `grad` as an INPUT that "will be modified in-place" (reference
+ *                            include/stochqn.h:356-358), and none of its callers reads it afterwards (src/Rwrapper.c:98-196,
+ *                            stochqn/pywrapper.pxi:161-207, example/c_rosen.c:103-118): off unless asked for.  Device
+ *                            callers always find the direction in `grad` (it is computed there).
+ * "fold_coef"   (default 1)  three-pass form: the scalar recursions run in the prologues of pass 2 / pass 3 (every
+ *                            workgroup) instead of in two one-workgroup kernels between the passes
+ * "keep_tail"   (default 0.35)  three-pass form: fraction of r0 / r -- the part written last, which the next pass reads
+ *                            first -- stored with the default cache policy; the rest streams out (sc1 nt)
+ * "fuse_apply"  (default 0)  three-pass form with check_nan = 0: the position update inside pass 3 (measured slower: DESIGN.md 3.0)
+ * -- host callers (arrays of R / numpy / malloc crossing the ABI; INTEGRATION.md "host callers") --
+ * "register_host" (default 1), "register_min_bytes" (default 4 MiB)  the caller's x / grad / hess_vec / x_sum / x_avg_prev are
+ *                            pinned in place with hipHostRegister the first time they are seen (kept until the context goes),
+ *                            so that their copies are DMA transfers at link speed; refused registrations fall back to staged copies
+ * "x_upload"    (default 0)  0: x is uploaded only when the device copy may be out of date -- first call, another array,
+ *                            after a request that was not at x, or when any of 256 spread-out probe values differs from
+ *                            what the library handed back (the reference forbids modifying *req, reference
+ *                            include/stochqn.h:364-366, and *req is x after an ordinary step); 1: on every call
+ * "upload_slices" (default 8)  three-pass form: pass 1 runs in this many slices, each as soon as its part of `grad` has landed
+ *                            (bit-identical to one launch: the lanes' accumulators are carried between the launches); 0 / 1: off
+ * "apply_chunks" (default 8) the update pass runs in this many slices so that the download of x overlaps it (bit-identical)
+ * "max_mirror_bytes" (default 0 = no cap)  cap on the device memory held by mirrors of host arrays: beyond it -- and whenever
+ *                            a device allocation fails -- the least recently used context that is not inside a call is moved
+ *                            to host memory owned by the library and comes back on its object's next call ("contexts_reclaimed")
+ * -- device callers --
+ * "null_stream" (default 2)  which stream a call works on.  0: the context's own blocking-flavour stream; 1: the NULL stream;
+ *                            2: the NULL stream for device-resident callers of problems up to 2^22 variables (handing work
+ *                            between the caller's NULL stream and another stream costs ~15 us each way per call, a third of
+ *                            a step at small n), the own stream otherwise.  Inputs must be complete on -- or ordered
+ *                            before -- the NULL stream either way.
+ * "async_device" (default 0) stream-ordered calls: with check_nan = 0 and min_curvature = 0 (nothing can be rejected) and every
+ *                            array in device memory, run_* returns once its kernels are enqueued; the context's stream is a
+ *                            blocking one, so work the caller then puts on the NULL stream is ordered after them.  Nothing is
+ *                            read back: buffer_rho / buffer_alpha / buffer_y are not filled, the kappa rule is off, a device
+ *                            fault surfaces at the caller's next synchronisation.
  * "twopass_kappa_max" (default 1e6)  the two-pass forms are used only while every pair in use has
  *                            |s||y| / |s'y| <= this (s almost orthogonal to y: every fp64 evaluation loses
  *                            digits, the expanded form somewhat more); beyond, the chain of sweeps. inf = off

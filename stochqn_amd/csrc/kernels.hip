@@ -397,7 +397,7 @@ template <bool NT, bool LAST, bool FUSE> struct FwdOp {
 			if (ap.x_sum) {
 				Pack<W> t;
 				#pragma unroll
-				for (int k = 0; k < W; k++) t.v[k] = v.xs.v[k] + xn.v[k];  // :283
+				for (int k = 0; k < W; k++) t.v[k] = v.xs.v[k] + (double) (real) xn.v[k];  // :283, x as stored
 				st<W>(ap.x_sum, i, t);
 			}
 			if (ap.s_slot) { st_nt<W>(ap.s_slot, i, sg); st<W>(r, i, sg); }
@@ -458,7 +458,7 @@ struct ApplyOp {
 		if (ap.x_sum) {
 			Pack<W> t;
 			#pragma unroll
-			for (int k = 0; k < W; k++) t.v[k] = v.xs.v[k] + xn.v[k];
+			for (int k = 0; k < W; k++) t.v[k] = v.xs.v[k] + (double) (real) xn.v[k];      // x as stored (:283 reads the array back)
 			st<W>(ap.x_sum, i, t);
 		}
 	}
@@ -485,7 +485,10 @@ struct PairSOp {
 		Pack<W> avg = v.xs, s;
 		#pragma unroll
 		for (int k = 0; k < W; k++) {
-			if (scale) avg.v[k] = v.xs.v[k] * inv_L;
+			// the average passes through the array x_sum in the reference (dscal, then the difference reads it back: :286-291,
+			// :861-870): in the float build it is rounded to float on the way, and s = x_avg - x_avg_prev, which cancels to
+			// ~1e-3 of its operands, follows that rounding
+			if (scale) avg.v[k] = (double) (real) (v.xs.v[k] * inv_L);
 			s.v[k] = avg.v[k] - v.xp.v[k];
 		}
 		if (scale) st<W>(x_sum, i, avg);
@@ -704,18 +707,35 @@ struct Probes { const real* p[3]; };
 // Single-probe pass A: one accumulator per row and lane, NG groups of 8 rows; the compiler hoists
 // the row loads of a pack ahead of the arithmetic (one wave per SIMD, up to 512 registers per lane),
 // which measured faster than the row-split form below for a single probe (5.1 vs 5.8 ms, n=1e8, 40 rows).
-template <int W, int NG, bool NT, int NPR>
+// A pass cut into slices of the traversal (host callers: slice s runs as soon as ITS part of the gradient has arrived over
+// PCIe, while the rest is still on its way): every lane's accumulators are carried from launch to launch through `carry`,
+// the slice boundaries are whole rounds of the grid, so each lane adds exactly the terms it adds in one launch, in the same
+// order -- the partials, and with them everything downstream, are bit-identical to the unsliced pass.
+struct Slice {
+	uint32_t p_begin, p_end;    // packs [p_begin, p_end) of the traversal; p_begin is a multiple of gridDim.x * kBlock
+	double* carry;              // [quantity][gridDim.x * kBlock] accumulators between the slices (NULL: one launch)
+	int first, last;
+};
+
+// SL = false is the pass as one launch (the slice argument is ignored: the device-resident path keeps its register budget --
+// 145 VGPRs and three waves per SIMD for the two-probe variant against 203 and two with the carry code in)
+template <int W, int NG, bool NT, int NPR, bool SL>
 __global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, Probes pr, real* copy_out, uint32_t n, int rev,
-                                                         double* parts)
+                                                         double* parts, Slice sl)
 {
 	__shared__ double sh[NPR * NG * 8 * kWaves];
 	double acc[NPR][NG * 8];
+	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
+	const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
 	#pragma unroll
 	for (int q = 0; q < NPR; q++)
 		#pragma unroll
-		for (int j = 0; j < NG * 8; j++) acc[q][j] = 0;
-	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
-	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
+		for (int j = 0; j < NG * 8; j++) {
+			if constexpr (SL) acc[q][j] = (!sl.first && j < rs.count) ? sl.carry[(size_t) (q * rs.count + j) * stride + gtid] : 0.0;
+			else acc[q][j] = 0;
+		}
+	const uint32_t p_end = SL ? sl.p_end : packs;
+	for (uint32_t p = (SL ? sl.p_begin : 0u) + gtid; p < p_end; p += stride) {
 		const uint32_t i = (rev ? last - p : p) * W;
 		Pack<W> pv[NPR];
 		#pragma unroll
@@ -735,6 +755,16 @@ __global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, Probes pr, r
 						#pragma unroll
 						for (int k = 0; k < W; k++) acc[q][g * 8 + u] = fma((double) f[u].v[k], pv[q].v[k], acc[q][g * 8 + u]);
 				}
+		}
+	}
+	if constexpr (SL) {
+		if (!sl.last) {                                       // hand the accumulators to the next slice
+			#pragma unroll
+			for (int q = 0; q < NPR; q++)
+				#pragma unroll
+				for (int j = 0; j < NG * 8; j++)
+					if (j < rs.count) sl.carry[(size_t) (q * rs.count + j) * stride + gtid] = acc[q][j];
+			return;
 		}
 	}
 	if (W > 1) {
@@ -1492,7 +1522,7 @@ __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, 
 					#pragma unroll
 					for (int e = 0; e < W; e++) {
 						xo[t].v[e] = fma(-ap.step, v.v[e], xv.v[e]);                  // :838
-						if (ap.x_sum) xso[t].v[e] = xs.v[e] + xo[t].v[e];             // :283
+						if (ap.x_sum) xso[t].v[e] = xs.v[e] + (double) (real) xo[t].v[e];     // :283, x as stored
 						if (ap.s_slot) v.v[e] = (-ap.step) * v.v[e];                  // :1006: grad <- -step r (and the s-slot)
 					}
 				} else {
@@ -1526,7 +1556,7 @@ __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, 
 			if constexpr (FUSE) {
 				const double xn = fma(-ap.step, v, (double) ap.x[i]);
 				ap.x[i] = (real) xn;
-				if (ap.x_sum) ap.x_sum[i] = (real) ((double) ap.x_sum[i] + xn);
+				if (ap.x_sum) ap.x_sum[i] = (real) ((double) ap.x_sum[i] + (double) (real) xn);
 				if (ap.s_slot) { v = (-ap.step) * v; ap.s_slot[i] = (real) v; }
 			} else { acc0 = fma(v, v, acc0); acc1 += (isfinite(v) ? 0.0 : 1.0); }
 			r[i] = (real) v;
@@ -1918,9 +1948,11 @@ static int rows_dot_dispatch(const Scratch& sc, int slot, size_t max_grid, int r
 
 template <int W, int NPR>
 static void rows_dot_all_dispatch(const Scratch& sc, int slot, int grid, int ng, const RowSet& rows, const Probes& probe,
-                                  real* copy_out, uint32_t n, int rev)
+                                  real* copy_out, uint32_t n, int rev, const Slice* slice = nullptr)
 {
-	#define SQN_RA(NG) hipLaunchKernelGGL((k_rows_dot_all<W, NG, true, NPR>), dim3(grid), dim3(kBlock), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[slot])
+	const Slice sl = slice ? *slice : Slice{0u, n / (uint32_t) W, nullptr, 1, 1};
+	#define SQN_RA(NG) { if (slice) hipLaunchKernelGGL((k_rows_dot_all<W, NG, true, NPR, true>), dim3(grid), dim3(kBlock), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[slot], sl); \
+	                     else hipLaunchKernelGGL((k_rows_dot_all<W, NG, true, NPR, false>), dim3(grid), dim3(kBlock), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[slot], sl); }
 	switch (ng) {
 	case 1: SQN_RA(1); break;
 	case 2: SQN_RA(2); break;
@@ -2025,9 +2057,17 @@ Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, 
 
 // ---- three-pass form ---------------------------------------------------------------------------------
 // pass 1: the single-probe / two-probe all-rows rows-dot over the k rows of S
-Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows, const real* g, real* copy_out, const real* probe_y)
+bool sdot_can_slice(const Scratch& sc, const RowSet& s_rows, const real* g, real* copy_out, const real* probe_y)
 {
-	if (!probe_y && sc.rows_split) return launch_rows_dot(sc, 0, n, s_rows, g, copy_out, K_SDOT);      // float build: the row-split kernel
+	return (probe_y || !sc.rows_split) && rows_aligned(s_rows) && all_aligned(g, copy_out, probe_y);
+}
+
+Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows, const real* g, real* copy_out, const real* probe_y, const SliceFeed* feed)
+{
+	if (!probe_y && sc.rows_split) {                           // float build: the row-split kernel (not sliced)
+		if (feed) feed->arrive(feed->user, 0, n, 0);
+		return launch_rows_dot(sc, 0, n, s_rows, g, copy_out, K_SDOT);
+	}
 	// the two-probe variant (2 x k accumulators, 145 VGPRs: three waves per SIMD) wants three workgroups per CU: 2.78 ms
 	// against 5.12 ms with one and 3.01 ms for the row-split shape (n = 1e8, k = 20; profiles/r02_ab_threepass_shapes.jsonl)
 	const int grid = sweep_grid(sc, n, probe_y ? (sc.sdot2_per_cu > 0 ? sc.sdot2_per_cu : 3) : (sc.sdot_per_cu > 0 ? sc.sdot_per_cu : 1));
@@ -2035,7 +2075,26 @@ Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows, const re
 	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
 	const Probes pr{{g, probe_y, nullptr}};
 	const int ng = (s_rows.count + 7) / 8;
-	{
+	const size_t packs = n / kVec, round = (size_t) grid * kBlock;
+	if (feed && vec && feed->slices >= 2 && packs >= 2 * round) {
+		// the pass in slices of whole grid rounds; before slice s its part of g is sent for (feed->arrive), and the kernel of
+		// that slice is what the stream runs once it has landed
+		size_t per = (packs + (size_t) feed->slices - 1) / (size_t) feed->slices;
+		per = (per + round - 1) / round * round;
+		const size_t last = packs - 1;
+		int s = 0;
+		for (size_t pb = 0; pb < packs; pb += per, s++) {
+			const size_t pe = pb + per < packs ? pb + per : packs;
+			size_t lo = rev ? (last - (pe - 1)) * kVec : pb * kVec, hi = rev ? (last - pb + 1) * kVec : pe * kVec;
+			if (hi == packs * kVec) hi = n;                      // the odd elements beyond the last pack travel with the slice next to them
+			feed->arrive(feed->user, lo, hi, s);
+			const Slice sl{(uint32_t) pb, (uint32_t) pe, feed->carry, pb == 0, pe == packs};
+			ProfScope ps(sc, probe_y ? K_SDOT2 : K_SDOT);
+			if (probe_y) rows_dot_all_dispatch<kVec, 2>(sc, 0, grid, ng, s_rows, pr, copy_out, (uint32_t) n, rev, &sl);
+			else         rows_dot_all_dispatch<kVec, 1>(sc, 0, grid, ng, s_rows, pr, copy_out, (uint32_t) n, rev, &sl);
+		}
+	} else {
+		if (feed) feed->arrive(feed->user, 0, n, 0);             // no slicing here: the whole vector at once
 		ProfScope ps(sc, probe_y ? K_SDOT2 : K_SDOT);
 		if (probe_y) {
 			if (vec) rows_dot_all_dispatch<kVec, 2>(sc, 0, grid, ng, s_rows, pr, copy_out, (uint32_t) n, rev);

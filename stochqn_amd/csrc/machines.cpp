@@ -44,6 +44,7 @@ struct Call {
 	bool g_host = false;
 	bool fresh = false;             // the device context was created by this call
 	bool x_down = false, g_down = false;   // the update pass already sent x / the direction to the host, slice by slice
+	bool g_pending = false;                // host gradient not uploaded yet: pass 1 of the three-pass form takes it in slices
 };
 
 inline size_t N(const DevCtx* c) { return (size_t) c->n; }
@@ -129,6 +130,10 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 	io.g_caller = grad;
 	io.host_caller = !is_device_pointer(x);
 	io.g_host = !is_device_pointer(grad);
+	// small problems of device-resident callers: no cross-stream hand-off per call (option "null_stream" = 2; nothing is
+	// pending on either stream between calls, every synchronous call ends with a synchronisation of the stream it used)
+	if (options().null_stream == 2 && !options().async_device)
+		c->sc.stream = (!io.host_caller && !io.g_host && N(c) <= ((size_t) 1 << 22)) ? nullptr : c->own_stream;
 	// option "async_device": a device-resident caller of a configuration where nothing can be rejected gets its call back
 	// as soon as the kernels are enqueued (sync() then only looks for launch errors)
 	c->async_call = options().async_device && !io.host_caller && !io.g_host && !c->S.mirror && !c->Y.mirror && check_nan == 0 &&
@@ -141,11 +146,42 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 	return true;
 }
 
-void stage_xg(Call& io, bool need_x, bool need_g)
+// may_defer (the call that takes the step): a large host gradient is not sent in one piece here -- the first pass of the
+// three-pass form fetches it slice by slice and starts on each slice as it lands (enqueue_three_pass); every other path
+// asks for it with flush_g first.
+void stage_xg(Call& io, bool need_x, bool need_g, bool may_defer = false)
 {
 	DevCtx* c = io.c;
 	if (need_x) io.x = io.host_caller ? stage_x(c, io.x_caller, N(c)) : io.x_caller;
-	if (need_g) io.g = stage_in(c, 1, io.g_caller, N(c), io.g_host);
+	if (!need_g) return;
+	const int slices = options().upload_slices;
+	if (may_defer && io.g_host && slices >= 2 && N(c) >= ((size_t) 1 << 21) && ensure_stage(c, 1) &&
+	    ensure_upload_slices(c, slices, (size_t) 2 * c->m * (size_t) c->sc.grid_cap * 3 * kBlock)) {
+		(void) ensure_registered(c, io.g_caller, N(c) * sizeof(real));
+		io.g = c->stage[1];
+		io.g_pending = true;
+		return;
+	}
+	io.g = stage_in(c, 1, io.g_caller, N(c), io.g_host);
+}
+
+void flush_g(Call& io)
+{
+	if (!io.g_pending) return;
+	SQN_HIP_OK(hipMemcpyAsync(io.g, io.g_caller, N(io.c) * sizeof(real), hipMemcpyHostToDevice, io.c->sc.stream));
+	io.g_pending = false;
+}
+
+// SliceFeed::arrive of a pending host gradient: elements [lo, hi) go up on the side stream, the main stream waits for them
+void gradient_slice_arrives(void* user, size_t lo, size_t hi, int slice)
+{
+	Call& io = *static_cast<Call*>(user);
+	DevCtx* c = io.c;
+	SQN_HIP_OK(hipMemcpyAsync(io.g + lo, io.g_caller + lo, (hi - lo) * sizeof(real), hipMemcpyHostToDevice, c->copy_stream));
+	SQN_HIP_OK(hipEventRecord(c->up_ev[(size_t) slice], c->copy_stream));
+	SQN_HIP_OK(hipStreamWaitEvent(c->sc.stream, c->up_ev[(size_t) slice], 0));
+	c->copy_busy = true;
+	io.g_pending = false;
 }
 
 // Make a workspace array readable where the caller expects to read `*req` from.
@@ -432,7 +468,7 @@ bool threepass_ok(DevCtx* c, size_t st, size_t used)
 // Returns the guard partials (sum r^2, nonfinite); the direction replaces g.  `qs` says how q0 is scaled:
 // all-NULL = scalar (gamma of the newest pair, or h0 > 0), H0_in = a given diagonal, G = adaQN's step.
 Partials enqueue_three_pass(DevCtx* c, real* g, size_t used, size_t st, double h0, real* gprev_out, const QdotScale& qs,
-                            const ApplyArgs* fuse = nullptr)
+                            const ApplyArgs* fuse = nullptr, Call* pending = nullptr)
 {
 	const size_t m = c->m, k = used;
 	RowSet ss{}, ys{};
@@ -449,7 +485,11 @@ Partials enqueue_three_pass(DevCtx* c, real* g, size_t used, size_t st, double h
 	ss.count = ys.count = (int) k;
 	ensure_rho(c, st, k);                                     // s'y, y'y of every pair in use (rho_i, gamma)
 	const int fresh = ensure_sy_columns(c, st, k, ss, a);
-	Partials b = launch_sdot(c->sc, N(c), ss, g, gprev_out, fresh >= 0 ? row(c->Y, (size_t) fresh, c) : nullptr);
+	const real* probe = fresh >= 0 ? row(c->Y, (size_t) fresh, c) : nullptr;
+	SliceFeed feed{options().upload_slices, c->carry, gradient_slice_arrives, pending};
+	const bool sliced = pending && pending->g_pending && sdot_can_slice(c->sc, ss, g, gprev_out, probe);
+	if (pending && !sliced) flush_g(*pending);
+	Partials b = launch_sdot(c->sc, N(c), ss, g, gprev_out, probe, sliced ? &feed : nullptr);
 	if (fresh >= 0) c->sy_ok[(size_t) fresh] = 1;             // stored by the coefficient kernel, ahead of the recursion
 	if (c->sc.fold_coef) {                                    // the recursions in the prologues of the passes themselves
 		Partials v = launch_qdot(c->sc, N(c), ys, g, qs, &b, &a, fresh);
@@ -600,6 +640,7 @@ void enqueue_step(Call& io, const StepIn& in)
 	fa.scal_reg = in.eps;
 
 	if (in.used == 0) {
+		flush_g(io);
 		fa.H0_out = nullptr;                                          // rescale in place (:811)
 		const bool need_first = in.check_nan || fa.gprev_out || fa.frow_out || fa.G;
 		Partials guard{nullptr, 0, 0};
@@ -615,10 +656,10 @@ void enqueue_step(Call& io, const StepIn& in)
 			if (in.G) { qs.G = in.G; qs.H0_out = in.H0; qs.frow_out = in.frow_out; qs.rmsprop_weight = in.w; qs.scal_reg = in.eps; }
 			// check_nan == 0: nothing waits for a verdict, the update rides in pass 3 (as in the sweep form below, reference :825-838)
 			const bool fuse = !in.check_nan && options().fuse_apply;
-			Partials guard = enqueue_three_pass(c, in.g, in.used, st, in.h0, in.gprev_out, qs, fuse ? &ap : nullptr);
+			Partials guard = enqueue_three_pass(c, in.g, in.used, st, in.h0, in.gprev_out, qs, fuse ? &ap : nullptr, &io);
 			if (!fuse) apply_step(io, guard, in.g, in.g, ap, in.check_nan != 0);
 			stat_add(ST_STEP_THREE_PASS);
-		} else if (!raw_cold && twopass_ok(c, st, in.used, in.G ? in.H0 : nullptr)) {
+		} else if (flush_g(io), !raw_cold && twopass_ok(c, st, in.used, in.G ? in.H0 : nullptr)) {
 			Partials guard = enqueue_two_pass(c, in.g, in.used, st, in.h0, in.gprev_out);
 			apply_step(io, guard, in.g, in.g, ap, in.check_nan != 0);
 			stat_add(ST_STEP_TWO_PASS);
@@ -808,7 +849,7 @@ static int run_oLBFGS_impl(real_t step_size, real_t x[], real_t grad[], real_t**
 	if (!bind(c, c->gprev, w->grad_prev, N(c), true)) return abandon(io, b, task, "oLBFGS");
 
 	if (w->section == 1) {                     // step; s-slot; ask for the gradient on the same batch
-		stage_xg(io, true, true);
+		stage_xg(io, true, true, true);
 		const size_t used = b->mem_used;
 		StepIn in;
 		in.step = step_size; in.x = io.x; in.g = io.g;
@@ -868,7 +909,7 @@ static int run_SQN_impl(real_t step_size, real_t x[], real_t grad[], real_t hess
 
 		switch (w->section) {
 		case 1: {
-			stage_xg(io, true, true);
+			stage_xg(io, true, true, true);
 			const size_t used = b->mem_used;
 			StepIn in;
 			in.step = step_size; in.x = io.x; in.g = io.g;
@@ -970,7 +1011,7 @@ static int run_adaQN_impl(real_t step_size, real_t x[], real_t f, real_t grad[],
 
 		switch (w->section) {
 		case 1: {
-			stage_xg(io, true, true);
+			stage_xg(io, true, true, true);
 			const size_t used = b->mem_used;
 			StepIn in;
 			in.step = step_size; in.x = io.x; in.g = io.g;

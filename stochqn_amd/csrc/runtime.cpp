@@ -194,7 +194,8 @@ void free_view(View& v)
 
 void destroy(DevCtx* c)
 {
-	if (c->sc.stream) SQN_HIP_OK(hipStreamSynchronize(c->sc.stream));
+	SQN_HIP_OK(hipStreamSynchronize(c->sc.stream));
+	if (c->own_stream && c->own_stream != c->sc.stream) SQN_HIP_OK(hipStreamSynchronize(c->own_stream));
 	delete static_cast<Spill*>(c->spill);
 	c->spill = nullptr;
 	c->prof.collect();
@@ -214,10 +215,12 @@ void destroy(DevCtx* c)
 	if (c->pin) SQN_HIP_OK(hipHostFree(c->pin));
 	if (c->copy_stream) { (void) hipStreamSynchronize(c->copy_stream); (void) hipStreamDestroy(c->copy_stream); }
 	for (hipEvent_t e : c->chunk_ev) (void) hipEventDestroy(e);
+	for (hipEvent_t e : c->up_ev) (void) hipEventDestroy(e);
+	if (c->carry) SQN_HIP_OK(hipFree(c->carry));
 	if (c->copy_done) (void) hipEventDestroy(c->copy_done);
 	for (auto& r : c->regs)
 		if (r.p) { if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError(); }   // the caller may have freed it already
-	if (c->sc.stream) SQN_HIP_OK(hipStreamDestroy(c->sc.stream));
+	if (c->own_stream) SQN_HIP_OK(hipStreamDestroy(c->own_stream));
 	delete c;
 }
 
@@ -286,7 +289,7 @@ bool reclaim_one()
 			std::unique_ptr<Spill> sp(new Spill());
 			sp->kind = victim->kind; sp->n = victim->n; sp->m = victim->m; sp->fsize = victim->fsize;
 			sp->niter = victim->last_niter; sp->section = victim->last_section;
-			if (victim->sc.stream) SQN_HIP_OK(hipStreamSynchronize(victim->sc.stream));
+			SQN_HIP_OK(hipStreamSynchronize(victim->sc.stream));
 			View* vs[10];
 			views_of(victim, vs);
 			bool ok = true;
@@ -389,6 +392,9 @@ int default_grid_cap()
 
 void begin_call(DevCtx* c)
 {
+	// the stream of this call: the context's own, or the NULL stream (whatever was enqueued on the other one has been
+	// synchronised at the end of the call that enqueued it, stream-ordered calls excepted: those stay on the NULL stream)
+	c->sc.stream = (g_opt.null_stream == 1 || g_opt.async_device) ? nullptr : c->own_stream;      // the automatic rule: open_call
 	c->sc.nontemporal = g_opt.nontemporal;
 	c->sc.grid_cap = g_opt.grid_cap > 0 ? g_opt.grid_cap : default_grid_cap();
 	c->sc.rows_grid = g_opt.rows_grid;
@@ -494,7 +500,8 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	c->n_global = (double) n;
 	c->last_use = ++g_clock;
 	c->in_call = true;
-	SQN_HIP_OK(hipStreamCreate(&c->sc.stream));   // blocking flavour: ordered after the null stream
+	SQN_HIP_OK(hipStreamCreate(&c->own_stream));   // blocking flavour: ordered after the null stream
+	c->sc.stream = c->own_stream;
 	// pool layout: part0 | part1 | red0 | red1 | sy | yy | report | rho | alpha | rows_part x2 | gsy | gyy | coef
 	const size_t part = (size_t) kMaxSums * kMaxGrid;
 	const size_t rows_part = (size_t) kRedMax * kMaxGrid;
@@ -743,6 +750,24 @@ void x_handed_back(DevCtx* c, const real* caller, size_t count)
 	for (int j = 0; j < DevCtx::kProbe; j++) c->x_probe[j] = (double) caller[probe_index(j, count)];
 }
 
+bool ensure_upload_slices(DevCtx* c, int slices, size_t carry_count)
+{
+	if (!ensure_copy_stream(c, 1)) return false;
+	while ((int) c->up_ev.size() < slices) {
+		hipEvent_t e;
+		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); return false; }
+		c->up_ev.push_back(e);
+	}
+	if (c->carry_count < carry_count) {
+		if (c->carry) SQN_HIP_OK(hipFree(c->carry));
+		c->carry = nullptr;
+		c->carry_count = 0;
+		if (!device_alloc((void**) &c->carry, carry_count * sizeof(double))) return false;
+		c->carry_count = carry_count;
+	}
+	return true;
+}
+
 bool ensure_copy_stream(DevCtx* c, int chunks)
 {
 	if (!c->copy_stream) {
@@ -938,6 +963,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "register_host")) g_opt.register_host = value != 0;
 	else if (!std::strcmp(name, "register_min_bytes")) g_opt.register_min_bytes = value < 0 ? 0 : (long) value;
 	else if (!std::strcmp(name, "x_upload")) g_opt.x_upload = (int) value;
+	else if (!std::strcmp(name, "upload_slices")) g_opt.upload_slices = value < 0 ? 0 : (value > 64 ? 64 : (int) value);
 	else if (!std::strcmp(name, "apply_chunks")) g_opt.apply_chunks = value < 1 ? 1 : (value > 64 ? 64 : (int) value);
 	else if (!std::strcmp(name, "max_mirror_bytes")) g_opt.max_mirror_bytes = value < 0 ? 0 : (long) value;
 	else if (!std::strcmp(name, "devices")) options().devices = value < 0 ? 0 : (int) value;
@@ -946,6 +972,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "verify_cache")) options().verify_cache = value != 0;
 	else if (!std::strcmp(name, "raw_reuse_cache")) options().raw_reuse_cache = value != 0;
 	else if (!std::strcmp(name, "async_device")) options().async_device = value != 0;
+	else if (!std::strcmp(name, "null_stream")) options().null_stream = (int) value;
 	else if (!std::strcmp(name, "fail_alloc_after")) g_fail_alloc_after.store((long) value);
 	else if (!std::strcmp(name, "inject_device_fault")) g_inject_device_fault.store(value != 0);
 	else return -1;

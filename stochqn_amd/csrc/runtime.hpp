@@ -62,6 +62,7 @@ struct Options {
 	long register_min_bytes = 4l << 20;   // ... for arrays of at least this many bytes (below, the runtime's staged copy is as fast)
 	int x_upload = 0;               // 0: x is not uploaded when the device copy is what the library handed back and the caller kept its hands off
 	                                //    (reference include/stochqn.h:364-366: "*req ... do NOT modify"); 1: always upload
+	int upload_slices = 8;          // host callers, three-pass form: pass 1 runs in this many slices, each as soon as its part of the gradient has arrived
 	int apply_chunks = 8;           // host callers: the update pass runs in this many slices so that the download of x overlaps it
 	long max_mirror_bytes = 0;      // > 0: cap on the device memory held by mirrors of host arrays (least recently used contexts are exported and dropped)
 	// Device-resident callers of configurations in which no decision depends on device data (check_nan = 0 and
@@ -70,6 +71,13 @@ struct Options {
 	// read back (buffer_rho / buffer_alpha / buffer_y stay untouched, the kappa rule is off), a device fault surfaces at
 	// the caller's next synchronisation.  What is left per call is launch cost: DESIGN.md 4.1.
 	bool async_device = false;
+	// Which stream a call works on: the context's own (blocking flavour, ordered after the NULL stream) or the NULL stream
+	// itself.  A device caller's gradient kernels run on the NULL stream (torch's default), and handing work from one
+	// stream to the other costs about 15 us each way per call -- a third of a step below n ~ 1e6, nothing
+	// that matters at n = 1e8.  The price of the NULL stream is that it serialises with every blocking stream of the process.
+	// 0: always the own stream; 1: always the NULL stream; 2 (default): the NULL stream for device-resident callers of
+	// problems up to 2^22 variables, the own stream otherwise.  async_device implies the NULL stream.
+	int null_stream = 2;
 	bool raw_reuse_cache = false;   // isolated entry points keep their cached s'y / Gram entries between calls (caller vouches for S, Y)
 	bool verify_cache = false;   // debugging aid for device callers: recompute cached dots every call and compare
 };
@@ -120,8 +128,11 @@ struct DevCtx {
 	struct HostRange { const void* p = nullptr; size_t bytes = 0; };
 	HostRange regs[6];
 	int reg_turn = 0;
+	hipStream_t own_stream = nullptr;  // the context's own (blocking-flavour) stream; sc.stream is this or the NULL stream (option "null_stream")
 	hipStream_t copy_stream = nullptr;
-	std::vector<hipEvent_t> chunk_ev;
+	std::vector<hipEvent_t> chunk_ev, up_ev;
+	double* carry = nullptr;           // accumulators of a sliced pass 1 between its launches (kernels.hip: Slice)
+	size_t carry_count = 0;
 	hipEvent_t copy_done = nullptr;
 	bool copy_busy = false;            // work was enqueued on copy_stream during this call
 	const void* x_host = nullptr;      // the host array stage[0] mirrors
@@ -209,6 +220,7 @@ bool ensure_registered(DevCtx* c, const void* p, size_t bytes);
 real* stage_x(DevCtx* c, real* caller, size_t count);
 void x_handed_back(DevCtx* c, const real* caller, size_t count);     // after the download of x has completed
 bool ensure_copy_stream(DevCtx* c, int chunks);
+bool ensure_upload_slices(DevCtx* c, int slices, size_t carry_count);      // side stream, events and carry scratch of a sliced pass 1
 bool ensure_stage(DevCtx* c, int which);               // device staging vector `which` exists
 real* stage_in(DevCtx* c, int which, real* caller, size_t count, bool host);       // H2D if host; nullptr = out of memory
 real* host_landing(DevCtx* c, int slot);               // host landing zone for *req / *req_vec (pinned if possible)

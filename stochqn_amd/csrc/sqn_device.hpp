@@ -219,7 +219,19 @@ Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& y_ro
 
 // ---- three-pass form: S twice, Y once -- (3k+5) n words (kernels.hip "three-pass form") -----------------------
 // pass 1: quantities [0,k) s_i'g, and with probe_y (the pair that just entered, ring row r) [k,2k) s_i'y_r
-Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows /*logical order*/, const real* g, real* copy_out, const real* probe_y);
+// `feed` (host callers): the pass runs in feed->slices slices of the traversal; before the kernel of a slice is enqueued
+// feed->arrive(user, lo, hi, slice) is called for the element range [lo, hi) of g that slice reads -- the caller enqueues the
+// upload of that range and makes the stream wait for it.  Bit-identical to the unsliced pass (kernels.hip: Slice).
+// carry: device scratch of at least 2 * kRowsMax * grid * kBlock doubles.
+struct SliceFeed {
+	int slices;
+	double* carry;
+	void (*arrive)(void* user, size_t lo, size_t hi, int slice);
+	void* user;
+};
+bool sdot_can_slice(const Scratch& sc, const RowSet& s_rows, const real* g, real* copy_out, const real* probe_y);
+Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows /*logical order*/, const real* g, real* copy_out, const real* probe_y,
+                     const SliceFeed* feed = nullptr);
 // totals, (fresh_row >= 0) the new column of the cached s_old'y_new block, backward recursion -> alpha (coef[1..k]), scale (coef[0])
 void launch_coef3a(const Scratch& sc, Partials b, const CoefArgs& a, int fresh_row);
 struct QdotScale {

@@ -117,22 +117,30 @@ def test_x_upload_option_always(hip_backend):
         lib.stochqn_hip_release_all()
 
 
-def test_sliced_update_equals_one_launch(hip_backend):
-    """apply_chunks = 1 (one launch, download afterwards) against the default slices: same bits."""
+@pytest.mark.parametrize("kind", ["SQN", "oLBFGS", "adaQN"])
+def test_sliced_passes_equal_whole_launches(kind, hip_backend):
+    """The two overlaps of the host path against their plain forms: pass 1 in slices that start as their part of the gradient
+    lands (upload_slices; the accumulators are carried from launch to launch) and the update in slices whose x goes down
+    while the next is computed (apply_chunks), against one launch each with the copies before / after: same bits."""
     lib = _lib()
     n = 2_200_003
     P = NoisyQuadratic(n, seed=3)
     out = []
     try:
-        for chunks in (1.0, 8.0, 3.0):
+        for chunks, slices in ((1.0, 0.0), (8.0, 8.0), (3.0, 5.0), (1.0, 16.0)):
             assert lib.stochqn_hip_set_option(b"apply_chunks", chunks) == 0
-            out.append(run_trace(OPTIMIZERS["SQN"](backend=hip_backend, space="host", mem_size=3, bfgs_upd_freq=2), P, P.x0(), 0.05, 14))
+            assert lib.stochqn_hip_set_option(b"upload_slices", slices) == 0
+            out.append(run_trace(OPTIMIZERS[kind](backend=hip_backend, space="host", **KW[kind]), P, P.x0(), 0.05, 16))
             lib.stochqn_hip_release_all()
     finally:
         lib.stochqn_hip_set_option(b"apply_chunks", 8.0)
+        lib.stochqn_hip_set_option(b"upload_slices", 8.0)
     for other in out[1:]:
         for a, b in zip(out[0], other):
-            assert np.array_equal(a["x"], b["x"]) and a["task"] == b["task"]
+            assert a["task"] == b["task"] and a["info"] == b["info"]
+            for k in ("x", "req", "req_vec"):
+                if k in a:
+                    assert np.array_equal(a[k], b[k]), k
 
 
 def test_step_counters_name_the_form_that_ran(hip_backend):

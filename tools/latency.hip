@@ -33,8 +33,11 @@ int main(int argc, char** argv)
 	// argv[7]: 0 = the synchronous ABI with the guard (default); 1 = check_nan = 0, still synchronous; 2 = check_nan = 0 and
 	// option "async_device" (stream-ordered calls: nothing can be rejected, so nothing is waited for)
 	const int mode = argc > 7 ? atoi(argv[7]) : 0;
+	// 3 = the synchronous ABI with the guard, on the NULL stream (option "null_stream")
 	if (mode == 2) stochqn_hip_set_option("async_device", 1);
-	const int check_nan = mode == 0 ? 1 : 0;
+	if (mode == 3) stochqn_hip_set_option("null_stream", 1);
+	if (mode == 4) stochqn_hip_set_option("null_stream", 0);     // the context's own stream, as in rounds 1-2
+	const int check_nan = (mode == 0 || mode == 3 || mode == 4) ? 1 : 0;
 	workspace_oLBFGS* wo = sqn ? nullptr : initialize_oLBFGS(n, m, 0, 0, 0, check_nan, 1);
 	workspace_SQN* ws = sqn ? initialize_SQN(n, m, 10, 0, 0, 0, check_nan, 1) : nullptr;
 	auto iter = [&](long& calls) {
