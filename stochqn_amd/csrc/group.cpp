@@ -129,6 +129,15 @@ struct Group {
 	bool has_last = false;
 	size_t last_niter = 0;
 	int last_section = 0;
+	// host callers: their x / grad / hess_vec pinned in place for all devices (hipHostRegisterPortable), and what is known
+	// about the shards' copies of x (same rules as for one device: runtime.cpp stage_x)
+	struct HostRange { const void* p = nullptr; size_t bytes = 0; };
+	HostRange regs[4];
+	int reg_turn = 0;
+	const void* x_host = nullptr;
+	bool x_valid = false;
+	static constexpr int kProbe = 256;
+	double x_probe[kProbe];
 };
 
 std::mutex g_gmu;
@@ -186,8 +195,47 @@ void rows_d2h(real_t* host, const real* dev, size_t rows, size_t n, size_t off, 
 	SQN_HIP_OK(hipMemcpy2D(host + off, n * sizeof(real), dev, cnt * sizeof(real), cnt * sizeof(real), rows, hipMemcpyDeviceToHost));
 }
 
+size_t probe_at(int j, size_t n) { return n <= 1 ? 0 : (size_t) (((unsigned __int128) j * (n - 1)) / (Group::kProbe - 1)); }
+
+// pin [p, p + bytes) of the caller's memory for every device of the process (once; at most 4 ranges per group)
+void pin_for_all_devices(Group* g, const void* p, size_t bytes)
+{
+	const Options& o = options();
+	if (!o.register_host || !p || (long) bytes < o.register_min_bytes) return;
+	for (auto& r : g->regs) if (r.p == p && r.bytes >= bytes) return;
+	hipPointerAttribute_t a;
+	if (hipPointerGetAttributes(&a, p) == hipSuccess) { if (a.type == hipMemoryTypeHost) return; }      // pinned by somebody else already
+	else (void) hipGetLastError();
+	Group::HostRange& slot = g->regs[g->reg_turn++ % 4];
+	if (slot.p) { if (hipHostUnregister(const_cast<void*>(slot.p)) != hipSuccess) (void) hipGetLastError(); slot = Group::HostRange{}; }
+	if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); return; }
+	slot.p = p;
+	slot.bytes = bytes;
+	stat_add(ST_HOST_REGISTERED);
+}
+
+// are the shards' copies of x what the caller's array holds?  (the library wrote both, *req == x went back, probes agree)
+bool x_is_current(Group* g, const real_t* x, size_t n)
+{
+	if (options().x_upload != 0 || !g->x_valid || g->x_host != x) return false;
+	for (int j = 0; j < Group::kProbe; j++) {
+		const double v = (double) x[probe_at(j, n)];
+		if (std::memcmp(&v, &g->x_probe[j], sizeof v) != 0) return false;
+	}
+	return true;
+}
+
+void x_went_back(Group* g, const real_t* x, size_t n, bool req_is_x)
+{
+	g->x_host = x;
+	g->x_valid = req_is_x;
+	for (int j = 0; j < Group::kProbe; j++) g->x_probe[j] = (double) x[probe_at(j, n)];
+}
+
 void destroy_group(Group* g)
 {
+	for (auto& r : g->regs)
+		if (r.p) { if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError(); }
 	for_all(g, [&](Shard& s) {
 		if (s.S) release(s.S);                                  // the shard's device context
 		dfree(s.S); dfree(s.Y); dfree(s.sbak); dfree(s.ybak); dfree(s.gprev); dfree(s.xsum); dfree(s.xprev);
@@ -515,6 +563,28 @@ void request_x(const void* key)
 		for (auto& s : g->sh) { s->req = s->bound ? s->bx : s->x; s->req_vec = nullptr; }
 }
 
+// Before the fan-out of a host caller's call: pin its vectors, and do not send x again when the shards still hold it.
+void prepare_io(Group* g, Io& io, size_t n)
+{
+	if (g->sh[0]->bound) return;                              // device-resident caller: its vectors live on the devices
+	pin_for_all_devices(g, io.x, n * sizeof(real));
+	pin_for_all_devices(g, io.grad, n * sizeof(real));
+	if (io.up_hv) pin_for_all_devices(g, io.hv, n * sizeof(real));
+	if (!io.up_x || !io.x) return;
+	if (x_is_current(g, io.x, n)) { io.up_x = false; stat_add(ST_X_UPLOAD_SKIPPED); }
+	else stat_add(ST_X_UPLOAD);
+}
+
+// After it: the shards' x and the caller's agree again when x was part of the call; a request that is not at x leaves the
+// caller free to edit x until the next call (reference include/stochqn.h:364-366 protects *req only).
+void settle_io(Group* g, const Io& io, size_t n, bool x_in_call, bool ok, bool req_is_x)
+{
+	if (g->sh[0]->bound) return;
+	if (!ok) { g->x_valid = false; return; }
+	if (x_in_call && io.x) x_went_back(g, io.x, n, req_is_x);
+	else if (!req_is_x) g->x_valid = false;
+}
+
 void note(Group* g, size_t niter, int section)
 {
 	g->has_last = true;
@@ -548,6 +618,8 @@ int group_run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, 
 	io.x = x; io.grad = grad;
 	io.up_x = io.down_x = io.down_g = w->section == 1;
 	io.up_g = true;
+	const bool x_in_call = io.up_x;
+	prepare_io(g, io, (size_t) w->n);
 	for_all(g, [&](Shard& s) {
 		sync_bfgs(s, b, s.rank == 0);
 		s.wo.bfgs_memory = &s.b; s.wo.grad_prev = s.gprev; s.wo.hess_init = w->hess_init; s.wo.niter = w->niter;
@@ -557,7 +629,8 @@ int group_run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, 
 		s.ret = local_run_oLBFGS(step_size, s.bound ? s.bx : s.x, s.bound ? s.bg : s.g, &s.req, &s.task, &s.wo, &s.info);
 		download(g, sp, s, io);
 	});
-	if (!agree(g, "run_oLBFGS")) { *task = invalid_input; return -1000; }
+	if (!agree(g, "run_oLBFGS")) { settle_io(g, io, (size_t) w->n, x_in_call, false, true); *task = invalid_input; return -1000; }
+	settle_io(g, io, (size_t) w->n, x_in_call, true, true);
 	const Shard& a = *g->sh[0];
 	b->mem_used = a.b.mem_used; b->mem_st_ix = a.b.mem_st_ix;
 	w->niter = a.wo.niter; w->section = a.wo.section;
@@ -593,6 +666,8 @@ int group_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[]
 	io.up_x = io.down_x = io.down_g = w->section == 1;
 	io.up_g = w->section != 4;
 	io.up_hv = w->section == 4;
+	const bool x_in_call = io.up_x;
+	prepare_io(g, io, (size_t) w->n);
 	for_all(g, [&](Shard& s) {
 		sync_bfgs(s, b, s.rank == 0);
 		s.ws.bfgs_memory = &s.b; s.ws.grad_prev = s.gprev; s.ws.x_sum = s.xsum; s.ws.x_avg_prev = s.xprev;
@@ -605,7 +680,7 @@ int group_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[]
 		if (s.task != calc_hess_vec) s.req_vec = nullptr;
 		download(g, sp, s, io);
 	});
-	if (!agree(g, "run_SQN")) { *task = invalid_input; return -1000; }
+	if (!agree(g, "run_SQN")) { settle_io(g, io, (size_t) w->n, x_in_call, false, true); *task = invalid_input; return -1000; }
 	const Shard& a = *g->sh[0];
 	b->mem_used = a.b.mem_used; b->mem_st_ix = a.b.mem_st_ix;
 	w->niter = a.ws.niter; w->section = a.ws.section;
@@ -613,6 +688,7 @@ int group_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[]
 	bool is_x = false;
 	*req = req_home(g, sp, a, a.req, x, &is_x);
 	if (a.req_vec) *req_vec = g->owned ? landing(g, 1) : b->s_mem + a.b.mem_st_ix * (size_t) w->n;
+	settle_io(g, io, (size_t) w->n, x_in_call, true, is_x);
 	note(g, w->niter, w->section);
 	return a.ret;
 }
@@ -654,6 +730,8 @@ int group_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
 	io.up_x = io.down_x = w->section == 1 || w->section == 5;
 	io.down_g = w->section == 1;
 	io.up_g = w->section != 5;
+	const bool x_in_call = io.up_x;
+	prepare_io(g, io, (size_t) w->n);
 	for_all(g, [&](Shard& s) {
 		sync_bfgs(s, b, s.rank == 0);
 		if (fm) {
@@ -671,7 +749,7 @@ int group_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
 		s.ret = local_run_adaQN(step_size, s.bound ? s.bx : s.x, f, s.bound ? s.bg : s.g, &s.req, &s.task, &s.wa, &s.info);
 		download(g, sp, s, io);
 	});
-	if (!agree(g, "run_adaQN")) { *task = invalid_input; return -1000; }
+	if (!agree(g, "run_adaQN")) { settle_io(g, io, (size_t) w->n, x_in_call, false, true); *task = invalid_input; return -1000; }
 	const Shard& a = *g->sh[0];
 	for (auto& s : g->sh)
 		if (fm && (s->f.mem_used != a.f.mem_used || s->f.mem_st_ix != a.f.mem_st_ix || s->wa.f_prev != a.wa.f_prev)) { *task = invalid_input; return -1000; }
@@ -682,6 +760,7 @@ int group_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
 	*task = a.task; *iter_info = a.info;
 	bool is_x = false;
 	*req = req_home(g, sp, a, a.req, x, &is_x);
+	settle_io(g, io, (size_t) w->n, x_in_call, true, is_x);
 	note(g, w->niter, w->section);
 	return a.ret;
 }

@@ -69,6 +69,50 @@ def test_host_caller_on_P_devices_equals_unsharded_oracle(name, n, devices, hip_
     opt.release()
 
 
+@pytest.mark.parametrize("kind,kw", [("SQN", dict(mem_size=3, bfgs_upd_freq=3)), ("oLBFGS", dict(mem_size=3)),
+                                     ("adaQN", dict(mem_size=3, fisher_size=5, bfgs_upd_freq=3, max_incr=1.01, rmsprop_weight=0.9))])
+def test_host_path_of_the_multi_device_mode(kind, kw, devices, hip_backend, oracle_backend):
+    """The host-caller machinery of one device applies to the shards too: the caller's x / grad / hess_vec are pinned once
+    for all devices (20 MB arrays here), and x goes up only when the shards' copies may be out of date -- and the caller that
+    edits x between two calls is still seen.  Bar: the unsharded oracle."""
+    lib = _lib()
+    lib.stochqn_hip_stat.argtypes = [C.c_char_p]
+    lib.stochqn_hip_stat.restype = C.c_longlong
+    n = 2_500_001
+    P = NoisyQuadratic(n, seed=5)
+
+    def drive(backend):
+        opt = OPTIMIZERS[kind](backend=backend, space="host", **kw)
+        x = P.x0()
+        xs, last = [], 999983
+        for call in range(18):
+            r = opt.run_optimizer(x, 0.05)
+            xs.append(x.copy())
+            if r["task"] == "calc_hess_vec":
+                rx, rv = r["requested_on"]
+                opt.update_hess_vec(P.hess_vec(np.asarray(rx).copy(), np.asarray(rv).copy()))
+            elif r["task"] == "calc_fun_val_batch":
+                opt.update_function(P.f(np.asarray(r["requested_on"]).copy(), call))
+            else:
+                if call == 11 and r["task"] == "calc_grad":
+                    x *= 0.75                                # the caller's own move between two calls
+                if r["task"] == "calc_grad":
+                    last = call
+                at = x if call == 11 and r["task"] == "calc_grad" else r["requested_on"]
+                opt.update_gradient(P.grad(np.asarray(at).copy(), last if r["task"] == "calc_grad_same_batch" else call))
+        return xs, opt
+
+    lib.stochqn_hip_stats_reset()
+    got, opt = drive(hip_backend)
+    assert lib.stochqn_hip_devices_active(C.c_void_p(opt.BFGS_mem.s_mem.ctypes.data)) == devices
+    skipped, uploads, pinned = (lib.stochqn_hip_stat(k) for k in (b"x_uploads_skipped", b"x_uploads", b"host_ranges_registered"))
+    want, _ = drive(oracle_backend)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert rel_err(g, w) <= 1e-9, i
+    assert skipped >= 3 and uploads >= 2 and pinned >= 2, (skipped, uploads, pinned)
+    opt.release()
+
+
 def test_c_rosen_protocol_on_P_devices(devices, hip_backend):
     """Profile A: initialize_SQN / run_SQN / dealloc_SQN exactly as reference example/c_rosen.c:100-125 does,
     the workspace sharded over the devices (n = 4: shards of 1-2 variables), *req and *req_vec read on the host."""
