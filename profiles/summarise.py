@@ -35,13 +35,18 @@ def short(name):
     return re.sub(r"\(.*", "", name)[:80]
 
 
-stats = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_stats", "*", "*_kernel_stats.csv"))
+def newest(pattern):
+    """gpurun merges every call's output into the same directories: take the most recent run's file"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
+
+stats = newest(os.path.join(ROOT, "gpurun_out", "prof_stats", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(out, tag + "_rocprofv3_kernel_stats.csv"))
 
 pmc = {}
 for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    files = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_" + kind, "*", "*_counter_collection.csv"))
+    files = newest(os.path.join(ROOT, "gpurun_out", "prof_" + kind, "*", "*_counter_collection.csv"))
     if not files:
         continue
     agg = collections.defaultdict(list)

@@ -84,7 +84,7 @@ def test_host_path_of_the_multi_device_mode(kind, kw, devices, hip_backend, orac
     def drive(backend):
         opt = OPTIMIZERS[kind](backend=backend, space="host", **kw)
         x = P.x0()
-        xs, last = [], 999983
+        xs, last, edited = [], 999983, False
         for call in range(18):
             r = opt.run_optimizer(x, 0.05)
             xs.append(x.copy())
@@ -94,11 +94,13 @@ def test_host_path_of_the_multi_device_mode(kind, kw, devices, hip_backend, orac
             elif r["task"] == "calc_fun_val_batch":
                 opt.update_function(P.f(np.asarray(r["requested_on"]).copy(), call))
             else:
-                if call == 11 and r["task"] == "calc_grad":
-                    x *= 0.75                                # the caller's own move between two calls
+                edit = call >= 10 and r["task"] == "calc_grad" and not edited
+                if edit:
+                    x *= 0.75                                # the caller's own move between two calls (once)
+                    edited = True
                 if r["task"] == "calc_grad":
                     last = call
-                at = x if call == 11 and r["task"] == "calc_grad" else r["requested_on"]
+                at = x if edit else r["requested_on"]
                 opt.update_gradient(P.grad(np.asarray(at).copy(), last if r["task"] == "calc_grad_same_batch" else call))
         return xs, opt
 
