@@ -45,7 +45,7 @@ int main(int argc, char **argv)
 	double *req = NULL, *req_vec = NULL;
 	task_enum task;
 	info_enum info;
-	double t_lib = 0, t_caller = 0, f0 = 0, f1 = 0;
+	double t_lib = 0, t_caller = 0, f0 = 0, f1 = 0, t_first = 0, t_min = 1e30;
 	#pragma omp parallel for reduction(+ : f0)
 	for (long i = 0; i < n; i++) f0 += 0.5 * d_of(i) * x[i] * x[i];
 	run_SQN(0.05, x, grad, hv, &req, &req_vec, &task, w, &info);
@@ -64,7 +64,10 @@ int main(int argc, char **argv)
 		double tl = now();
 		t_caller += tl - tc;
 		int rc = run_SQN(0.05, x, grad, hv, &req, &req_vec, &task, w, &info);
-		t_lib += now() - tl;
+		const double dt = now() - tl;
+		t_lib += dt;
+		if (calls < 2) t_first += dt;                 /* one-time work: the caller's vectors are pinned, staging is allocated */
+		else if (task == calc_grad && dt < t_min) t_min = dt;
 		if (rc != 0 && rc != 1) { fprintf(stderr, "run_SQN returned %d\n", rc); return 5; }
 		if (info != no_problems_encountered) bad++;
 		calls++;
@@ -75,6 +78,8 @@ int main(int argc, char **argv)
 	       w->bfgs_memory->mem_used, f0, f1);
 	printf("inside run_SQN: %.3f s = %.1f ms per step (PCIe-inclusive); caller's own gradient / Hv loops: %.3f s\n", t_lib,
 	       1e3 * t_lib / (double) w->niter, t_caller);
+	printf("  of which the first two calls (pinning the caller's vectors, staging): %.3f s; after them %.1f ms per step, fastest ordinary step %.1f ms\n",
+	       t_first, 1e3 * (t_lib - t_first) / (double) (w->niter > 2 ? w->niter - 2 : 1), 1e3 * t_min);
 	dealloc_SQN(w);
 	free(x); free(grad); free(hv);
 	return (f1 < f0 && bad == 0) ? 0 : 6;
