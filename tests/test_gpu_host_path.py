@@ -261,3 +261,4 @@ def test_running_out_of_device_memory_reclaims_instead_of_failing(hip_backend, o
         del ballast
         torch.cuda.empty_cache()
         lib.stochqn_hip_release_all()
+
