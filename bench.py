@@ -177,9 +177,9 @@ class Workload:
         self.d = self.uniform(torch.empty(n, dtype=f64, device=dev), ST_D, 0, 0.5, 1.0)          # d_i = 0.5 + u(i,0,0)
         self.x = self.uniform(torch.empty(n, dtype=f64, device=dev), ST_X0, 0, 1.0, 1.0)         # x0_i = 1 + u(i,3,0)
         # Hessian mini-batch of `bs` sample vectors, stored dense [bs][n].  The samples have disjoint
-        # supports (a_k,i = sqrt(bs*d_i) for i = k mod bs, else 0) so that A'A/bs = diag(d) exactly:
-        # the product streams the full dense batch (2*bs*n words, like any real mini-batch) while the
-        # optimiser sees the true Hessian of the quadratic and stays in a sane regime for any n >> bs.
+        # supports (a_k,i = sqrt(bs*d_i) for i = k mod bs, else 0): A'A/bs has the diagonal d and couples only
+        # variables of the same residue class mod bs.  The product streams the full dense batch (2*bs*n words,
+        # like any real mini-batch); Hv = A'(Av)/bs is the exact Hessian-vector product of the batch loss.
         self.A = torch.empty(bs * n, dtype=f64, device=dev)
         for k in range(bs):
             assert lib.stochqn_hip_synth_batch_row(self.A.data_ptr() + 8 * k * n, self.d.data_ptr(), n, first, k, bs) == 0
@@ -204,6 +204,20 @@ class Workload:
         self.ptr2t = {self.x.data_ptr(): self.x, self.x_sum.data_ptr(): self.x_sum, self.x_avg_prev.data_ptr(): self.x_avg_prev}
         self.counters = {"calls": 0, "hv": 0, "bad": 0, "rejected": 0}
         self.t_idx = 0
+        # the caller's Hessian-vector routine A'(A v)/bs, checked once (on v = x0) against plain torch products over the same batch.
+        # This is also where its one-time set-up happens (the product's scratch and stream: 5.8 ms on the first call, which would
+        # otherwise land in whichever timed step builds the first pair -- 2.7 % of a K = 20 window)
+        assert lib.stochqn_hip_fisher_product(self.A.data_ptr(), bs, n, self.x.data_ptr(), self.t_buf.data_ptr(), self.hv.data_ptr()) == 0
+        A2 = self.A.view(bs, n)
+        t = A2 @ self.x
+        if ctx["dist"] is not None:
+            th = t.to(ctx["cpu_or_dev"])
+            ctx["dist"].all_reduce(th)
+            t = th.to(dev)
+        want = (t @ A2) / bs
+        err = float(torch.linalg.vector_norm(self.hv - want) / torch.linalg.vector_norm(want))
+        assert err <= 1e-12, "Hessian-vector product A'(Av)/bs: %r from torch's" % err
+        del A2, t, want
 
     def uniform(self, out, stream, t, a, b):
         assert self.ctx["lib"].stochqn_hip_synth_uniform(out.data_ptr(), out.numel(), self.first, SEED, stream, t, a, b) == 0

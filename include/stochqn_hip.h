@@ -158,7 +158,7 @@ int stochqn_hip_profile_get(int kernel_id, long long *launches, double *total_ms
  * uniform    : out_j  = a + b * u(first_index + j)
  * noisy_grad : grad_j = d_j x_j (1 + amp (2 u(first_index + j) - 1)), the stochastic gradient of 1/2 sum d x^2
  * batch_row  : row k of a `bs`-sample Hessian mini-batch with disjoint supports, a_j = sqrt(bs d_j) if
- *              (first_index + j) mod bs == k else 0, so that A'A/bs = diag(d)
+ *              (first_index + j) mod bs == k else 0: A'A/bs has the diagonal d (and couples only j of one residue class)
  * Device pointers only; the kernels are enqueued on the null stream and NOT synchronised. 0 or -1000. */
 int stochqn_hip_synth_uniform(real_t *out, size_t count, unsigned long long first_index, unsigned long long seed,
 	unsigned long long stream, unsigned long long t, double a, double b);
