@@ -209,13 +209,20 @@ class Workload:
         # otherwise land in whichever timed step builds the first pair -- 2.7 % of a K = 20 window)
         assert lib.stochqn_hip_fisher_product(self.A.data_ptr(), bs, n, self.x.data_ptr(), self.t_buf.data_ptr(), self.hv.data_ptr()) == 0
         A2 = self.A.view(bs, n)
-        t = A2 @ self.x
+        chunk = 1 << 24                                           # (one [32 x 1e8] gemv overflows rocBLAS's 32-bit indexing)
+        t = torch.zeros(bs, dtype=f64, device=dev)
+        for c0 in range(0, n, chunk):
+            t += A2[:, c0:c0 + chunk] @ self.x[c0:c0 + chunk]
         if ctx["dist"] is not None:
             th = t.to(ctx["cpu_or_dev"])
             ctx["dist"].all_reduce(th)
             t = th.to(dev)
-        want = (t @ A2) / bs
-        err = float(torch.linalg.vector_norm(self.hv - want) / torch.linalg.vector_norm(want))
+        num = den = 0.0
+        for c0 in range(0, n, chunk):
+            want = (t @ A2[:, c0:c0 + chunk]) / bs
+            num += float(torch.sum((self.hv[c0:c0 + chunk] - want) ** 2))
+            den += float(torch.sum(want ** 2))
+        err = (num / den) ** 0.5
         assert err <= 1e-12, "Hessian-vector product A'(Av)/bs: %r from torch's" % err
         del A2, t, want
 

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <time.h>
 #include "stochqn.h"
+#include "stochqn_hip.h"
 
 static double now(void)
 {
@@ -66,6 +67,7 @@ int main(int argc, char **argv)
 		int rc = run_SQN(0.05, x, grad, hv, &req, &req_vec, &task, w, &info);
 		const double dt = now() - tl;
 		t_lib += dt;
+		if (getenv("C5_VERBOSE")) printf("  call %3d niter %3zu next task %d: %.1f ms\n", calls, w->niter, (int) task, 1e3 * dt);
 		if (calls < 2) t_first += dt;                 /* one-time work: the caller's vectors are pinned, staging is allocated */
 		else if (task == calc_grad && dt < t_min) t_min = dt;
 		if (rc != 0 && rc != 1) { fprintf(stderr, "run_SQN returned %d\n", rc); return 5; }
@@ -80,6 +82,9 @@ int main(int argc, char **argv)
 	       1e3 * t_lib / (double) w->niter, t_caller);
 	printf("  of which the first two calls (pinning the caller's vectors, staging): %.3f s; after them %.1f ms per step, fastest ordinary step %.1f ms\n",
 	       t_first, 1e3 * (t_lib - t_first) / (double) (w->niter > 2 ? w->niter - 2 : 1), 1e3 * t_min);
+	printf("  x uploads %lld, skipped %lld; host ranges pinned %lld; steps by form: three-pass %lld, sweeps %lld, no pairs yet %lld\n",
+	       stochqn_hip_stat("x_uploads"), stochqn_hip_stat("x_uploads_skipped"), stochqn_hip_stat("host_ranges_registered"),
+	       stochqn_hip_stat("steps_three_pass"), stochqn_hip_stat("steps_sweeps"), stochqn_hip_stat("steps_plain"));
 	dealloc_SQN(w);
 	free(x); free(grad); free(hv);
 	return (f1 < f0 && bad == 0) ? 0 : 6;
