@@ -208,23 +208,18 @@ class Workload:
         # This is also where its one-time set-up happens (the product's scratch and stream: 5.8 ms on the first call, which would
         # otherwise land in whichever timed step builds the first pair -- 2.7 % of a K = 20 window)
         assert lib.stochqn_hip_fisher_product(self.A.data_ptr(), bs, n, self.x.data_ptr(), self.t_buf.data_ptr(), self.hv.data_ptr()) == 0
-        A2 = self.A.view(bs, n)
-        chunk = 1 << 24                                           # (one [32 x 1e8] gemv overflows rocBLAS's 32-bit indexing)
-        t = torch.zeros(bs, dtype=f64, device=dev)
-        for c0 in range(0, n, chunk):
-            t += A2[:, c0:c0 + chunk] @ self.x[c0:c0 + chunk]
+        rows = [self.A[k * n:(k + 1) * n] for k in range(bs)]       # row by row: one [32 x 1e8] gemv is beyond rocBLAS's 32-bit indexing
+        t = torch.stack([torch.dot(r, self.x) for r in rows])
         if ctx["dist"] is not None:
             th = t.to(ctx["cpu_or_dev"])
             ctx["dist"].all_reduce(th)
             t = th.to(dev)
-        num = den = 0.0
-        for c0 in range(0, n, chunk):
-            want = (t @ A2[:, c0:c0 + chunk]) / bs
-            num += float(torch.sum((self.hv[c0:c0 + chunk] - want) ** 2))
-            den += float(torch.sum(want ** 2))
-        err = (num / den) ** 0.5
+        want = torch.zeros(n, dtype=f64, device=dev)
+        for k in range(bs):
+            want.add_(rows[k], alpha=float(t[k]) / bs)
+        err = float(torch.linalg.vector_norm(self.hv - want) / torch.linalg.vector_norm(want))
         assert err <= 1e-12, "Hessian-vector product A'(Av)/bs: %r from torch's" % err
-        del A2, t, want
+        del rows, t, want
 
     def uniform(self, out, stream, t, a, b):
         assert self.ctx["lib"].stochqn_hip_synth_uniform(out.data_ptr(), out.numel(), self.first, SEED, stream, t, a, b) == 0
