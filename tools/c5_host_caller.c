@@ -35,7 +35,10 @@ int main(int argc, char **argv)
 	if (n <= 0 || n > 2147483647L) { fprintf(stderr, "n must fit an int (reference include/stochqn.h:172-174)\n"); return 2; }
 	double *x = malloc((size_t) n * sizeof(double)), *grad = malloc((size_t) n * sizeof(double)), *hv = malloc((size_t) n * sizeof(double));
 	if (!x || !grad || !hv) { fprintf(stderr, "host memory\n"); return 2; }
-	#pragma omp parallel for
+	/* first touch by this one thread: the pages of x / grad / hv then sit on one NUMA node, like the arrays of an R or numpy
+	 * caller.  (Touched by the OpenMP team of an unpinned process on a two-socket host they end up spread over both sockets,
+	 * and the PCIe copies of the half behind the inter-socket link ran at less than half the speed: 97 instead of 57 ms per
+	 * step at n = 2e8, profiles/r03_c5_host_caller_one_device.log.) */
 	for (long i = 0; i < n; i++) { x[i] = 1.0 + (double) (i % 97) / 97.0; grad[i] = 0; hv[i] = 0; }
 
 	double t0 = now();
