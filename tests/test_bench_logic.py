@@ -1,0 +1,77 @@
+"""CPU checks of bench.py's bookkeeping (no GPU): the roofline object is algorithmic bytes per launch over the measured
+launch time against 8 TB/s, the two-loop summary uses the bytes its form moves, the C5 yardstick comes from the newest
+committed 1-GPU profile, and N > 1 without a launcher is never silently run as one rank."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_roofline_object_of_the_dominant_kernel():
+    b = _bench()
+    n, m, bs, steps = 100_000_000, 20, 32, 20
+    kern = {"sdot": (18, 18 * 2.5), "sdot2": (2, 2 * 2.7), "qdot": (20, 20 * 3.2), "sadd": (20, 20 * 3.0), "apply": (20, 20 * 0.7)}
+    detail, roof, two_loop, what = b.analyse_kernels(kern, n, m, bs, steps, 1)
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s"
+    assert roof["kernel"].startswith("qdot")                              # the largest share of device time
+    assert roof["alg_bytes_per_launch"] == (m + 2) * n * 8
+    assert abs(roof["achieved"] - (m + 2) * n * 8 / 3.2e-3 / 1e9) < 0.1 and abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-4
+    assert two_loop["form"] == "three-pass" and two_loop["bytes_moved"] == (3 * m + 5) * n * 8
+    assert abs(two_loop["ms"] - (18 * 2.5 + 2 * 2.7 + 20 * 3.2 + 20 * 3.0) / steps) < 1e-3
+    assert two_loop["reference_form_bytes"] == 64 * m * n
+    assert abs(detail["apply"]["alg_GBps"] - 5 * n * 8 / 0.7e-3 / 1e9) < 0.1
+    # the reference's own sweep form: the fused backward sweep moves 4 n words per launch
+    k2 = {"first": (10, 10 * 0.4), "bwd": (190, 190 * 0.52), "mid": (10, 10 * 0.45), "fwd": (190, 190 * 0.52), "fwd_last": (10, 10 * 0.45)}
+    _, roof2, tl2, _ = b.analyse_kernels(k2, n, m, bs, 10, 1)
+    assert roof2["kernel"].startswith(("bwd", "fwd")) and roof2["alg_bytes_per_launch"] == 4 * n * 8
+    assert tl2["form"] == "sweeps" and tl2["bytes_moved"] == 8 * m * n * 8
+
+
+def test_c5_yardstick_comes_from_the_newest_committed_profile():
+    b = _bench()
+    one = b.shard_reference(1, 80.0)
+    assert one["source"] == "this run" and abs(one["within_15pct_means_at_least"] - 68.0) < 1e-9
+    ref = b.shard_reference(8, 70.0)
+    assert ref and ref["source"].startswith("profiles/r") and ref["source"].endswith("_c5_shard_1gpu.json")
+    newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_c5_shard_1gpu.json"))[-1]
+    assert ref["source"] == "profiles/" + newest
+    assert abs(ref["this_run_over_reference"] - 70.0 / ref["steps_per_s"]) < 1e-3
+    assert abs(ref["within_15pct_means_at_least"] - 0.85 * ref["steps_per_s"]) < 1e-2
+
+
+def test_committed_profiles_carry_the_contract():
+    """The default run committed under profiles/ has every key the driver and the judge read."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default_run.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["traffic"] / r["alg_bytes_per_launch"] - 1) < 0.02          # no wasted re-reads (PMC, counted in the run)
+    c = d["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] == "port"
+    assert d["forms"]["three_pass"] == d["steps"] and d["host_caller"]["strict_grad_0"]["ms_per_step"] < 60
+
+
+def test_more_gpus_than_visible_is_refused_before_anything_runs():
+    """--gpus 2 without a launcher on a machine with fewer devices: non-zero exit, no JSON line (decided before HIP is touched)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a box with fewer than two devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "device(s) are visible" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
