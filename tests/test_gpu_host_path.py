@@ -262,3 +262,44 @@ def test_running_out_of_device_memory_reclaims_instead_of_failing(hip_backend, o
         torch.cuda.empty_cache()
         lib.stochqn_hip_release_all()
 
+
+
+def test_function_increase_rolls_x_back_for_host_callers_too(hip_backend):
+    """adaQN's `func_increased` branch writes x itself (x <- x_avg_prev, reference src/stochqn.c:1275-1283) in a call that
+    takes no step: the device copy, the host array and the 'x is current' bookkeeping must all follow -- host and device
+    callers bit for bit, with a spike in f forcing the branch."""
+    import torch
+    lib = _lib()
+    n = 2_300_000
+    P = NoisyQuadratic(n, seed=6, f_spike_calls=range(12, 15))
+    kw = dict(mem_size=3, fisher_size=4, bfgs_upd_freq=3, max_incr=1.01, rmsprop_weight=0.9)
+    host = run_trace(OPTIMIZERS["adaQN"](backend=hip_backend, space="host", **kw), P, P.x0(), 0.02, 30)
+    x = torch.as_tensor(P.x0(), device="cuda:0")
+    dev = run_trace(OPTIMIZERS["adaQN"](backend=hip_backend, space="device", device="cuda:0", **kw), P, x, 0.02, 30)
+    assert any(r["info"] == "func_increased" for r in host)
+    for i, (h, d) in enumerate(zip(host, dev)):
+        assert h["task"] == d["task"] and h["info"] == d["info"] and h["niter"] == d["niter"], i
+        assert np.array_equal(h["x"], d["x"]) and np.array_equal(h["req"], d["req"]), i
+    lib.stochqn_hip_release_all()
+
+
+@pytest.mark.parametrize("kind", ["SQN", "adaQN"])
+def test_float_host_and_device_callers_agree_bit_for_bit(kind):
+    """The same for the single-precision library (libstochqn_f32.so): pinned float arrays, sliced pass 1, sliced update."""
+    import stochqn_amd
+    import torch
+    be = stochqn_amd.lib(use_float=True)
+    lib = stochqn_amd.cdll(use_float=True)
+    n = 4_500_001
+    P = NoisyQuadratic(n, seed=5)
+    kw = dict(KW[kind], use_float=True)
+    x0 = P.x0().astype(np.float32)
+    host = run_trace(OPTIMIZERS[kind](backend=be, space="host", **kw), P, x0.copy(), 0.05, 16)
+    x = torch.as_tensor(x0.copy(), device="cuda:0")
+    dev = run_trace(OPTIMIZERS[kind](backend=be, space="device", device="cuda:0", **kw), P, x, 0.05, 16)
+    for i, (h, d) in enumerate(zip(host, dev)):
+        assert h["task"] == d["task"] and h["info"] == d["info"], i
+        for k in ("x", "req", "req_vec"):
+            if k in h:
+                assert np.array_equal(h[k], d[k]), (i, k)
+    lib.stochqn_hip_release_all()
