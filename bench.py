@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="N = 1: take roofline.traffic from the committed profiles/ instead of counting it now (two rocprofv3 --pmc "
                          "passes over a 5-step child run of this workload, about a minute)")
+    ap.add_argument("--strict-legs", action="store_true",
+                    help="N > 1: a failing secondary leg makes the whole run fail (non-zero exit, no JSON line) instead of being "
+                         "reported in `legs_failed` next to the primary result")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="N > 1: only the primary weak-scaling leg (default: also config 5's n = 1.25e8 per GPU, the strong-scaling "
                          "split of n = 1e8, the all-reduce latency and the one-process / N-devices mode, all in the same JSON line)")
@@ -698,6 +701,9 @@ def run(args):
     if want_legs:
         out["legs"] = legs
         out["legs_failed"] = legs_failed
+        if legs_failed and args.strict_legs:
+            sys.stderr.write("bench.py: leg(s) %s failed: %s\n" % (", ".join(legs_failed), json.dumps({k: legs[k] for k in legs_failed})))
+            raise SystemExit(3)
     if args.config == "c5" or n_gpu == CONFIGS["c5"]:
         out["shard_reference_1gpu"] = shard_reference(world, steps_per_s)
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
