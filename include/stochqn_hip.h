@@ -192,8 +192,7 @@ int stochqn_hip_comm_allreduce_probe(int count, int reps, double *median_us, dou
  *                               |s||y|/|s'y| > "twopass_kappa_max" sent to the reference's chain of sweeps;
  *   "allreduces", "allreduce_doubles"   reductions issued by this process (per shard context) and doubles summed;
  *   "contexts_created", "contexts_reclaimed"   device contexts made / exported-and-dropped under memory pressure;
- *   "x_uploads", "x_uploads_skipped", "host_ranges_registered"   host-caller path;
- *   "graph_launches"            steps replayed from a captured HIP graph (option "graphs").
+ *   "x_uploads", "x_uploads_skipped", "host_ranges_registered"   host-caller path.
  * Returns the count, or -1 for an unknown name. */
 long long stochqn_hip_stat(const char *name);
 void stochqn_hip_stats_reset(void);

@@ -42,5 +42,30 @@ int main()
 		for (int i = 0; i < R; i++) { for (int k = 0; k < 4; k++) hipExtLaunchKernelGGL(k_write, dim3(1), dim3(64), 0, st, e0, e1, 0, dev, (double) i); CK(hipStreamSynchronize(st)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); acc_ms += ms; }
 		printf("4 x hipExtLaunchKernelGGL(start, stop events) + sync: %.2f us (kernel %.2f us by its events)\n", 1e6 * (now() - t0) / R, 1e3 * acc_ms / R);
 	}
+	// The same four dependent kernels (+ the 64-byte read-back) as ONE captured graph, replayed: what a graph of
+	// the default step's chain would cost per call.
+	for (int with_copy = 0; with_copy < 2; with_copy++) {
+		hipGraph_t g; hipGraphExec_t ge;
+		CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+		for (int k = 0; k < 4; k++) hipLaunchKernelGGL(k_write, dim3(1), dim3(64), 0, st, dev, 1.0 + k);
+		if (with_copy) CK(hipMemcpyAsync(pin, dev, 64, hipMemcpyDeviceToHost, st));
+		CK(hipStreamEndCapture(st, &g));
+		CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+		for (int w = 0; w < 2; w++) {
+			t0 = now();
+			for (int i = 0; i < R; i++) { CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st)); }
+			printf("graph of 4 kernels%s, launch + sync: %.2f us\n", with_copy ? " + D2H(64 B)" : "", 1e6 * (now() - t0) / R);
+		}
+		// stream-ordered (no wait per call): what async_device would see
+		t0 = now();
+		for (int i = 0; i < R; i++) CK(hipGraphLaunch(ge, st));
+		CK(hipStreamSynchronize(st));
+		printf("graph of 4 kernels%s, %d launches then one sync: %.2f us each\n", with_copy ? " + D2H(64 B)" : "", R, 1e6 * (now() - t0) / R);
+		CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+	}
+	t0 = now();
+	for (int i = 0; i < R; i++) for (int k = 0; k < 4; k++) hipLaunchKernelGGL(k_write, dim3(1), dim3(64), 0, st, dev, (double) i);
+	CK(hipStreamSynchronize(st));
+	printf("4 kernels, %d rounds then one sync: %.2f us per round\n", R, 1e6 * (now() - t0) / R);
 	return 0;
 }

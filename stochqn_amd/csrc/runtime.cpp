@@ -49,7 +49,7 @@ std::atomic<long long> g_stats[ST_COUNT];
 const char* const kStatNames[ST_COUNT] = {
 	"steps_three_pass", "steps_two_pass", "steps_two_pass_h0", "steps_sweeps", "steps_plain", "steps_kappa_fallback",
 	"allreduces", "allreduce_doubles", "contexts_created", "contexts_reclaimed", "x_uploads", "x_uploads_skipped",
-	"host_ranges_registered", "graph_launches"};
+	"host_ranges_registered"};
 
 bool alloc_should_fail()
 {

@@ -176,7 +176,7 @@ struct DevCtx {
 enum StatId {
 	ST_STEP_THREE_PASS = 0, ST_STEP_TWO_PASS, ST_STEP_TWO_PASS_H0, ST_STEP_SWEEPS, ST_STEP_PLAIN, ST_KAPPA_FALLBACK,
 	ST_ALLREDUCE, ST_ALLREDUCE_DOUBLES, ST_CTX_CREATED, ST_CTX_RECLAIMED, ST_X_UPLOAD, ST_X_UPLOAD_SKIPPED,
-	ST_HOST_REGISTERED, ST_GRAPH_LAUNCH, ST_COUNT
+	ST_HOST_REGISTERED, ST_COUNT
 };
 void stat_add(int id, long long v = 1);
 
