@@ -108,6 +108,10 @@ int stochqn_hip_export(const void *s_mem);
  * "upload_slices" (default 8)  three-pass form: pass 1 runs in this many slices, each as soon as its part of `grad` has landed
  *                            (bit-identical to one launch: the lanes' accumulators are carried between the launches); 0 / 1: off
  * "apply_chunks" (default 8) the update pass runs in this many slices so that the download of x overlaps it (bit-identical)
+ * "spec_x"      (default 1)  three-pass form, n even and >= ~4e6: pass 3 runs in `apply_chunks` slices and x - step r of each finished
+ *                            slice starts its way to the caller's x at once, BEFORE the guard (a sum over all of r) has spoken; the
+ *                            guarded update then runs under the transfer, and a step it rejects (NaN / Inf / norm test: rare) is
+ *                            put right by sending the untouched x again.  What the caller reads on return is unchanged, bit for bit
  * "max_mirror_bytes" (default 0 = no cap)  cap on the device memory held by mirrors of host arrays: beyond it -- and whenever
  *                            a device allocation fails -- the least recently used context that is not inside a call is moved
  *                            to host memory owned by the library and comes back on its object's next call ("contexts_reclaimed")
@@ -192,7 +196,9 @@ int stochqn_hip_comm_allreduce_probe(int count, int reps, double *median_us, dou
  *                               |s||y|/|s'y| > "twopass_kappa_max" sent to the reference's chain of sweeps;
  *   "allreduces", "allreduce_doubles"   reductions issued by this process (per shard context) and doubles summed;
  *   "contexts_created", "contexts_reclaimed"   device contexts made / exported-and-dropped under memory pressure;
- *   "x_uploads", "x_uploads_skipped", "host_ranges_registered"   host-caller path.
+ *   "x_uploads", "x_uploads_skipped", "host_ranges_registered", "x_sent_ahead", "x_sent_again"   host-caller path
+ *                               (INTEGRATION.md): the last two count steps whose x started its way to the host while pass 3 was still
+ *                               running (option "spec_x"), and those of them that the guard then rejected (the old x was sent again).
  * Returns the count, or -1 for an unknown name. */
 long long stochqn_hip_stat(const char *name);
 void stochqn_hip_stats_reset(void);

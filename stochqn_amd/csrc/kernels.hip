@@ -464,6 +464,31 @@ struct ApplyOp {
 	}
 };
 
+// x as the guarded update WILL write it if the guard passes (same expression as ApplyOp, so the same bits), into a vector of
+// its own: the source of the slices of x that a host caller is sent while pass 3 is still running (machines.cpp: enqueue_step).
+struct SpecXOp {
+	const real* r;
+	const real* x;
+	real* out;
+	double step;
+	template <int W> struct In { Pack<W> r, x; };
+	__device__ void prologue(double*) {}
+	template <int W> __device__ __forceinline__ In<W> load(uint32_t i) const
+	{
+		In<W> v;
+		v.r = ld<W, false>(r, i);
+		v.x = ld<W, false>(x, i);
+		return v;
+	}
+	template <int W> __device__ __forceinline__ void apply(uint32_t i, const In<W>& v, double (&)[1]) const
+	{
+		Pack<W> xn;
+		#pragma unroll
+		for (int k = 0; k < W; k++) xn.v[k] = fma(-step, v.r.v[k], v.x.v[k]);
+		st<W>(out, i, xn);
+	}
+};
+
 // ------------------------------------------------------------------------------------------------
 // correction pairs
 // ------------------------------------------------------------------------------------------------
@@ -1477,9 +1502,11 @@ __global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, const double* coef, 
 // pass 3: r = r0 + sum_j c_j s_j, oldest pair first (:702-707); guard sums (sum r^2, #non-finite).
 // FUSE (check_nan == 0: the update does not wait for a verdict, reference :825-838): x -= step r, x_sum += x and
 // oLBFGS's s-slot / grad <- -step r in the same pass, as the sweep form's last forward sweep does -- no guard sums, no apply pass.
-template <int W, bool NT, int T, bool SS, bool FUSE>
+// SL: the pass in slices of the traversal (whole rounds of T packs per lane), the two guard sums carried from slice to slice
+// per lane exactly like the accumulators of pass 1 (k_rows_dot_all): same terms, same order, same bits as one launch.
+template <int W, bool NT, int T, bool SS, bool FUSE, bool SL>
 __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, Fold3 fo, real* r, ApplyArgs ap, uint32_t n, int rev,
-                                                 uint32_t keep_from, double* parts)
+                                                 uint32_t keep_from, double* parts, Slice sl)
 {
 	__shared__ double sh[kWaves];
 	__shared__ double cf[kPairsMax3];
@@ -1493,7 +1520,12 @@ __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, 
 	}
 	double acc0 = 0, acc1 = 0;
 	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
-	for (uint32_t p0 = blockIdx.x * kBlock + threadIdx.x; p0 < packs; p0 += T * stride) {
+	const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+	if constexpr (SL) {
+		if (!sl.first) { acc0 = sl.carry[gtid]; acc1 = sl.carry[(size_t) stride + gtid]; }
+	}
+	const uint32_t p_end = SL ? sl.p_end : packs;
+	for (uint32_t p0 = (SL ? sl.p_begin : 0u) + gtid; p0 < p_end; p0 += T * stride) {
 		Pack<W> out[T], xo[T], xso[T];
 		#pragma unroll
 		for (int t = 0; t < T; t++) {
@@ -1547,6 +1579,9 @@ __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, 
 				} else st<W>(r, i, out[t]);
 			}
 		}
+	}
+	if constexpr (SL) {
+		if (!sl.last) { sl.carry[gtid] = acc0; sl.carry[(size_t) stride + gtid] = acc1; return; }
 	}
 	if (W > 1) {
 		const uint32_t i = packs * W + threadIdx.x;
@@ -2175,8 +2210,27 @@ void launch_coef3b(const Scratch& sc, Partials v, const CoefArgs& a)
 	hipLaunchKernelGGL(k_coef3b, dim3(1), dim3(kCoefBlock), 0, sc.stream, v.parts, v.count, v.stride, a, sc.gsy, sc.sy, sc.alpha, sc.coef);
 }
 
+// pass 3 can run in slices when every lane works on whole 16-byte packs and n has no odd tail (the tail is written by the
+// last launch, wherever the traversal ends: not worth a slice of its own)
+bool sadd_can_slice(const Scratch& sc, size_t n, const RowSet& s_rows, const real* r, const ApplyArgs* fuse, const SliceFeed* drain)
+{
+	if (!drain || fuse || drain->slices < 2 || n % kVec != 0 || !rows_aligned(s_rows) || !all_aligned(r)) return false;
+	const int grid = sweep_grid(sc, n, sc.sadd_per_cu > 0 ? sc.sadd_per_cu : 2);
+	const int T = sc.combine_batch;
+	const size_t round = (size_t) grid * kBlock * (size_t) (T >= 8 ? 8 : (T >= 4 ? 4 : 1));
+	return n / kVec >= 2 * round;
+}
+
+void launch_spec_x(const Scratch& sc, size_t n, const real* r, const real* x, double step, real* out)
+{
+	Scratch local = sc;
+	local.phase = nullptr;                                     // element-wise: the direction of the traversal is of no consequence
+	const int grid = sweep_grid(local, n, 2);
+	run_sweep<0>(local, K_APPLY, n, all_aligned(r, x, out), SpecXOp{r, x, out, step}, nullptr, grid);
+}
+
 Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r, const Partials* fold_in, const CoefArgs* fold_a,
-                     const ApplyArgs* fuse)
+                     const ApplyArgs* fuse, const SliceFeed* drain)
 {
 	const int grid = sweep_grid(sc, n, sc.sadd_per_cu > 0 ? sc.sadd_per_cu : 2);
 	const bool vec = rows_aligned(s_rows) && all_aligned(r) && (!fuse || all_aligned(fuse->x, fuse->x_sum, fuse->s_slot));
@@ -2187,10 +2241,30 @@ Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows,
 	const double* cf = sc.coef + 1 + kPairsMax3;
 	{
 		ProfScope ps(sc, K_SADD);
-		#define SQN_SA2(WW, T, SS, FU) hipLaunchKernelGGL((k_sadd<WW, true, T, SS, FU>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, cf, fo, r, ap, (uint32_t) n, rev, keep, sc.part[buf])
+		#define SQN_SA2(WW, T, SS, FU) hipLaunchKernelGGL((k_sadd<WW, true, T, SS, FU, false>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, cf, fo, r, ap, (uint32_t) n, rev, keep, sc.part[buf], Slice{})
 		#define SQN_SA(WW, T) { if (fuse) SQN_SA2(WW, (T > 4 ? 4 : T), false, true); else if (sc.stream_stores) SQN_SA2(WW, T, true, false); else SQN_SA2(WW, T, false, false); }
 		const int T = sc.combine_batch;
-		if (vec) { if (T >= 8) SQN_SA(kVec, 8) else if (T >= 4) SQN_SA(kVec, 4) else SQN_SA(kVec, 1) }
+		if (sadd_can_slice(sc, n, s_rows, r, fuse, drain)) {
+			// the pass in slices of whole rounds (T packs per lane and round); after the launch of slice s its part of r is final
+			// and drain->arrive is told: a host caller's x is sent on its way from there (machines.cpp: enqueue_step)
+			const size_t packs = n / kVec, round = (size_t) grid * kBlock * (size_t) (T >= 8 ? 8 : (T >= 4 ? 4 : 1));
+			size_t per = (packs + (size_t) drain->slices - 1) / (size_t) drain->slices;
+			per = (per + round - 1) / round * round;
+			const size_t last = packs - 1;
+			int s = 0;
+			for (size_t pb = 0; pb < packs; pb += per, s++) {
+				const size_t pe = pb + per < packs ? pb + per : packs;
+				const size_t lo = rev ? (last - (pe - 1)) * kVec : pb * kVec, hi = rev ? (last - pb + 1) * kVec : pe * kVec;
+				const Slice sl{(uint32_t) pb, (uint32_t) pe, drain->carry, pb == 0, pe == packs};
+				#define SQN_SAS(T, SS) hipLaunchKernelGGL((k_sadd<kVec, true, T, SS, false, true>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, cf, fo, r, ap, (uint32_t) n, rev, keep, sc.part[buf], sl)
+				if (T >= 8) { if (sc.stream_stores) SQN_SAS(8, true); else SQN_SAS(8, false); }
+				else if (T >= 4) { if (sc.stream_stores) SQN_SAS(4, true); else SQN_SAS(4, false); }
+				else { if (sc.stream_stores) SQN_SAS(1, true); else SQN_SAS(1, false); }
+				#undef SQN_SAS
+				drain->arrive(drain->user, lo, hi, s);
+			}
+		}
+		else if (vec) { if (T >= 8) SQN_SA(kVec, 8) else if (T >= 4) SQN_SA(kVec, 4) else SQN_SA(kVec, 1) }
 		else     { if (T >= 4) SQN_SA(1, 4) else SQN_SA(1, 1) }
 		#undef SQN_SA
 		#undef SQN_SA2

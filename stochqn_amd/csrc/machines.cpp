@@ -45,6 +45,7 @@ struct Call {
 	bool fresh = false;             // the device context was created by this call
 	bool x_down = false, g_down = false;   // the update pass already sent x / the direction to the host, slice by slice
 	bool g_pending = false;                // host gradient not uploaded yet: pass 1 of the three-pass form takes it in slices
+	bool x_spec = false;                   // slices of x went to the host before the guard had spoken (step_was_bad puts a rejected step right)
 };
 
 inline size_t N(const DevCtx* c) { return (size_t) c->n; }
@@ -468,7 +469,7 @@ bool threepass_ok(DevCtx* c, size_t st, size_t used)
 // Returns the guard partials (sum r^2, nonfinite); the direction replaces g.  `qs` says how q0 is scaled:
 // all-NULL = scalar (gamma of the newest pair, or h0 > 0), H0_in = a given diagonal, G = adaQN's step.
 Partials enqueue_three_pass(DevCtx* c, real* g, size_t used, size_t st, double h0, real* gprev_out, const QdotScale& qs,
-                            const ApplyArgs* fuse = nullptr, Call* pending = nullptr)
+                            const ApplyArgs* fuse = nullptr, Call* pending = nullptr, const SliceFeed* drain = nullptr)
 {
 	const size_t m = c->m, k = used;
 	RowSet ss{}, ys{};
@@ -493,12 +494,12 @@ Partials enqueue_three_pass(DevCtx* c, real* g, size_t used, size_t st, double h
 	if (fresh >= 0) c->sy_ok[(size_t) fresh] = 1;             // stored by the coefficient kernel, ahead of the recursion
 	if (c->sc.fold_coef) {                                    // the recursions in the prologues of the passes themselves
 		Partials v = launch_qdot(c->sc, N(c), ys, g, qs, &b, &a, fresh);
-		return launch_sadd(c->sc, c->next_buf(), N(c), ss, g, &v, &a, fuse);
+		return launch_sadd(c->sc, c->next_buf(), N(c), ss, g, &v, &a, fuse, drain);
 	}
 	launch_coef3a(c->sc, b, a, fresh);
 	Partials v = launch_qdot(c->sc, N(c), ys, g, qs);
 	launch_coef3b(c->sc, v, a);
-	return launch_sadd(c->sc, c->next_buf(), N(c), ss, g, nullptr, nullptr, fuse);
+	return launch_sadd(c->sc, c->next_buf(), N(c), ss, g, nullptr, nullptr, fuse, drain);
 }
 
 // adaQN (diagonal H0) in two passes: all inner products incl. the H0-weighted ones + the side effects
@@ -622,6 +623,55 @@ void verify_cache(DevCtx* c, size_t st, size_t used)
 	}
 }
 
+// apply_step for the three-pass form, one pass earlier.  Pass 3 runs in slices; as soon as a slice of the direction is final, x as
+// the update WILL write it -- x - step r, ApplyOp's expression -- is computed into a vector of the library's own and sent to
+// the caller's array, while the later slices of pass 3 are still running.  The guard (a sum over ALL of r) has not spoken at
+// that point: the transfer is speculative.  The guarded update itself then runs as one launch on x proper, under the
+// transfer; if it rejects the step (NaN / Inf / the norm test, reference src/stochqn.c:825-836: rare, the ring is flushed)
+// the device x is untouched and step_was_bad sends it down again over what went ahead.  What the caller finds in x on
+// return is what the one-launch path leaves there, bit for bit.
+struct SpecDrain {
+	Call* io;
+	const real* r;
+	const real* x;
+	real* xs;
+	double step;
+	bool want_g;          // strict_grad: the direction goes back too (SQN / adaQN: the update leaves it as pass 3 wrote it)
+};
+
+void direction_slice_done(void* user, size_t lo, size_t hi, int slice)
+{
+	SpecDrain& d = *static_cast<SpecDrain*>(user);
+	Call& io = *d.io;
+	DevCtx* c = io.c;
+	launch_spec_x(c->sc, hi - lo, d.r + lo, d.x + lo, d.step, d.xs + lo);
+	SQN_HIP_OK(hipEventRecord(c->chunk_ev[(size_t) slice], c->sc.stream));
+	SQN_HIP_OK(hipStreamWaitEvent(c->copy_stream, c->chunk_ev[(size_t) slice], 0));
+	SQN_HIP_OK(hipMemcpyAsync(io.x_caller + lo, d.xs + lo, (hi - lo) * sizeof(real), hipMemcpyDeviceToHost, c->copy_stream));
+	if (d.want_g) {
+		SQN_HIP_OK(hipMemcpyAsync(io.g_caller + lo, d.r + lo, (hi - lo) * sizeof(real), hipMemcpyDeviceToHost, c->copy_stream));
+		io.g_down = true;
+	}
+	c->copy_busy = true;
+	io.x_spec = true;
+}
+
+// may pass 3 of this call send x ahead?  (a host caller's x of a large problem, nobody waiting for the direction itself)
+bool spec_x_ready(Call& io, const StepIn& in)
+{
+	DevCtx* c = io.c;
+	const size_t n = N(c);
+	const int chunks = options().apply_chunks;
+	// oLBFGS with strict_grad: what goes back in grad is -step r, written by the update itself -- the plain path does that
+	if (!options().spec_x || !io.host_caller || io.x != in.x || (io.g_host && options().strict_grad && in.s_slot) || chunks < 2 || n < ((size_t) 2 << 20))
+		return false;
+	if (!ensure_upload_slices(c, 1, (size_t) 2 * kMaxGrid * kBlock) || !ensure_copy_stream(c, chunks)) return false;
+	if (!c->spec && !device_alloc((void**) &c->spec, n * sizeof(real))) { c->spec = nullptr; return false; }
+	(void) ensure_registered(c, io.x_caller, n * sizeof(real));
+	if (io.g_host && options().strict_grad) (void) ensure_registered(c, io.g_caller, n * sizeof(real));
+	return true;
+}
+
 // take_step (reference src/stochqn.c:802-840) + the caller's follow-up that only depends on the
 // guard (x_sum += x, oLBFGS s-slot).  Enqueues everything and the read-back of the report block.
 void enqueue_step(Call& io, const StepIn& in)
@@ -656,8 +706,17 @@ void enqueue_step(Call& io, const StepIn& in)
 			if (in.G) { qs.G = in.G; qs.H0_out = in.H0; qs.frow_out = in.frow_out; qs.rmsprop_weight = in.w; qs.scal_reg = in.eps; }
 			// check_nan == 0: nothing waits for a verdict, the update rides in pass 3 (as in the sweep form below, reference :825-838)
 			const bool fuse = !in.check_nan && options().fuse_apply;
-			Partials guard = enqueue_three_pass(c, in.g, in.used, st, in.h0, in.gprev_out, qs, fuse ? &ap : nullptr, &io);
-			if (!fuse) apply_step(io, guard, in.g, in.g, ap, in.check_nan != 0);
+			SpecDrain sd{&io, in.g, in.x, c->spec, in.step, io.g_host && options().strict_grad && io.g == in.g};
+			const bool ahead = !fuse && spec_x_ready(io, in);
+			sd.xs = c->spec;
+			const SliceFeed drain{options().apply_chunks, c->carry, direction_slice_done, &sd};
+			Partials guard = enqueue_three_pass(c, in.g, in.used, st, in.h0, in.gprev_out, qs, fuse ? &ap : nullptr, &io, ahead ? &drain : nullptr);
+			if (io.x_spec) {                                          // every slice of x is on its way already: the update in one launch, no copies
+				launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
+				io.x_down = true;
+				stat_add(ST_X_AHEAD);
+			}
+			else if (!fuse) apply_step(io, guard, in.g, in.g, ap, in.check_nan != 0);
 			stat_add(ST_STEP_THREE_PASS);
 		} else if (flush_g(io), !raw_cold && twopass_ok(c, st, in.used, in.G ? in.H0 : nullptr)) {
 			Partials guard = enqueue_two_pass(c, in.g, in.used, st, in.h0, in.gprev_out);
@@ -690,7 +749,14 @@ bool step_was_bad(Call& io, bfgs_mem* b, size_t used_before, int check_nan)
 		hand_back(b->buffer_rho, c->pin + 8, used_before);
 		hand_back(b->buffer_alpha, c->pin + 8 + c->m, used_before);
 	}
-	return check_nan && c->pin[0] != 0.0;       // unguarded: the step is always taken
+	const bool bad = check_nan && c->pin[0] != 0.0;       // unguarded: the step is always taken
+	if (bad && io.x_spec) {                     // the caller's x received the step that was then rejected: send the device's (untouched) x again
+		vec_to_host(c, io.x_caller, io.x, N(c));
+		sync(c);
+		x_handed_back(c, io.x_caller, N(c));
+		stat_add(ST_X_RESENT);
+	}
+	return bad;
 }
 
 // ---- correction pairs ----------------------------------------------------------------------------

@@ -49,7 +49,7 @@ std::atomic<long long> g_stats[ST_COUNT];
 const char* const kStatNames[ST_COUNT] = {
 	"steps_three_pass", "steps_two_pass", "steps_two_pass_h0", "steps_sweeps", "steps_plain", "steps_kappa_fallback",
 	"allreduces", "allreduce_doubles", "contexts_created", "contexts_reclaimed", "x_uploads", "x_uploads_skipped",
-	"host_ranges_registered"};
+	"host_ranges_registered", "x_sent_ahead", "x_sent_again"};
 
 bool alloc_should_fail()
 {
@@ -217,6 +217,7 @@ void destroy(DevCtx* c)
 	for (hipEvent_t e : c->chunk_ev) (void) hipEventDestroy(e);
 	for (hipEvent_t e : c->up_ev) (void) hipEventDestroy(e);
 	if (c->carry) SQN_HIP_OK(hipFree(c->carry));
+	if (c->spec) SQN_HIP_OK(hipFree(c->spec));
 	if (c->copy_done) (void) hipEventDestroy(c->copy_done);
 	for (auto& r : c->regs)
 		if (r.p) { if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError(); }   // the caller may have freed it already
@@ -949,6 +950,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "qdot_stream")) g_opt.qdot_stream = value != 0;
 	else if (!std::strcmp(name, "fold_coef")) g_opt.fold_coef = value != 0;
 	else if (!std::strcmp(name, "fuse_apply")) g_opt.fuse_apply = value != 0;
+	else if (!std::strcmp(name, "spec_x")) g_opt.spec_x = value != 0;
 	else if (!std::strcmp(name, "keep_tail")) g_opt.keep_tail = value < 0 ? 0 : (value > 1 ? 1 : value);
 	else if (!std::strcmp(name, "qdot_per_cu")) g_opt.qdot_per_cu = (int) value;
 	else if (!std::strcmp(name, "sadd_per_cu")) g_opt.sadd_per_cu = (int) value;

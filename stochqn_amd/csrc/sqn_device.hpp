@@ -249,8 +249,12 @@ Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows /*logical
 void launch_coef3b(const Scratch& sc, Partials v, const CoefArgs& a);
 // pass 3: r = r0 + sum c_j s_j; returns the guard partials (sum r^2, nonfinite).  fold_in / fold_a: the forward recursion of
 // coef3b in the prologue, on the partials of pass 2.  `fuse` (check_nan == 0): the position update in the same pass, no partials.
+// `drain`: the pass in slices (sadd_can_slice), drain->arrive(user, lo, hi, slice) right after the launch that makes r[lo, hi) final.
+bool sadd_can_slice(const Scratch& sc, size_t n, const RowSet& s_rows, const real* r, const ApplyArgs* fuse, const SliceFeed* drain);
 Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r, const Partials* fold_in = nullptr,
-                     const CoefArgs* fold_a = nullptr, const ApplyArgs* fuse = nullptr);
+                     const CoefArgs* fold_a = nullptr, const ApplyArgs* fuse = nullptr, const SliceFeed* drain = nullptr);
+// out = x - step * r, the expression (and the bits) of the guarded update, without touching x
+void launch_spec_x(const Scratch& sc, size_t n, const real* r, const real* x, double step, real* out);
 void launch_store_column(const Scratch& sc, Partials in /*k: s_i'y_col*/, const CoefArgs& a, int col_row);
 
 // ---- two-pass form with the diagonal H0 of adaQN -----------------------------------------------------

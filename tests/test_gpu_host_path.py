@@ -143,6 +143,53 @@ def test_sliced_passes_equal_whole_launches(kind, hip_backend):
                     assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("strict", [0, 1])
+@pytest.mark.parametrize("kind", ["SQN", "oLBFGS", "adaQN"])
+def test_x_sent_ahead_of_the_guard_leaves_the_same_bits(kind, strict, hip_backend):
+    """Option spec_x (default): pass 3 of the three-pass form in slices, each finished slice's x - step r on its way to the host
+    before the guard has seen all of r, the guarded update under the transfer.  Against the plain host path (update, then the
+    copies) and against a device-resident caller: the same bits in every x, request and counter -- also across a step that the
+    guard REJECTS (NaN gradients around calls 9 and 17: the host array already holds the rejected step's x when the verdict
+    comes, and must get the old x back).  With strict_grad the direction travels the same way (SQN / adaQN; oLBFGS hands
+    back -step r, which the update itself writes: the plain path)."""
+    import torch
+    lib = _lib()
+    n = 6_291_456                                 # even, and three rounds of pass 3's grid: the smallest shape that is sliced
+    P = NoisyQuadratic(n, seed=11, nan_calls=(9, 10, 17))      # consecutive calls: one of them feeds a step whatever the call pattern
+    calls = 24
+    out, grads = {}, {}
+    speculates = not (kind == "oLBFGS" and strict)
+    try:
+        assert lib.stochqn_hip_set_option(b"strict_grad", float(strict)) == 0     # 0 is the library's default (the suite runs with 1)
+        for mode in (1.0, 0.0):
+            assert lib.stochqn_hip_set_option(b"spec_x", mode) == 0
+            lib.stochqn_hip_stats_reset()
+            opt = OPTIMIZERS[kind](backend=hip_backend, space="host", **KW[kind])
+            out[mode] = run_trace(opt, P, P.x0(), 0.05, calls)
+            grads[mode] = np.array(opt.gradient, copy=True)
+            ahead, again = stat(lib, "x_sent_ahead"), stat(lib, "x_sent_again")
+            assert (ahead >= (2 if kind == "adaQN" else 6)) if (mode and speculates) else (ahead == 0), (mode, ahead)
+            if mode and speculates and kind != "adaQN":
+                assert again >= 1, "no step that went ahead was rejected: the test does not reach the path it is for"
+            assert again <= ahead
+            lib.stochqn_hip_release_all()
+    finally:
+        lib.stochqn_hip_set_option(b"spec_x", 1.0)
+        lib.stochqn_hip_set_option(b"strict_grad", 1.0)
+    assert np.array_equal(grads[1.0], grads[0.0], equal_nan=True), "the caller's gradient array differs between the two host paths"
+    x = torch.as_tensor(P.x0(), device="cuda:0")
+    dev = run_trace(OPTIMIZERS[kind](backend=hip_backend, space="device", device="cuda:0", **KW[kind]), P, x, 0.05, calls)
+    assert any(t["info"] == "search_direction_was_nan" for t in dev), "the NaN gradient was meant to get a step rejected"
+    for name, other in (("plain host path", out[0.0]), ("device caller", dev)):
+        for i, (a, b) in enumerate(zip(out[1.0], other)):
+            for k in ("task", "info", "changed", "niter", "section", "mem_used", "mem_st_ix", "req_id"):
+                assert a[k] == b[k], (name, i, k)
+            for k in ("x", "req", "req_vec"):
+                if k in a:
+                    assert np.array_equal(a[k], b[k], equal_nan=True), "call %d: %s differs from the %s" % (i, k, name)
+    lib.stochqn_hip_release_all()
+
+
 def test_step_counters_name_the_form_that_ran(hip_backend):
     """stochqn_hip_stat: which form of the recursion each step took."""
     import torch
