@@ -94,7 +94,7 @@ struct Shard {
 	workspace_adaQN wa{};
 	real *S = nullptr, *Y = nullptr, *sbak = nullptr, *ybak = nullptr, *gprev = nullptr, *xsum = nullptr, *xprev = nullptr,
 	     *H0 = nullptr, *G = nullptr, *F = nullptr;
-	real *x = nullptr, *g = nullptr, *hv = nullptr;          // device copies of the caller's per-call vectors
+	real_t *lx = nullptr;                                    // x as the last call handed it to the shard's machine (host slice or bx)
 	real *bx = nullptr, *bg = nullptr, *bhv = nullptr;       // device-resident caller: its own per-shard vectors, used in place
 	bool bound = false;
 	std::vector<real_t> rho, alpha, fy;                      // buffer_rho / buffer_alpha / buffer_y of ranks > 0
@@ -129,15 +129,12 @@ struct Group {
 	bool has_last = false;
 	size_t last_niter = 0;
 	int last_section = 0;
-	// host callers: their x / grad / hess_vec pinned in place for all devices (hipHostRegisterPortable), and what is known
-	// about the shards' copies of x (same rules as for one device: runtime.cpp stage_x)
+	// host callers: their x / grad / hess_vec pinned in place for all devices (hipHostRegisterPortable); everything else about
+	// them -- x not sent again while a shard's copy is current, passes in slices under the transfers -- is the single-device
+	// host path, run per shard on its slice (machines.cpp)
 	struct HostRange { const void* p = nullptr; size_t bytes = 0; };
 	HostRange regs[4];
 	int reg_turn = 0;
-	const void* x_host = nullptr;
-	bool x_valid = false;
-	static constexpr int kProbe = 256;
-	double x_probe[kProbe];
 };
 
 std::mutex g_gmu;
@@ -195,8 +192,6 @@ void rows_d2h(real_t* host, const real* dev, size_t rows, size_t n, size_t off, 
 	SQN_HIP_OK(hipMemcpy2D(host + off, n * sizeof(real), dev, cnt * sizeof(real), cnt * sizeof(real), rows, hipMemcpyDeviceToHost));
 }
 
-size_t probe_at(int j, size_t n) { return n <= 1 ? 0 : (size_t) (((unsigned __int128) j * (n - 1)) / (Group::kProbe - 1)); }
-
 // pin [p, p + bytes) of the caller's memory for every device of the process (once; at most 4 ranges per group)
 void pin_for_all_devices(Group* g, const void* p, size_t bytes)
 {
@@ -214,24 +209,6 @@ void pin_for_all_devices(Group* g, const void* p, size_t bytes)
 	stat_add(ST_HOST_REGISTERED);
 }
 
-// are the shards' copies of x what the caller's array holds?  (the library wrote both, *req == x went back, probes agree)
-bool x_is_current(Group* g, const real_t* x, size_t n)
-{
-	if (options().x_upload != 0 || !g->x_valid || g->x_host != x) return false;
-	for (int j = 0; j < Group::kProbe; j++) {
-		const double v = (double) x[probe_at(j, n)];
-		if (std::memcmp(&v, &g->x_probe[j], sizeof v) != 0) return false;
-	}
-	return true;
-}
-
-void x_went_back(Group* g, const real_t* x, size_t n, bool req_is_x)
-{
-	g->x_host = x;
-	g->x_valid = req_is_x;
-	for (int j = 0; j < Group::kProbe; j++) g->x_probe[j] = (double) x[probe_at(j, n)];
-}
-
 void destroy_group(Group* g)
 {
 	for (auto& r : g->regs)
@@ -239,7 +216,7 @@ void destroy_group(Group* g)
 	for_all(g, [&](Shard& s) {
 		if (s.S) release(s.S);                                  // the shard's device context
 		dfree(s.S); dfree(s.Y); dfree(s.sbak); dfree(s.ybak); dfree(s.gprev); dfree(s.xsum); dfree(s.xprev);
-		dfree(s.H0); dfree(s.G); dfree(s.F); dfree(s.x); dfree(s.g); dfree(s.hv);
+		dfree(s.H0); dfree(s.G); dfree(s.F);
 	});
 	for (auto& s : g->sh) s->wk.stop();
 	for (void* c : g->comms) comm_destroy(c);
@@ -304,16 +281,16 @@ Group* create_group(const Shape& sp, int P, bool owned, bool resumed)
 	const bool bak = sp.b->min_curvature > 0;
 	for_all(g.get(), [&](Shard& s) {
 		const size_t c = s.cnt;
-		bool ok = dalloc(&s.S, m * c, false) && dalloc(&s.Y, m * c, false) && dalloc(&s.x, c, false) && dalloc(&s.g, c, false);
+		bool ok = dalloc(&s.S, m * c, false) && dalloc(&s.Y, m * c, false);
 		if (ok && bak) ok = dalloc(&s.sbak, c, true) && dalloc(&s.ybak, c, true);
 		if (ok && sp.need_gprev) ok = dalloc(&s.gprev, c, false);
 		if (ok && sp.need_avg) ok = dalloc(&s.xsum, c, true) && dalloc(&s.xprev, c, false);
 		if (ok && sp.need_diag) ok = dalloc(&s.H0, c, false) && dalloc(&s.G, c, true);
 		if (ok && fsz) ok = dalloc(&s.F, fsz * c, false);
-		if (ok && sp.kind == KIND_SQN) ok = dalloc(&s.hv, c, false);
 		// the shard's device context (scratch pool, pinned read-back block, Fisher partials) now, not inside the first
 		// call: a shard that ran out of memory there would leave the others waiting in an all-reduce
-		if (ok) ok = prepare_context(s.S, sp.kind, (int) c, m, fsz);
+		// -- and with it the staging vectors a host caller's slices of x / grad / hess_vec go through
+		if (ok) ok = prepare_context(s.S, sp.kind, (int) c, m, fsz, sp.kind == KIND_SQN ? 3 : 2);
 		s.ok = ok;
 		if (!ok || owned) return;
 		// profile B: the caller's host arrays are the initial state (fresh R / numpy objects hold zeros
@@ -450,7 +427,7 @@ real* landing(Group* g, int slot) { return g->landing[slot]; }      // allocated
 real_t* req_home(Group* g, const Shape& sp, const Shard& s, const real_t* req, real_t* x_caller, bool* is_x)
 {
 	*is_x = false;
-	if (req == (s.bound ? s.bx : s.x)) { *is_x = true; return x_caller; }
+	if (req == s.lx) { *is_x = true; return x_caller; }
 	if (g->owned) return landing(g, 0);
 	if (req == s.xsum) return sp.xsum;
 	if (req == s.xprev) return sp.xprev;
@@ -528,21 +505,26 @@ struct Io {                       // the caller's per-call vectors (host memory)
 	bool down_x = false, down_g = false;                // slices to bring back after it
 };
 
-void upload(Shard& s, const Io& io)
+// The shard's view of the caller's per-call vectors: its own device vectors (bound), or ITS SLICE of the caller's host arrays
+// -- the shard's machine then treats it like any host caller's: copies, slices and all (machines.cpp).
+struct Local { real_t *x, *g, *hv; };
+Local local_vectors(Shard& s, const Io& io)
 {
-	if (s.bound) return;                                       // the caller's vectors already live on this device
-	const size_t bytes = s.cnt * sizeof(real);
-	if (io.up_x && io.x) SQN_HIP_OK(hipMemcpy(s.x, io.x + s.off, bytes, hipMemcpyDefault));
-	if (io.up_g && io.grad) SQN_HIP_OK(hipMemcpy(s.g, io.grad + s.off, bytes, hipMemcpyDefault));
-	if (io.up_hv && io.hv) SQN_HIP_OK(hipMemcpy(s.hv, io.hv + s.off, bytes, hipMemcpyDefault));
+	Local v;
+	v.x = s.bound ? s.bx : (io.x ? io.x + s.off : nullptr);
+	v.g = s.bound ? s.bg : (io.grad ? io.grad + s.off : nullptr);
+	v.hv = s.bound ? s.bhv : (io.hv ? io.hv + s.off : nullptr);
+	s.lx = v.x;
+	set_thread_dev_requests(!s.bound);
+	return v;
 }
 
+// what the machine left on the device for the caller: the vector *req designates, SQN's s-slot
 void download(Group* g, const Shape& sp, Shard& s, const Io& io)
 {
 	const size_t bytes = s.cnt * sizeof(real);
+	set_thread_dev_requests(false);
 	if (s.ret == -1000 || s.bound) return;                     // bound: *req / *req_vec are fetched per shard (devices_request)
-	if (io.down_x && io.x) SQN_HIP_OK(hipMemcpy(io.x + s.off, s.x, bytes, hipMemcpyDefault));
-	if (io.down_g && io.grad && options().strict_grad) SQN_HIP_OK(hipMemcpy(io.grad + s.off, s.g, bytes, hipMemcpyDefault));
 	bool is_x = false;
 	if (s.req) {
 		real_t* home = req_home(g, sp, s, s.req, io.x, &is_x);
@@ -560,7 +542,7 @@ void download(Group* g, const Shape& sp, Shard& s, const Io& io)
 void request_x(const void* key)
 {
 	if (Group* g = find_group(key))
-		for (auto& s : g->sh) { s->req = s->bound ? s->bx : s->x; s->req_vec = nullptr; }
+		for (auto& s : g->sh) { s->req = s->bound ? s->bx : nullptr; s->req_vec = nullptr; }
 }
 
 // Before the fan-out of a host caller's call: pin its vectors, and do not send x again when the shards still hold it.
@@ -570,20 +552,10 @@ void prepare_io(Group* g, Io& io, size_t n)
 	pin_for_all_devices(g, io.x, n * sizeof(real));
 	pin_for_all_devices(g, io.grad, n * sizeof(real));
 	if (io.up_hv) pin_for_all_devices(g, io.hv, n * sizeof(real));
-	if (!io.up_x || !io.x) return;
-	if (x_is_current(g, io.x, n)) { io.up_x = false; stat_add(ST_X_UPLOAD_SKIPPED); }
-	else stat_add(ST_X_UPLOAD);
 }
 
-// After it: the shards' x and the caller's agree again when x was part of the call; a request that is not at x leaves the
-// caller free to edit x until the next call (reference include/stochqn.h:364-366 protects *req only).
-void settle_io(Group* g, const Io& io, size_t n, bool x_in_call, bool ok, bool req_is_x)
-{
-	if (g->sh[0]->bound) return;
-	if (!ok) { g->x_valid = false; return; }
-	if (x_in_call && io.x) x_went_back(g, io.x, n, req_is_x);
-	else if (!req_is_x) g->x_valid = false;
-}
+// (what the shards know about their copies of x is kept per shard by the machines: runtime.cpp stage_x / note_state)
+void settle_io(Group*, const Io&, size_t, bool, bool, bool) {}
 
 void note(Group* g, size_t niter, int section)
 {
@@ -624,9 +596,9 @@ int group_run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, 
 		sync_bfgs(s, b, s.rank == 0);
 		s.wo.bfgs_memory = &s.b; s.wo.grad_prev = s.gprev; s.wo.hess_init = w->hess_init; s.wo.niter = w->niter;
 		s.wo.section = w->section; s.wo.nthreads = w->nthreads; s.wo.check_nan = w->check_nan; s.wo.n = (int) s.cnt;
-		upload(s, io);
+		const Local v = local_vectors(s, io);
 		s.req = nullptr; s.req_vec = nullptr;
-		s.ret = local_run_oLBFGS(step_size, s.bound ? s.bx : s.x, s.bound ? s.bg : s.g, &s.req, &s.task, &s.wo, &s.info);
+		s.ret = local_run_oLBFGS(step_size, v.x, v.g, &s.req, &s.task, &s.wo, &s.info);
 		download(g, sp, s, io);
 	});
 	if (!agree(g, "run_oLBFGS")) { settle_io(g, io, (size_t) w->n, x_in_call, false, true); *task = invalid_input; return -1000; }
@@ -674,9 +646,9 @@ int group_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[]
 		s.ws.use_grad_diff = w->use_grad_diff; s.ws.niter = w->niter; s.ws.section = w->section;
 		s.ws.nthreads = w->nthreads; s.ws.check_nan = w->check_nan; s.ws.n = (int) s.cnt;
 		if (w->use_grad_diff && !s.gprev) { s.ok = dalloc(&s.gprev, s.cnt, false); s.ws.grad_prev = s.gprev; }
-		upload(s, io);
+		const Local v = local_vectors(s, io);
 		s.req = nullptr; s.req_vec = nullptr;
-		s.ret = local_run_SQN(step_size, s.bound ? s.bx : s.x, s.bound ? s.bg : s.g, s.bound ? s.bhv : s.hv, &s.req, &s.req_vec, &s.task, &s.ws, &s.info);
+		s.ret = local_run_SQN(step_size, v.x, v.g, v.hv, &s.req, &s.req_vec, &s.task, &s.ws, &s.info);
 		if (s.task != calc_hess_vec) s.req_vec = nullptr;
 		download(g, sp, s, io);
 	});
@@ -744,9 +716,9 @@ int group_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
 		s.wa.use_grad_diff = w->use_grad_diff; s.wa.niter = w->niter; s.wa.section = w->section;
 		s.wa.nthreads = w->nthreads; s.wa.check_nan = w->check_nan; s.wa.n = (int) s.cnt;
 		if (w->use_grad_diff && !s.gprev) { s.ok = dalloc(&s.gprev, s.cnt, false); s.wa.grad_prev = s.gprev; }
-		upload(s, io);
+		const Local v = local_vectors(s, io);
 		s.req = nullptr; s.req_vec = nullptr;
-		s.ret = local_run_adaQN(step_size, s.bound ? s.bx : s.x, f, s.bound ? s.bg : s.g, &s.req, &s.task, &s.wa, &s.info);
+		s.ret = local_run_adaQN(step_size, v.x, f, v.g, &s.req, &s.task, &s.wa, &s.info);
 		download(g, sp, s, io);
 	});
 	if (!agree(g, "run_adaQN")) { settle_io(g, io, (size_t) w->n, x_in_call, false, true); *task = invalid_input; return -1000; }

@@ -33,6 +33,9 @@ static_assert(sizeof(real) == sizeof(real_t), "library element type and ABI real
 
 namespace {
 
+// set by a shard thread of the single-process multi-device mode around its local_run_* calls (group.cpp)
+thread_local bool t_dev_requests = false;
+
 // ---- one run_* invocation -----------------------------------------------------------------------
 struct Call {
 	DevCtx* c = nullptr;
@@ -45,6 +48,7 @@ struct Call {
 	bool fresh = false;             // the device context was created by this call
 	bool x_down = false, g_down = false;   // the update pass already sent x / the direction to the host, slice by slice
 	bool g_pending = false;                // host gradient not uploaded yet: pass 1 of the three-pass form takes it in slices
+	bool dev_requests = false;             // shard of a multi-device group: *req / *req_vec stay device pointers, the group copies them out
 	bool x_spec = false;                   // slices of x went to the host before the guard had spoken (step_was_bad puts a rejected step right)
 };
 
@@ -118,6 +122,7 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 	}
 	io.c = c;
 	io.fresh = fresh;
+	io.dev_requests = t_dev_requests;
 	if (fresh) attach_spill(c, niter, section);      // reclaimed while idle?  then its state comes back from the library's host copy
 	// a context that could not be completed is dropped again: the next call starts over (and
 	// re-imports host arrays) instead of continuing on half-bound views
@@ -190,7 +195,7 @@ real* publish(Call& io, View& v, size_t offset, int slot)
 {
 	DevCtx* c = io.c;
 	real* dev = v.dev + offset;
-	if (!io.host_caller) return dev;
+	if (!io.host_caller || io.dev_requests) return dev;
 	if (v.mirror) {                       // caller's own host array: refresh it, hand it back
 		real* host = (real*) const_cast<void*>(v.caller) + offset;
 		if (v.count == N(c)) (void) ensure_registered(c, host, N(c) * sizeof(real));      // x_sum / x_avg_prev: one array, requested every L steps
@@ -210,8 +215,10 @@ real* publish(Call& io, View& v, size_t offset, int slot)
 void close_call(Call& io, bool x_changed, bool g_changed)
 {
 	DevCtx* c = io.c;
-	if (x_changed && io.host_caller && io.x && !io.x_down) vec_to_host(c, io.x_caller, io.x, N(c));
-	if (g_changed && io.g_host && io.g && options().strict_grad && !io.g_down) vec_to_host(c, io.g_caller, io.g, N(c));
+	// a reduction that failed while the call was being enqueued (c->fault: the call is going to return -1000) left the update
+	// working on un-reduced sums: the caller's arrays are not touched with that
+	if (x_changed && io.host_caller && io.x && !io.x_down && !c->fault) vec_to_host(c, io.x_caller, io.x, N(c));
+	if (g_changed && io.g_host && io.g && options().strict_grad && !io.g_down && !c->fault) vec_to_host(c, io.g_caller, io.g, N(c));
 	sync(c);
 	if (io.host_caller && io.x) x_handed_back(c, io.x_caller, N(c));      // device and host copies of x agree from here on
 }
@@ -227,7 +234,7 @@ void apply_step(Call& io, Partials guard, const real* r_in, real* grad_out, cons
 	const bool want_x = io.host_caller && io.x == ap.x, want_g = io.g_host && options().strict_grad && io.g == grad_out;
 	const int chunks = options().apply_chunks;
 	const size_t min_chunk = (size_t) 1 << 20;               // elements: below this a slice is all launch overhead
-	if ((!want_x && !want_g) || chunks < 2 || n < 2 * min_chunk || !ensure_copy_stream(c, chunks)) {
+	if ((!want_x && !want_g) || c->fault || chunks < 2 || n < 2 * min_chunk || !ensure_copy_stream(c, chunks)) {
 		launch_apply(sc, n, c->n_global, guard, r_in, grad_out, ap, guarded);
 		return;
 	}
@@ -644,6 +651,7 @@ void direction_slice_done(void* user, size_t lo, size_t hi, int slice)
 	SpecDrain& d = *static_cast<SpecDrain*>(user);
 	Call& io = *d.io;
 	DevCtx* c = io.c;
+	if (c->fault) return;                    // a reduction of this call failed: nothing of it reaches the caller's arrays (close_call)
 	launch_spec_x(c->sc, hi - lo, d.r + lo, d.x + lo, d.step, d.xs + lo);
 	SQN_HIP_OK(hipEventRecord(c->chunk_ev[(size_t) slice], c->sc.stream));
 	SQN_HIP_OK(hipStreamWaitEvent(c->copy_stream, c->chunk_ev[(size_t) slice], 0));
@@ -1188,6 +1196,7 @@ static int run_adaQN_impl(real_t step_size, real_t x[], real_t f, real_t grad[],
 // One shard's call (group.cpp) or the whole call (below): the state machine between the two hooks that
 // tie a device context to the caller-visible state.
 namespace sqn {
+void set_thread_dev_requests(bool on) { t_dev_requests = on; }
 int local_run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, task_enum* task, workspace_oLBFGS* w,
                      info_enum* iter_info)
 {

@@ -12,6 +12,10 @@ int local_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[]
                   task_enum* task, workspace_SQN* w, info_enum* iter_info);
 int local_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_t** req, task_enum* task,
                     workspace_adaQN* w, info_enum* iter_info);
+// A shard hands the machine its SLICE of the caller's host x / grad / hess_vec, so the whole host-caller path (pinned copies,
+// x not uploaded again, passes in slices under the transfers) works per shard; with this switch on for the calling thread,
+// *req / *req_vec of workspace arrays come back as DEVICE pointers (the group copies them into the caller's arrays itself).
+void set_thread_dev_requests(bool on);
 
 // ---- group.cpp: n sharded over P devices inside one process, behind the unchanged ABI ------------
 // Does this workspace run sharded?  (option "devices" >= 2 and the arrays are not device pointers)

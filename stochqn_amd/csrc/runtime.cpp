@@ -548,12 +548,16 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	return c;
 }
 
-bool prepare_context(const void* key, int kind, int n, size_t m, size_t fsize)
+bool prepare_context(const void* key, int kind, int n, size_t m, size_t fsize, int stages)
 {
 	bool fresh = false;
 	DevCtx* c = acquire(key, kind, n, m, fsize, &fresh);
-	if (c) c->in_call = false;
-	return c != nullptr;
+	if (!c) return false;
+	bool ok = true;
+	for (int i = 0; i < stages && i < 3 && ok; i++) ok = ensure_stage(c, i);
+	c->in_call = false;
+	if (!ok) { release(key); return false; }
+	return true;
 }
 
 void end_use(DevCtx* c) { if (c) c->in_call = false; }

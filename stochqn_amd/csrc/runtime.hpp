@@ -196,7 +196,7 @@ DevCtx* lookup(const void* key);
 // Create the context of a workspace ahead of its first call (all its allocations, no collective): the shards of
 // a multi-device group do this together, so that none of them can fail on memory while the others are already
 // waiting in an all-reduce.
-bool prepare_context(const void* key, int kind, int n, size_t m, size_t fsize);
+bool prepare_context(const void* key, int kind, int n, size_t m, size_t fsize, int stages = 0);   // stages: staging vectors for host x / grad / hess_vec made now
 // registry key of the context behind the isolated entry points (stochqn_hip_two_loop / _take_step) for the arrays at `s_mem`
 inline const void* raw_key(const void* s_mem) { return static_cast<const char*>(s_mem) + 1; }
 // remember the caller-visible state on return; true if the context saw a HIP error during the call
