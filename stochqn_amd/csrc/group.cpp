@@ -501,8 +501,7 @@ struct Io {                       // the caller's per-call vectors (host memory)
 	real_t* x = nullptr;
 	real_t* grad = nullptr;
 	real_t* hv = nullptr;
-	bool up_x = false, up_g = false, up_hv = false;     // slices to upload before the shard call
-	bool down_x = false, down_g = false;                // slices to bring back after it
+	bool has_hv = false;                                // this call reads hess_vec (SQN section 4)
 };
 
 // The shard's view of the caller's per-call vectors: its own device vectors (bound), or ITS SLICE of the caller's host arrays
@@ -513,7 +512,7 @@ Local local_vectors(Shard& s, const Io& io)
 	Local v;
 	v.x = s.bound ? s.bx : (io.x ? io.x + s.off : nullptr);
 	v.g = s.bound ? s.bg : (io.grad ? io.grad + s.off : nullptr);
-	v.hv = s.bound ? s.bhv : (io.hv ? io.hv + s.off : nullptr);
+	v.hv = s.bound ? s.bhv : ((io.hv && io.has_hv) ? io.hv + s.off : nullptr);   // a 1-element hess_vec (gradient differences) is never offset
 	s.lx = v.x;
 	set_thread_dev_requests(!s.bound);
 	return v;
@@ -551,11 +550,10 @@ void prepare_io(Group* g, Io& io, size_t n)
 	if (g->sh[0]->bound) return;                              // device-resident caller: its vectors live on the devices
 	pin_for_all_devices(g, io.x, n * sizeof(real));
 	pin_for_all_devices(g, io.grad, n * sizeof(real));
-	if (io.up_hv) pin_for_all_devices(g, io.hv, n * sizeof(real));
+	if (io.has_hv) pin_for_all_devices(g, io.hv, n * sizeof(real));
 }
 
 // (what the shards know about their copies of x is kept per shard by the machines: runtime.cpp stage_x / note_state)
-void settle_io(Group*, const Io&, size_t, bool, bool, bool) {}
 
 void note(Group* g, size_t niter, int section)
 {
@@ -588,9 +586,6 @@ int group_run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, 
 	if (!g) return fail(task, "oLBFGS", "could not set up the device shards of this workspace.");
 	Io io;
 	io.x = x; io.grad = grad;
-	io.up_x = io.down_x = io.down_g = w->section == 1;
-	io.up_g = true;
-	const bool x_in_call = io.up_x;
 	prepare_io(g, io, (size_t) w->n);
 	for_all(g, [&](Shard& s) {
 		sync_bfgs(s, b, s.rank == 0);
@@ -601,8 +596,7 @@ int group_run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, 
 		s.ret = local_run_oLBFGS(step_size, v.x, v.g, &s.req, &s.task, &s.wo, &s.info);
 		download(g, sp, s, io);
 	});
-	if (!agree(g, "run_oLBFGS")) { settle_io(g, io, (size_t) w->n, x_in_call, false, true); *task = invalid_input; return -1000; }
-	settle_io(g, io, (size_t) w->n, x_in_call, true, true);
+	if (!agree(g, "run_oLBFGS")) { *task = invalid_input; return -1000; }
 	const Shard& a = *g->sh[0];
 	b->mem_used = a.b.mem_used; b->mem_st_ix = a.b.mem_st_ix;
 	w->niter = a.wo.niter; w->section = a.wo.section;
@@ -635,10 +629,7 @@ int group_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[]
 	if (w->section == 4 && !hess_vec) return fail(task, "SQN", "got an invalid workspace as input.");
 	Io io;
 	io.x = x; io.grad = grad; io.hv = hess_vec;
-	io.up_x = io.down_x = io.down_g = w->section == 1;
-	io.up_g = w->section != 4;
-	io.up_hv = w->section == 4;
-	const bool x_in_call = io.up_x;
+	io.has_hv = w->section == 4;
 	prepare_io(g, io, (size_t) w->n);
 	for_all(g, [&](Shard& s) {
 		sync_bfgs(s, b, s.rank == 0);
@@ -652,7 +643,7 @@ int group_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[]
 		if (s.task != calc_hess_vec) s.req_vec = nullptr;
 		download(g, sp, s, io);
 	});
-	if (!agree(g, "run_SQN")) { settle_io(g, io, (size_t) w->n, x_in_call, false, true); *task = invalid_input; return -1000; }
+	if (!agree(g, "run_SQN")) { *task = invalid_input; return -1000; }
 	const Shard& a = *g->sh[0];
 	b->mem_used = a.b.mem_used; b->mem_st_ix = a.b.mem_st_ix;
 	w->niter = a.ws.niter; w->section = a.ws.section;
@@ -660,7 +651,6 @@ int group_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[]
 	bool is_x = false;
 	*req = req_home(g, sp, a, a.req, x, &is_x);
 	if (a.req_vec) *req_vec = g->owned ? landing(g, 1) : b->s_mem + a.b.mem_st_ix * (size_t) w->n;
-	settle_io(g, io, (size_t) w->n, x_in_call, true, is_x);
 	note(g, w->niter, w->section);
 	return a.ret;
 }
@@ -699,10 +689,6 @@ int group_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
 	if (!g) return fail(task, "adaQN", "could not set up the device shards of this workspace.");
 	Io io;
 	io.x = x; io.grad = grad;
-	io.up_x = io.down_x = w->section == 1 || w->section == 5;
-	io.down_g = w->section == 1;
-	io.up_g = w->section != 5;
-	const bool x_in_call = io.up_x;
 	prepare_io(g, io, (size_t) w->n);
 	for_all(g, [&](Shard& s) {
 		sync_bfgs(s, b, s.rank == 0);
@@ -721,7 +707,7 @@ int group_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
 		s.ret = local_run_adaQN(step_size, v.x, f, v.g, &s.req, &s.task, &s.wa, &s.info);
 		download(g, sp, s, io);
 	});
-	if (!agree(g, "run_adaQN")) { settle_io(g, io, (size_t) w->n, x_in_call, false, true); *task = invalid_input; return -1000; }
+	if (!agree(g, "run_adaQN")) { *task = invalid_input; return -1000; }
 	const Shard& a = *g->sh[0];
 	for (auto& s : g->sh)
 		if (fm && (s->f.mem_used != a.f.mem_used || s->f.mem_st_ix != a.f.mem_st_ix || s->wa.f_prev != a.wa.f_prev)) { *task = invalid_input; return -1000; }
@@ -732,7 +718,6 @@ int group_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
 	*task = a.task; *iter_info = a.info;
 	bool is_x = false;
 	*req = req_home(g, sp, a, a.req, x, &is_x);
-	settle_io(g, io, (size_t) w->n, x_in_call, true, is_x);
 	note(g, w->niter, w->section);
 	return a.ret;
 }
