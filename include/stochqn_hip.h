@@ -108,6 +108,9 @@ int stochqn_hip_export(const void *s_mem);
  * "upload_slices" (default 8)  three-pass form: pass 1 runs in this many slices, each as soon as its part of `grad` has landed
  *                            (bit-identical to one launch: the lanes' accumulators are carried between the launches); 0 / 1: off
  * "apply_chunks" (default 8) the update pass runs in this many slices so that the download of x overlaps it (bit-identical)
+ * "x_prefetch"  (default 1)  a call that returns with *req == x while the device copy of x is out of date (the request before was at
+ *                            x_avg) starts the upload of x on a side stream and returns: it runs while the caller evaluates its
+ *                            gradient; the next call orders itself behind it and still compares the probe values ("x_prefetched")
  * "spec_x"      (default 1)  three-pass form, n even and >= ~4e6: pass 3 runs in `apply_chunks` slices and x - step r of each finished
  *                            slice starts its way to the caller's x at once, BEFORE the guard (a sum over all of r) has spoken; the
  *                            guarded update then runs under the transfer, and a step it rejects (NaN / Inf / norm test: rare) is
@@ -196,7 +199,7 @@ int stochqn_hip_comm_allreduce_probe(int count, int reps, double *median_us, dou
  *                               |s||y|/|s'y| > "twopass_kappa_max" sent to the reference's chain of sweeps;
  *   "allreduces", "allreduce_doubles"   reductions issued by this process (per shard context) and doubles summed;
  *   "contexts_created", "contexts_reclaimed"   device contexts made / exported-and-dropped under memory pressure;
- *   "x_uploads", "x_uploads_skipped", "host_ranges_registered", "x_sent_ahead", "x_sent_again"   host-caller path
+ *   "x_uploads", "x_uploads_skipped", "host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched"   host-caller path
  *                               (INTEGRATION.md): the last two count steps whose x started its way to the host while pass 3 was still
  *                               running (option "spec_x"), and those of them that the guard then rejected (the old x was sent again).
  * Returns the count, or -1 for an unknown name. */

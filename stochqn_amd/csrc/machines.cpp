@@ -869,9 +869,9 @@ template <class W> void before_call(W* w)
 {
 	if (w && w->bfgs_memory && w->section == 0) release(w->bfgs_memory->s_mem);
 }
-template <class W> int after_call(W* w, int rc, task_enum* task, bool req_is_x)
+template <class W> int after_call(W* w, int rc, task_enum* task, bool req_is_x, const real_t* x)
 {
-	if (w && w->bfgs_memory && note_state(w->bfgs_memory->s_mem, w->niter, w->section, req_is_x)) {
+	if (w && w->bfgs_memory && note_state(w->bfgs_memory->s_mem, w->niter, w->section, req_is_x, rc == -1000 ? nullptr : x)) {
 		*task = invalid_input;                    // a HIP error surfaced during this call
 		return -1000;
 	}
@@ -1204,7 +1204,7 @@ int local_run_oLBFGS(real_t step_size, real_t x[], real_t grad[], real_t** req, 
 		ApiRange range("run_oLBFGS", w ? w->section : -1);
 		before_call(w);
 		const int rc = run_oLBFGS_impl(step_size, x, grad, req, task, w, iter_info);
-		return after_call(w, rc, task, req && *req == x);
+		return after_call(w, rc, task, req && *req == x, x);
 	});
 }
 
@@ -1215,7 +1215,7 @@ int local_run_SQN(real_t step_size, real_t x[], real_t grad[], real_t hess_vec[]
 		ApiRange range("run_SQN", w ? w->section : -1);
 		before_call(w);
 		const int rc = run_SQN_impl(step_size, x, grad, hess_vec, req, req_vec, task, w, iter_info);
-		return after_call(w, rc, task, req && *req == x);
+		return after_call(w, rc, task, req && *req == x, x);
 	});
 }
 
@@ -1226,7 +1226,7 @@ int local_run_adaQN(real_t step_size, real_t x[], real_t f, real_t grad[], real_
 		ApiRange range("run_adaQN", w ? w->section : -1);
 		before_call(w);
 		const int rc = run_adaQN_impl(step_size, x, f, grad, req, task, w, iter_info);
-		return after_call(w, rc, task, req && *req == x);
+		return after_call(w, rc, task, req && *req == x, x);
 	});
 }
 }  // namespace sqn

@@ -49,7 +49,7 @@ std::atomic<long long> g_stats[ST_COUNT];
 const char* const kStatNames[ST_COUNT] = {
 	"steps_three_pass", "steps_two_pass", "steps_two_pass_h0", "steps_sweeps", "steps_plain", "steps_kappa_fallback",
 	"allreduces", "allreduce_doubles", "contexts_created", "contexts_reclaimed", "x_uploads", "x_uploads_skipped",
-	"host_ranges_registered", "x_sent_ahead", "x_sent_again"};
+	"host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched"};
 
 bool alloc_should_fail()
 {
@@ -218,6 +218,7 @@ void destroy(DevCtx* c)
 	for (hipEvent_t e : c->up_ev) (void) hipEventDestroy(e);
 	if (c->carry) SQN_HIP_OK(hipFree(c->carry));
 	if (c->spec) SQN_HIP_OK(hipFree(c->spec));
+	if (c->x_pre_ev) (void) hipEventDestroy(c->x_pre_ev);
 	if (c->copy_done) (void) hipEventDestroy(c->copy_done);
 	for (auto& r : c->regs)
 		if (r.p) { if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError(); }   // the caller may have freed it already
@@ -588,7 +589,28 @@ bool has_spill(const void* key)
 	return g_spill.count(key) != 0;
 }
 
-bool note_state(const void* key, size_t niter, int section, bool req_is_x)
+// The call returns with *req == x -- the caller will now evaluate something AT x and must not modify it (reference
+// include/stochqn.h:364-366) -- but the device copy of x is stale (the request before was at x_avg: the caller was free to edit
+// x) and the next call will need it.  Its upload starts now, on the side stream, and runs while the caller computes; the next
+// call finds x in place (stage_x orders itself behind the copy, and still compares the probe values).  Pinned arrays only:
+// a copy from pageable memory would be done before this call returned.
+static void prefetch_x(DevCtx* c, const real* x)
+{
+	const Options& o = options();
+	if (!o.x_prefetch || o.x_upload != 0 || !x || c->fault || c->kind == KIND_RAW || c->async_call || (c->x_valid && c->x_host == x)) return;
+	const size_t n = (size_t) c->n, bytes = n * sizeof(real);
+	if ((long) bytes < o.register_min_bytes || is_device_pointer(x)) return;
+	if (!ensure_stage(c, 0) || !ensure_copy_stream(c, 1) || !ensure_registered(c, x, bytes)) return;
+	if (!c->x_pre_ev && hipEventCreateWithFlags(&c->x_pre_ev, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); c->x_pre_ev = nullptr; return; }
+	if (c->x_pre_pending) SQN_HIP_OK(hipStreamWaitEvent(c->copy_stream, c->x_pre_ev, 0));
+	SQN_HIP_OK(hipMemcpyAsync(c->stage[0], x, bytes, hipMemcpyHostToDevice, c->copy_stream));
+	SQN_HIP_OK(hipEventRecord(c->x_pre_ev, c->copy_stream));
+	c->x_pre_pending = true;
+	x_handed_back(c, x, n);                          // the probe values of what is on its way
+	stat_add(ST_X_PREFETCH);
+}
+
+bool note_state(const void* key, size_t niter, int section, bool req_is_x, const real* x)
 {
 	std::lock_guard<std::recursive_mutex> lk(g_mu);
 	auto it = g_ctx.find(key);
@@ -598,6 +620,7 @@ bool note_state(const void* key, size_t niter, int section, bool req_is_x)
 	// x is only known to be untouched until the next call while it is what *req designates ("do NOT modify", reference
 	// include/stochqn.h:364-366); a request at x_avg leaves the caller free to edit x
 	if (!req_is_x) it->second->x_valid = false;
+	else if (x && !it->second->fault) prefetch_x(it->second, x);
 	it->second->has_last = true;
 	it->second->last_niter = niter;
 	it->second->last_section = section;
@@ -731,6 +754,10 @@ static inline size_t probe_index(int j, size_t count)
 real* stage_x(DevCtx* c, real* caller, size_t count)
 {
 	if (!ensure_stage(c, 0)) return nullptr;
+	if (c->x_pre_pending) {                  // an upload of x that started when the last call returned: whatever touches the staging vector comes after it
+		SQN_HIP_OK(hipStreamWaitEvent(c->sc.stream, c->x_pre_ev, 0));
+		c->x_pre_pending = false;
+	}
 	bool current = options().x_upload == 0 && c->kind != KIND_RAW && c->x_valid && c->x_host == caller;
 	if (current) {
 		// belt and braces: the values at kProbe spread-out positions must still be the ones handed back (a caller that
@@ -955,6 +982,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "fold_coef")) g_opt.fold_coef = value != 0;
 	else if (!std::strcmp(name, "fuse_apply")) g_opt.fuse_apply = value != 0;
 	else if (!std::strcmp(name, "spec_x")) g_opt.spec_x = value != 0;
+	else if (!std::strcmp(name, "x_prefetch")) g_opt.x_prefetch = value != 0;
 	else if (!std::strcmp(name, "keep_tail")) g_opt.keep_tail = value < 0 ? 0 : (value > 1 ? 1 : value);
 	else if (!std::strcmp(name, "qdot_per_cu")) g_opt.qdot_per_cu = (int) value;
 	else if (!std::strcmp(name, "sadd_per_cu")) g_opt.sadd_per_cu = (int) value;

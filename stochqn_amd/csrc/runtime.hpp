@@ -46,6 +46,7 @@ struct Options {
 	// three-pass form: fraction of r0 / r stored with the default (cacheable) policy -- the part the next pass, which walks
 	// the other way, reads first; the rest leaves with sc1 nt.  0.25-0.5 measured 1 % ahead of 0 and of 1 (profiles/r03_ab_fold_tail.jsonl)
 	double keep_tail = 0.35;
+	bool x_prefetch = true;       // host callers: when a call hands *req == x back and the device copy of x is stale, x starts its way up on a side stream while the caller evaluates its gradient
 	bool spec_x = true;           // host callers, three-pass form: slices of x start their way down while pass 3 is still running
 	bool stream_stores = true;   // pass B: sc1 nt stores (kernels.hip: st_stream)
 	bool twopass_h0 = true;      // adaQN (diagonal H0) in the two-pass form as well
@@ -123,6 +124,8 @@ struct DevCtx {
 	int phase = 1;                     // sweep parity inside the current API call (reset by begin_call)
 	double* pool = nullptr;            // one allocation behind sc.part/red/sy/yy/alpha/rho/report
 	double* fisher_t = nullptr;        // [fsize] F*s on device
+	hipEvent_t x_pre_ev = nullptr;                    // option "x_prefetch": the upload of x that was started when the last call returned
+	bool x_pre_pending = false;
 	real* spec = nullptr;                             // x as the pending update will write it (option "spec_x"), source of the early slices
 	real* stage[3] = {nullptr, nullptr, nullptr};     // device staging for host x / grad / hess_vec
 	// host-caller path: the caller's arrays pinned in place, the side stream the download of x runs on while the
@@ -178,7 +181,7 @@ struct DevCtx {
 enum StatId {
 	ST_STEP_THREE_PASS = 0, ST_STEP_TWO_PASS, ST_STEP_TWO_PASS_H0, ST_STEP_SWEEPS, ST_STEP_PLAIN, ST_KAPPA_FALLBACK,
 	ST_ALLREDUCE, ST_ALLREDUCE_DOUBLES, ST_CTX_CREATED, ST_CTX_RECLAIMED, ST_X_UPLOAD, ST_X_UPLOAD_SKIPPED,
-	ST_HOST_REGISTERED, ST_X_AHEAD, ST_X_RESENT, ST_COUNT
+	ST_HOST_REGISTERED, ST_X_AHEAD, ST_X_RESENT, ST_X_PREFETCH, ST_COUNT
 };
 void stat_add(int id, long long v = 1);
 
@@ -206,7 +209,7 @@ void detach_spill(DevCtx* c);
 bool has_spill(const void* key);
 bool export_spill(const void* key);
 void enforce_mirror_cap();
-bool note_state(const void* key, size_t niter, int section, bool req_is_x = true);
+bool note_state(const void* key, size_t niter, int section, bool req_is_x = true, const real* x = nullptr);
 void release(const void* key);
 void release_all();
 

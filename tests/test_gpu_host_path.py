@@ -190,6 +190,56 @@ def test_x_sent_ahead_of_the_guard_leaves_the_same_bits(kind, strict, hip_backen
     lib.stochqn_hip_release_all()
 
 
+@pytest.mark.parametrize("kind", ["SQN", "adaQN"])
+def test_x_sent_up_while_the_caller_computes_changes_nothing(kind, hip_backend):
+    """Option x_prefetch (default): a call that returns with *req == x while the device copy of x is stale (the request before was
+    at x_avg: Hessian-vector product, big-batch gradient, function value) starts the upload of x on a side stream and returns;
+    the copy runs while the caller evaluates its gradient, the next call orders itself behind it.  Same bits as with the upload
+    inside the next call -- also when the caller, against the contract, edits x while it is on its way (the probe values catch
+    that and x goes up again)."""
+    lib = _lib()
+    n = 2_500_001
+    P = NoisyQuadratic(n, seed=9)
+
+    def drive(edit_at):
+        opt = OPTIMIZERS[kind](backend=hip_backend, space="host", **KW[kind])
+        x = P.x0()
+        xs, last = [], 999983
+        for call in range(30):
+            r = opt.run_optimizer(x, 0.05)
+            xs.append(x.copy())
+            task = r["task"]
+            if task == "calc_hess_vec":
+                rx, rv = r["requested_on"]
+                opt.update_hess_vec(P.hess_vec(to_np(rx), to_np(rv)))
+            elif task == "calc_fun_val_batch":
+                opt.update_function(P.f(to_np(r["requested_on"]), call))
+            else:
+                if call == edit_at and task == "calc_grad":
+                    x *= 0.5                                 # while the prefetched copy may still be in flight
+                if task == "calc_grad":
+                    last = call
+                opt.update_gradient(P.grad(to_np(x if call == edit_at else r["requested_on"]), last if task == "calc_grad_same_batch" else call))
+        opt.release()
+        return xs
+
+    out = {}
+    try:
+        for mode in (1.0, 0.0):
+            assert lib.stochqn_hip_set_option(b"x_prefetch", mode) == 0
+            for edit_at in (-1, 13, 14, 15, 16):
+                lib.stochqn_hip_stats_reset()
+                out[mode, edit_at] = drive(edit_at)
+                pre = stat(lib, "x_prefetched")
+                assert (pre >= 2) if mode else (pre == 0), (mode, edit_at, pre)
+                lib.stochqn_hip_release_all()
+    finally:
+        lib.stochqn_hip_set_option(b"x_prefetch", 1.0)
+    for edit_at in (-1, 13, 14, 15, 16):
+        for i, (a, b) in enumerate(zip(out[1.0, edit_at], out[0.0, edit_at])):
+            assert np.array_equal(a, b), "x after call %d differs (caller's edit at call %d)" % (i, edit_at)
+
+
 def test_step_counters_name_the_form_that_ran(hip_backend):
     """stochqn_hip_stat: which form of the recursion each step took."""
     import torch
