@@ -111,7 +111,7 @@ int stochqn_hip_export(const void *s_mem);
  * "x_prefetch"  (default 1)  a call that returns with *req == x while the device copy of x is out of date (the request before was at
  *                            x_avg) starts the upload of x on a side stream and returns: it runs while the caller evaluates its
  *                            gradient; the next call orders itself behind it and still compares the probe values ("x_prefetched")
- * "spec_x"      (default 1)  three-pass form, n even and >= ~4e6: pass 3 runs in `apply_chunks` slices and x - step r of each finished
+ * "spec_x"      (default 1)  three-pass form, n >= ~4e6: pass 3 runs in `apply_chunks` slices and x - step r of each finished
  *                            slice starts its way to the caller's x at once, BEFORE the guard (a sum over all of r) has spoken; the
  *                            guarded update then runs under the transfer, and a step it rejects (NaN / Inf / norm test: rare) is
  *                            put right by sending the untouched x again.  What the caller reads on return is unchanged, bit for bit

@@ -2210,11 +2210,11 @@ void launch_coef3b(const Scratch& sc, Partials v, const CoefArgs& a)
 	hipLaunchKernelGGL(k_coef3b, dim3(1), dim3(kCoefBlock), 0, sc.stream, v.parts, v.count, v.stride, a, sc.gsy, sc.sy, sc.alpha, sc.coef);
 }
 
-// pass 3 can run in slices when every lane works on whole 16-byte packs and n has no odd tail (the tail is written by the
-// last launch, wherever the traversal ends: not worth a slice of its own)
+// pass 3 can run in slices when the lanes work on packs (the elements beyond the last pack are written by the last launch,
+// wherever the traversal ends: they are reported on their own when that is not where the last slice lies)
 bool sadd_can_slice(const Scratch& sc, size_t n, const RowSet& s_rows, const real* r, const ApplyArgs* fuse, const SliceFeed* drain)
 {
-	if (!drain || fuse || drain->slices < 2 || n % kVec != 0 || !rows_aligned(s_rows) || !all_aligned(r)) return false;
+	if (!drain || fuse || drain->slices < 2 || !rows_aligned(s_rows) || !all_aligned(r)) return false;
 	const int grid = sweep_grid(sc, n, sc.sadd_per_cu > 0 ? sc.sadd_per_cu : 2);
 	const int T = sc.combine_batch;
 	const size_t round = (size_t) grid * kBlock * (size_t) (T >= 8 ? 8 : (T >= 4 ? 4 : 1));
@@ -2254,7 +2254,9 @@ Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows,
 			int s = 0;
 			for (size_t pb = 0; pb < packs; pb += per, s++) {
 				const size_t pe = pb + per < packs ? pb + per : packs;
-				const size_t lo = rev ? (last - (pe - 1)) * kVec : pb * kVec, hi = rev ? (last - pb + 1) * kVec : pe * kVec;
+				const size_t lo = rev ? (last - (pe - 1)) * kVec : pb * kVec;
+				size_t hi = rev ? (last - pb + 1) * kVec : pe * kVec;
+				if (!rev && pe == packs) hi = n;                  // forward: the odd elements lie next to the last slice
 				const Slice sl{(uint32_t) pb, (uint32_t) pe, drain->carry, pb == 0, pe == packs};
 				#define SQN_SAS(T, SS) hipLaunchKernelGGL((k_sadd<kVec, true, T, SS, false, true>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, cf, fo, r, ap, (uint32_t) n, rev, keep, sc.part[buf], sl)
 				if (T >= 8) { if (sc.stream_stores) SQN_SAS(8, true); else SQN_SAS(8, false); }
@@ -2263,6 +2265,7 @@ Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows,
 				#undef SQN_SAS
 				drain->arrive(drain->user, lo, hi, s);
 			}
+			if (rev && n > packs * kVec) drain->arrive(drain->user, packs * kVec, n, s);   // reversed: they lie at the other end
 		}
 		else if (vec) { if (T >= 8) SQN_SA(kVec, 8) else if (T >= 4) SQN_SA(kVec, 4) else SQN_SA(kVec, 1) }
 		else     { if (T >= 4) SQN_SA(1, 4) else SQN_SA(1, 1) }

@@ -673,7 +673,7 @@ bool spec_x_ready(Call& io, const StepIn& in)
 	// oLBFGS with strict_grad: what goes back in grad is -step r, written by the update itself -- the plain path does that
 	if (!options().spec_x || !io.host_caller || io.x != in.x || (io.g_host && options().strict_grad && in.s_slot) || chunks < 2 || n < ((size_t) 2 << 20))
 		return false;
-	if (!ensure_upload_slices(c, 1, (size_t) 2 * kMaxGrid * kBlock) || !ensure_copy_stream(c, chunks)) return false;
+	if (!ensure_upload_slices(c, 1, (size_t) 2 * kMaxGrid * kBlock) || !ensure_copy_stream(c, chunks + 1)) return false;   // + 1: the odd tail
 	if (!c->spec && !device_alloc((void**) &c->spec, n * sizeof(real))) { c->spec = nullptr; return false; }
 	(void) ensure_registered(c, io.x_caller, n * sizeof(real));
 	if (io.g_host && options().strict_grad) (void) ensure_registered(c, io.g_caller, n * sizeof(real));

@@ -196,6 +196,7 @@ void destroy(DevCtx* c)
 {
 	SQN_HIP_OK(hipStreamSynchronize(c->sc.stream));
 	if (c->own_stream && c->own_stream != c->sc.stream) SQN_HIP_OK(hipStreamSynchronize(c->own_stream));
+	if (c->copy_stream) (void) hipStreamSynchronize(c->copy_stream);      // an upload of x started when the last call returned may still be writing the staging vector
 	delete static_cast<Spill*>(c->spill);
 	c->spill = nullptr;
 	c->prof.collect();

@@ -143,9 +143,9 @@ def test_sliced_passes_equal_whole_launches(kind, hip_backend):
                     assert np.array_equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("strict", [0, 1])
+@pytest.mark.parametrize("strict,odd", [(0, 0), (1, 0), (0, 1)])
 @pytest.mark.parametrize("kind", ["SQN", "oLBFGS", "adaQN"])
-def test_x_sent_ahead_of_the_guard_leaves_the_same_bits(kind, strict, hip_backend):
+def test_x_sent_ahead_of_the_guard_leaves_the_same_bits(kind, strict, odd, hip_backend):
     """Option spec_x (default): pass 3 of the three-pass form in slices, each finished slice's x - step r on its way to the host
     before the guard has seen all of r, the guarded update under the transfer.  Against the plain host path (update, then the
     copies) and against a device-resident caller: the same bits in every x, request and counter -- also across a step that the
@@ -154,7 +154,7 @@ def test_x_sent_ahead_of_the_guard_leaves_the_same_bits(kind, strict, hip_backen
     back -step r, which the update itself writes: the plain path)."""
     import torch
     lib = _lib()
-    n = 6_291_456                                 # even, and three rounds of pass 3's grid: the smallest shape that is sliced
+    n = 6_291_456 + odd                           # three rounds of pass 3's grid: the smallest shape that is sliced; odd: every other ring row off the 16-byte grid, one element beyond the last pack
     P = NoisyQuadratic(n, seed=11, nan_calls=(9, 10, 17))      # consecutive calls: one of them feeds a step whatever the call pattern
     calls = 24
     out, grads = {}, {}
@@ -343,6 +343,13 @@ def test_running_out_of_device_memory_reclaims_instead_of_failing(hip_backend, o
     a = OPTIMIZERS["SQN"](backend=hip_backend, space="host", **kw)
     xa = P.x0()
     _advance(a, P, xa, 6, 0)
+    # every hardware queue of the process exists before the device is filled: the runtime creates them lazily with the first
+    # streams that need them (a few hundred MB of context-save area each) and does not survive failing to
+    warm = [torch.cuda.Stream() for _ in range(8)]
+    for s in warm:
+        with torch.cuda.stream(s):
+            torch.zeros(16, device="cuda:0").add_(1)
+    torch.cuda.synchronize()
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     ballast = torch.empty(free - (700 << 20), dtype=torch.uint8, device="cuda:0")     # leaves less than a second optimiser needs
