@@ -792,10 +792,10 @@ bool ensure_upload_slices(DevCtx* c, int slices, size_t carry_count)
 		c->up_ev.push_back(e);
 	}
 	if (c->carry_count < carry_count) {
+		double* bigger = nullptr;                        // the old one stays until the new one exists: a sliced pass of this very call may already count on it
+		if (!device_alloc((void**) &bigger, carry_count * sizeof(double))) return false;
 		if (c->carry) SQN_HIP_OK(hipFree(c->carry));
-		c->carry = nullptr;
-		c->carry_count = 0;
-		if (!device_alloc((void**) &c->carry, carry_count * sizeof(double))) return false;
+		c->carry = bigger;
 		c->carry_count = carry_count;
 	}
 	return true;
