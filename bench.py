@@ -1277,12 +1277,15 @@ def host_caller_leg(args, lib, be, hostc, gpu, n, m, L, step_size, two_loop):
             "link_GBps_per_ordinary_step": None if not dev_ms or ord_ms <= dev_ms else round((up + down) / ((ord_ms - dev_ms) * 1e-3) / 1e9, 1),
             "first_call_s": round(t_first, 2),
             "x_uploads": int(lib.stochqn_hip_stat(b"x_uploads")), "x_uploads_skipped": int(lib.stochqn_hip_stat(b"x_uploads_skipped")),
-            "host_ranges_pinned": int(lib.stochqn_hip_stat(b"host_ranges_registered"))}
+            "host_ranges_pinned": int(lib.stochqn_hip_stat(b"host_ranges_registered")),
+            "x_sent_ahead_of_the_guard": int(lib.stochqn_hip_stat(b"x_sent_ahead")), "x_sent_again": int(lib.stochqn_hip_stat(b"x_sent_again")),
+            "x_prefetched": int(lib.stochqn_hip_stat(b"x_prefetched"))}
     lib.stochqn_hip_set_option(b"strict_grad", 0.0)
     lib.stochqn_hip_release_all()
     res["note"] = ("strict_grad = 0 is the library's default (the reference documents `grad` as an input that is clobbered, no shipped caller "
-                   "reads it back); ms_per_step = one whole L-cycle on the clock (the pair-building step and the step after it, "
-                   "which uploads x again because the request in between was at x_avg, included); link_GBps = (bytes up + down) / "
+                   "reads it back); ms_per_step = one whole L-cycle on the clock (the pair-building step and the step after it included: "
+                   "x has to go up again after a request at x_avg, which the library starts in the background when the call before "
+                   "returns -- x_prefetched; the caller here spends its time in between on a numpy gradient); link_GBps = (bytes up + down) / "
                    "(ordinary step - the device-resident step's kernels). Round 2 measured 91.6 ms per step on this path (pageable "
                    "copies, x and the direction moved on every call).")
     return res
