@@ -115,6 +115,40 @@ def test_host_path_of_the_multi_device_mode(kind, kw, devices, hip_backend, orac
     opt.release()
 
 
+def test_large_shards_run_the_overlaps_of_the_host_path(hip_backend, oracle_backend):
+    """Shards large enough for every overlap of the single-device host path (each shard's machine is handed its slice of the
+    caller's arrays as host pointers): pass 1 in slices under the upload, x sent ahead of the guard, x sent up in the background
+    after a request at x_avg -- on three shards, n odd.  Bar: the unsharded oracle, with a NaN gradient in the middle (a step
+    that went ahead is rejected on every shard)."""
+    lib = _lib()
+    lib.stochqn_hip_stat.argtypes = [C.c_char_p]
+    lib.stochqn_hip_stat.restype = C.c_longlong
+    assert lib.stochqn_hip_set_option(b"virtual_devices", 1.0) == 0
+    assert lib.stochqn_hip_set_option(b"devices_min_n", 1.0) == 0
+    assert lib.stochqn_hip_set_option(b"devices", 3.0) == 0
+    n = 13_000_001
+    P = NoisyQuadratic(n, seed=8, nan_calls=(10, 11))
+    kw = dict(mem_size=3, bfgs_upd_freq=3)
+    try:
+        assert lib.stochqn_hip_set_option(b"strict_grad", 0.0) == 0
+        want = run_trace(OPTIMIZERS["SQN"](backend=oracle_backend, space="host", **kw), P, P.x0(), 0.05, 20)
+        lib.stochqn_hip_stats_reset()
+        opt = OPTIMIZERS["SQN"](backend=hip_backend, space="host", **kw)
+        got = run_trace(opt, P, P.x0(), 0.05, 20)
+        assert lib.stochqn_hip_devices_active(C.c_void_p(opt.BFGS_mem.s_mem.ctypes.data)) == 3
+        ahead, again, pre = (lib.stochqn_hip_stat(k) for k in (b"x_sent_ahead", b"x_sent_again", b"x_prefetched"))
+        assert ahead >= 3 * 4 and again >= 3 and pre >= 3, (ahead, again, pre)      # per shard
+        assert any(t["info"] == "search_direction_was_nan" for t in want)
+        compare_traces(got, want, 1e-9)
+        opt.release()
+    finally:
+        lib.stochqn_hip_set_option(b"strict_grad", 1.0)
+        lib.stochqn_hip_release_all()
+        lib.stochqn_hip_set_option(b"devices", 0.0)
+        lib.stochqn_hip_set_option(b"virtual_devices", 0.0)
+        lib.stochqn_hip_set_option(b"devices_min_n", float(1 << 20))
+
+
 def test_c_rosen_protocol_on_P_devices(devices, hip_backend):
     """Profile A: initialize_SQN / run_SQN / dealloc_SQN exactly as reference example/c_rosen.c:100-125 does,
     the workspace sharded over the devices (n = 4: shards of 1-2 variables), *req and *req_vec read on the host."""
