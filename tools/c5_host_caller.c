@@ -5,6 +5,7 @@
  *
  *   gcc -O2 -fopenmp -std=c99 -I include tools/c5_host_caller.c -L stochqn_amd/lib -lstochqn -lm -o c5_host_caller
  *   STOCHQN_HIP_DEVICES=8 ./c5_host_caller 1000000000 20 30        # n = 1e9, m = 20: 320 GB of S and Y, 40 GB per GPU
+ *   ./c5_host_caller 200000000 20 64 2                              # optional 4th argument: L (default 10)
  *
  * Problem: f(x) = 1/2 sum d_i x_i^2, gradient d.x with a deterministic +-1 % ripple, Hessian-vector product
  * d.v, all computed on the host with OpenMP (the caller's business; timed separately).  Prints the time
@@ -31,7 +32,7 @@ int main(int argc, char **argv)
 	const long n = argc > 1 ? atol(argv[1]) : 1000000000L;
 	const size_t m = argc > 2 ? (size_t) atol(argv[2]) : 20;
 	const int steps = argc > 3 ? atoi(argv[3]) : 30;
-	const size_t L = 10;
+	const size_t L = argc > 4 ? (size_t) atol(argv[4]) : 10;      /* a small L fills the ring quickly: the steady state of a full ring within a short run */
 	if (n <= 0 || n > 2147483647L) { fprintf(stderr, "n must fit an int (reference include/stochqn.h:172-174)\n"); return 2; }
 	double *x = malloc((size_t) n * sizeof(double)), *grad = malloc((size_t) n * sizeof(double)), *hv = malloc((size_t) n * sizeof(double));
 	if (!x || !grad || !hv) { fprintf(stderr, "host memory\n"); return 2; }
@@ -49,7 +50,8 @@ int main(int argc, char **argv)
 	double *req = NULL, *req_vec = NULL;
 	task_enum task;
 	info_enum info;
-	double t_lib = 0, t_caller = 0, f0 = 0, f1 = 0, t_first = 0, t_min = 1e30;
+	double t_lib = 0, t_caller = 0, f0 = 0, f1 = 0, t_first = 0, t_min = 1e30, t_full_min = 1e30, t_full_sum = 0;
+	int full_steps = 0;
 	#pragma omp parallel for reduction(+ : f0)
 	for (long i = 0; i < n; i++) f0 += 0.5 * d_of(i) * x[i] * x[i];
 	run_SQN(0.05, x, grad, hv, &req, &req_vec, &task, w, &info);
@@ -73,6 +75,10 @@ int main(int argc, char **argv)
 		if (getenv("C5_VERBOSE")) printf("  call %3d niter %3zu next task %d: %.1f ms\n", calls, w->niter, (int) task, 1e3 * dt);
 		if (calls < 2) t_first += dt;                 /* one-time work: the caller's vectors are pinned, staging is allocated */
 		else if (task == calc_grad && dt < t_min) t_min = dt;
+		if (calls >= 2 && task == calc_grad && w->bfgs_memory->mem_used == m && rc == 1) {   /* ordinary steps on a full ring */
+			full_steps++; t_full_sum += dt;
+			if (dt < t_full_min) t_full_min = dt;
+		}
 		if (rc != 0 && rc != 1) { fprintf(stderr, "run_SQN returned %d\n", rc); return 5; }
 		if (info != no_problems_encountered) bad++;
 		calls++;
@@ -85,6 +91,7 @@ int main(int argc, char **argv)
 	       1e3 * t_lib / (double) w->niter, t_caller);
 	printf("  of which the first two calls (pinning the caller's vectors, staging): %.3f s; after them %.1f ms per step, fastest ordinary step %.1f ms\n",
 	       t_first, 1e3 * (t_lib - t_first) / (double) (w->niter > 2 ? w->niter - 2 : 1), 1e3 * t_min);
+	if (full_steps) printf("  ordinary steps with the ring full (%zu pairs): %d, fastest %.1f ms, mean %.1f ms\n", m, full_steps, 1e3 * t_full_min, 1e3 * t_full_sum / full_steps);
 	printf("  x uploads %lld, skipped %lld; host ranges pinned %lld; steps by form: three-pass %lld, sweeps %lld, no pairs yet %lld\n",
 	       stochqn_hip_stat("x_uploads"), stochqn_hip_stat("x_uploads_skipped"), stochqn_hip_stat("host_ranges_registered"),
 	       stochqn_hip_stat("steps_three_pass"), stochqn_hip_stat("steps_sweeps"), stochqn_hip_stat("steps_plain"));
