@@ -389,12 +389,17 @@ def test_function_increase_rolls_x_back_for_host_callers_too(hip_backend):
 
 @pytest.mark.parametrize("kind", ["SQN", "adaQN"])
 def test_float_host_and_device_callers_agree_bit_for_bit(kind):
-    """The same for the single-precision library (libstochqn_f32.so): pinned float arrays, sliced pass 1, sliced update."""
+    """The same for the single-precision library (libstochqn_f32.so): pinned float arrays, sliced pass 1, sliced pass 3 with x on
+    its way ahead of the guard (packs of four floats: n = 9,000,003 leaves three elements beyond the last pack and is two
+    rounds of pass 3's grid)."""
     import stochqn_amd
     import torch
     be = stochqn_amd.lib(use_float=True)
     lib = stochqn_amd.cdll(use_float=True)
-    n = 4_500_001
+    lib.stochqn_hip_stat.argtypes = [C.c_char_p]
+    lib.stochqn_hip_stat.restype = C.c_longlong
+    lib.stochqn_hip_stats_reset()
+    n = 9_000_003
     P = NoisyQuadratic(n, seed=5)
     kw = dict(KW[kind], use_float=True)
     x0 = P.x0().astype(np.float32)
@@ -406,4 +411,5 @@ def test_float_host_and_device_callers_agree_bit_for_bit(kind):
         for k in ("x", "req", "req_vec"):
             if k in h:
                 assert np.array_equal(h[k], d[k]), (i, k)
+    assert lib.stochqn_hip_stat(b"x_sent_ahead") >= 3, lib.stochqn_hip_stat(b"x_sent_ahead")
     lib.stochqn_hip_release_all()
