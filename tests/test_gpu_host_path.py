@@ -343,8 +343,8 @@ def test_running_out_of_device_memory_reclaims_instead_of_failing(hip_backend, o
     a = OPTIMIZERS["SQN"](backend=hip_backend, space="host", **kw)
     xa = P.x0()
     _advance(a, P, xa, 6, 0)
-    # every hardware queue of the process exists before the device is filled: the runtime creates them lazily with the first
-    # streams that need them (a few hundred MB of context-save area each) and does not survive failing to
+    # a few more streams in use before the device is filled (cheap insurance; streams first used with 300 MB left work too:
+    # scratch/queue_oom.hip)
     warm = [torch.cuda.Stream() for _ in range(8)]
     for s in warm:
         with torch.cuda.stream(s):
