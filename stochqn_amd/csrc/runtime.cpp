@@ -51,6 +51,39 @@ const char* const kStatNames[ST_COUNT] = {
 	"allreduces", "allreduce_doubles", "contexts_created", "contexts_reclaimed", "x_uploads", "x_uploads_skipped",
 	"host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched"};
 
+// Copies between device memory and ORDINARY host memory on the reclaim path, which by definition runs when the device is
+// full: through a small pinned buffer made while memory was still plentiful (with the first mirror), so that the runtime
+// does not have to pin hundreds of MB of the destination on the fly -- and find page-table space for that -- at the worst
+// possible moment.  Falls back to a plain hipMemcpy when the buffer could not be made.
+constexpr size_t kBounceBytes = (size_t) 32 << 20;
+void* g_bounce = nullptr;
+bool g_bounce_tried = false;
+
+void ensure_bounce()
+{
+	if (g_bounce_tried) return;
+	g_bounce_tried = true;
+	if (hipHostMalloc(&g_bounce, kBounceBytes, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); g_bounce = nullptr; }
+}
+
+hipError_t bounced_copy(void* dst, const void* src, size_t bytes, bool to_host)
+{
+	if (!g_bounce) return hipMemcpy(dst, src, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice);
+	for (size_t off = 0; off < bytes; off += kBounceBytes) {
+		const size_t k = bytes - off < kBounceBytes ? bytes - off : kBounceBytes;
+		if (to_host) {
+			const hipError_t e = hipMemcpy(g_bounce, (const char*) src + off, k, hipMemcpyDeviceToHost);
+			if (e != hipSuccess) return e;
+			std::memcpy((char*) dst + off, g_bounce, k);
+		} else {
+			std::memcpy(g_bounce, (const char*) src + off, k);
+			const hipError_t e = hipMemcpy((char*) dst + off, g_bounce, k, hipMemcpyHostToDevice);
+			if (e != hipSuccess) return e;
+		}
+	}
+	return hipSuccess;
+}
+
 bool alloc_should_fail()
 {
 	long left = g_fail_alloc_after.load();
@@ -301,7 +334,7 @@ bool reclaim_one()
 				SpillPiece pc;
 				pc.caller = v->caller; pc.count = v->count;
 				pc.data = (real*) std::malloc(v->count * sizeof(real));
-				if (!pc.data || hipMemcpy(pc.data, v->dev, v->count * sizeof(real), hipMemcpyDeviceToHost) != hipSuccess) {
+				if (!pc.data || bounced_copy(pc.data, v->dev, v->count * sizeof(real), true) != hipSuccess) {
 					(void) hipGetLastError();
 					std::free(pc.data);
 					ok = false;
@@ -663,11 +696,15 @@ bool bind(DevCtx* c, View& v, real* caller, size_t count, bool import)
 		return false;
 	}
 	v.mirror = true;
+	{
+		std::lock_guard<std::recursive_mutex> lk(g_mu);
+		ensure_bounce();                         // reclaim_one is going to need it when memory is short
+	}
 	// a context that was reclaimed while idle comes back from the library's own host copy, not from the caller's (stale) arrays
 	if (Spill* sp = static_cast<Spill*>(c->spill)) {
 		for (auto& pc : sp->pieces)
 			if (pc.caller == caller && pc.count == count && pc.data) {
-				SQN_HIP_OK(hipMemcpy(v.dev, pc.data, count * sizeof(real), hipMemcpyHostToDevice));
+				SQN_HIP_OK(bounced_copy(v.dev, pc.data, count * sizeof(real), false));
 				std::free(pc.data);
 				pc.data = nullptr;
 				enforce_mirror_cap();
