@@ -704,7 +704,10 @@ bool bind(DevCtx* c, View& v, real* caller, size_t count, bool import)
 	if (Spill* sp = static_cast<Spill*>(c->spill)) {
 		for (auto& pc : sp->pieces)
 			if (pc.caller == caller && pc.count == count && pc.data) {
-				SQN_HIP_OK(bounced_copy(v.dev, pc.data, count * sizeof(real), false));
+				{
+					std::lock_guard<std::recursive_mutex> lk(g_mu);      // one bounce buffer for the process
+					SQN_HIP_OK(bounced_copy(v.dev, pc.data, count * sizeof(real), false));
+				}
 				std::free(pc.data);
 				pc.data = nullptr;
 				enforce_mirror_cap();
