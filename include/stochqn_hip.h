@@ -86,7 +86,9 @@ int stochqn_hip_export(const void *s_mem);
  * "twopass_h0"  (default 1)  two-pass form only: adaQN's diagonal H0 as well (the H0-weighted inner products
  *                            are recomputed every step in the pass that also applies adaQN's side effects
  *                            on the raw gradient); the three-pass form needs no such entries
- * "rows_grid", "rows_split", "combine_batch", "h0_per_cu": kernel-shape knobs, see DESIGN.md 3.2
+ * "rows_grid", "rows_split", "rows_waves", "combine_batch", "h0_per_cu", "stream_stores", "qdot_stream", "sdot_per_cu",
+ * "sdot2_per_cu", "qdot_per_cu", "sadd_per_cu": kernel-shape knobs (grid sizes in workgroups per compute unit, packs a lane
+ *                            finishes before it stores, store policy of r0 / r); the defaults are the measured optima, DESIGN.md 3.0 / 3.2
  * "strict_grad" (default 0)  host callers: copy the search direction back into `grad` (n words over PCIe per step).  The
  *                            reference documents `grad` as an INPUT that "will be modified in-place" (reference
  *                            include/stochqn.h:356-358), and none of its callers reads it afterwards (src/Rwrapper.c:98-196,

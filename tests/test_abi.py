@@ -6,6 +6,7 @@ import os
 import re
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -223,3 +224,39 @@ def test_library_and_torch_share_one_hip_runtime():
     pytest.importorskip("torch")
     out = subprocess.check_output([os.sys.executable, "-c", _ONE_RUNTIME % ROOT], stderr=subprocess.STDOUT).decode()
     assert "one-runtime True" in out, out
+
+
+def test_every_option_and_counter_the_header_names_exists():
+    """include/stochqn_hip.h documents options (stochqn_hip_set_option) and counters (stochqn_hip_stat) by name: every quoted
+    name in those two comment blocks must be one the library knows -- and every name the library knows must be documented.
+    Runs in a child process (set_option changes process-wide state)."""
+    code = r'''
+import ctypes as C, re, sys
+sys.path.insert(0, %r)
+import stochqn_amd
+lib = stochqn_amd.cdll()
+lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+lib.stochqn_hip_stat.argtypes = [C.c_char_p]
+lib.stochqn_hip_stat.restype = C.c_longlong
+text = open(%r).read()
+opts = text[text.index("/* ---- options"):text.index("int stochqn_hip_set_option(")]
+stats = text[text.index("/* ---- event counters"):text.index("long long stochqn_hip_stat(")]
+is_opt = lambda n: lib.stochqn_hip_set_option(n.encode(), 1.0) == 0
+is_stat = lambda n: lib.stochqn_hip_stat(n.encode()) >= 0
+quoted = lambda block: sorted(set(re.findall(r'"([a-z][a-z_0-9]+)"', block)))
+bad = [n for n in quoted(opts) if not (is_opt(n) or is_stat(n))]
+bad += [n for n in quoted(stats) if not (is_stat(n) or is_opt(n))]
+assert not bad, "named in the header, unknown to the library: %%s" %% bad
+assert lib.stochqn_hip_set_option(b"no_such_option", 1.0) == -1 and lib.stochqn_hip_stat(b"no_such_counter") == -1
+# the other way round: what the sources accept is in the header
+src = open(%r).read()
+known_opts = set(re.findall(r'std::strcmp\(name, "([a-z_0-9]+)"\)', src))
+known_stats = set(re.findall(r'"([a-z_0-9]+)"', src[src.index("kStatNames[ST_COUNT] = {"):src.index("};", src.index("kStatNames[ST_COUNT] = {"))]))
+assert len(known_opts) > 30 and len(known_stats) > 10
+missing = sorted(n for n in known_opts if '"%%s"' %% n not in opts) + sorted(n for n in known_stats if '"%%s"' %% n not in stats)
+assert not missing, "known to the library, missing from the header: %%s" %% missing
+print("ok", len(known_opts), len(known_stats))
+''' % (ROOT, os.path.join(ROOT, "include", "stochqn_hip.h"), os.path.join(ROOT, "stochqn_amd", "csrc", "runtime.cpp"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("ok")
