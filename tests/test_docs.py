@@ -26,3 +26,22 @@ def test_every_path_cited_in_the_documents_exists():
             if not os.path.exists(full):
                 missing.append((doc, path))
     assert not missing, missing
+
+
+def test_tests_named_in_the_documents_exist():
+    """Evidence is cited by test name (`test_...`, optionally `file.py::test_...`): every such name must be a test in tests/."""
+    defined = set()
+    for fn in os.listdir(os.path.join(ROOT, "tests")):
+        if fn.endswith(".py"):
+            defined |= set(re.findall(r"^\s*def (test_[A-Za-z0-9_]+)\(", open(os.path.join(ROOT, "tests", fn)).read(), re.M))
+    missing = []
+    for doc in DOCS:
+        text = open(os.path.join(ROOT, doc)).read()
+        for name in set(re.findall(r"\b(test_[a-z0-9_]+[a-z0-9])\b", text)):
+            if name in defined or name + ".py" in os.listdir(os.path.join(ROOT, "tests")):
+                continue
+            # a name cut short with an ellipsis ("test_bench_starts_its_own_ranks…") counts when it is the start of exactly one test
+            if re.search(re.escape(name) + r"(…|\.\.\.)", text) and sum(d.startswith(name) for d in defined) >= 1:
+                continue
+            missing.append((doc, name))
+    assert not missing, "tests named in the documents but not in tests/: %s" % missing
