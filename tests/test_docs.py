@@ -45,3 +45,29 @@ def test_tests_named_in_the_documents_exist():
                 continue
             missing.append((doc, name))
     assert not missing, "tests named in the documents but not in tests/: %s" % missing
+
+
+def test_functions_named_in_the_documents_exist_in_the_named_source():
+    """`machines.cpp: apply_step / gradient_slice_arrives`, `kernels.hip: Slice`, `bench.py `live_pmc`` ...: the identifier must
+    occur in that source file."""
+    sources = {"runtime.cpp": "stochqn_amd/csrc/runtime.cpp", "machines.cpp": "stochqn_amd/csrc/machines.cpp",
+               "group.cpp": "stochqn_amd/csrc/group.cpp", "kernels.hip": "stochqn_amd/csrc/kernels.hip", "free.py": "stochqn_amd/free.py",
+               "bench.py": "bench.py"}
+    texts = {k: open(os.path.join(ROOT, v)).read() for k, v in sources.items()}
+    missing, checked = [], 0
+    for doc in DOCS:
+        text = open(os.path.join(ROOT, doc)).read()
+        for fname, names in re.findall(r"`((?:runtime|machines|group)\.cpp|kernels\.hip|free\.py): ([A-Za-z0-9_ /:<>|]+)`", text):
+            for ident in re.split(r"\s*/\s*", names):
+                ident = ident.strip().split("<")[0]
+                if not re.fullmatch(r"[A-Za-z_][A-Za-z0-9_]*", ident):
+                    continue
+                checked += 1
+                if not re.search(r"\b" + re.escape(ident) + r"\b", texts[fname]):
+                    missing.append((doc, fname, ident))
+        for ident in re.findall(r"bench\.py `([A-Za-z_][A-Za-z0-9_]*)`", text):
+            checked += 1
+            if not re.search(r"\b" + re.escape(ident) + r"\b", texts["bench.py"]):
+                missing.append((doc, "bench.py", ident))
+    assert checked >= 15, checked
+    assert not missing, missing
