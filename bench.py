@@ -722,7 +722,7 @@ def in_process_leg(args, world, n_gpu, steps):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
                                                              "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=420)      # a child that hangs must not cost the line its primary result
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     if r.returncode != 0 or not lines:
         raise RuntimeError("exit code %d: %s" % (r.returncode, r.stderr[-600:].replace("\n", " | ")))
