@@ -42,6 +42,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -596,17 +597,87 @@ def run(args):
         del hostc
         gpu = None
 
+    par = ("n sharded over %d GPU(s), one process per GPU; one RCCL all-reduce per dot product" % world)
+    if args.rehearse:
+        par = "REHEARSAL: %d ranks sharing one GPU, all-reduce over gloo -- not a measurement" % world
+    def build_out():
+        return {
+            "metric": "optimizer steps/sec + achieved HBM GB/s, two-loop at n=10^8 m=20 fp64",
+            "value": round(value, 3),
+            "unit": "steps/s" if n_total == 100_000_000 else "steps/s normalised to n=1e8 (steps/s * n_total/1e8)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "SQN n=%g per GPU (n_total=%g), m=%d, L=%d, Hessian-vector pairs via A'(Av)/%d, "
+                                   "check_nan=1, ring full, fp64" % (n_gpu, n_total, m, L, bs),
+                       "name": args.config if args.n <= 0 else "custom",
+                       "parallelism": par,
+                       "inputs": "counter-based generator (stochqn_hip_synth_*, seed %d): shard-invariant" % SEED,
+                       "calls": timed_counters["calls"], "hess_vec_requests": timed_counters["hv"],
+                       "rejected_steps": timed_counters["bad"], "rejected_pairs": timed_counters["rejected"],
+                       "options": args.opt,
+                       "f_start": f0, "f_end": f1},
+            "rccl_nranks": rccl_nranks,
+            "per_rank_ms_per_step": per_rank_ms,
+            "steps_per_s_unnormalised": round(steps_per_s, 3),
+            "profiled_pass": None if prof_elapsed is None else {"steps": prof_steps, "ms_per_step": round(1e3 * prof_elapsed / prof_steps, 3)},
+            "sustained": sustained,
+            "roofline": roof,
+            "two_loop": two_loop,
+            "two_loop_micro": micro,
+            "reference_form": ref_form,
+            "kernels": detail,
+            "forms": {"three_pass": forms["steps_three_pass"], "two_pass": forms["steps_two_pass"], "sweeps": forms["steps_sweeps"],
+                      "sweeps_because_of_kappa": forms["steps_kappa_fallback"], "no_pairs_yet": forms["steps_plain"],
+                      "note": "steps of the timed region by the form of the two-loop recursion that ran (stochqn_hip_stat)"},
+            "allreduces_per_step": round(forms["allreduces"] / args.steps, 2),
+            "host_caller": host_leg,
+            "cpu_baseline": cpu,
+        }
+
     # ---- N > 1 with no further flags: what BASELINE config 5 and SURVEY 8e ask for, in the same line ----
     legs, legs_failed = {}, []
     want_legs = world > 1 and not args.no_extra_legs and args.config == "c3" and args.n <= 0 and not args.strong
+    emitted, emit_lock, legs_done, stage = threading.Event(), threading.Lock(), threading.Event(), {"name": None}
+
+    def emit(extra_failed=()):
+        """THE line (once).  Normally at the very end; from the watchdog when an auxiliary leg hangs, with what there is."""
+        with emit_lock:
+            if emitted.is_set():
+                return
+            out = build_out()
+            if want_legs:
+                out["legs"] = legs
+                out["legs_failed"] = legs_failed + list(extra_failed)
+            if args.config == "c5" or n_gpu == CONFIGS["c5"]:
+                out["shard_reference_1gpu"] = shard_reference(world, steps_per_s)
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            emitted.set()
+
+    def watchdog(limit):
+        # the primary result is in hand; a collective of an auxiliary leg that never completes (first contact with RCCL on N > 1
+        # ranks happens on the driver's node) must not take it along: every rank leaves at the limit, rank 0 prints first
+        if legs_done.wait(limit):
+            return
+        if rank == 0:
+            emit(["watchdog: leg '%s' had not finished after %g s; nothing after it was run" % (stage["name"], limit)])
+        else:
+            time.sleep(3.0)
+        os._exit(0)
     wl.free()
     del x, S, Y, A, d
     if want_legs:
         leg_steps = max(20, args.steps)
 
+        threading.Thread(target=watchdog, args=(float(os.environ.get("BENCH_WATCHDOG_S", "300")),), daemon=True).start()
+
         def attempt(name, fn):
             res, ok = None, True
+            stage["name"] = name
             try:
+                if os.environ.get("BENCH_TEST_HANG_LEG") == name:      # tests: a leg that never comes back
+                    time.sleep(1e6)
                 res = fn()
             except Exception as e:                              # a failing leg is reported, it does not take the headline down with it
                 res, ok = {"error": "%s: %s" % (type(e).__name__, e)}, False
@@ -631,9 +702,11 @@ def run(args):
             legs["allreduce_us"]["allreduces_per_step"] = round(forms["allreduces"] / args.steps, 2)
 
     if dist is not None:
+        stage["name"] = "teardown of the communicators"
         barrier(ctx)
         lib.stochqn_hip_comm_finalize()
         dist.destroy_process_group()
+    legs_done.set()
     lib.stochqn_hip_release_all()
     if rank != 0:
         return                                                 # rank 0 alone starts the in-process child and prints
@@ -661,52 +734,10 @@ def run(args):
         else:
             roof["traffic_note"] = "live PMC passes unavailable here: committed profile quoted"
 
-    par = ("n sharded over %d GPU(s), one process per GPU; one RCCL all-reduce per dot product" % world)
-    if args.rehearse:
-        par = "REHEARSAL: %d ranks sharing one GPU, all-reduce over gloo -- not a measurement" % world
-    out = {
-        "metric": "optimizer steps/sec + achieved HBM GB/s, two-loop at n=10^8 m=20 fp64",
-        "value": round(value, 3),
-        "unit": "steps/s" if n_total == 100_000_000 else "steps/s normalised to n=1e8 (steps/s * n_total/1e8)",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "SQN n=%g per GPU (n_total=%g), m=%d, L=%d, Hessian-vector pairs via A'(Av)/%d, "
-                               "check_nan=1, ring full, fp64" % (n_gpu, n_total, m, L, bs),
-                   "name": args.config if args.n <= 0 else "custom",
-                   "parallelism": par,
-                   "inputs": "counter-based generator (stochqn_hip_synth_*, seed %d): shard-invariant" % SEED,
-                   "calls": timed_counters["calls"], "hess_vec_requests": timed_counters["hv"],
-                   "rejected_steps": timed_counters["bad"], "rejected_pairs": timed_counters["rejected"],
-                   "options": args.opt,
-                   "f_start": f0, "f_end": f1},
-        "rccl_nranks": rccl_nranks,
-        "per_rank_ms_per_step": per_rank_ms,
-        "steps_per_s_unnormalised": round(steps_per_s, 3),
-        "profiled_pass": None if prof_elapsed is None else {"steps": prof_steps, "ms_per_step": round(1e3 * prof_elapsed / prof_steps, 3)},
-        "sustained": sustained,
-        "roofline": roof,
-        "two_loop": two_loop,
-        "two_loop_micro": micro,
-        "reference_form": ref_form,
-        "kernels": detail,
-        "forms": {"three_pass": forms["steps_three_pass"], "two_pass": forms["steps_two_pass"], "sweeps": forms["steps_sweeps"],
-                  "sweeps_because_of_kappa": forms["steps_kappa_fallback"], "no_pairs_yet": forms["steps_plain"],
-                  "note": "steps of the timed region by the form of the two-loop recursion that ran (stochqn_hip_stat)"},
-        "allreduces_per_step": round(forms["allreduces"] / args.steps, 2),
-        "host_caller": host_leg,
-        "cpu_baseline": cpu,
-    }
-    if want_legs:
-        out["legs"] = legs
-        out["legs_failed"] = legs_failed
-        if legs_failed and args.strict_legs:
-            sys.stderr.write("bench.py: leg(s) %s failed: %s\n" % (", ".join(legs_failed), json.dumps({k: legs[k] for k in legs_failed})))
-            raise SystemExit(3)
-    if args.config == "c5" or n_gpu == CONFIGS["c5"]:
-        out["shard_reference_1gpu"] = shard_reference(world, steps_per_s)
-    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if want_legs and legs_failed and args.strict_legs:
+        sys.stderr.write("bench.py: leg(s) %s failed: %s\n" % (", ".join(legs_failed), json.dumps({k: legs[k] for k in legs_failed})))
+        raise SystemExit(3)
+    emit()
 
 
 def in_process_leg(args, world, n_gpu, steps):

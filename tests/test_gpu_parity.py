@@ -1679,6 +1679,26 @@ def test_bench_default_multi_gpu_run_carries_every_leg():
     assert d["forms"]["three_pass"] == d["steps"] and d["forms"]["sweeps"] == 0
 
 
+def test_bench_keeps_its_primary_result_when_an_auxiliary_leg_hangs():
+    """First contact with RCCL on N > 1 ranks happens on the driver's node: a collective of an auxiliary leg that never
+    completes must not cost the run its primary (weak-scaling) number.  With the `c5` leg made to hang (test hook) and the
+    watchdog's limit at 10 s, the ONE line still comes, with the primary result and the leg named in `legs_failed`; every rank
+    leaves with code 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_TEST_HANG_LEG="c5", BENCH_WATCHDOG_S="10")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rehearse"], capture_output=True, text=True,
+                         timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["value"] > 0 and d["config"]["name"] == "c3"
+    assert d["legs"] == {} and len(d["legs_failed"]) == 1 and "watchdog" in d["legs_failed"][0] and "'c5'" in d["legs_failed"][0]
+
+
 @pytest.mark.parametrize("config,n", [("c3", 100_000_000), ("c5", 125_000_000)])
 def test_bench_headline_workload_runs_clean(config, n):
     """bench.py's own workload under pytest: BASELINE config 3 exactly as measured (SQN n = 1e8, m = 20, L = 10, pairs from
