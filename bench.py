@@ -393,13 +393,34 @@ def run(args):
     for kv in args.opt:
         name, val = kv.split("=")
         assert lib.stochqn_hip_set_option(name.encode(), float(val)) == 0, kv
-    dist = None
+    dist, reducer = None, None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if args.rehearse:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # The harness's own collectives (barriers, max over ranks, the communicator id) travel over gloo on the CPU: a few bytes
+        # per call, and one RCCL communicator fewer in the process -- the library's.  Its reductions go over RCCL; in a
+        # rehearsal (ranks sharing one GPU, which RCCL refuses) or when RCCL cannot be brought up they go over gloo too.
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        reducer = "gloo (rehearsal: the ranks share one GPU)" if args.rehearse else "rccl"
+        if not args.rehearse:
+            uid = torch.zeros(129, dtype=torch.uint8)
+            if rank == 0:
+                buf = (C.c_ubyte * 128)()
+                if lib.stochqn_hip_comm_unique_id(buf) == 0:
+                    uid = torch.tensor(list(buf) + [1], dtype=torch.uint8)
+            dist.broadcast(uid, 0)
+            rc = lib.stochqn_hip_comm_init(rank, world, bytes(uid[:128].tolist())) if int(uid[128]) == 1 else -1
+            if os.environ.get("BENCH_TEST_RCCL_FAILS"):              # tests: the fall-back below
+                rc = -1
+            up = torch.tensor([1.0 if rc == 0 else 0.0], dtype=torch.float64)
+            dist.all_reduce(up, op=dist.ReduceOp.MIN)
+            if float(up.item()) < 0.5:
+                sys.stderr.write("bench.py: rank %d: the library's RCCL communicator could not be set up (rc %d here): the reductions of this "
+                                 "run go over gloo on the host instead -- three sums of a few dozen doubles per step\n" % (rank, rc))
+                lib.stochqn_hip_comm_finalize()
+                reducer = "gloo (the library's RCCL communicator could not be set up)"
+        if reducer != "rccl":
             hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))   # the runtime already loaded
             hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
             REDUCER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
@@ -416,18 +437,7 @@ def run(args):
             run.keep_alive = REDUCER(gloo_allreduce)
             lib.stochqn_hip_comm_init_custom.argtypes = [C.c_int, C.c_int, REDUCER, C.c_void_p]
             assert lib.stochqn_hip_comm_init_custom(rank, world, run.keep_alive, None) == 0
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
-            uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                buf = (C.c_ubyte * 128)()
-                assert lib.stochqn_hip_comm_unique_id(buf) == 0
-                uid = torch.tensor(list(buf), dtype=torch.uint8)
-            uid = uid.to(dev)
-            dist.broadcast(uid, 0)
-            raw = bytes(uid.cpu().tolist())
-            assert lib.stochqn_hip_comm_init(rank, world, raw) == 0, "RCCL communicator init failed"
-    cpu_or_dev = "cpu" if args.rehearse else dev
+    cpu_or_dev = "cpu"
     ctx = {"lib": lib, "be": be, "dev": dev, "dist": dist, "cpu_or_dev": cpu_or_dev, "rank": rank, "world": world}
 
     def config_n(name):
@@ -600,6 +610,9 @@ def run(args):
     par = ("n sharded over %d GPU(s), one process per GPU; one RCCL all-reduce per dot product" % world)
     if args.rehearse:
         par = "REHEARSAL: %d ranks sharing one GPU, all-reduce over gloo -- not a measurement" % world
+    elif reducer is not None and reducer != "rccl":
+        par = ("n sharded over %d GPU(s), one process per GPU; RCCL COULD NOT BE BROUGHT UP: every reduction (a few dozen doubles, "
+               "three per step) goes device -> host -> gloo -> device instead" % world)
     def build_out():
         return {
             "metric": "optimizer steps/sec + achieved HBM GB/s, two-loop at n=10^8 m=20 fp64",
@@ -618,7 +631,8 @@ def run(args):
                        "rejected_steps": timed_counters["bad"], "rejected_pairs": timed_counters["rejected"],
                        "options": args.opt,
                        "f_start": f0, "f_end": f1},
-            "rccl_nranks": rccl_nranks,
+            "rccl_nranks": 0 if (reducer or "").startswith("gloo (the library") else rccl_nranks,      # ranks of the communicator the reductions used
+            "reducer": reducer,
             "per_rank_ms_per_step": per_rank_ms,
             "steps_per_s_unnormalised": round(steps_per_s, 3),
             "profiled_pass": None if prof_elapsed is None else {"steps": prof_steps, "ms_per_step": round(1e3 * prof_elapsed / prof_steps, 3)},

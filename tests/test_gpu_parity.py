@@ -1609,11 +1609,11 @@ def test_bench_multi_process_control_flow_on_one_gpu(tmp_path):
     assert "REHEARSAL" in d["config"]["parallelism"]
 
 
-def _bench(args, timeout=600):
+def _bench(args, timeout=600, env=None):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in (env or os.environ).items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     if "--sustain-seconds" not in args and "--in-process" not in args:
         args = args + ["--sustain-seconds", "0"]               # the tests that want the sustained leg ask for it
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
@@ -1677,6 +1677,24 @@ def test_bench_default_multi_gpu_run_carries_every_leg():
     assert ip["device_shards"] == 3 and ip["n_per_gpu"] == 100_000_000 // 50 and ip["steps_per_s"] > 0 and ip["rejected_steps"] == 0
     assert 3.0 <= ip["allreduces_per_step"] <= 4.5 and ip["allreduce_us"]["median_us"] > 0
     assert d["forms"]["three_pass"] == d["steps"] and d["forms"]["sweeps"] == 0
+
+
+def test_bench_falls_back_to_the_host_reducer_when_rccl_cannot_be_set_up():
+    """The harness's own collectives go over gloo; only the library's reductions need RCCL.  If that communicator cannot be
+    brought up (test hook: the init is declared failed on a one-rank group), the run goes on with the reductions over gloo and
+    says so in the line instead of dying without one."""
+    env = dict(os.environ, BENCH_TEST_RCCL_FAILS="1")
+    out = _bench(["--force-dist", "--vars-per-gpu", "3000000", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-host-caller",
+                  "--no-live-pmc", "--sustain-seconds", "0"], timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert d["reducer"].startswith("gloo (the library") and d["rccl_nranks"] == 0 and "COULD NOT BE BROUGHT UP" in d["config"]["parallelism"]
+    assert d["value"] > 0 and d["allreduces_per_step"] >= 3
+    assert "could not be set up" in out.stderr
+    ok = _bench(["--force-dist", "--vars-per-gpu", "3000000", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-host-caller",
+                 "--no-live-pmc", "--sustain-seconds", "0"], timeout=600)
+    d2 = json.loads([l for l in ok.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert d2["reducer"] == "rccl" and d2["rccl_nranks"] == 1
 
 
 def test_bench_keeps_its_primary_result_when_an_auxiliary_leg_hangs():
