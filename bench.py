@@ -101,7 +101,7 @@ def parse():
                     help="skip the extra untimed steps in the reference's sweep form and the two-loop micro-benchmark")
     ap.add_argument("--dump-x", default="", help="write the final x of this rank to <path>.<rank>.npy (sharded-vs-unsharded checks)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
-                    help="stochqn_hip_set_option before the run (grid_cap, reverse, nontemporal, twopass ...)")
+                    help="stochqn_hip_set_option before the run (grid_cap, reverse, nontemporal, threepass ...)")
     return ap.parse_args()
 
 
@@ -308,7 +308,7 @@ def all_ok(ctx, ok):
     return float(t.item()) > 0.5
 
 
-STAT_NAMES = ("steps_three_pass", "steps_two_pass", "steps_two_pass_h0", "steps_sweeps", "steps_plain", "steps_kappa_fallback",
+STAT_NAMES = ("steps_three_pass", "steps_sweeps", "steps_plain", "steps_kappa_fallback",
               "allreduces", "allreduce_doubles")
 
 
@@ -523,8 +523,8 @@ def run(args):
     # ---- outside the timed region: the same workload in the reference's own dependency structure
     # (2m+1 dependent fused sweeps, 64*m*n algorithmic bytes) for the roofline the north star names --
     ref_form = None
-    if ("combine" in kern or "sadd" in kern) and not args.no_reference_form:
-        lib.stochqn_hip_set_option(b"twopass", 0.0)
+    if "sadd" in kern and not args.no_reference_form:
+        lib.stochqn_hip_set_option(b"threepass", 0.0)
         wl.steps(2)
         lib.stochqn_hip_profile_enable(1)
         lib.stochqn_hip_profile_reset()
@@ -535,14 +535,14 @@ def run(args):
         barrier(ctx)
         el2 = time.perf_counter() - t1
         lib.stochqn_hip_profile_enable(0)
-        lib.stochqn_hip_set_option(b"twopass", 1.0)
+        lib.stochqn_hip_set_option(b"threepass", 1.0)
         k2 = kernel_table(lib)
         if "bwd" in k2:
             cnt, ms = k2["bwd"]
             ach = 4 * n_gpu * 8 / (ms / cnt * 1e-3) / 1e9
             tl = sum(k2[k][1] for k in ("first", "bwd", "mid", "fwd", "fwd_last") if k in k2) / extra
             tr, src = pmc_traffic("bwd", n_gpu, m)
-            ref_form = {"note": "same workload with --opt twopass=0, %d steps after the timed region" % extra,
+            ref_form = {"note": "same workload with --opt threepass=0, %d steps after the timed region" % extra,
                         "steps_per_s": round(extra / el2 * n_total / 1e8, 3),
                         "two_loop_ms": round(tl, 3), "two_loop_alg_bytes": 64 * m * n_gpu,
                         "two_loop_alg_GBps": round(64.0 * m * n_gpu / (tl * 1e-3) / 1e9, 1),
@@ -564,10 +564,9 @@ def run(args):
         gq = torch.empty_like(g0)
         micro = {"note": "stochqn_hip_two_loop alone: mem_used=%d, oldest pair in row %d, H0=NULL, 3 warm-up + 20 calls, median; "
                          "reference-form bytes = SURVEY 8d's 64*m*n (the sweeps form moves exactly those; the three-pass form moves "
-                         "(3m+5)*n*8, the two-pass form (4m+3)*n*8)" % (m, wl.b.mem_st_ix)}
+                         "(3m+5)*n*8)" % (m, wl.b.mem_st_ix)}
         lib.stochqn_hip_set_option(b"raw_reuse_cache", 1.0)      # S and Y do not change between these calls
-        for form, flag, three in (("three_pass", 1.0, 1.0), ("two_pass", 1.0, 0.0), ("sweeps", 0.0, 1.0)):
-            lib.stochqn_hip_set_option(b"twopass", flag)
+        for form, three in (("three_pass", 1.0), ("sweeps", 0.0)):
             lib.stochqn_hip_set_option(b"threepass", three)
             ts = []
             for rep in range(23):
@@ -579,12 +578,11 @@ def run(args):
                 assert rc == 0
                 ts.append(time.perf_counter() - tq)
             med = max_over_ranks(ctx, sorted(ts[3:])[10])
-            moved = {"three_pass": 3 * m + 5, "two_pass": 4 * m + 3, "sweeps": 8 * m}[form] * n * 8        # bytes this form has to stream
+            moved = {"three_pass": 3 * m + 5, "sweeps": 8 * m}[form] * n * 8        # bytes this form has to stream
             micro[form] = {"median_ms": round(1e3 * med, 3), "bytes_moved": moved,
                            "GBps_on_bytes_moved": round(moved / med / 1e9, 1),
                            "frac_of_8TBps_on_bytes_moved": round(moved / med / 1e9 / PEAK, 4),
                            "GBps_on_reference_form_bytes": round(64.0 * m * n / med / 1e9, 1)}
-        lib.stochqn_hip_set_option(b"twopass", 1.0)
         lib.stochqn_hip_set_option(b"threepass", 1.0)
         lib.stochqn_hip_set_option(b"raw_reuse_cache", 0.0)
         lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))      # the raw context keyed by S; the optimiser is finished
@@ -642,7 +640,7 @@ def run(args):
             "two_loop_micro": micro,
             "reference_form": ref_form,
             "kernels": detail,
-            "forms": {"three_pass": forms["steps_three_pass"], "two_pass": forms["steps_two_pass"], "sweeps": forms["steps_sweeps"],
+            "forms": {"three_pass": forms["steps_three_pass"], "sweeps": forms["steps_sweeps"],
                       "sweeps_because_of_kappa": forms["steps_kappa_fallback"], "no_pairs_yet": forms["steps_plain"],
                       "note": "steps of the timed region by the form of the two-loop recursion that ran (stochqn_hip_stat)"},
             "allreduces_per_step": round(forms["allreduces"] / args.steps, 2),
@@ -982,7 +980,7 @@ def run_in_process(args):
         "device_shards": P,
         "allreduces_per_step": round(forms["allreduces"] / args.steps / P, 2),
         "allreduce_us": allreduce_us,
-        "forms": {"three_pass": forms["steps_three_pass"] // P, "two_pass": forms["steps_two_pass"] // P, "sweeps": forms["steps_sweeps"] // P,
+        "forms": {"three_pass": forms["steps_three_pass"] // P, "sweeps": forms["steps_sweeps"] // P,
                   "sweeps_because_of_kappa": forms["steps_kappa_fallback"] // P},
         "steps_per_s_unnormalised": round(steps_per_s, 3),
         "profiled_pass": None if prof_elapsed is None else {"steps": prof_steps, "ms_per_step": round(1e3 * prof_elapsed / prof_steps, 3)},
@@ -1013,13 +1011,10 @@ def analyse_kernels(kern, n_gpu, m, bs, prof_steps, shards):
     `shards` = device shards whose launches the table aggregates (1 per process except --in-process)."""
     # algorithmic n-words per launch (DESIGN.md section 3)
     words = {"first": 2, "bwd": 4, "mid": 3, "fwd": 4, "fwd_last": 3, "apply": 5,
-             "rows_dot": 2 * m + 1, "rows_dot3": 2 * m + 3, "combine": 2 * m + 2,
              "sdot": m + 1, "sdot2": m + 2, "qdot": m + 2, "sadd": m + 2,
              "fisher_t": bs + 1, "fisher_y": bs + 2, "pair_s": 4, "pair_y_hv": 6}
     what = {"bwd": "fused backward sweep: read y_i, q, s_{i-1}; write q",
             "fwd": "fused forward sweep: read s_i, r, y_{i+1}; write r",
-            "combine": "two-pass form, pass B: read g and the %d rows of S and Y; write r" % (2 * m),
-            "rows_dot": "two-pass form, pass A: read g and the %d rows of S and Y" % (2 * m),
             "sdot": "three-pass form, pass 1: read g and the %d rows of S" % m,
             "qdot": "three-pass form, pass 2: read g and the %d rows of Y; write r0" % m,
             "sadd": "three-pass form, pass 3: read r0 and the %d rows of S; write r" % m}
@@ -1044,12 +1039,12 @@ def analyse_kernels(kern, n_gpu, m, bs, prof_steps, shards):
                 "alg_bytes_per_launch": alg, "avg_launch_ms": round(ms / cnt, 4),
                 "measured": "HIP events on the library's stream, %d steps of the same workload right after the timed "
                             "region (the timed region itself runs with the event profiler off)" % prof_steps}
-    chain = ("first", "bwd", "mid", "fwd", "fwd_last", "rows_dot", "rows_dot3", "coef", "combine", "sdot", "sdot2", "qdot", "sadd")
+    chain = ("first", "bwd", "mid", "fwd", "fwd_last", "coef", "sdot", "sdot2", "qdot", "sadd")
     two_loop_ms = sum(kern[k][1] for k in chain if k in kern) / max(prof_steps * shards, 1)
     two_loop = None
     if two_loop_ms > 0:
-        form = "three-pass" if "sadd" in kern else ("two-pass" if "combine" in kern else "sweeps")
-        own = {"three-pass": 3 * m + 5, "two-pass": 4 * m + 3, "sweeps": 8 * m}[form]      # n-words this form has to move
+        form = "three-pass" if "sadd" in kern else "sweeps"
+        own = {"three-pass": 3 * m + 5, "sweeps": 8 * m}[form]      # n-words this form has to move
         two_loop = {"form": form, "ms": round(two_loop_ms, 3),
                     "bytes_moved": own * n_gpu * 8, "GBps_on_bytes_moved": round(own * n_gpu * 8 / (two_loop_ms * 1e-3) / 1e9, 1),
                     "frac_of_8TBps_on_bytes_moved": round(own * n_gpu * 8 / (two_loop_ms * 1e-3) / 1e9 / PEAK, 4),
@@ -1077,7 +1072,7 @@ def shard_reference(n_gpus, steps_per_s):
     return None
 
 
-PMC_KEYS = {"bwd": "BwdOp", "fwd": "FwdOp<true, false, false>", "combine": "k_combine<2", "rows_dot": "k_rows_dot_all<2, 5",
+PMC_KEYS = {"bwd": "BwdOp", "fwd": "FwdOp<true, false, false>",
             "sdot": "k_rows_dot_all<2, 3, true, 1", "qdot": "k_qdot<2, 3", "sadd": "k_sadd<2"}
 
 
@@ -1122,7 +1117,7 @@ def live_pmc(args, kernel):
                           if r.get("Counter_Name") == ctr and key in r.get("Kernel_Name", "").replace("sqn::(anonymous namespace)::", ""))
             if not vals:
                 return None
-            got[ctr] = (vals[-1] if kernel in ("rows_dot", "sdot") else vals[len(vals) // 2], len(vals))
+            got[ctr] = (vals[-1] if kernel == "sdot" else vals[len(vals) // 2], len(vals))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     b = got["FETCH_SIZE"][0] * 1024 * 2 + got["WRITE_SIZE"][0] * 1024
@@ -1143,9 +1138,8 @@ def pmc_traffic(kernel, n, m):
         for k, v in d.items():
             if key in k and (m == 20 or kernel in ("bwd", "fwd")):
                 raw = v["raw"]
-                # rows_dot: the same kernel also runs Gram maintenance with the probe among the rows
-                # (one stream fewer); pass A is the largest dispatch
-                stat = "max_KiB" if kernel in ("rows_dot", "sdot") else "median_KiB"
+                # sdot: the same kernel also rebuilds columns of the cached block (a y row as the probe); pass 1 is the largest dispatch
+                stat = "max_KiB" if kernel == "sdot" else "median_KiB"
                 b = raw.get("FETCH_SIZE", {}).get(stat, 0.0) * 1024 * 2 + raw.get("WRITE_SIZE", {}).get(stat, 0.0) * 1024
                 return int(round(b * n / 1e8)), os.path.relpath(f, ROOT) + " (measured at n=1e8, m=20)"
     return None, None

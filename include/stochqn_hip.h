@@ -25,10 +25,10 @@ int stochqn_hip_available(void);
  * pointers; buffer_rho/buffer_alpha receive rho_i and alpha_i by logical index.
  * Like the function it stands for, every call recomputes every inner product from the arrays as they
  * are (a pure function of its arguments).  A caller that calls repeatedly on UNCHANGED s_mem / y_mem may
- * set option "raw_reuse_cache" = 1: s'y, y'y and the Gram blocks of the two-pass form are then kept per
- * (s_mem, row) between calls (stochqn_hip_invalidate(s_mem) after changing rows).  With a caller-supplied
- * diagonal H0 the three-pass form scales q0 by it in its second pass (the two-pass form has no kernel for a
- * GIVEN diagonal).  Without "raw_reuse_cache" an isolated call runs as the chain of sweeps: when every inner
+ * set option "raw_reuse_cache" = 1: s'y, y'y and the cached products s_a'y_b of the three-pass form are then kept
+ * per (s_mem, row) between calls (stochqn_hip_invalidate(s_mem) after changing rows).  With a caller-supplied
+ * diagonal H0 the three-pass form scales q0 by it in its second pass.
+ * Without "raw_reuse_cache" an isolated call runs as the chain of sweeps: when every inner
  * product has to be rebuilt for one call that is the cheapest way to evaluate it.
  * The state behind these isolated entries is separate from any optimiser's using the same arrays and
  * is freed by stochqn_hip_release(s_mem) / stochqn_hip_release_all().
@@ -55,7 +55,7 @@ int stochqn_hip_fisher_product(real_t F[], size_t fu, int n, real_t s[], real_t 
  *   Inputs must be complete on (or ordered before) the NULL stream when a call is entered; outputs are
  *   complete when it returns.  Work on hipStreamNonBlocking / per-thread / side streams must be
  *   synchronised by the caller first.
- * Caches: s'y, y'y and the Gram rows of the pairs in the ring are cached per (s_mem, ring row).  run_*
+ * Caches: s'y, y'y and the products s_a'y_b of the pairs in the ring are cached per (s_mem, ring row).  run_*
  *   notices a different optimiser at the same address (counters that do not continue) but NOT rows of
  *   s_mem / y_mem edited or restored in place at the same counters: call stochqn_hip_invalidate(s_mem)
  *   after such an edit.  Option "verify_cache" = 1 re-derives one pair's cached numbers per step and fails
@@ -76,19 +76,15 @@ int stochqn_hip_export(const void *s_mem);
  * "nontemporal" (default 1)  stream pair / Fisher rows with non-temporal loads
  * "grid_cap"    (default 0 = one workgroup per compute unit) maximum workgroups per sweep
  * "reverse"     (default 1)  alternate the traversal direction of consecutive sweeps
- * "twopass"     (default 1)  the two-loop recursion from cached inner products between the stored pairs
- *                            instead of the chain of 2m+1 dependent sweeps (8mn words; always used for
- *                            m > 48 -- m > 24 with "threepass" = 0 --, for ill-conditioned pairs and with 0 here)
- * "threepass"   (default 1)  which cached form: 1 = three passes -- S'g, then q0 / r0 / Y'r0 with Y held in
- *                            registers, then r0 + S'c: S is read twice, Y once, (3m+5)n words; 0 = round 1's
- *                            two passes -- [S;Y]g, O(m^2) scalar recursion over the Gram blocks, one
- *                            combine pass: (4m+3)n words
- * "twopass_h0"  (default 1)  two-pass form only: adaQN's diagonal H0 as well (the H0-weighted inner products
- *                            are recomputed every step in the pass that also applies adaQN's side effects
- *                            on the raw gradient); the three-pass form needs no such entries
- * "rows_grid", "rows_split", "rows_waves", "combine_batch", "h0_per_cu", "stream_stores", "qdot_stream", "sdot_per_cu",
+ * "threepass"   (default 1)  1: the two-loop recursion from cached inner products between the stored pairs, in three
+ *                            passes -- S'g, then q0 / r0 / Y'r0 with Y held in registers, then r0 + S'c: S is read twice,
+ *                            Y once, (3m+5)n words; 0: always the reference's chain of 2m+1 dependent sweeps (8mn words; also
+ *                            used for m > 48 and for ill-conditioned pairs, "kappa_max").  (Round 1's two-pass form -- [S;Y]g,
+ *                            a recursion over Gram blocks, one combine pass: (4m+3)n words -- was retired in round 4 together
+ *                            with its options: the three-pass form dominated it on bytes, time and accuracy.)
+ * "rows_grid", "rows_split", "rows_waves", "combine_batch", "stream_stores", "qdot_stream", "sdot_per_cu",
  * "sdot2_per_cu", "qdot_per_cu", "sadd_per_cu": kernel-shape knobs (grid sizes in workgroups per compute unit, packs a lane
- *                            finishes before it stores, store policy of r0 / r); the defaults are the measured optima, DESIGN.md 3.0 / 3.2
+ *                            finishes before it stores, store policy of r0 / r); the defaults are the measured optima, DESIGN.md 3.0
  * "strict_grad" (default 0)  host callers: copy the search direction back into `grad` (n words over PCIe per step).  The
  *                            reference documents `grad` as an INPUT that "will be modified in-place" (reference
  *                            include/stochqn.h:356-358), and none of its callers reads it afterwards (src/Rwrapper.c:98-196,
@@ -131,13 +127,19 @@ int stochqn_hip_export(const void *s_mem);
  *                            blocking one, so work the caller then puts on the NULL stream is ordered after them.  Nothing is
  *                            read back: buffer_rho / buffer_alpha / buffer_y are not filled, the kappa rule is off, a device
  *                            fault surfaces at the caller's next synchronisation.
- * "twopass_kappa_max" (default 1e6)  the two-pass forms are used only while every pair in use has
+ * "kappa_max"   (default 1e6)  the three-pass form is used only while every pair in use has
  *                            |s||y| / |s'y| <= this (s almost orthogonal to y: every fp64 evaluation loses
- *                            digits, the expanded form somewhat more); beyond, the chain of sweeps. inf = off
+ *                            digits); beyond, the chain of sweeps. inf = off
  * "fisher_rows" (default 16) Fisher rows one workgroup accumulates per pass (8, 16, 32)
  * "verify_cache" (default 0) see "contract for callers that pass DEVICE pointers"
  * "raw_reuse_cache" (default 0)  stochqn_hip_two_loop / _take_step keep cached inner products between calls
  * "devices", "virtual_devices", "devices_min_n": single-process multi-device mode, see below
+ * "devices_rccl_single" (default 0)  with "devices" < 2: eligible workspaces (host arrays or library-owned, n >= "devices_min_n")
+ *                            run as a group of ONE shard on the current device over a real RCCL communicator (ncclCommInitAll
+ *                            of one device, the shard's own thread, ncclAllReduce per reduction): the multi-device mode's code,
+ *                            exercised where only one GPU exists
+ * "reducer_patience_s" (default 120)  host-side rendezvous reducer (virtual devices, loop-back): seconds a shard waits for the
+ *                            others in a reduction before the call fails (-1000); a shard that failed on its own never arrives
  * "fail_alloc_after" (default -1 = off)  fault injection for tests: the (value+1)-th device or
  *                             pinned allocation from now fails once
  * "inject_device_fault" (default 0)      fault injection for tests: the next stream synchronisation
@@ -187,7 +189,7 @@ int stochqn_hip_comm_unique_id(void *out128);
 int stochqn_hip_comm_init(int rank, int nranks, const void *unique_id128);
 int stochqn_hip_comm_nranks(void);
 void stochqn_hip_comm_finalize(void);
-/* Latency of one reduction as the kernel chain pays it: `reps` in-place sums of `count` (<= 384) doubles through the
+/* Latency of one reduction as the kernel chain pays it: `reps` in-place sums of `count` (<= 128) doubles through the
  * reducer of the calling thread (the RCCL communicator, a caller-supplied reducer, the loop-back), each followed by a
  * stream synchronisation.  Collective -- every rank (every shard thread under stochqn_hip_devices_foreach) calls it
  * alike.  Median and minimum in microseconds.  0, -1 when no reducer is installed, -1000 on failure. */
@@ -195,10 +197,10 @@ int stochqn_hip_comm_allreduce_probe(int count, int reps, double *median_us, dou
 
 /* ---- event counters ---------------------------------------------------------------------------------
  * Process-wide counts since start (or the last reset).  Names:
- *   "steps_three_pass", "steps_two_pass", "steps_two_pass_h0", "steps_sweeps"  take_step calls with pairs in memory, by the
+ *   "steps_three_pass", "steps_sweeps"  take_step calls with pairs in memory, by the
  *                               form of the two-loop recursion that ran; "steps_plain": no pairs yet (reference :808-812);
- *   "steps_kappa_fallback"      of the sweeps: steps a cached form was configured for but a pair with
- *                               |s||y|/|s'y| > "twopass_kappa_max" sent to the reference's chain of sweeps;
+ *   "steps_kappa_fallback"      of the sweeps: steps the three-pass form was configured for but a pair with
+ *                               |s||y|/|s'y| > "kappa_max" sent to the reference's chain of sweeps;
  *   "allreduces", "allreduce_doubles"   reductions issued by this process (per shard context) and doubles summed;
  *   "contexts_created", "contexts_reclaimed"   device contexts made / exported-and-dropped under memory pressure;
  *   "x_uploads", "x_uploads_skipped", "host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched"   host-caller path

@@ -153,10 +153,14 @@ int physical_devices()
 	return c;
 }
 
+// shards a workspace of n variables runs on: 0 = the mode is off for it.  One shard only with option "devices_rccl_single":
+// the whole mode -- worker thread, ncclCommInitAll, per-thread all-reduce, teardown -- on ONE device over a real communicator.
 int shards_for(int n)
 {
 	const Options& o = options();
-	if (o.devices < 2 || n <= 0 || (long) n < o.devices_min_n) return 0;
+	if (n <= 0) return 0;
+	if (o.devices < 2) return (o.devices_rccl_single && !o.virtual_devices && (long) n >= o.devices_min_n && physical_devices() >= 1) ? 1 : 0;
+	if ((long) n < o.devices_min_n) return 0;
 	int P = o.devices;
 	const int phys = physical_devices();
 	if (phys < 1) return 0;
@@ -168,6 +172,7 @@ int shards_for(int n)
 	if (P > n) P = n;
 	return P >= 2 ? P : 0;
 }
+
 
 bool dalloc(real** p, size_t count, bool zero_fill)
 {
@@ -247,17 +252,20 @@ Group* create_group(const Shape& sp, int P, bool owned, bool resumed)
 	g->owned = owned;
 	const int phys = physical_devices();
 	g->virt = P > phys || options().virtual_devices;
+	int dev_single = 0;                                    // one shard ("devices_rccl_single"): on the device the caller is on
+	(void) hipGetDevice(&dev_single);
 	if (!g->virt) {
 		std::vector<int> devs((size_t) P);
-		for (int p = 0; p < P; p++) devs[(size_t) p] = p;
-		g->comms.assign((size_t) P, nullptr);
 		int cur = 0;
 		(void) hipGetDevice(&cur);
+		for (int p = 0; p < P; p++) devs[(size_t) p] = P == 1 ? cur : p;      // one shard ("devices_rccl_single"): where the caller is
+		g->comms.assign((size_t) P, nullptr);
 		const bool up = comm_init_all(P, devs.data(), g->comms.data());
 		(void) hipSetDevice(cur);
 		if (!up) return nullptr;
 	} else {
 		g->loop.nranks = P;
+		g->loop.patience_s = options().reducer_patience_s;
 		g->loop.slots.assign((size_t) P * kRedMax, 0.0);
 	}
 	const size_t n = (size_t) sp.n, base = n / (size_t) P, extra = n % (size_t) P;
@@ -265,7 +273,7 @@ Group* create_group(const Shape& sp, int P, bool owned, bool resumed)
 	for (int p = 0; p < P; p++) {
 		std::unique_ptr<Shard> s(new Shard());
 		s->rank = p;
-		s->device = g->virt ? p % phys : p;
+		s->device = g->virt ? p % phys : (P == 1 ? dev_single : p);
 		s->off = off;
 		s->cnt = base + ((size_t) p < extra ? 1 : 0);
 		off += s->cnt;
@@ -365,7 +373,7 @@ Group* group_for(const Shape& sp)
 	}
 	if (!g) {
 		const int P = shards_for(sp.n);
-		if (P < 2) return nullptr;
+		if (P < 1) return nullptr;
 		g = create_group(sp, P, false, sp.niter > 0 || sp.b->mem_used > 0);
 		if (!g) return nullptr;
 		std::lock_guard<std::mutex> lk(g_gmu);
@@ -436,7 +444,7 @@ real_t* req_home(Group* g, const Shape& sp, const Shard& s, const real_t* req, r
 
 }  // namespace
 
-bool group_mode_for(int n) { return shards_for(n) >= 2; }
+bool group_mode_for(int n) { return shards_for(n) >= 1; }
 
 bool group_owns(const void* s_mem)
 {
@@ -448,9 +456,9 @@ bool group_applies(const bfgs_mem* b, int n)
 {
 	if (!b || !b->s_mem) return false;
 	if (group_owns(b->s_mem)) return true;
-	if (options().devices < 2) return false;
+	if (options().devices < 2 && !options().devices_rccl_single) return false;
 	if (is_device_pointer(b->s_mem)) return false;            // the caller keeps its arrays on one device: single-device path
-	return shards_for(n) >= 2;
+	return shards_for(n) >= 1;
 }
 
 int group_shards(const void* key)
@@ -823,7 +831,7 @@ bfgs_mem* owned_bfgs(void* block, size_t mem_size, real_t min_curvature, real_t 
 bool register_owned(const Shape& sp, void* block)
 {
 	const int P = shards_for(sp.n);
-	if (P < 2) return false;
+	if (P < 1) return false;
 	Group* g = create_group(sp, P, true, false);
 	if (!g) return false;
 	g->token = block;

@@ -24,10 +24,10 @@
 // that q / r keep what cache residency they can.  These are BLAS-1 reductions at 0.25 flop/B:
 // no MFMA; in the sweeps LDS only carries the per-workgroup reduction.
 //
-// The second half of the file is the default two-pass (Gram) form of the same recursion -- pass A
-// (rows-dot: [S;Y]g and, after a new pair, its Gram row), the coefficient recursion in one
-// workgroup, pass B (combine) -- and adaQN's variant with the diagonal H0 inside the Gram
-// quantities (k_gram_h0, the one kernel that tiles through LDS).  DESIGN.md section 3.
+// The second half of the file is the default, three-pass form of the same recursion over cached inner products
+// between the stored pairs -- pass 1 (rows-dot: S g and, after a new pair, its column of the cached block), pass 2
+// (q0, r0, Y'r0 with Y held in registers), pass 3 (r = r0 + S c), the scalar recursions in the prologues of
+// passes 2 and 3.  DESIGN.md section 3.
 #include "sqn_device.hpp"
 
 #include <cmath>
@@ -42,7 +42,6 @@ constexpr int kWaves = kBlock / 64;
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef real rvec __attribute__((ext_vector_type(kVec)));     // one 16-byte pack of vector elements
-typedef real real2 __attribute__((ext_vector_type(2)));       // two neighbouring columns (Gram tile staging)
 // The same packs as they sit in memory: element-aligned only.  Row j of the ring starts at element
 // j*n, so for odd n every other row of S, Y and F is off the 16-byte grid.  gfx950 executes
 // global_load / global_store_dwordx4 at any element alignment (the compiler emits them for these
@@ -50,7 +49,6 @@ typedef real real2 __attribute__((ext_vector_type(2)));       // two neighbourin
 // 5.15 ms aligned -- and 13.8 ms for the element-wise path that alignment gating used to fall back
 // to (scratch/tune5.hip).
 typedef rvec rvec_u __attribute__((aligned(sizeof(real))));
-typedef real2 real2_u __attribute__((aligned(sizeof(real))));
 
 // W elements of a vector, widened to double for the arithmetic.  W = kVec: one 16-byte access per
 // lane (any element alignment); W = 1: one element.
@@ -721,17 +719,16 @@ __global__ void __launch_bounds__(kBlock) k_fisher_y(const real* F, size_t ld_, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// two-pass form: rows-dot (pass A, Gram maintenance), coefficient recursion, combine (pass B)
+// rows-dot: pass 1 of the three-pass form (and the rebuild of a column of the cached block)
 // ------------------------------------------------------------------------------------------------
 // partial[j][workgroup] = sum over this workgroup's packs of rows[j] . probe.  NG groups of 8 rows,
 // one accumulator per row and lane; the probe pack is loaded once and reused for every row.
-// NPR probes: quantity (pr * rows + j) = rows[j] . probe[pr].  With NPR = 3 the pass that computes
-// [S;Y]g for the recursion also produces the new pair's row of the Gram blocks (probes y_r, s_r).
-struct Probes { const real* p[3]; };
+// NPR probes: quantity (pr * rows + j) = rows[j] . probe[pr].  With NPR = 2 the pass that computes
+// S g for the recursion also produces the new pair's column s_i'y_new of the cached block.
+struct Probes { const real* p[2]; };
 
-// Single-probe pass A: one accumulator per row and lane, NG groups of 8 rows; the compiler hoists
-// the row loads of a pack ahead of the arithmetic (one wave per SIMD, up to 512 registers per lane),
-// which measured faster than the row-split form below for a single probe (5.1 vs 5.8 ms, n=1e8, 40 rows).
+// One accumulator per row, probe and lane, NG groups of 8 rows; the compiler hoists the row loads of a
+// pack ahead of the arithmetic (up to 512 registers per lane).
 // A pass cut into slices of the traversal (host callers: slice s runs as soon as ITS part of the gradient has arrived over
 // PCIe, while the rest is still on its way): every lane's accumulators are carried from launch to launch through `carry`,
 // the slice boundaries are whole rounds of the grid, so each lane adds exactly the terms it adds in one launch, in the same
@@ -826,77 +823,48 @@ __global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, Probes pr, r
 	}
 }
 
-// Work split: the 4 waves of a workgroup share the same columns and divide the ROWS among them
-// (wave w owns rows [w*RPW, (w+1)*RPW)), so a lane carries only RPW*NPR accumulators and the loads
-// of a whole pack fit in registers (all issued before the first use).  The probe packs are read
-// by every wave with default-policy loads: one HBM fetch, three L2/L1 hits.
-template <int W, int RPW, int NPR, bool NT, int NW>
-__global__ void __launch_bounds__(64 * NW) k_rows_dot(RowSet rs, Probes pr, real* copy_out, uint32_t n, int rev, double* parts)
+// Work split (single probe; the float build's pass 1: 2.5 against 5.9 ms for the all-rows form): the NW waves of a
+// workgroup share the same columns and divide the ROWS among them (wave w owns rows [w*RPW, (w+1)*RPW)), so a lane
+// carries only RPW accumulators and the loads of a whole pack fit in registers (all issued before the first use).
+// The probe packs are read by every wave with default-policy loads: one HBM fetch, the rest L2/L1 hits.
+template <int W, int RPW, bool NT, int NW>
+__global__ void __launch_bounds__(64 * NW) k_rows_dot(RowSet rs, const real* probe, real* copy_out, uint32_t n, int rev, double* parts)
 {
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int row0 = wave * RPW;
-	double acc[NPR][RPW];
+	double acc[RPW];
 	#pragma unroll
-	for (int q = 0; q < NPR; q++)
-		#pragma unroll
-		for (int j = 0; j < RPW; j++) acc[q][j] = 0;
+	for (int j = 0; j < RPW; j++) acc[j] = 0;
 	const uint32_t packs = n / W, stride = gridDim.x * 64, last = packs - 1;
 	for (uint32_t p = blockIdx.x * 64 + lane; p < packs; p += stride) {
 		const uint32_t i = (rev ? last - p : p) * W;
-		Pack<W> pv[NPR];
 		RPack<W> f[RPW];
-		#pragma unroll
-		for (int q = 0; q < NPR; q++) pv[q] = ld<W, false>(pr.p[q], i);
+		const Pack<W> pv = ld<W, false>(probe, i);
 		#pragma unroll
 		for (int j = 0; j < RPW; j++)
 			if (row0 + j < rs.count) f[j] = ldr<W, NT>(rs.row[row0 + j], i);
-		if (copy_out && wave == 0) st<W>(copy_out, i, pv[0]);
+		if (copy_out && wave == 0) st<W>(copy_out, i, pv);
 		#pragma unroll
 		for (int j = 0; j < RPW; j++)
 			if (row0 + j < rs.count) {
 				#pragma unroll
-				for (int q = 0; q < NPR; q++)
-					#pragma unroll
-					for (int k = 0; k < W; k++) acc[q][j] = fma((double) f[j].v[k], pv[q].v[k], acc[q][j]);
+				for (int k = 0; k < W; k++) acc[j] = fma((double) f[j].v[k], pv.v[k], acc[j]);
 			}
 	}
 	if (W > 1) {
 		const uint32_t i = packs * W + lane;                           // tail elements (n not a multiple of W)
 		if (blockIdx.x == gridDim.x - 1 && i < n) {
-			if (copy_out && wave == 0) copy_out[i] = pr.p[0][i];
+			if (copy_out && wave == 0) copy_out[i] = probe[i];
+			const double pv = (double) probe[i];
 			#pragma unroll
-			for (int q = 0; q < NPR; q++) {
-				const double pv = (double) pr.p[q][i];
-				#pragma unroll
-				for (int j = 0; j < RPW; j++)
-					if (row0 + j < rs.count) acc[q][j] = fma((double) rs.row[row0 + j][i], pv, acc[q][j]);
-			}
+			for (int j = 0; j < RPW; j++)
+				if (row0 + j < rs.count) acc[j] = fma((double) rs.row[row0 + j][i], pv, acc[j]);
 		}
 	}
 	#pragma unroll
-	for (int q = 0; q < NPR; q++)
-		#pragma unroll
-		for (int j = 0; j < RPW; j++) {
-			const double t = wave_sum(acc[q][j]);
-			if (lane == 0 && row0 + j < rs.count) parts[(size_t) (q * rs.count + row0 + j) * kMaxGrid + blockIdx.x] = t;
-		}
-}
-
-// Gram maintenance for ring row r: a[j] = s_j'y_r (j < m), a[m+j] = y_j'y_r, b[j] = y_j's_r
-__global__ void __launch_bounds__(kBlock) k_gram_store(const double* a, int a_count, int a_stride, const double* b, int b_count,
-                                                       int b_stride, int m, int r, double* gsy, double* gyy)
-{
-	__shared__ double sh[kWaves];
-	for (int j = 0; j < m; j++) {
-		const double sjyr = total_of(a + (size_t) j * a_stride, a_count, sh);
-		const double yjyr = total_of(a + (size_t) (m + j) * a_stride, a_count, sh);
-		const double yjsr = total_of(b + (size_t) j * b_stride, b_count, sh);
-		if (threadIdx.x == 0) {
-			gsy[(size_t) j * m + r] = sjyr;
-			gsy[(size_t) r * m + j] = yjsr;
-			gyy[(size_t) j * m + r] = yjyr;
-			gyy[(size_t) r * m + j] = yjyr;
-		}
+	for (int j = 0; j < RPW; j++) {
+		const double t = wave_sum(acc[j]);
+		if (lane == 0 && row0 + j < rs.count) parts[(size_t) (row0 + j) * kMaxGrid + blockIdx.x] = t;
 	}
 }
 
@@ -910,382 +878,8 @@ __global__ void __launch_bounds__(kBlock) k_store_column(const double* a, int a_
 	}
 }
 
-// The scalar part of the recursion (reference src/stochqn.c:671-707 with every inner product
-// expanded over the cached Gram blocks).  One workgroup of 16 waves; one wave runs the recursion from LDS.
-// `fresh_row` >= 0: pass A was the 3-probe form over the k pairs in use (rows 0..k-1 = S, k..2k-1 = Y,
-// logical order) with probes (g, y_r, s_r), r = fresh_row: quantities 2k.. are the dots with y_r,
-// 4k.. the dots with s_r.  Ring row r's Gram row and column are stored first (no kernel of their own).
-__global__ void __launch_bounds__(kCoefBlock) k_coef(const double* bparts, int count, int stride, CoefArgs a, int fresh_row,
-                                                     double* gsy, double* gyy, double* alpha_out, double* rho_out, double* coef)
-{
-	__shared__ double SY[kPairsMax * kPairsMax], YY[kPairsMax * kPairsMax], bS[kPairsMax], bY[kPairsMax];
-	const int k = a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	if (fresh_row >= 0) {
-		const int m = a.m, r = fresh_row;
-		for (int i = wave; i < k; i += kCoefWaves) {
-			const int j = a.rows[i];
-			const double sjyr = wave_total_of(bparts + (size_t) (2 * k + i) * stride, count);       // s_j'y_r
-			const double yjyr = wave_total_of(bparts + (size_t) (2 * k + k + i) * stride, count);   // y_j'y_r
-			const double yjsr = wave_total_of(bparts + (size_t) (4 * k + k + i) * stride, count);   // y_j's_r
-			if (lane == 0) {
-				gsy[(size_t) j * m + r] = sjyr;
-				gsy[(size_t) r * m + j] = yjsr;
-				gyy[(size_t) j * m + r] = yjyr;
-				gyy[(size_t) r * m + j] = yjyr;
-			}
-		}
-		__threadfence_block();
-		__syncthreads();                                     // the copies below read what was just stored
-	}
-	for (int e = threadIdx.x; e < k * k; e += kCoefBlock) {  // logical-order copies of the Gram blocks
-		const int i = e / k, j = e % k;
-		SY[e] = gsy[(size_t) a.rows[i] * a.m + a.rows[j]];
-		YY[e] = gyy[(size_t) a.rows[i] * a.m + a.rows[j]];
-	}
-	for (int q = wave; q < 2 * k; q += kCoefWaves) {         // b = [S;Y]g, one wave per quantity
-		const double t = wave_total_of(bparts + (size_t) q * stride, count);
-		if (lane == 0) { if (q < k) bS[q] = t; else bY[q - k] = t; }
-	}
-	__syncthreads();
-	if (wave != 0) return;
-	// The recursion proper, by one wave: lane j keeps alpha_j and c_j, every inner sum over the pairs
-	// is one product per lane and a shuffle reduction (k <= kPairsMax < 64).
-	const bool mine = lane < k;
-	double al = 0, c = 0;
-	for (int i = k - 1; i >= 0; i--) {                       // backward loop: alpha_i = rho_i s_i'q_{i+1}
-		const double t = (mine && lane > i) ? al * SY[i * k + lane] : 0.0;
-		const double sq = bS[i] - wave_sum_all(t);
-		const double rho_i = 1.0 / SY[i * k + i];
-		if (lane == i) { al = rho_i * sq; alpha_out[i] = al; rho_out[i] = rho_i; }
-	}
-	const double gamma = (a.h0 > 0) ? a.h0 : SY[(k - 1) * k + (k - 1)] / YY[(k - 1) * k + (k - 1)];
-	for (int i = 0; i < k; i++) {                            // forward loop: beta_i = rho_i y_i'r_i
-		// y_i'r_i = gamma (y_i'g - sum_j alpha_j y_i'y_j) + sum_{j<i} c_j s_j'y_i
-		double t = mine ? -gamma * (al * YY[i * k + lane]) : 0.0;
-		if (lane < i) t = fma(c, SY[lane * k + i], t);
-		const double yr = fma(gamma, bY[i], wave_sum_all(t));
-		if (lane == i) c = al - (1.0 / SY[i * k + i]) * yr;         // alpha_i - rho_i y_i'r_i
-	}
-	if (lane == 0) coef[0] = gamma;
-	if (mine) {
-		coef[1 + lane] = -(gamma * al);                      // coefficient of y_lane
-		coef[1 + k + lane] = c;                              // coefficient of s_lane
-	}
-}
-
-// pass B: r = gamma g + sum_i cy_i y_i + sum_i cs_i s_i  (pairs visited oldest to newest).
-// A lane finishes T packs before it stores any of them: the single store stream (1 of 2k+2) costs
-// disproportionately when it trickles out between the loads, less when it leaves in groups.
-template <int W, bool NT, int T, bool H0V, bool SS>
-__global__ void __launch_bounds__(kBlock) k_combine(RowSet ys, RowSet ss, const double* coef, real* g, const real* H0,
-                                                    uint32_t n, int rev, double* parts)
-{
-	__shared__ double sh[kWaves];
-	__shared__ double cf[1 + 2 * kPairsMax];
-	const int k = ys.count;
-	for (int e = threadIdx.x; e < 1 + 2 * k; e += kBlock) cf[e] = coef[e];
-	__syncthreads();
-	double acc0 = 0, acc1 = 0;
-	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
-	for (uint32_t p0 = blockIdx.x * kBlock + threadIdx.x; p0 < packs; p0 += T * stride) {
-		Pack<W> out[T];
-		#pragma unroll
-		for (int t = 0; t < T; t++) {
-			const uint32_t p = p0 + t * stride;
-			if (p < packs) {
-				const uint32_t i = (rev ? last - p : p) * W;
-				Pack<W> r = ld<W, false>(g, i);
-				if constexpr (H0V) {
-					// q_0 = g - sum alpha_j y_j (newest pair first), r_0 = q_0 .* H0, then the s terms
-					const Pack<W> h = ld<W, false>(H0, i);
-					for (int j0 = k; j0 > 0; j0 -= 4) {
-						RPack<W> fy[4];
-						#pragma unroll
-						for (int u = 0; u < 4; u++)
-							if (j0 - 1 - u >= 0) fy[u] = ldr<W, NT>(ys.row[j0 - 1 - u], i);
-						#pragma unroll
-						for (int u = 0; u < 4; u++)
-							if (j0 - 1 - u >= 0) {
-								#pragma unroll
-								for (int e = 0; e < W; e++) r.v[e] = fma(cf[1 + j0 - 1 - u], (double) fy[u].v[e], r.v[e]);
-							}
-					}
-					#pragma unroll
-					for (int e = 0; e < W; e++) r.v[e] = r.v[e] * h.v[e];
-					for (int j0 = 0; j0 < k; j0 += 4) {
-						RPack<W> fs[4];
-						#pragma unroll
-						for (int u = 0; u < 4; u++)
-							if (j0 + u < k) fs[u] = ldr<W, NT>(ss.row[j0 + u], i);
-						#pragma unroll
-						for (int u = 0; u < 4; u++)
-							if (j0 + u < k) {
-								#pragma unroll
-								for (int e = 0; e < W; e++) r.v[e] = fma(cf[1 + k + j0 + u], (double) fs[u].v[e], r.v[e]);
-							}
-					}
-				} else {
-					#pragma unroll
-					for (int e = 0; e < W; e++) r.v[e] = cf[0] * r.v[e];
-					for (int j0 = 0; j0 < k; j0 += 4) {
-						RPack<W> fy[4], fs[4];
-						#pragma unroll
-						for (int u = 0; u < 4; u++)
-							if (j0 + u < k) { fy[u] = ldr<W, NT>(ys.row[j0 + u], i); fs[u] = ldr<W, NT>(ss.row[j0 + u], i); }
-						#pragma unroll
-						for (int u = 0; u < 4; u++)
-							if (j0 + u < k) {
-								#pragma unroll
-								for (int e = 0; e < W; e++) {
-									r.v[e] = fma(cf[1 + j0 + u], (double) fy[u].v[e], r.v[e]);
-									r.v[e] = fma(cf[1 + k + j0 + u], (double) fs[u].v[e], r.v[e]);
-								}
-							}
-					}
-				}
-				#pragma unroll
-				for (int e = 0; e < W; e++) { acc0 = fma(r.v[e], r.v[e], acc0); acc1 += (isfinite(r.v[e]) ? 0.0 : 1.0); }
-				out[t] = r;
-			}
-		}
-		#pragma unroll
-		for (int t = 0; t < T; t++) {
-			const uint32_t p = p0 + t * stride;
-			if (p < packs) {
-				if constexpr (SS) st_stream<W>(g, (rev ? last - p : p) * W, out[t]);
-				else st<W>(g, (rev ? last - p : p) * W, out[t]);
-			}
-		}
-	}
-	if (W > 1) {
-		const uint32_t i = packs * W + threadIdx.x;
-		if (blockIdx.x == gridDim.x - 1 && i < n) {
-			double r;
-			if constexpr (H0V) {
-				r = g[i];
-				for (int j = k - 1; j >= 0; j--) r = fma(cf[1 + j], ys.row[j][i], r);
-				r = r * H0[i];
-				for (int j = 0; j < k; j++) r = fma(cf[1 + k + j], ss.row[j][i], r);
-			} else {
-				r = cf[0] * g[i];
-				for (int j = 0; j < k; j++) { r = fma(cf[1 + j], ys.row[j][i], r); r = fma(cf[1 + k + j], ss.row[j][i], r); }
-			}
-			acc0 = fma(r, r, acc0); acc1 += (isfinite(r) ? 0.0 : 1.0);
-			g[i] = r;
-		}
-	}
-	const double t0 = block_sum(acc0, sh), t1 = block_sum(acc1, sh);
-	if (threadIdx.x == 0) { parts[blockIdx.x] = t0; parts[kMaxGrid + blockIdx.x] = t1; }
-}
-
 // ------------------------------------------------------------------------------------------------
-// pass A with adaQN's diagonal H0: all inner products of one step in one pass over S and Y.
-// A workgroup stages a tile of kTile columns of every row in LDS (one 1 KiB wave-load per row tile,
-// rows dealt round-robin to the 4 waves), wave 0 applies the side effects on the raw gradient and
-// publishes h = g/sqrt(G+eps), the waves write z_i = y_i .* h next to their y_i, and then every
-// THREAD owns one or two of the Q = 3k + k(k+1)/2 quantities and walks the tile:
-// quantity(rowA, rowB) += sum_e L[rowA][e] L[rowB][e].  No cross-lane reduction at all; the
-// per-workgroup partial of a quantity is that thread's accumulator.
-// ------------------------------------------------------------------------------------------------
-constexpr int kTile = 128;             // columns per tile: lane l stages columns 2l, 2l+1 and accumulates l, l+64
-constexpr int kTileLd = kTile + 2;     // LDS row stride in doubles (even: 16-B aligned pairs)
-
-// two neighbouring columns of a row, widened to double: one real2 access (VEC; any element alignment,
-// the last column of an odd n on its own), else two scalar accesses; columns at or beyond n read as
-// `fill` and are never written
-template <bool VEC, bool NT, bool FULL> __device__ __forceinline__ d2 ld_cols(const real* p, uint32_t i, uint32_t n, double fill)
-{
-	d2 v = {fill, fill};
-	if constexpr (VEC) {
-		if (FULL || i + 1 < n) {                             // FULL: the whole tile is inside [0, n), no per-lane checks
-			const real2 t = NT ? __builtin_nontemporal_load(reinterpret_cast<const real2_u*>(p + i)) : *reinterpret_cast<const real2_u*>(p + i);
-			v.x = (double) t.x; v.y = (double) t.y;
-		} else if (i < n) v.x = (double) p[i];
-	} else {
-		if (FULL || i < n) v.x = (double) (NT ? __builtin_nontemporal_load(p + i) : p[i]);
-		if (FULL || i + 1 < n) v.y = (double) (NT ? __builtin_nontemporal_load(p + i + 1) : p[i + 1]);
-	}
-	return v;
-}
-template <bool VEC, bool FULL> __device__ __forceinline__ void st_cols(real* p, uint32_t i, uint32_t n, d2 v)
-{
-	if constexpr (VEC) {
-		if (FULL || i + 1 < n) { real2 t; t.x = (real) v.x; t.y = (real) v.y; *reinterpret_cast<real2_u*>(p + i) = t; }
-		else if (i < n) p[i] = (real) v.x;
-	} else { if (FULL || i < n) p[i] = (real) v.x; if (FULL || i + 1 < n) p[i + 1] = (real) v.y; }
-}
-
-// The body of k_gram_h0 for wave WAVE of the workgroup.  KT = ring size rounded up (compile time), so
-// that every accumulator has a compile-time register: this wave owns the pairs whose older index is
-// i = WAVE, WAVE+4, ...: u_i, y_i'g, s_i'g and W_ij for j >= i -- per lane, per column, summed over
-// the lane's two columns of every tile; one shuffle reduction per quantity at the very end.
-template <int KT, int WAVE, bool VEC>
-__device__ __forceinline__ void gram_h0_wave(const GramH0Args& a, bool rms, double w_old, double w_new, uint32_t n, double* parts,
-                                             double* L)
-{
-	constexpr int kMine = (KT - WAVE + kWaves - 1) / kWaves;      // rows i = WAVE + 4*ii owned by this wave
-	const int k = a.s_rows.count;
-	const int lane = threadIdx.x & 63;
-	const int rowG = 2 * k, rowH = 2 * k + 1;
-	double aS[kMine], aY[kMine], aU[kMine], aW[kMine][KT];         // aW[ii][j] used for j >= i only (rest folds away)
-	#pragma unroll
-	for (int ii = 0; ii < kMine; ii++) {
-		aS[ii] = aY[ii] = aU[ii] = 0;
-		#pragma unroll
-		for (int j = 0; j < KT; j++) aW[ii][j] = 0;
-	}
-	const uint32_t tiles = (n + kTile - 1) / kTile;
-	for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-		const uint32_t i0 = tile * kTile + 2 * lane;               // the two columns this lane stages
-		// -- stage: rows r = WAVE + 4u of S and Y (all loads first), wave 0 also g, G and the side effects.
-		// Two copies of this code: tiles that lie wholly inside [0, n) -- all but the last -- carry no
-		// per-lane bounds checks (with them the kernel ran 8.0 instead of 6.7 ms at n = 1e8, k = 20).
-		auto stage = [&](auto full_tag) {
-			constexpr bool FULL = decltype(full_tag)::value;
-			d2 sv[kMine], yv[kMine];
-			#pragma unroll
-			for (int u = 0; u < kMine; u++) {
-				const int r = WAVE + u * kWaves;
-				sv[u] = (r < k) ? ld_cols<VEC, true, FULL>(a.s_rows.row[r], i0, n, 0.0) : d2{0, 0};
-				yv[u] = (r < k) ? ld_cols<VEC, true, FULL>(a.y_rows.row[r], i0, n, 0.0) : d2{0, 0};
-			}
-			if constexpr (WAVE == 0) {
-				const d2 gv = ld_cols<VEC, false, FULL>(a.g, i0, n, 0.0);
-				const d2 Gv = ld_cols<VEC, false, FULL>(a.G, i0, n, 1.0);
-				d2 Gn, h;
-				Gn.x = rms ? (w_old * Gv.x + w_new * (gv.x * gv.x)) : (Gv.x + gv.x * gv.x);      // reference :738 / :745
-				Gn.y = rms ? (w_old * Gv.y + w_new * (gv.y * gv.y)) : (Gv.y + gv.y * gv.y);
-				h.x = gv.x / sqrt(Gn.x + a.scal_reg);                                                // :781
-				h.y = gv.y / sqrt(Gn.y + a.scal_reg);
-				st_cols<VEC, FULL>(a.G, i0, n, Gn);
-				st_cols<VEC, FULL>(a.H0_out, i0, n, h);
-				if (a.frow_out) st_cols<VEC, FULL>(a.frow_out, i0, n, gv);
-				if (!FULL && i0 >= n) h.x = 0;                         // columns beyond n must not contribute
-				if (!FULL && i0 + 1 >= n) h.y = 0;
-				*reinterpret_cast<d2*>(L + rowG * kTileLd + 2 * lane) = gv;
-				*reinterpret_cast<d2*>(L + rowH * kTileLd + 2 * lane) = h;
-			}
-			#pragma unroll
-			for (int u = 0; u < kMine; u++) {
-				const int r = WAVE + u * kWaves;
-				if (r < k) {
-					*reinterpret_cast<d2*>(L + r * kTileLd + 2 * lane) = sv[u];
-					*reinterpret_cast<d2*>(L + (k + r) * kTileLd + 2 * lane) = yv[u];
-				}
-			}
-		};
-		if (tile * kTile + kTile <= n) stage(std::true_type{}); else stage(std::false_type{});
-		__syncthreads();
-		// -- accumulate: columns lane and lane + 64 of the tile, all of this wave's quantities in registers
-		#pragma unroll
-		for (int half = 0; half < 2; half++) {
-			const int c = lane + 64 * half;
-			const double gc = L[rowG * kTileLd + c], hc = L[rowH * kTileLd + c];
-			double y[KT];
-			#pragma unroll
-			for (int j = 0; j < KT; j++) y[j] = (j < k) ? L[(k + j) * kTileLd + c] : 0.0;
-			#pragma unroll
-			for (int ii = 0; ii < kMine; ii++) {
-				constexpr int dummy = 0; (void) dummy;
-				const int i = WAVE + ii * kWaves;
-				if (i < k) {
-					const double sc_ = L[i * kTileLd + c];
-					const double z = y[i] * hc;
-					aS[ii] = fma(sc_, gc, aS[ii]);
-					aY[ii] = fma(y[i], gc, aY[ii]);
-					aU[ii] = fma(z, gc, aU[ii]);
-					#pragma unroll
-					for (int j = 0; j < KT; j++)
-						if (j >= i) aW[ii][j] = fma(z, y[j], aW[ii][j]);   // j >= k adds z*0
-				}
-			}
-		}
-		__syncthreads();
-	}
-	// -- one partial per quantity and workgroup
-	#pragma unroll
-	for (int ii = 0; ii < kMine; ii++) {
-		const int i = WAVE + ii * kWaves;
-		if (i < k) {
-			const double tS = wave_sum(aS[ii]), tY = wave_sum(aY[ii]), tU = wave_sum(aU[ii]);
-			if (lane == 0) {
-				parts[(size_t) i * kMaxGrid + blockIdx.x] = tS;
-				parts[(size_t) (k + i) * kMaxGrid + blockIdx.x] = tY;
-				parts[(size_t) (2 * k + i) * kMaxGrid + blockIdx.x] = tU;
-			}
-			const int base = 3 * k + i * k - (i * (i - 1)) / 2;        // first W_ij of row i (i-major, j >= i)
-			#pragma unroll
-			for (int j = 0; j < KT; j++) {
-				if (j >= i && j < k) {
-					const double t = wave_sum(aW[ii][j]);
-					if (lane == 0) parts[(size_t) (base + j - i) * kMaxGrid + blockIdx.x] = t;
-				}
-			}
-		}
-	}
-}
-
-template <int KT, bool VEC>
-__global__ void __launch_bounds__(kBlock) k_gram_h0(GramH0Args a, bool rms, double w_old, double w_new, uint32_t n, double* parts)
-{
-	extern __shared__ __attribute__((aligned(16))) double L[];       // (2k+2) rows x kTileLd: S | Y | g | h
-	switch (threadIdx.x >> 6) {
-	case 0: gram_h0_wave<KT, 0, VEC>(a, rms, w_old, w_new, n, parts, L); break;
-	case 1: gram_h0_wave<KT, 1, VEC>(a, rms, w_old, w_new, n, parts, L); break;
-	case 2: gram_h0_wave<KT, 2, VEC>(a, rms, w_old, w_new, n, parts, L); break;
-	default: gram_h0_wave<KT, 3, VEC>(a, rms, w_old, w_new, n, parts, L); break;
-	}
-}
-
-// Scalar recursion for the diagonal-H0 form.  Backward loop as in k_coef; forward loop with
-// y_i'r_0 = u_i - sum_j alpha_j W_ij.  coef: [1+j] = -alpha_j (inside the H0 bracket), [1+k+j] = c_j.
-__global__ void __launch_bounds__(kCoefBlock) k_coef_h0(const double* bparts, int count, int stride, CoefArgs a, const double* gsy,
-                                                        double* alpha_out, double* rho_out, double* coef)
-{
-	__shared__ double SY[kPairsMax * kPairsMax], Wm[kPairsMax * kPairsMax], bS[kPairsMax], U[kPairsMax];
-	const int k = a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int Q = 3 * k + k * (k + 1) / 2;
-	for (int e = threadIdx.x; e < k * k; e += kCoefBlock) SY[e] = gsy[(size_t) a.rows[e / k] * a.m + a.rows[e % k]];
-	for (int q = wave; q < Q; q += kCoefWaves) {
-		if (q >= k && q < 2 * k) continue;                   // y_i'g: not needed by this form
-		const double t = wave_total_of(bparts + (size_t) q * stride, count);
-		if (lane == 0) {
-			if (q < k) bS[q] = t;
-			else if (q < 3 * k) U[q - 2 * k] = t;
-			else {
-				int r = q - 3 * k, i = 0;
-				while (r >= k - i) { r -= k - i; i++; }
-				Wm[i * k + i + r] = t;
-				Wm[(i + r) * k + i] = t;
-			}
-		}
-	}
-	__syncthreads();
-	if (wave != 0) return;
-	const bool mine = lane < k;                              // lane j keeps alpha_j and c_j (see k_coef)
-	double al = 0, c = 0;
-	for (int i = k - 1; i >= 0; i--) {
-		const double t = (mine && lane > i) ? al * SY[i * k + lane] : 0.0;
-		const double sq = bS[i] - wave_sum_all(t);
-		const double rho_i = 1.0 / SY[i * k + i];
-		if (lane == i) { al = rho_i * sq; alpha_out[i] = al; rho_out[i] = rho_i; }
-	}
-	for (int i = 0; i < k; i++) {
-		// y_i'r_i = y_i'(H0 .* g) - sum_j alpha_j y_i'(H0 .* y_j) + sum_{j<i} c_j s_j'y_i
-		double t = mine ? -(al * Wm[i * k + lane]) : 0.0;
-		if (lane < i) t = fma(c, SY[lane * k + i], t);
-		const double yr = U[i] + wave_sum_all(t);
-		if (lane == i) c = al - (1.0 / SY[i * k + i]) * yr;         // alpha_i - rho_i y_i'r_i
-	}
-	if (lane == 0) coef[0] = 1.0;
-	if (mine) {
-		coef[1 + lane] = -al;
-		coef[1 + k + lane] = c;
-	}
-}
-
-// ------------------------------------------------------------------------------------------------
-// three-pass form: S is streamed twice, Y ONCE -- (3k+5) n words per two-loop instead of (4k+3) n.
+// three-pass form: S is streamed twice, Y ONCE -- (3k+5) n words per two-loop instead of the sweeps' 8k n.
 //   pass 1  b_i = s_i'g                      (k rows of S + g; after a new pair: + the probe y_new -> s_i'y_new)
 //   coef a  backward recursion:  alpha_i = rho_i (b_i - sum_{j>i} alpha_j s_i'y_j)          (cached s_old'y_new)
 //   pass 2  q0 = g - sum_j alpha_j y_j (newest first, element by element exactly as the reference's sweeps);
@@ -1294,9 +888,9 @@ __global__ void __launch_bounds__(kCoefBlock) k_coef_h0(const double* bparts, in
 //   coef b  forward recursion:   beta_i = rho_i (v_i + sum_{j<i} c_j s_j'y_i),  c_i = alpha_i - beta_i
 //   pass 3  r = r0 + sum_j c_j s_j (oldest first, as the sweeps), guard sums
 // The only cached inner products are s_a'y_b for pairs a older than b (+ the diagonal): when pair b enters the
-// ring as the newest, one extra probe in the next pass 1 yields its column.  Compared with the two-pass form
-// the inner products with Y (y_i'g, y_i'y_j, the H0-weighted W_ij of adaQN) disappear: y_i'r0 is a direct dot
-// with the vector it belongs to.  Reference: src/stochqn.c:663-708.
+// ring as the newest, one extra probe in the next pass 1 yields its column.  No inner products with Y are cached
+// (round 1's two-pass form kept y_i'g, y_i'y_j and adaQN's H0-weighted W_ij, and read Y twice; retired in round 4):
+// y_i'r0 is a direct dot with the vector it belongs to.  Reference: src/stochqn.c:663-708.
 // ------------------------------------------------------------------------------------------------
 // The scalar recursions of the three-pass form inside the prologues of pass 2 and pass 3 (option "fold_coef"): every
 // workgroup totals the previous pass's partials and runs the recursion itself -- the same functions in the same order as
@@ -1794,8 +1388,7 @@ const char* kernel_name(int id)
 {
 	static const char* names[K_COUNT] = {
 		"first", "bwd", "mid", "fwd", "fwd_last", "apply", "pair_s", "pair_y_diff", "pair_y_hv",
-		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy", "rows_dot", "coef", "combine", "gram", "rows_dot3", "gram_h0",
-		"sdot", "sdot2", "qdot", "sadd"};
+		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy", "coef", "sdot", "sdot2", "qdot", "sadd"};
 	return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
@@ -1949,9 +1542,8 @@ static bool rows_aligned(const RowSet& r)
 	return true;
 }
 
-// Workgroups of the row-split kernel that are resident per CU (register-limited: 3 at 10 rows per
-// wave and 3 probes).  The grid is a whole number of such rounds: 1024 workgroups at 3 per CU ran
-// 40 % slower than 768 (a second, quarter-full round).
+// Workgroups of the row-split kernel that are resident per CU (register-limited).  The grid is a whole
+// number of such rounds: 1024 workgroups at 3 per CU ran 40 % slower than 768 (a second, quarter-full round).
 template <class K> static int resident_per_cu(K kernel, int threads)
 {
 	int blocks = 0;
@@ -1959,19 +1551,18 @@ template <class K> static int resident_per_cu(K kernel, int threads)
 	return blocks > 8 ? 8 : blocks;
 }
 
-template <int W, int NPR, int NW>
-static int rows_dot_dispatch(const Scratch& sc, int slot, size_t max_grid, int rpw, const RowSet& rows, const Probes& pr,
-                             real* copy_out, uint32_t n, int rev)
+template <int W, int NW>
+static int rows_dot_dispatch(const Scratch& sc, size_t max_grid, int rpw, const RowSet& rows, const real* probe, real* copy_out, uint32_t n, int rev)
 {
 	int grid = 1;
 	#define SQN_RD(RPW)                                                                                                  \
 		{                                                                                                                \
-			static const int per_cu = resident_per_cu(k_rows_dot<W, RPW, NPR, true, NW>, 64 * NW);                         \
+			static const int per_cu = resident_per_cu(k_rows_dot<W, RPW, true, NW>, 64 * NW);                             \
 			size_t g = sc.rows_grid > 0 ? (size_t) sc.rows_grid : (size_t) sc.grid_cap * per_cu;                          \
 			if (g > max_grid) g = max_grid;                                                                              \
 			if (g > (size_t) kMaxGrid) g = kMaxGrid;                                                                     \
 			grid = (int) g;                                                                                              \
-			hipLaunchKernelGGL((k_rows_dot<W, RPW, NPR, true, NW>), dim3(grid), dim3(64 * NW), 0, sc.stream, rows, pr, copy_out, n, rev, sc.rows_part[slot]); \
+			hipLaunchKernelGGL((k_rows_dot<W, RPW, true, NW>), dim3(grid), dim3(64 * NW), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[0]); \
 		}
 	if (rpw <= 2) SQN_RD(2)
 	else if (rpw <= 4) SQN_RD(4)
@@ -1999,99 +1590,40 @@ static void rows_dot_all_dispatch(const Scratch& sc, int slot, int grid, int ng,
 	#undef SQN_RA
 }
 
-Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& rows, const real* probe, real* copy_out,
-                         int kernel_id, const real* probe_y, const real* probe_s)
+// pass 1 without a second probe as the row-split kernel (option "rows_split": the float build's default); one launch, never sliced.
+// A workgroup covers 64 packs per step here (its waves split the rows), so it takes more workgroups than a sweep to keep
+// the same number of lanes on the columns.
+static int sdot_row_split(const Scratch& sc, size_t n, const RowSet& rows, const real* probe, real* copy_out, int rev)
 {
-	// Single probe: every lane keeps all rows.  (The same shape with the three probes of the Gram-row pass --
-	// 3 x 40 accumulators per lane -- measured 12.3 ms against 6.85 ms for the row-split kernel at n = 1e8,
-	// k = 20, and 0.58 against 0.35 ms at n = 1e7, k = 10: profiles/r02_ab_rows3_fisher.jsonl; not instantiated.)
-	if (!probe_y && !sc.rows_split) {
-		const int grid = sweep_grid(sc, n);
-		const bool vec = rows_aligned(rows) && all_aligned(probe, copy_out);
-		const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
-		const Probes pr{{probe, nullptr, nullptr}};
-		const int ng = (rows.count + 7) / 8;
-		{
-			ProfScope ps(sc, kernel_id);
-			if (vec) rows_dot_all_dispatch<kVec, 1>(sc, slot, grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
-			else     rows_dot_all_dispatch<1, 1>(sc, slot, grid, ng, rows, pr, copy_out, (uint32_t) n, rev);
-		}
-		const int nq = rows.count;
-		Partials raw{sc.rows_part[slot], grid, kMaxGrid};
-		if (!sc.allreduce) return raw;
-		launch_fin(sc, raw, nq, sc.red[slot]);
-		sc.allreduce(sc.user, sc.red[slot], nq, sc.stream);
-		return Partials{sc.red[slot], 1, 1};
-	}
-
-	// a workgroup covers 64 packs per step here (its 4 waves split the rows), so it takes 4x the
-	// workgroups of a sweep to keep the same number of lanes on the columns
-	const bool vec = rows_aligned(rows) && all_aligned(probe, copy_out, probe_y, probe_s);
-	size_t max_grid = (n / (vec ? kVec : 1) + 63) / 64;         // a workgroup covers 64 packs per step here
+	const bool vec = rows_aligned(rows) && all_aligned(probe, copy_out);
+	size_t max_grid = (n / (vec ? kVec : 1) + 63) / 64;
 	if (max_grid < 1) max_grid = 1;
-	int grid = 1;
-	// waves of a workgroup that split the rows; measured: 8 for a single probe (4.94 vs 5.10 ms of the
-	// all-rows form, n = 1e8, 40 rows), 4 with three probes (7.00 vs 7.08 ms)
-	const int npr_ = probe_y ? 3 : 1;
-	const int nw = sc.rows_waves == 8 ? 8 : (sc.rows_waves == 4 ? kWaves : (npr_ == 1 ? 8 : kWaves));
-	const int ng = (rows.count + nw - 1) / nw;              // rows per wave
-	const int npr = probe_y ? 3 : 1;
-	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
-	const Probes pr{{probe, probe_y, probe_s}};
-	{
-		ProfScope ps(sc, kernel_id);
-		#define SQN_GO(WW, PP) (nw == 8 ? rows_dot_dispatch<WW, PP, 8>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev) \
-		                                : rows_dot_dispatch<WW, PP, 4>(sc, slot, max_grid, ng, rows, pr, copy_out, (uint32_t) n, rev))
-		if (npr == 3) grid = vec ? SQN_GO(kVec, 3) : SQN_GO(1, 3);
-		else          grid = vec ? SQN_GO(kVec, 1) : SQN_GO(1, 1);
-		#undef SQN_GO
-	}
-	const int nq = npr * rows.count;
-	Partials raw{sc.rows_part[slot], grid, kMaxGrid};
-	if (!sc.allreduce) return raw;
-	launch_fin(sc, raw, nq, sc.red[slot]);
-	sc.allreduce(sc.user, sc.red[slot], nq, sc.stream);
-	return Partials{sc.red[slot], 1, 1};
-}
-
-void launch_gram_store(const Scratch& sc, Partials a, Partials b, int m, int r)
-{
-	ProfScope ps(sc, K_SMALL);
-	hipLaunchKernelGGL(k_gram_store, dim3(1), dim3(kBlock), 0, sc.stream, a.parts, a.count, a.stride, b.parts, b.count, b.stride,
-	                   m, r, sc.gsy, sc.gyy);
-}
-
-void launch_coef(const Scratch& sc, Partials b, const CoefArgs& a, int fresh_row)
-{
-	ProfScope ps(sc, K_COEF);
-	hipLaunchKernelGGL(k_coef, dim3(1), dim3(kCoefBlock), 0, sc.stream, b.parts, b.count, b.stride, a, fresh_row, sc.gsy, sc.gyy,
-	                   sc.alpha, sc.rho, sc.coef);
-}
-
-Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& ys, const RowSet& ss, real* g, const real* H0)
-{
-	const int grid = sweep_grid(sc, n, 2);
-	const bool vec = rows_aligned(ys) && rows_aligned(ss) && all_aligned(g, H0);
-	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
-	{
-		ProfScope ps(sc, K_COMBINE);
-		#define SQN_CB(W, T, HV) { if (sc.stream_stores) hipLaunchKernelGGL((k_combine<W, true, T, HV, true>), dim3(grid), dim3(kBlock), 0, sc.stream, ys, ss, sc.coef, g, H0, (uint32_t) n, rev, sc.part[buf]); \
-		                           else hipLaunchKernelGGL((k_combine<W, true, T, HV, false>), dim3(grid), dim3(kBlock), 0, sc.stream, ys, ss, sc.coef, g, H0, (uint32_t) n, rev, sc.part[buf]); }
-		const int T = sc.combine_batch;
-		if (H0) {
-			if (vec) { if (T >= 4) SQN_CB(kVec, 4, true) else SQN_CB(kVec, 1, true) }
-			else     { if (T >= 4) SQN_CB(1, 4, true) else SQN_CB(1, 1, true) }
-		} else {
-			if (vec) { if (T >= 16) SQN_CB(kVec, 16, false) else if (T >= 8) SQN_CB(kVec, 8, false) else if (T >= 4) SQN_CB(kVec, 4, false) else if (T >= 2) SQN_CB(kVec, 2, false) else SQN_CB(kVec, 1, false) }
-			else     { if (T >= 8) SQN_CB(1, 8, false) else if (T >= 4) SQN_CB(1, 4, false) else if (T >= 2) SQN_CB(1, 2, false) else SQN_CB(1, 1, false) }
-		}
-		#undef SQN_CB
-	}
-	return finish(sc, buf, 2, grid);
+	// waves of a workgroup that split the rows; measured: 8 (4.94 vs 5.10 ms of the all-rows form, n = 1e8, 40 rows)
+	const int nw = sc.rows_waves == 4 ? kWaves : 8;
+	const int rpw = (rows.count + nw - 1) / nw;             // rows per wave
+	ProfScope ps(sc, K_SDOT);
+	#define SQN_GO(WW) (nw == 8 ? rows_dot_dispatch<WW, 8>(sc, max_grid, rpw, rows, probe, copy_out, (uint32_t) n, rev) \
+	                            : rows_dot_dispatch<WW, 4>(sc, max_grid, rpw, rows, probe, copy_out, (uint32_t) n, rev))
+	return vec ? SQN_GO(kVec) : SQN_GO(1);
+	#undef SQN_GO
 }
 
 // ---- three-pass form ---------------------------------------------------------------------------------
 // pass 1: the single-probe / two-probe all-rows rows-dot over the k rows of S
+static int sdot_grid(const Scratch& sc, size_t n, bool two_probes)
+{
+	// the two-probe variant (2 x k accumulators, 145 VGPRs: three waves per SIMD) wants three workgroups per CU: 2.78 ms
+	// against 5.12 ms with one and 3.01 ms for the row-split shape (n = 1e8, k = 20; profiles/r02_ab_threepass_shapes.jsonl)
+	return sweep_grid(sc, n, two_probes ? (sc.sdot2_per_cu > 0 ? sc.sdot2_per_cu : 3) : (sc.sdot_per_cu > 0 ? sc.sdot_per_cu : 1));
+}
+
+// doubles of carry scratch a sliced pass 1 over k rows needs (either probe variant): one accumulator per quantity and lane of the grid
+size_t sdot_carry_count(const Scratch& sc, size_t n, int k)
+{
+	const size_t one = (size_t) k * (size_t) sdot_grid(sc, n, false), two = 2 * (size_t) k * (size_t) sdot_grid(sc, n, true);
+	return (one > two ? one : two) * kBlock;
+}
+
 bool sdot_can_slice(const Scratch& sc, const RowSet& s_rows, const real* g, real* copy_out, const real* probe_y)
 {
 	return (probe_y || !sc.rows_split) && rows_aligned(s_rows) && all_aligned(g, copy_out, probe_y);
@@ -2099,19 +1631,17 @@ bool sdot_can_slice(const Scratch& sc, const RowSet& s_rows, const real* g, real
 
 Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows, const real* g, real* copy_out, const real* probe_y, const SliceFeed* feed)
 {
-	if (!probe_y && sc.rows_split) {                           // float build: the row-split kernel (not sliced)
-		if (feed) feed->arrive(feed->user, 0, n, 0);
-		return launch_rows_dot(sc, 0, n, s_rows, g, copy_out, K_SDOT);
-	}
-	// the two-probe variant (2 x k accumulators, 145 VGPRs: three waves per SIMD) wants three workgroups per CU: 2.78 ms
-	// against 5.12 ms with one and 3.01 ms for the row-split shape (n = 1e8, k = 20; profiles/r02_ab_threepass_shapes.jsonl)
-	const int grid = sweep_grid(sc, n, probe_y ? (sc.sdot2_per_cu > 0 ? sc.sdot2_per_cu : 3) : (sc.sdot_per_cu > 0 ? sc.sdot_per_cu : 1));
+	int grid = sdot_grid(sc, n, probe_y != nullptr);
 	const bool vec = rows_aligned(s_rows) && all_aligned(g, copy_out, probe_y);
 	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
-	const Probes pr{{g, probe_y, nullptr}};
+	const Probes pr{{g, probe_y}};
 	const int ng = (s_rows.count + 7) / 8;
 	const size_t packs = n / kVec, round = (size_t) grid * kBlock;
-	if (feed && vec && feed->slices >= 2 && packs >= 2 * round) {
+	if (!probe_y && sc.rows_split) {
+		if (feed) feed->arrive(feed->user, 0, n, 0);
+		grid = sdot_row_split(sc, n, s_rows, g, copy_out, rev);
+	} else if (feed && vec && feed->slices >= 2 && packs >= 2 * round && feed->carry &&
+	           feed->carry_count >= (size_t) (probe_y ? 2 : 1) * (size_t) s_rows.count * round) {
 		// the pass in slices of whole grid rounds; before slice s its part of g is sent for (feed->arrive), and the kernel of
 		// that slice is what the stream runs once it has landed
 		size_t per = (packs + (size_t) feed->slices - 1) / (size_t) feed->slices;
@@ -2216,6 +1746,7 @@ bool sadd_can_slice(const Scratch& sc, size_t n, const RowSet& s_rows, const rea
 {
 	if (!drain || fuse || drain->slices < 2 || !rows_aligned(s_rows) || !all_aligned(r)) return false;
 	const int grid = sweep_grid(sc, n, sc.sadd_per_cu > 0 ? sc.sadd_per_cu : 2);
+	if (!drain->carry || drain->carry_count < 2 * (size_t) grid * kBlock) return false;
 	const int T = sc.combine_batch;
 	const size_t round = (size_t) grid * kBlock * (size_t) (T >= 8 ? 8 : (T >= 4 ? 4 : 1));
 	return n / kVec >= 2 * round;
@@ -2281,53 +1812,6 @@ void launch_store_column(const Scratch& sc, Partials in, const CoefArgs& a, int 
 {
 	ProfScope ps(sc, K_SMALL);
 	hipLaunchKernelGGL(k_store_column, dim3(1), dim3(kBlock), 0, sc.stream, in.parts, in.count, in.stride, a, col_row, sc.gsy);
-}
-
-template <int KT>
-static void gram_h0_dispatch(const Scratch& sc, int grid, size_t shmem, bool vec, const GramH0Args& a, bool rms, uint32_t n)
-{
-	static bool lds_opt_in = false;
-	if (!lds_opt_in) {
-		const int bytes = (int) ((2 * kPairsMax + 2) * kTileLd * sizeof(double));
-		(void) hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_h0<KT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-		(void) hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_h0<KT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-		lds_opt_in = true;
-	}
-	if (vec) hipLaunchKernelGGL((k_gram_h0<KT, true>), dim3(grid), dim3(kBlock), shmem, sc.stream, a, rms, a.rmsprop_weight, 1 - a.rmsprop_weight, n, sc.rows_part[0]);
-	else     hipLaunchKernelGGL((k_gram_h0<KT, false>), dim3(grid), dim3(kBlock), shmem, sc.stream, a, rms, a.rmsprop_weight, 1 - a.rmsprop_weight, n, sc.rows_part[0]);
-}
-
-Partials launch_gram_h0(const Scratch& sc, size_t n, const GramH0Args& a)
-{
-	const int k = a.s_rows.count;
-	const int Q = 3 * k + k * (k + 1) / 2;
-	const size_t shmem = (size_t) (2 * k + 2) * kTileLd * sizeof(double);
-	size_t tiles = (n + kTile - 1) / kTile;
-	size_t g = (size_t) sc.grid_cap * (sc.h0_per_cu > 0 ? sc.h0_per_cu : 2);   // workgroups that stage while others accumulate
-	if (g > tiles) g = tiles;
-	if (g > (size_t) kMaxGrid) g = kMaxGrid;
-	if (g < 1) g = 1;
-	const int grid = (int) g;
-	const bool rms = a.rmsprop_weight > 0 && a.rmsprop_weight < 1;
-	const bool vec = all_aligned(a.g, a.G, a.H0_out, a.frow_out) && rows_aligned(a.s_rows) && rows_aligned(a.y_rows);
-	{
-		ProfScope ps(sc, K_GRAM_H0);
-		if (k <= 12) gram_h0_dispatch<12>(sc, grid, shmem, vec, a, rms, (uint32_t) n);
-		else if (k <= 20) gram_h0_dispatch<20>(sc, grid, shmem, vec, a, rms, (uint32_t) n);
-		else gram_h0_dispatch<24>(sc, grid, shmem, vec, a, rms, (uint32_t) n);
-	}
-	// Q = 3k + k(k+1)/2 quantities (270 at k = 20): reduce them with one workgroup each before the
-	// single-workgroup recursion kernel (which would otherwise spend 0.2 ms adding partials)
-	Partials raw{sc.rows_part[0], grid, kMaxGrid};
-	launch_fin(sc, raw, Q, sc.red[0]);
-	if (sc.allreduce) sc.allreduce(sc.user, sc.red[0], Q, sc.stream);
-	return Partials{sc.red[0], 1, 1};
-}
-
-void launch_coef_h0(const Scratch& sc, Partials b, const CoefArgs& a)
-{
-	ProfScope ps(sc, K_COEF);
-	hipLaunchKernelGGL(k_coef_h0, dim3(1), dim3(kCoefBlock), 0, sc.stream, b.parts, b.count, b.stride, a, sc.gsy, sc.alpha, sc.rho, sc.coef);
 }
 
 void launch_fin(const Scratch& sc, Partials in, int nsums, double* out)

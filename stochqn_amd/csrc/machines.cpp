@@ -109,6 +109,7 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 {
 	if (!b || !b->s_mem || !b->y_mem || n <= 0 || b->mem_size == 0) return false;
 	(void) hipGetLastError();        // errors other code left behind on this thread are not ours (see sync())
+	(void) take_hip_failure();
 	bool fresh = false;
 	DevCtx* c = acquire(b->s_mem, kind, n, b->mem_size, fsize, &fresh);
 	if (!c) return false;
@@ -124,9 +125,9 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 	io.fresh = fresh;
 	io.dev_requests = t_dev_requests;
 	if (fresh) attach_spill(c, niter, section);      // reclaimed while idle?  then its state comes back from the library's host copy
-	// a context that could not be completed is dropped again: the next call starts over (and
-	// re-imports host arrays) instead of continuing on half-bound views
-	if (!bind_bfgs(c, b, fresh && resumed)) { release(b->s_mem); return false; }
+	// a context that could not be completed is dropped again: the next call starts over (and re-imports host arrays, or
+	// finds the state a reclaimed predecessor left in host memory once more) instead of continuing on half-bound views
+	if (!bind_bfgs(c, b, fresh && resumed)) { abandon_context(b->s_mem); return false; }
 	if (!c->attached) {                  // first call on this context (created now, or ahead of time by a shard group)
 		comm_attach(c);
 		c->forget_rows();
@@ -146,7 +147,8 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 	                !(b->min_curvature > 0) && !options().verify_cache && c->sc.allreduce == nullptr;
 	// staging vectors for host x / grad exist before anything is enqueued: stage_xg cannot fail later
 	if ((io.host_caller && !ensure_stage(c, 0)) || (io.g_host && !ensure_stage(c, 1))) {
-		if (fresh) release(b->s_mem);
+		if (fresh) abandon_context(b->s_mem);
+		else end_use(c);
 		return false;
 	}
 	return true;
@@ -162,7 +164,7 @@ void stage_xg(Call& io, bool need_x, bool need_g, bool may_defer = false)
 	if (!need_g) return;
 	const int slices = options().upload_slices;
 	if (may_defer && io.g_host && slices >= 2 && N(c) >= ((size_t) 1 << 21) && ensure_stage(c, 1) &&
-	    ensure_upload_slices(c, slices, (size_t) 2 * c->m * (size_t) c->sc.grid_cap * 3 * kBlock)) {
+	    ensure_upload_slices(c, slices, sdot_carry_count(c->sc, N(c), (int) c->m))) {
 		(void) ensure_registered(c, io.g_caller, N(c) * sizeof(real));
 		io.g = c->stage[1];
 		io.g_pending = true;
@@ -338,19 +340,19 @@ Partials enqueue_two_loop(DevCtx* c, real* g, size_t used, size_t st, const Firs
 	return launch_fwd_last(sc, c->next_buf(), n, p, sc.sy + r_of(k - 1), (int) (k - 1), row(c->S, r_of(k - 1), c), g, fuse);
 }
 
-// ---- two-pass form (scalar H0): Gram maintenance + rows-dot / coef / combine ----------------------
-// The fallback rule of the two-pass form.  Expanding the recursion over cached inner products is the same
-// arithmetic as the reference's sequential sweeps associated differently: on every input class probed
-// (tests/test_gpu_adversarial.py: Hessian condition 1e8, nearly collinear pairs, inconsistent and negative
-// curvature, g in the span of Y, |g| ~ 1e+-150) both forms sit within a few ulps of an extended-precision
-// evaluation.  The exception is pairs with s almost orthogonal to y (rho_i = 1/s'y huge): there every form
-// loses digits -- about kappa_i = |s||y|/|s'y| per pair -- and the expanded form loses up to ~16x more than
-// the sequential one.  So the two-pass form is used only while every pair in use has kappa_i <= option
-// "twopass_kappa_max" (default 1e6); beyond, the step runs as the reference's own chain of sweeps.
+// ---- the cached (three-pass) form and its fallback rule ------------------------------------------------
+// Expanding the recursion over cached inner products is the same arithmetic as the reference's sequential
+// sweeps associated differently: on every input class probed (tests/test_gpu_adversarial.py: Hessian
+// condition 1e8, nearly collinear pairs, inconsistent and negative curvature, g in the span of Y,
+// |g| ~ 1e+-150) both forms sit within a few ulps of an extended-precision evaluation.  The exception is
+// pairs with s almost orthogonal to y (rho_i = 1/s'y huge): there every form loses digits -- about
+// kappa_i = |s||y|/|s'y| per pair.  The three-pass form tracks the sweeps within 1.1x up to kappa = 1e10
+// (profiles/r03_kappa_sweep_k20.json); it is used only while every pair in use has kappa_i <= option
+// "kappa_max" (default 1e6, conservative); beyond, the step runs as the reference's own chain of sweeps.
 // kappa comes from the all-reduced (s'y, s's, y'y) of the pair: identical on every rank.
 bool pairs_tame(DevCtx* c, size_t st, size_t used)
 {
-	const double kmax = options().twopass_kappa_max;
+	const double kmax = options().kappa_max;
 	if (!(kmax > 0) || std::isinf(kmax)) return true;            // rule switched off
 	const size_t m = c->m;
 	size_t unknown = 0;
@@ -383,67 +385,6 @@ bool pairs_tame(DevCtx* c, size_t st, size_t used)
 	return true;
 }
 
-bool twopass_ok(DevCtx* c, size_t st, size_t used, const real* H0_vec)
-{
-	return options().twopass && H0_vec == nullptr && used >= 1 && c->m <= (size_t) kPairsMax && pairs_tame(c, st, used);
-}
-
-// Refresh row r and column r of the Gram blocks: s_j'y_r, y_j'y_r, y_j's_r for every ring row j.
-void ensure_gram(DevCtx* c, size_t st, size_t used)
-{
-	const size_t m = c->m;
-	for (size_t i = 0; i < used; i++) {
-		const size_t r = (st + i) % m;
-		if (c->gram_ok[r]) continue;
-		RowSet all{}, ys{};
-		for (size_t j = 0; j < m; j++) {
-			all.row[j] = row(c->S, j, c);
-			all.row[m + j] = row(c->Y, j, c);
-			ys.row[j] = row(c->Y, j, c);
-		}
-		all.count = (int) (2 * m);
-		ys.count = (int) m;
-		Partials a = launch_rows_dot(c->sc, 0, N(c), all, row(c->Y, r, c), nullptr, K_GRAM);
-		Partials b = launch_rows_dot(c->sc, 1, N(c), ys, row(c->S, r, c), nullptr, K_GRAM);
-		launch_gram_store(c->sc, a, b, (int) m, (int) r);
-		c->gram_ok[r] = 1;
-	}
-}
-
-// Returns the guard partials (sum r^2, nonfinite); the direction replaces g.
-Partials enqueue_two_pass(DevCtx* c, real* g, size_t used, size_t st, double h0, real* gprev_out)
-{
-	const size_t m = c->m, k = used;
-	RowSet rows{}, ys{}, ss{};
-	CoefArgs a{};
-	a.k = (int) k;
-	a.m = (int) m;
-	a.h0 = h0;
-	int stale = 0, stale_row = -1;
-	for (size_t i = 0; i < k; i++) {
-		const size_t r = (st + i) % m;
-		a.rows[i] = (int) r;
-		rows.row[i] = ss.row[i] = row(c->S, r, c);
-		rows.row[k + i] = ys.row[i] = row(c->Y, r, c);
-		if (!c->gram_ok[r]) { stale++; stale_row = (int) r; }
-	}
-	rows.count = (int) (2 * k);
-	ys.count = ss.count = (int) k;
-	Partials b;
-	if (stale == 1) {
-		// the usual case -- exactly one pair entered the ring since the last step: its Gram row comes
-		// out of the same pass over S and Y that computes [S;Y]g (2 extra probe vectors, no extra pass)
-		b = launch_rows_dot(c->sc, 0, N(c), rows, g, gprev_out, K_ROWS_DOT3, row(c->Y, stale_row, c), row(c->S, stale_row, c));
-		c->gram_ok[stale_row] = 1;                       // stored by the coefficient kernel, ahead of the recursion
-	} else {
-		ensure_gram(c, st, k);
-		b = launch_rows_dot(c->sc, 0, N(c), rows, g, gprev_out);
-		stale_row = -1;
-	}
-	launch_coef(c->sc, b, a, stale == 1 ? stale_row : -1);
-	return launch_combine(c->sc, c->next_buf(), N(c), ys, ss, g);
-}
-
 // ---- three-pass form: S twice, Y once (kernels.hip "three-pass form") ------------------------------------------
 // The cached block holds s_a'y_b for pairs a older than b.  Column b is computed when pair b is the newest: in
 // the normal course exactly one column is missing on the step after a pair was accepted, and it comes out of
@@ -470,7 +411,7 @@ int ensure_sy_columns(DevCtx* c, size_t st, size_t used, const RowSet& s_rows, c
 
 bool threepass_ok(DevCtx* c, size_t st, size_t used)
 {
-	return options().twopass && options().threepass && used >= 1 && c->m <= (size_t) kPairsMax3 && pairs_tame(c, st, used);
+	return options().threepass && used >= 1 && c->m <= (size_t) kPairsMax3 && pairs_tame(c, st, used);
 }
 
 // Returns the guard partials (sum r^2, nonfinite); the direction replaces g.  `qs` says how q0 is scaled:
@@ -494,7 +435,7 @@ Partials enqueue_three_pass(DevCtx* c, real* g, size_t used, size_t st, double h
 	ensure_rho(c, st, k);                                     // s'y, y'y of every pair in use (rho_i, gamma)
 	const int fresh = ensure_sy_columns(c, st, k, ss, a);
 	const real* probe = fresh >= 0 ? row(c->Y, (size_t) fresh, c) : nullptr;
-	SliceFeed feed{options().upload_slices, c->carry, gradient_slice_arrives, pending};
+	SliceFeed feed{options().upload_slices, c->carry, c->carry_count, gradient_slice_arrives, pending};
 	const bool sliced = pending && pending->g_pending && sdot_can_slice(c->sc, ss, g, gprev_out, probe);
 	if (pending && !sliced) flush_g(*pending);
 	Partials b = launch_sdot(c->sc, N(c), ss, g, gprev_out, probe, sliced ? &feed : nullptr);
@@ -509,48 +450,12 @@ Partials enqueue_three_pass(DevCtx* c, real* g, size_t used, size_t st, double h
 	return launch_sadd(c->sc, c->next_buf(), N(c), ss, g, nullptr, nullptr, fuse, drain);
 }
 
-// adaQN (diagonal H0) in two passes: all inner products incl. the H0-weighted ones + the side effects
-// on the raw gradient in one pass over S and Y, the scalar recursion, the combine pass.
-bool twopass_h0_ok(DevCtx* c, size_t st, size_t used, const StepIn& in)
-{
-	// like twopass_ok: only quantities that are identical on every rank of a sharded run may select
-	// the algorithm (local n, alignment ... merely select kernel variants with the same reductions)
-	return options().twopass && options().twopass_h0 && in.G != nullptr && in.H0 != nullptr && used >= 1 &&
-	       c->m <= (size_t) kPairsMax && pairs_tame(c, st, used);
-}
-
-Partials enqueue_two_pass_h0(DevCtx* c, const StepIn& in, size_t st)
-{
-	const size_t m = c->m, k = in.used;
-	ensure_gram(c, st, k);
-	GramH0Args ga{};
-	CoefArgs a{};
-	a.k = (int) k;
-	a.m = (int) m;
-	for (size_t i = 0; i < k; i++) {
-		const size_t r = (st + i) % m;
-		a.rows[i] = (int) r;
-		ga.s_rows.row[i] = row(c->S, r, c);
-		ga.y_rows.row[i] = row(c->Y, r, c);
-	}
-	ga.s_rows.count = ga.y_rows.count = (int) k;
-	ga.g = in.g;
-	ga.G = in.G;
-	ga.H0_out = in.H0;
-	ga.frow_out = in.frow_out;
-	ga.rmsprop_weight = in.w;
-	ga.scal_reg = in.eps;
-	Partials b = launch_gram_h0(c->sc, N(c), ga);
-	launch_coef_h0(c->sc, b, a);
-	return launch_combine(c->sc, c->next_buf(), N(c), ga.y_rows, ga.s_rows, in.g, in.H0);
-}
-
-// Option "verify_cache" (debugging aid for DEVICE callers).  The library caches s'y, y'y and the Gram rows of
-// the pairs in the ring; it learns about changes to S and Y only through its own writes or
+// Option "verify_cache" (debugging aid for DEVICE callers).  The library caches s'y, y'y and the products
+// s_a'y_b of the pairs in the ring; it learns about changes to S and Y only through its own writes or
 // stochqn_hip_invalidate.  A caller that restores or edits rows in place without saying so gets a direction
 // built from stale inner products and no diagnostic.  With the option on, every step re-derives the cached
 // numbers of ONE pair in use (round robin) from the arrays as they are and compares; a mismatch fails the
-// call (-1000, message on stderr).  Costs a synchronisation and up to (2k+2) n words per step.
+// call (-1000, message on stderr).  Costs a synchronisation and up to (k+4) n words per step.
 void verify_cache(DevCtx* c, size_t st, size_t used)
 {
 	const size_t m = c->m;
@@ -562,19 +467,7 @@ void verify_cache(DevCtx* c, size_t st, size_t used)
 	to_host(c, land, c->kap_dev, 3);
 	to_host(c, land + 3, c->sc.sy + r, 1);
 	to_host(c, land + 4, c->sc.yy + r, 1);
-	std::vector<double> fresh, gsy, gyy;
-	const bool gram = c->gram_ok[r] && m <= (size_t) kPairsMax;
-	if (gram) {
-		RowSet all{};
-		for (size_t j = 0; j < m; j++) { all.row[j] = row(c->S, j, c); all.row[m + j] = row(c->Y, j, c); }
-		all.count = (int) (2 * m);
-		Partials a = launch_rows_dot(c->sc, 0, N(c), all, row(c->Y, r, c), nullptr, K_GRAM);      // s_j'y_r, y_j'y_r
-		fresh.assign(2 * m, 0.0); gsy.assign(m * m, 0.0); gyy.assign(m * m, 0.0);
-		if (a.stride != 1) { launch_fin(c->sc, a, (int) (2 * m), c->sc.red[0]); a = Partials{c->sc.red[0], 1, 1}; }   // totals, contiguous
-		SQN_HIP_OK(hipMemcpyAsync(fresh.data(), a.parts, 2 * m * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
-		SQN_HIP_OK(hipMemcpyAsync(gsy.data(), c->sc.gsy, m * m * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
-		SQN_HIP_OK(hipMemcpyAsync(gyy.data(), c->sc.gyy, m * m * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
-	}
+	std::vector<double> gsy;
 	// three-pass form: the cached column s_q'y_r of every pair q in use that is older than r
 	std::vector<double> col;
 	size_t r_logical = used;
@@ -594,23 +487,6 @@ void verify_cache(DevCtx* c, size_t st, size_t used)
 	const double scale = std::sqrt(std::fabs(land[1])) * std::sqrt(std::fabs(land[2]));     // |s_r||y_r|
 	bool stale = !(std::fabs(land[0] - land[3]) <= 1e-8 * scale) || !(std::fabs(land[2] - land[4]) <= 1e-8 * std::fabs(land[2]));
 	if (stale) std::fprintf(stderr, "stochqn: verify_cache: row %zu: s'y now %.17g cached %.17g, y'y now %.17g cached %.17g\n", r, land[0], land[3], land[2], land[4]);
-	if (gram && !stale) {
-		double big = 0;
-		for (size_t j = 0; j < used; j++) {
-			const size_t q = (st + j) % m;
-			if (!c->gram_ok[q]) continue;
-			big = std::fmax(big, std::fmax(std::fabs(fresh[q]), std::fabs(fresh[m + q])));
-		}
-		for (size_t j = 0; j < used && !stale; j++) {
-			const size_t q = (st + j) % m;
-			if (!c->gram_ok[q]) continue;
-			if (!(std::fabs(fresh[q] - gsy[q * m + r]) <= 1e-7 * big) || !(std::fabs(fresh[m + q] - gyy[q * m + r]) <= 1e-7 * big)) {
-				stale = true;
-				std::fprintf(stderr, "stochqn: verify_cache: Gram entries of rows (%zu, %zu): s'y now %.17g cached %.17g, y'y now %.17g cached %.17g\n",
-				             q, r, fresh[q], gsy[q * m + r], fresh[m + q], gyy[q * m + r]);
-			}
-		}
-	}
 	if (column && !stale) {
 		double big = 0;
 		for (size_t i = 0; i < r_logical; i++) big = std::fmax(big, std::fabs(col[i]));
@@ -717,7 +593,7 @@ void enqueue_step(Call& io, const StepIn& in)
 			SpecDrain sd{&io, in.g, in.x, c->spec, in.step, io.g_host && options().strict_grad && io.g == in.g};
 			const bool ahead = !fuse && spec_x_ready(io, in);
 			sd.xs = c->spec;
-			const SliceFeed drain{options().apply_chunks, c->carry, direction_slice_done, &sd};
+			const SliceFeed drain{options().apply_chunks, c->carry, c->carry_count, direction_slice_done, &sd};
 			Partials guard = enqueue_three_pass(c, in.g, in.used, st, in.h0, in.gprev_out, qs, fuse ? &ap : nullptr, &io, ahead ? &drain : nullptr);
 			if (io.x_spec) {                                          // every slice of x is on its way already: the update in one launch, no copies
 				launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
@@ -726,19 +602,11 @@ void enqueue_step(Call& io, const StepIn& in)
 			}
 			else if (!fuse) apply_step(io, guard, in.g, in.g, ap, in.check_nan != 0);
 			stat_add(ST_STEP_THREE_PASS);
-		} else if (flush_g(io), !raw_cold && twopass_ok(c, st, in.used, in.G ? in.H0 : nullptr)) {
-			Partials guard = enqueue_two_pass(c, in.g, in.used, st, in.h0, in.gprev_out);
-			apply_step(io, guard, in.g, in.g, ap, in.check_nan != 0);
-			stat_add(ST_STEP_TWO_PASS);
-		} else if (!raw_cold && twopass_h0_ok(c, st, in.used, in)) {
-			Partials guard = enqueue_two_pass_h0(c, in, st);
-			apply_step(io, guard, in.g, in.g, ap, in.check_nan != 0);
-			stat_add(ST_STEP_TWO_PASS_H0);
 		} else {
+			flush_g(io);
 			stat_add(ST_STEP_SWEEPS);
 			// was a cached form configured for this ring, and only the kappa rule said no?  (kappa is cached per row: no extra work)
-			if (!raw_cold && options().twopass && (!in.G || in.H0) &&
-			    c->m <= (size_t) (options().threepass ? kPairsMax3 : kPairsMax) && !pairs_tame(c, st, in.used))
+			if (!raw_cold && options().threepass && (!in.G || in.H0) && c->m <= (size_t) kPairsMax3 && !pairs_tame(c, st, in.used))
 				stat_add(ST_KAPPA_FALLBACK);
 			Partials guard = enqueue_two_loop(c, in.g, in.used, st, fa, in.h0, in.G ? in.H0 : nullptr,
 			                                  in.check_nan ? nullptr : &ap);
@@ -797,7 +665,6 @@ void accept_or_reject(DevCtx* c, bfgs_mem* b, Partials p, info_enum* info)
 	launch_verdict(c->sc, p, (double) b->min_curvature, c->sc.sy + st, c->sc.yy + st, verdict);
 	if (c->async_call) {                 // min_curvature == 0: the pair is accepted whatever its dots are (:893); no read-back
 		c->rho_ok[st] = 1;
-		c->gram_ok[st] = 0;
 		c->kappa[st] = 0;                // the kappa rule needs the dots on the host: off in stream-ordered calls (documented)
 		ring_advance(b);
 		return;
@@ -813,7 +680,6 @@ void accept_or_reject(DevCtx* c, bfgs_mem* b, Partials p, info_enum* info)
 		return;
 	}
 	c->rho_ok[st] = 1;
-	c->gram_ok[st] = 0;            // cross products with the other rows: refreshed lazily by ensure_gram
 	{
 		const double k = std::sqrt(c->pin[5]) * std::sqrt(c->pin[6]) / std::fabs(c->pin[4]);   // |s||y| / |s'y|
 		c->kappa[st] = (k >= 0) ? k : INFINITY;
@@ -836,7 +702,7 @@ int invalid(task_enum* task, const char* who);
 // failure after open_call succeeded (a view could not be bound)
 int abandon(Call& io, const bfgs_mem* b, task_enum* task, const char* who)
 {
-	if (io.fresh) release(b->s_mem);
+	if (io.fresh) abandon_context(b->s_mem);
 	return invalid(task, who);
 }
 
@@ -1486,7 +1352,7 @@ static DevCtx* raw_context(real_t s_mem[], real_t y_mem[], int n, size_t mem_siz
 	if (c->S.mirror && !*fresh) SQN_HIP_OK(hipMemcpyAsync(c->S.dev, s_mem, mem_size * nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
 	if (c->Y.mirror && !*fresh) SQN_HIP_OK(hipMemcpyAsync(c->Y.dev, y_mem, mem_size * nn * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
 	// The pure functions these entries stand for (approx_inv_hess_grad, take_step) recompute every inner
-	// product on every call.  Here s'y, y'y and the Gram blocks are cached per row, and nothing tells the
+	// product on every call.  Here s'y, y'y and the products s_a'y_b are cached per row, and nothing tells the
 	// library that a caller rewrote S / Y in place (or that an allocator handed the same address to new
 	// arrays): so the caches are dropped on every call unless the caller vouches for the arrays with
 	// option "raw_reuse_cache" = 1 (the two-loop micro-benchmark does).
@@ -1501,6 +1367,7 @@ static int two_loop_impl(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 	if (!device_ready() || !grad || !y_mem || !s_mem || n <= 0 || mem_size == 0 || mem_used == 0 || mem_used > mem_size)
 		return -1000;
 	(void) hipGetLastError();
+	(void) take_hip_failure();
 	bool fresh = false;
 	DevCtx* c = raw_context(s_mem, y_mem, n, mem_size, &fresh);
 	if (!c) return -1000;
@@ -1516,8 +1383,6 @@ static int two_loop_impl(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 		QdotScale qs{};
 		qs.H0_in = H0 ? c->H0.dev : nullptr;
 		(void) enqueue_three_pass(c, g, mem_used, mem_st_ix % mem_size, h0, nullptr, qs);
-	} else if (!cold && twopass_ok(c, mem_st_ix % mem_size, mem_used, H0 ? c->H0.dev : nullptr)) {
-		(void) enqueue_two_pass(c, g, mem_used, mem_st_ix % mem_size, h0, nullptr);
 	} else {
 		FirstArgs fa{};
 		(void) enqueue_two_loop(c, g, mem_used, mem_st_ix % mem_size, fa, h0, H0 ? c->H0.dev : nullptr, nullptr);
@@ -1525,7 +1390,7 @@ static int two_loop_impl(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 	to_host(c, c->pin, c->sc.report, 8 + 2 * c->m);
 	if (g_host) vec_to_host(c, grad, g, nn);
 	sync(c);
-	if (c->fault) { c->fault = false; return -1000; }
+	if (c->fault | take_hip_failure()) { c->fault = false; return -1000; }
 	hand_back(buffer_rho, c->pin + 8, mem_used);
 	hand_back(buffer_alpha, c->pin + 8 + c->m, mem_used);
 	return 0;
@@ -1540,8 +1405,8 @@ int stochqn_hip_two_loop(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 }
 
 // take_step of reference src/stochqn.c:802-840 on its own: [diagonal rescale ->] two-loop -> guard -> x update.
-// With grad_sum_sq != NULL this is adaQN's step (H0 receives g/sqrt(G+eps), G is updated), i.e. the
-// diagonal-H0 kernels of the two-pass form when the "twopass" options are on.
+// With grad_sum_sq != NULL this is adaQN's step (H0 receives g/sqrt(G+eps), G is updated): pass 2 of the
+// three-pass form in its adaQN mode, or the sweeps with option "threepass" = 0.
 static int take_step_impl(real_t step_size, int n, real_t x[], real_t grad[], bfgs_mem* b, real_t rmsprop_weight, real_t H0[],
                           real_t h0, real_t grad_sum_sq[], real_t scal_reg, int check_nan, info_enum* iter_info)
 {
@@ -1550,6 +1415,7 @@ static int take_step_impl(real_t step_size, int n, real_t x[], real_t grad[], bf
 	    b->mem_st_ix >= b->mem_size || (grad_sum_sq && b->mem_used > 0 && !H0))
 		return -1000;
 	(void) hipGetLastError();
+	(void) take_hip_failure();
 	bool fresh = false;
 	DevCtx* c = raw_context(b->s_mem, b->y_mem, n, b->mem_size, &fresh);
 	if (!c) return -1000;
@@ -1576,7 +1442,7 @@ static int take_step_impl(real_t step_size, int n, real_t x[], real_t grad[], bf
 	if (c->G.mirror) export_view(c, c->G);
 	if (c->H0.mirror && b->mem_used > 0) export_view(c, c->H0);
 	close_call(io, true, true);
-	if (c->fault) { c->fault = false; return -1000; }
+	if (c->fault | take_hip_failure()) { c->fault = false; return -1000; }
 	if (step_was_bad(io, b, b->mem_used, check_nan)) {
 		ring_reset(b);                                         // :831
 		if (iter_info) *iter_info = search_direction_was_nan;
@@ -1596,6 +1462,7 @@ static int fisher_product_impl(real_t F[], size_t fu, int n, real_t s[], real_t 
 {
 	if (!device_ready() || !F || !s || !y || n <= 0 || fu == 0) return -1000;
 	(void) hipGetLastError();
+	(void) take_hip_failure();
 	bool fresh = false;
 	DevCtx* c = acquire(raw_key(F), KIND_RAW, n, 1, fu, &fresh);
 	if (!c) return -1000;
@@ -1613,7 +1480,7 @@ static int fisher_product_impl(real_t F[], size_t fu, int n, real_t s[], real_t 
 	to_host(c, c->pin + 8 + 2 * c->m, c->fisher_t, fu);
 	if (y_host) vec_to_host(c, y, yd, nn);
 	sync(c);
-	if (c->fault) { c->fault = false; return -1000; }
+	if (c->fault | take_hip_failure()) { c->fault = false; return -1000; }
 	hand_back(buffer_y, c->pin + 8 + 2 * c->m, fu);
 	return 0;
 }

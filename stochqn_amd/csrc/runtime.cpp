@@ -33,7 +33,7 @@ unsigned long long g_clock = 0;                 // registry clock: DevCtx::last_
 // caller's arrays: the object may be long gone and its arrays freed.  If the object does come back (same address, counters
 // that continue where the spilled context stopped) the first call re-creates the context from the spill; if something
 // else turns up at that address the spill is dropped.
-struct SpillPiece { const void* caller = nullptr; size_t count = 0; real* data = nullptr; };
+struct SpillPiece { const void* caller = nullptr; size_t count = 0; real* data = nullptr; };      // data stays until the first call after the resume has completed
 struct Spill {
 	int kind = 0, n = 0;
 	size_t m = 0, fsize = 0, niter = 0, bytes = 0;
@@ -47,7 +47,7 @@ std::atomic<int> g_inject_device_fault{0};      // fault injection: the next str
 
 std::atomic<long long> g_stats[ST_COUNT];
 const char* const kStatNames[ST_COUNT] = {
-	"steps_three_pass", "steps_two_pass", "steps_two_pass_h0", "steps_sweeps", "steps_plain", "steps_kappa_fallback",
+	"steps_three_pass", "steps_sweeps", "steps_plain", "steps_kappa_fallback",
 	"allreduces", "allreduce_doubles", "contexts_created", "contexts_reclaimed", "x_uploads", "x_uploads_skipped",
 	"host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched"};
 
@@ -113,8 +113,10 @@ struct Comm {
 bool load_rccl()
 {
 	if (g_comm.dl) return true;
-	const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+	// STOCHQN_HIP_RCCL_LIB names the library to load (a particular RCCL build; tests/hostsim: a host-side stand-in)
+	const char* names[] = {std::getenv("STOCHQN_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
 	for (const char* nm : names) {
+		if (!nm || !*nm) continue;
 		g_comm.dl = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
 		if (g_comm.dl) break;
 	}
@@ -187,7 +189,7 @@ bool loop_barrier(Loopback& lp)
 		lp.cv.notify_all();
 		return true;
 	}
-	if (!lp.cv.wait_for(lk, std::chrono::seconds(lp.patience_s), [&] { return lp.generation != gen || lp.broken; }) || lp.broken) {
+	if (!lp.cv.wait_for(lk, std::chrono::duration<double>(lp.patience_s), [&] { return lp.generation != gen || lp.broken; }) || lp.broken) {
 		lp.broken = true;
 		lp.cv.notify_all();
 		return false;
@@ -225,13 +227,18 @@ void free_view(View& v)
 	v = View{};
 }
 
-void destroy(DevCtx* c)
+void destroy(DevCtx* c, bool keep_spill = false)
 {
 	SQN_HIP_OK(hipStreamSynchronize(c->sc.stream));
 	if (c->own_stream && c->own_stream != c->sc.stream) SQN_HIP_OK(hipStreamSynchronize(c->own_stream));
 	if (c->copy_stream) (void) hipStreamSynchronize(c->copy_stream);      // an upload of x started when the last call returned may still be writing the staging vector
-	delete static_cast<Spill*>(c->spill);
-	c->spill = nullptr;
+	if (Spill* sp = static_cast<Spill*>(c->spill)) {
+		// keep_spill: a resume that could not be completed (a mirror could not be had) -- the state goes back where the
+		// object's next call looks for it, instead of being lost with the half-made context
+		if (keep_spill && !g_spill.count(c->key)) g_spill[c->key] = sp;
+		else delete sp;
+		c->spill = nullptr;
+	}
 	c->prof.collect();
 	for (int i = 0; i < K_COUNT; i++) { g_retired_ms[i] += c->prof.total_ms[i]; g_retired_launches[i] += c->prof.launches[i]; }
 	for (auto& p : c->prof.pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
@@ -281,6 +288,22 @@ void at_exit()
 
 void stat_add(int id, long long v) { g_stats[id].fetch_add(v, std::memory_order_relaxed); }
 
+namespace { thread_local bool t_hip_failed = false; }
+
+void note_hip_failure(const char* expr, hipError_t e, const char* file, int line)
+{
+	std::fprintf(stderr, "stochqn: %s failed: %s (%s:%d)\n", expr, hipGetErrorString(e), file, line);
+	(void) hipGetLastError();
+	t_hip_failed = true;
+}
+
+bool take_hip_failure()
+{
+	const bool f = t_hip_failed;
+	t_hip_failed = false;
+	return f;
+}
+
 namespace {
 
 void views_of(DevCtx* c, View** out)
@@ -306,16 +329,17 @@ void drop_spill(const void* key)
 	g_spill.erase(it);
 }
 
-void destroy(DevCtx* c);
+void destroy(DevCtx* c, bool keep_spill);
 
-// Spill and destroy the least recently used idle context that holds mirrors.  g_mu held.  false: nothing to reclaim.
-bool reclaim_one()
+// Spill and destroy the least recently used idle context that holds mirrors ON DEVICE `device` (< 0: on any device: the cap on
+// mirrors counts them all).  g_mu held.  false: nothing to reclaim.
+bool reclaim_one(int device)
 {
 	for (;;) {
 		DevCtx* victim = nullptr;
 		for (auto& kv : g_ctx) {
 			DevCtx* c = kv.second;
-			if (c->in_call || c->no_spill || mirror_bytes(c) == 0) continue;
+			if (c->in_call || c->no_spill || mirror_bytes(c) == 0 || (device >= 0 && c->device != device)) continue;
 			if (!victim || c->last_use < victim->last_use) victim = c;
 		}
 		if (!victim) return false;
@@ -325,11 +349,13 @@ bool reclaim_one()
 			std::unique_ptr<Spill> sp(new Spill());
 			sp->kind = victim->kind; sp->n = victim->n; sp->m = victim->m; sp->fsize = victim->fsize;
 			sp->niter = victim->last_niter; sp->section = victim->last_section;
-			SQN_HIP_OK(hipStreamSynchronize(victim->sc.stream));
+			// a victim whose stream reports a failure holds nothing worth keeping a copy of -- and is not touched any further
+			bool ok = hipStreamSynchronize(victim->sc.stream) == hipSuccess;
+			if (!ok) (void) hipGetLastError();
 			View* vs[10];
 			views_of(victim, vs);
-			bool ok = true;
 			for (View* v : vs) {
+				if (!ok) break;
 				if (!v->mirror || !v->dev || v->count == 0) continue;
 				SpillPiece pc;
 				pc.caller = v->caller; pc.count = v->count;
@@ -343,7 +369,7 @@ bool reclaim_one()
 				sp->bytes += v->count * sizeof(real);
 				sp->pieces.push_back(pc);
 			}
-			if (!ok) { victim->no_spill = true; continue; }     // no host memory for it: leave it alone, look for another
+			if (!ok) { victim->no_spill = true; continue; }     // no host memory for it (or its stream failed): leave it alone, look for another
 			drop_spill(key);
 			g_spill[key] = sp.release();
 		}
@@ -351,7 +377,7 @@ bool reclaim_one()
 			std::fprintf(stderr, "stochqn: device memory is short: the idle context of the workspace at %p (%zu MB of mirrors) was moved to host memory\n",
 			             key, mirror_bytes(victim) >> 20);
 		g_ctx.erase(key);
-		destroy(victim);
+		destroy(victim, false);
 		stat_add(ST_CTX_RECLAIMED);
 		return true;
 	}
@@ -368,7 +394,7 @@ void enforce_mirror_cap()
 	for (;;) {
 		size_t total = 0;
 		for (auto& kv : g_ctx) total += mirror_bytes(kv.second);
-		if (total <= (size_t) cap || !reclaim_one()) return;
+		if (total <= (size_t) cap || !reclaim_one(-1)) return;
 	}
 }
 
@@ -388,17 +414,21 @@ bool device_alloc(void** p, size_t bytes)
 {
 	for (;;) {
 		*p = nullptr;
-		if (!alloc_should_fail() && hipMalloc(p, bytes ? bytes : 1) == hipSuccess) return true;
+		const hipError_t e = alloc_should_fail() ? hipErrorOutOfMemory : hipMalloc(p, bytes ? bytes : 1);
+		if (e == hipSuccess) return true;
 		(void) hipGetLastError();
 		*p = nullptr;
-		// out of device memory: give up the mirrors of an optimiser nobody has called for the longest time, try again
-		bool freed;
-		{
+		// out of device memory (and only then: any other failure would not be cured by it): give up the mirrors of an optimiser
+		// ON THIS DEVICE that nobody has called for the longest time, try again
+		bool freed = false;
+		if (e == hipErrorOutOfMemory) {
+			int dev = 0;
+			if (hipGetDevice(&dev) != hipSuccess) { (void) hipGetLastError(); dev = -1; }
 			std::lock_guard<std::recursive_mutex> lk(g_mu);
-			freed = reclaim_one();
+			freed = dev >= 0 && reclaim_one(dev);
 		}
 		if (freed) continue;
-		std::fprintf(stderr, "stochqn: could not allocate %zu bytes of device memory\n", bytes);
+		std::fprintf(stderr, "stochqn: could not allocate %zu bytes of device memory (%s)\n", bytes, hipGetErrorString(e));
 		return false;
 	}
 }
@@ -438,7 +468,6 @@ void begin_call(DevCtx* c)
 	c->sc.rows_split = g_opt.rows_split;
 	c->sc.rows_waves = g_opt.rows_waves;
 	c->sc.combine_batch = g_opt.combine_batch;
-	c->sc.h0_per_cu = g_opt.h0_per_cu;
 	c->sc.fisher_rows = g_opt.fisher_rows;
 	c->sc.stream_stores = g_opt.stream_stores;
 	c->sc.qdot_stream = g_opt.qdot_stream;
@@ -515,6 +544,22 @@ DevCtx* lookup(const void* key)
 	return it == g_ctx.end() ? nullptr : it->second;
 }
 
+DevCtx* hold(const void* key)
+{
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
+	auto it = g_ctx.find(key);
+	if (it == g_ctx.end() || it->second->in_call) return nullptr;      // inside a call of another thread: not ours to touch
+	it->second->in_call = true;
+	return it->second;
+}
+
+void forget_rows_of(const void* key)
+{
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
+	auto it = g_ctx.find(key);
+	if (it != g_ctx.end()) it->second->forget_rows();
+}
+
 DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* fresh)
 {
 	std::lock_guard<std::recursive_mutex> lk(g_mu);
@@ -528,7 +573,7 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 			c->in_call = true;
 			return c;
 		}
-		destroy(c);              // same address, different problem: the old owner is gone
+		destroy(c, false);       // same address, different problem: the old owner is gone
 		g_ctx.erase(it);
 	}
 	DevCtx* c = new DevCtx();
@@ -536,19 +581,26 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	c->n_global = (double) n;
 	c->last_use = ++g_clock;
 	c->in_call = true;
-	SQN_HIP_OK(hipStreamCreate(&c->own_stream));   // blocking flavour: ordered after the null stream
+	if (hipGetDevice(&c->device) != hipSuccess) { (void) hipGetLastError(); c->device = 0; }
+	if (hipStreamCreate(&c->own_stream) != hipSuccess) {      // blocking flavour: ordered after the null stream
+		(void) hipGetLastError();
+		std::fprintf(stderr, "stochqn: could not create the stream of a device context\n");
+		c->own_stream = nullptr;
+		delete c;
+		return nullptr;
+	}
 	c->sc.stream = c->own_stream;
-	// pool layout: part0 | part1 | red0 | red1 | sy | yy | report | rho | alpha | rows_part x2 | gsy | gyy | coef
+	// pool layout: part0 | part1 | red0 | red1 | sy | yy | report | rho | alpha | rows_part x2 | gsy | coef | kap
 	const size_t part = (size_t) kMaxSums * kMaxGrid;
 	const size_t rows_part = (size_t) kRedMax * kMaxGrid;
-	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + 2 * m * m + (2 + 2 * kPairsMax3) + 3 * m;
+	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + m * m + (2 + 2 * kPairsMax3) + 3 * m;
 	c->pin_count = 16 + 2 * m + fsize + 3 * m + 8;
 	if (!device_alloc((void**) &c->pool, total * sizeof(double)) ||
 	    !pinned_alloc((void**) &c->pin, c->pin_count * sizeof(double)) ||
 	    (fsize > 0 && (!device_alloc((void**) &c->sc.fisher_part, fsize * kMaxGrid * sizeof(double)) ||
 	                   !device_alloc((void**) &c->fisher_t, fsize * sizeof(double))))) {
 		std::fprintf(stderr, "stochqn: could not allocate the scratch of a device context\n");
-		destroy(c);
+		destroy(c, false);
 		return nullptr;
 	}
 	SQN_HIP_OK(hipMemset(c->pool, 0, total * sizeof(double)));
@@ -565,7 +617,6 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	c->sc.rows_part[0] = p; p += rows_part;
 	c->sc.rows_part[1] = p; p += rows_part;
 	c->sc.gsy = p; p += m * m;
-	c->sc.gyy = p; p += m * m;
 	c->sc.coef = p; p += 2 + 2 * kPairsMax3;
 	c->kap_dev = p;
 	c->forget_rows();
@@ -658,7 +709,7 @@ bool note_state(const void* key, size_t niter, int section, bool req_is_x, const
 	it->second->has_last = true;
 	it->second->last_niter = niter;
 	it->second->last_section = section;
-	const bool fault = it->second->fault;
+	const bool fault = it->second->fault | take_hip_failure();
 	it->second->fault = false;
 	return fault;
 }
@@ -669,14 +720,23 @@ void release(const void* key)
 	drop_spill(key);
 	auto it = g_ctx.find(key);
 	if (it == g_ctx.end()) return;
-	destroy(it->second);
+	destroy(it->second, false);
+	g_ctx.erase(it);
+}
+
+void abandon_context(const void* key)
+{
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
+	auto it = g_ctx.find(key);
+	if (it == g_ctx.end()) return;
+	destroy(it->second, true);
 	g_ctx.erase(it);
 }
 
 void release_all()
 {
 	std::lock_guard<std::recursive_mutex> lk(g_mu);
-	for (auto& kv : g_ctx) destroy(kv.second);
+	for (auto& kv : g_ctx) destroy(kv.second, false);
 	g_ctx.clear();
 	for (auto& kv : g_spill) delete kv.second;
 	g_spill.clear();
@@ -704,14 +764,19 @@ bool bind(DevCtx* c, View& v, real* caller, size_t count, bool import)
 	if (Spill* sp = static_cast<Spill*>(c->spill)) {
 		for (auto& pc : sp->pieces)
 			if (pc.caller == caller && pc.count == count && pc.data) {
-				{
-					std::lock_guard<std::recursive_mutex> lk(g_mu);      // one bounce buffer for the process
-					SQN_HIP_OK(bounced_copy(v.dev, pc.data, count * sizeof(real), false));
-				}
-				std::free(pc.data);
-				pc.data = nullptr;
-				enforce_mirror_cap();
-				return true;
+					hipError_t e;
+					{
+						std::lock_guard<std::recursive_mutex> lk(g_mu);      // one bounce buffer for the process
+						e = bounced_copy(v.dev, pc.data, count * sizeof(real), false);
+					}
+					if (e != hipSuccess) {                                   // the mirror holds garbage: the call fails, the host copy stays (abandon_context)
+						(void) hipGetLastError();
+						std::fprintf(stderr, "stochqn: could not bring a reclaimed array back to the device: %s\n", hipGetErrorString(e));
+						free_view(v);
+						return false;
+					}
+					enforce_mirror_cap();                                    // the host copy stays until the call has completed (detach_spill)
+					return true;
 			}
 	}
 	// without `import` the mirror starts with indeterminate contents, like the reference's malloc
@@ -953,8 +1018,7 @@ void stochqn_hip_invalidate(const void* s_mem)
 {
 	if (group_invalidate(s_mem)) return;
 	if (!s_mem) return;
-	for (const void* key : {s_mem, raw_key(s_mem)})
-		if (DevCtx* c = lookup(key)) c->forget_rows();
+	for (const void* key : {s_mem, raw_key(s_mem)}) forget_rows_of(key);
 }
 
 void stochqn_hip_release(const void* s_mem)
@@ -988,12 +1052,16 @@ int stochqn_hip_export(const void* s_mem)
 {
 	int grc = 0;
 	if (group_export(s_mem, &grc)) return grc;
-	DevCtx* c = lookup(s_mem);
+	DevCtx* c = hold(s_mem);                             // not reclaimed from under the copies (another thread's failed allocation)
 	if (!c) return export_spill(s_mem) ? 0 : -1000;      // reclaimed while idle: its state sits in host memory
+	(void) take_hip_failure();
 	View* vs[] = {&c->S, &c->Y, &c->sbak, &c->ybak, &c->gprev, &c->xsum, &c->xprev, &c->H0, &c->G, &c->F};
 	for (View* v : vs) export_view(c, *v);
 	sync(c);
-	return 0;
+	const bool failed = c->fault || take_hip_failure();
+	c->fault = false;
+	end_use(c);
+	return failed ? -1000 : 0;
 }
 
 int stochqn_hip_set_option(const char* name, double value)
@@ -1016,7 +1084,6 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "rows_split")) g_opt.rows_split = value != 0;
 	else if (!std::strcmp(name, "rows_waves")) g_opt.rows_waves = (int) value;
 	else if (!std::strcmp(name, "combine_batch")) g_opt.combine_batch = (int) value;
-	else if (!std::strcmp(name, "h0_per_cu")) g_opt.h0_per_cu = (int) value;
 	else if (!std::strcmp(name, "fisher_rows")) g_opt.fisher_rows = (int) value;
 	else if (!std::strcmp(name, "stream_stores")) g_opt.stream_stores = value != 0;
 	else if (!std::strcmp(name, "qdot_stream")) g_opt.qdot_stream = value != 0;
@@ -1030,10 +1097,8 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "sdot2_per_cu")) g_opt.sdot2_per_cu = (int) value;
 	else if (!std::strcmp(name, "sdot_per_cu")) g_opt.sdot_per_cu = (int) value;
 	else if (!std::strcmp(name, "reverse")) g_opt.reverse = value != 0;
-	else if (!std::strcmp(name, "twopass")) g_opt.twopass = value != 0;
-	else if (!std::strcmp(name, "twopass_h0")) g_opt.twopass_h0 = value != 0;
 	else if (!std::strcmp(name, "threepass")) g_opt.threepass = value != 0;
-	else if (!std::strcmp(name, "twopass_kappa_max")) g_opt.twopass_kappa_max = value;
+	else if (!std::strcmp(name, "kappa_max")) g_opt.kappa_max = value;
 	else if (!std::strcmp(name, "strict_grad")) g_opt.strict_grad = value != 0;
 	else if (!std::strcmp(name, "register_host")) g_opt.register_host = value != 0;
 	else if (!std::strcmp(name, "register_min_bytes")) g_opt.register_min_bytes = value < 0 ? 0 : (long) value;
@@ -1043,7 +1108,9 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "max_mirror_bytes")) g_opt.max_mirror_bytes = value < 0 ? 0 : (long) value;
 	else if (!std::strcmp(name, "devices")) options().devices = value < 0 ? 0 : (int) value;
 	else if (!std::strcmp(name, "virtual_devices")) options().virtual_devices = value != 0;
+	else if (!std::strcmp(name, "devices_rccl_single")) options().devices_rccl_single = value != 0;
 	else if (!std::strcmp(name, "devices_min_n")) options().devices_min_n = (long) value;
+	else if (!std::strcmp(name, "reducer_patience_s")) options().reducer_patience_s = value > 0 ? value : 120;
 	else if (!std::strcmp(name, "verify_cache")) options().verify_cache = value != 0;
 	else if (!std::strcmp(name, "raw_reuse_cache")) options().raw_reuse_cache = value != 0;
 	else if (!std::strcmp(name, "async_device")) options().async_device = value != 0;
@@ -1198,6 +1265,7 @@ int stochqn_hip_loopback_init(int nranks)
 	g_loop.nranks = nranks;
 	g_loop.arrived = 0;
 	g_loop.broken = false;
+	g_loop.patience_s = options().reducer_patience_s;
 	g_loop.slots.assign((size_t) nranks * kRedMax, 0.0);
 	return 0;
 }

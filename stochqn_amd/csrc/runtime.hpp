@@ -25,16 +25,16 @@ struct View {
 struct Options {
 	bool nontemporal = true;
 	int grid_cap = 0;            // 0 = one workgroup per compute unit (measured optimum)
-	int rows_grid = 0;           // 0 = four workgroups per compute unit for the row-split rows-dot pass
-	// single-probe pass A: every lane keeps all rows (fp64: 5.1-5.2 ms; the row-split form is within
+	int rows_grid = 0;           // 0 = as many workgroups of the row-split rows-dot pass as are resident per compute unit
+	// pass 1 without a second probe: every lane keeps all rows (fp64: 5.1-5.2 ms; the row-split form is within
 	// +-3 % of it depending on the device) or the waves of a workgroup split the rows (fp32: 2.5 vs 5.9 ms)
 	bool rows_split = sizeof(real) == 4;
-	int rows_waves = 0;          // waves per workgroup of the row-split rows-dot kernel (0 = 8 for one probe, 4 for three)
-	int combine_batch = 8;       // packs a lane finishes in pass B before it stores them
+	int rows_waves = 0;          // waves per workgroup of the row-split rows-dot kernel (0 = 8)
+	int combine_batch = 8;       // packs a lane finishes in pass 3 before it stores them
 	bool reverse = true;
-	bool threepass = true;       // the three-pass form (S twice, Y once: (3k+5) n words) instead of the two-pass form, when "twopass" is on
-	bool twopass = true;         // 0: the reference's chain of dependent sweeps; 1: a cached-inner-product form when the ring has <= kPairsMax pairs
-	int h0_per_cu = 0;
+	// 1: the three-pass form (S twice, Y once: (3k+5) n words) when the ring has <= kPairsMax3 pairs and every pair in use is
+	// tame ("kappa_max"); 0: always the reference's chain of dependent sweeps (8k n words)
+	bool threepass = true;
 	int fisher_rows = 16;        // Fisher rows per workgroup pass (8, 16, 32)
 	int qdot_per_cu = 0, sadd_per_cu = 0, sdot2_per_cu = 0, sdot_per_cu = 0;
 	bool qdot_stream = true;
@@ -48,9 +48,8 @@ struct Options {
 	double keep_tail = 0.35;
 	bool x_prefetch = true;       // host callers: when a call hands *req == x back and the device copy of x is stale, x starts its way up on a side stream while the caller evaluates its gradient
 	bool spec_x = true;           // host callers, three-pass form: slices of x start their way down while pass 3 is still running
-	bool stream_stores = true;   // pass B: sc1 nt stores (kernels.hip: st_stream)
-	bool twopass_h0 = true;      // adaQN (diagonal H0) in the two-pass form as well
-	double twopass_kappa_max = 1e6;   // two-pass form only while every pair in use has |s||y|/|s'y| <= this (else: sweeps)
+	bool stream_stores = true;   // pass 2 / pass 3: sc1 nt stores (kernels.hip: st_stream)
+	double kappa_max = 1e6;      // three-pass form only while every pair in use has |s||y|/|s'y| <= this (else: sweeps)
 	// host callers: copy the search direction back into `grad` (n words over PCIe).  The reference documents `grad` as an
 	// input that "will be modified in-place" (include/stochqn.h:356-358), not as an output, and no shipped caller reads it
 	// afterwards (Rwrapper.c, pywrapper.pxi, c_rosen.c): off by default, on for callers that do.
@@ -58,7 +57,11 @@ struct Options {
 	// single-process multi-device mode (group.cpp): shard n over `devices` GPUs of this process
 	int devices = 0;             // 0 / 1 = off; also STOCHQN_HIP_DEVICES in the environment
 	bool virtual_devices = false;   // shards may share a physical device (host-side reducer): rehearsal on one GPU
+	// with "devices" < 2: run eligible workspaces as a group of ONE shard over a real RCCL communicator (ncclCommInitAll(1)): every
+	// line of the multi-device mode that a one-GPU box can execute, executed
+	bool devices_rccl_single = false;
 	long devices_min_n = 1 << 20;   // problems smaller than this stay on one device (SURVEY.md 8e "no-shard fallback")
+	double reducer_patience_s = 120;   // host-side rendezvous reducer: how long a shard waits for the others before the reduction fails
 	// host callers (R / numpy / malloc arrays crossing the ABI): PCIe is what a step costs, so
 	int register_host = 1;          // pin the caller's x / grad / hess_vec in place (hipHostRegister, once per array) so that their copies are DMA at link speed
 	long register_min_bytes = 4l << 20;   // ... for arrays of at least this many bytes (below, the runtime's staged copy is as fast)
@@ -80,7 +83,7 @@ struct Options {
 	// 0: always the own stream; 1: always the NULL stream; 2 (default): the NULL stream for device-resident callers of
 	// problems up to 2^22 variables, the own stream otherwise.  async_device implies the NULL stream.
 	int null_stream = 2;
-	bool raw_reuse_cache = false;   // isolated entry points keep their cached s'y / Gram entries between calls (caller vouches for S, Y)
+	bool raw_reuse_cache = false;   // isolated entry points keep their cached inner products between calls (caller vouches for S, Y)
 	bool verify_cache = false;   // debugging aid for device callers: recompute cached dots every call and compare
 };
 int default_grid_cap();
@@ -96,7 +99,7 @@ struct Loopback {
 	int arrived = 0;
 	long generation = 0;
 	bool broken = false;            // a shard failed to show up: every later reduction fails immediately
-	int patience_s = 120;           // how long a shard waits for the others before giving up
+	double patience_s = 120;        // how long a shard waits for the others before giving up (option "reducer_patience_s")
 	std::vector<double> slots;      // [nranks][kRedMax]
 };
 
@@ -144,6 +147,7 @@ struct DevCtx {
 	bool x_valid = false;              // stage[0] holds the caller's current x (the library wrote both; *req == x went back)
 	static constexpr int kProbe = 256;
 	double x_probe[kProbe];            // the caller's x at kProbe spread-out positions when it was last handed back
+	int device = 0;                    // the HIP device the context (its mirrors, scratch and streams) lives on
 	unsigned long long last_use = 0;   // registry clock at the last call (least-recently-used reclaim)
 	bool in_call = false;              // between acquire() and the end of the API call: never reclaimed
 	bool async_call = false;           // this call returns without synchronising (option "async_device"; set by open_call)
@@ -161,17 +165,16 @@ struct DevCtx {
 	size_t last_niter = 0;
 	int last_section = 0;
 	std::vector<char> rho_ok;          // per physical row: sc.sy / sc.yy hold this row's dots
-	std::vector<char> gram_ok;         // per physical row: its row and column of sc.gsy / sc.gyy are current
 	// per physical row: |s||y| / |s'y| of the pair (1 / cosine of the angle between s and y; < 0 = not known yet).
 	// From all-reduced dots, so identical on every rank of a sharded run.  Pairs that are almost orthogonal
-	// make the recursion amplify rounding errors by about this factor per pair; the two-pass form is only
-	// used while every pair in use stays below option "twopass_kappa_max" (machines.cpp: pairs_tame).
+	// make the recursion amplify rounding errors by about this factor per pair; the three-pass form is only
+	// used while every pair in use stays below option "kappa_max" (machines.cpp: pairs_tame).
 	std::vector<char> sy_ok;           // per physical row r: the cached s_i'y_r of every pair i in use (three-pass form) are current
 	std::vector<double> kappa;
 	size_t verify_turn = 0;            // option verify_cache: which pair in use is re-derived on the next call
 	double* kap_dev = nullptr;         // [3 m] landing zone of (s'y, s's, y'y) for rows whose kappa has to be computed
-	void touch_row(size_t r) { rho_ok[r] = 0; gram_ok[r] = 0; sy_ok[r] = 0; kappa[r] = -1; }   // row r of S or Y was rewritten
-	void forget_rows() { rho_ok.assign(m, 0); gram_ok.assign(m, 0); sy_ok.assign(m, 0); kappa.assign(m, -1.0); }
+	void touch_row(size_t r) { rho_ok[r] = 0; sy_ok[r] = 0; kappa[r] = -1; }   // row r of S or Y was rewritten
+	void forget_rows() { rho_ok.assign(m, 0); sy_ok.assign(m, 0); kappa.assign(m, -1.0); }
 
 	int next_buf() { int b = buf; buf ^= 1; return b; }
 };
@@ -179,7 +182,7 @@ struct DevCtx {
 // Event counters behind stochqn_hip_stat(): which form of the recursion each step took, how many reductions crossed
 // the shards, what the context manager did.  Process-wide, relaxed atomics; stochqn_hip_stats_reset() zeroes them.
 enum StatId {
-	ST_STEP_THREE_PASS = 0, ST_STEP_TWO_PASS, ST_STEP_TWO_PASS_H0, ST_STEP_SWEEPS, ST_STEP_PLAIN, ST_KAPPA_FALLBACK,
+	ST_STEP_THREE_PASS = 0, ST_STEP_SWEEPS, ST_STEP_PLAIN, ST_KAPPA_FALLBACK,
 	ST_ALLREDUCE, ST_ALLREDUCE_DOUBLES, ST_CTX_CREATED, ST_CTX_RECLAIMED, ST_X_UPLOAD, ST_X_UPLOAD_SKIPPED,
 	ST_HOST_REGISTERED, ST_X_AHEAD, ST_X_RESENT, ST_X_PREFETCH, ST_COUNT
 };
@@ -196,6 +199,12 @@ bool is_device_pointer(const void* p);
 // Find or create the context of a workspace.  `fresh` tells the caller whether it was created now.
 DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* fresh);
 DevCtx* lookup(const void* key);
+// lookup + mark the context as inside a call (never reclaimed meanwhile), under the registry lock; pair with end_use()
+DevCtx* hold(const void* key);
+void forget_rows_of(const void* key);                  // stochqn_hip_invalidate: drop the cached inner products of the context at `key`
+// Destroy a context whose creation could not be completed (a mirror could not be had), KEEPING what a reclaimed predecessor
+// left in host memory: the object's next call finds it again.  release() drops that state too (another object / explicit release).
+void abandon_context(const void* key);
 // Create the context of a workspace ahead of its first call (all its allocations, no collective): the shards of
 // a multi-device group do this together, so that none of them can fail on memory while the others are already
 // waiting in an all-reduce.
@@ -248,12 +257,16 @@ void set_thread_reducer(const Reducer& r);             // contexts created by th
 bool comm_init_all(int ndev, const int* devices, void** comms_out);   // ncclCommInitAll (one process, ndev devices)
 void comm_destroy(void* comm);
 
+// A HIP call whose failure nobody can repair on the spot: it is reported, and the API call the calling thread is inside of
+// FAILS (-1000 / invalid_input; machines.cpp: after_call and the isolated entries) instead of carrying on with whatever the
+// failed copy / synchronisation left behind.  (Reference src/stochqn.c:362-432, 1033-1035: a failure is a message and an
+// error code, never an abort and never a silently wrong result.)
+void note_hip_failure(const char* expr, hipError_t e, const char* file, int line);
+bool take_hip_failure();               // true, once, when a SQN_HIP_OK call failed on this thread since the last take
 #define SQN_HIP_OK(expr)                                                                             \
 	do {                                                                                             \
 		hipError_t e_ = (expr);                                                                      \
-		if (e_ != hipSuccess)                                                                        \
-			std::fprintf(stderr, "stochqn: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_),  \
-			             __FILE__, __LINE__);                                                        \
+		if (e_ != hipSuccess) ::sqn::note_hip_failure(#expr, e_, __FILE__, __LINE__);               \
 	} while (0)
 
 }  // namespace sqn

@@ -21,21 +21,18 @@ typedef double real;
 constexpr int kVec = 16 / (int) sizeof(real);    // elements per 16-byte pack: 2 doubles or 4 floats
 
 constexpr int kBlock = 256;       // threads per workgroup (4 wave64)
-constexpr int kCoefBlock = 1024;  // the one-workgroup coefficient kernels: 16 waves to total the partials of pass A
+constexpr int kCoefBlock = 1024;  // the one-workgroup coefficient kernels: 16 waves to total the partials of a pass
 constexpr int kCoefWaves = kCoefBlock / 64;
 constexpr int kMaxGrid = 2048;    // 256 CUs x 8 resident workgroups; also the partial-sum stride
 constexpr int kMaxSums = 3;       // sums one sweep can produce (s'y, s's, y'y)
 constexpr int kRowsMax = 48;      // rows one rows-dot launch can take (one accumulator per row and lane)
-constexpr int kPairsMax = 24;     // largest ring the two-pass form handles (2*kPairsMax rows per launch)
 constexpr int kPairsMax3 = 48;    // largest ring the three-pass form handles (its passes take k rows each; one lane per pair in the recursion)
-constexpr int kQuantMax = 3 * kPairsMax + kPairsMax * (kPairsMax + 1) / 2;   // 372: quantities of the diagonal-H0 pass A
-constexpr int kRedMax = 384;      // doubles per all-reduce landing zone (>= kQuantMax, >= 3*kRowsMax)
+constexpr int kRedMax = 128;      // doubles per all-reduce landing zone and quantities per rows-dot pass (>= 2*kPairsMax3: pass 1 with the new column)
 
 // Kernel ids for the built-in HIP-event profiler (stochqn_hip_profile_*).
 enum KernelId {
 	K_FIRST = 0, K_BWD, K_MID, K_FWD, K_FWD_LAST, K_APPLY, K_PAIR_S, K_PAIR_Y_DIFF, K_PAIR_Y_HV,
-	K_DOTS3, K_FISHER_T, K_FISHER_Y, K_FIN, K_SMALL, K_COPY, K_ROWS_DOT, K_COEF, K_COMBINE, K_GRAM, K_ROWS_DOT3, K_GRAM_H0,
-	K_SDOT, K_SDOT2, K_QDOT, K_SADD, K_COUNT
+	K_DOTS3, K_FISHER_T, K_FISHER_Y, K_FIN, K_SMALL, K_COPY, K_COEF, K_SDOT, K_SDOT2, K_QDOT, K_SADD, K_COUNT
 };
 const char* kernel_name(int id);
 
@@ -98,22 +95,20 @@ struct Scratch {
 	double* alpha;        // [m] alpha by logical index
 	double* rho;          // [m] rho by logical index (for buffer_rho write-back)
 	double* report;       // [4]: bad flag, sum r^2, nonfinite count, spare
-	double* rows_part[2]; // two [kRedMax][kMaxGrid] partial buffers of rows-dot / Gram passes
-	double* gsy;          // [m][m] Gram block  gsy[i*m+j] = s_i'y_j   (physical rows)
-	double* gyy;          // [m][m] Gram block  gyy[i*m+j] = y_i'y_j
-	double* coef;         // [1 + 2*kPairsMax3]: gamma, then the y- and s-coefficients of the combine pass (three-pass: alpha, then c at 1 + kPairsMax3)
+	double* rows_part[2]; // two [kRedMax][kMaxGrid] partial buffers of the rows-dot passes (pass 1, pass 2)
+	double* gsy;          // [m][m] cached block  gsy[i*m+j] = s_i'y_j   (physical rows; pair i older than pair j)
+	double* coef;         // [2 + 2*kPairsMax3]: the scale of q0, then alpha (pass 2), then c at 1 + kPairsMax3 (pass 3)
 	int grid_cap;         // max workgroups per sweep (<= kMaxGrid); default = one per CU
 	int rows_grid;        // workgroups of a row-split rows-dot pass; 0 = CUs x resident workgroups per CU
-	bool rows_split;      // use the row-split rows-dot kernel for single-probe passes too
+	bool rows_split;      // pass 1 without a second probe as the row-split rows-dot kernel (float build)
 	int rows_waves;       // waves per workgroup of the row-split kernel: 4 or 8
-	int combine_batch;    // packs a lane finishes in pass B before storing them (1, 2, 4, 8)
-	int h0_per_cu;        // workgroups per CU of the diagonal-H0 Gram pass (0 = 2)
+	int combine_batch;    // packs a lane finishes in pass 3 before storing them (1, 4, 8)
 	int fisher_rows;      // Fisher rows one workgroup accumulates per pass over its columns: 8, 16 or 32
 	int qdot_per_cu, sadd_per_cu, sdot2_per_cu, sdot_per_cu;   // workgroups per CU of the three-pass kernels (0 = default)
 	bool fold_coef;       // three-pass form: the scalar recursions run in the prologues of pass 2 / pass 3 instead of in kernels of their own
 	double keep_tail;     // three-pass form: fraction of r0 / r (the part written last) stored with the default policy instead of sc1 nt
 	bool qdot_stream;     // pass 2 of the three-pass form stores r0 with the streaming policy too
-	bool stream_stores;   // pass B stores its result with the agent-scope non-temporal policy (sc1 nt)
+	bool stream_stores;   // pass 2 / pass 3 store their result with the agent-scope non-temporal policy (sc1 nt)
 	bool nontemporal;     // stream S/Y/F rows with nt loads
 	bool reverse;         // alternate the traversal direction from sweep to sweep (Infinity-Cache reuse of q / r)
 	int* phase;           // sweep counter of the current API call (parity = direction)
@@ -185,51 +180,37 @@ Partials launch_dots3(const Scratch& sc, int buf, size_t n, const real* s, const
 Partials launch_fisher(const Scratch& sc, int buf, size_t n, const real* F, size_t fu, const real* s,
                        double* t_dev, real* y_out);
 
-// ---- two-pass ("Gram") form of the two-loop recursion for scalar H0 -------------------------------
-// The recursion only needs the inner products of g with every stored s_i, y_i and the inner
-// products among the stored vectors; the latter are cached when a pair enters the ring.  So:
-//   pass A  b = [S;Y] g                      (reads every row once + g)            launch_rows_dot
-//   coef    alpha_i, beta_i from b and the Gram blocks, O(k^2) scalars, one wave   launch_coef
-//   pass B  r = gamma g - gamma sum alpha_j y_j + sum (alpha_j - beta_j) s_j       launch_combine
-// = (4k+3) n words instead of 8k n.  Same quantities as reference src/stochqn.c:663-708, other
-// association of the floating-point sums (measured difference ~1e-15 relative).
+// ---- rows of the ring handed to one launch ----------------------------------------------------------
 struct RowSet {
 	const real* row[kRowsMax];
 	int count;
 };
-// out partials: quantity j = rows.row[j]' probe.  Optional copy of the probe (oLBFGS grad_prev).
-// With probe_y / probe_s (the pair just accepted into ring row r) the same pass also yields
-// rows[j]'probe_y (quantities count..2count-1) and rows[j]'probe_s (2count..3count-1).
-Partials launch_rows_dot(const Scratch& sc, int slot, size_t n, const RowSet& rows, const real* probe, real* copy_out,
-                         int kernel_id = K_ROWS_DOT, const real* probe_y = nullptr, const real* probe_s = nullptr);
-// scatter the dots of one ring row against all rows into the Gram blocks
-void launch_gram_store(const Scratch& sc, Partials sy_yy /*2m: s_j'y_r then y_j'y_r*/, Partials ys /*m: y_j's_r*/, int m, int r);
 struct CoefArgs {
 	int k;                    // pairs in use
-	int m;                    // ring size (Gram leading dimension)
+	int m;                    // ring size (leading dimension of the cached block)
 	int rows[kPairsMax3];     // physical row of logical pair i (oldest first)
 	double h0;                // > 0: scalar H0, else gamma from the newest pair
 };
-// fresh_row >= 0: b comes from a 3-probe pass A; ring row fresh_row's Gram row / column is stored first
-void launch_coef(const Scratch& sc, Partials b /*2k: s_i'g then y_i'g, logical order*/, const CoefArgs& a, int fresh_row = -1);
-// r (in place of g) and the guard sums (sum r^2, nonfinite).  With H0 != NULL (adaQN):
-// r = H0 .* (g + sum cy_j y_j) + sum cs_j s_j, else r = coef[0] g + sum cy_j y_j + sum cs_j s_j.
-Partials launch_combine(const Scratch& sc, int buf, size_t n, const RowSet& y_rows, const RowSet& s_rows, real* g,
-                        const real* H0 = nullptr);
 
 // ---- three-pass form: S twice, Y once -- (3k+5) n words (kernels.hip "three-pass form") -----------------------
+// The recursion only needs the inner products of g with the stored vectors and the inner products among the
+// stored vectors; the latter (s_a'y_b, a older than b) are cached when a pair enters the ring.  Same quantities as
+// reference src/stochqn.c:663-708, other association of the floating-point sums.
 // pass 1: quantities [0,k) s_i'g, and with probe_y (the pair that just entered, ring row r) [k,2k) s_i'y_r
 // `feed` (host callers): the pass runs in feed->slices slices of the traversal; before the kernel of a slice is enqueued
 // feed->arrive(user, lo, hi, slice) is called for the element range [lo, hi) of g that slice reads -- the caller enqueues the
 // upload of that range and makes the stream wait for it.  Bit-identical to the unsliced pass (kernels.hip: Slice).
-// carry: device scratch of at least 2 * kRowsMax * grid * kBlock doubles.
+// carry: device scratch of carry_count doubles; a pass whose grid needs more than that (sdot_carry_count for pass 1, two
+// per lane of the grid for pass 3) runs as one launch.
 struct SliceFeed {
 	int slices;
 	double* carry;
+	size_t carry_count;
 	void (*arrive)(void* user, size_t lo, size_t hi, int slice);
 	void* user;
 };
 bool sdot_can_slice(const Scratch& sc, const RowSet& s_rows, const real* g, real* copy_out, const real* probe_y);
+size_t sdot_carry_count(const Scratch& sc, size_t n, int k);
 Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows /*logical order*/, const real* g, real* copy_out, const real* probe_y,
                      const SliceFeed* feed = nullptr);
 // totals, (fresh_row >= 0) the new column of the cached s_old'y_new block, backward recursion -> alpha (coef[1..k]), scale (coef[0])
@@ -256,23 +237,6 @@ Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows,
 // out = x - step * r, the expression (and the bits) of the guarded update, without touching x
 void launch_spec_x(const Scratch& sc, size_t n, const real* r, const real* x, double step, real* out);
 void launch_store_column(const Scratch& sc, Partials in /*k: s_i'y_col*/, const CoefArgs& a, int col_row);
-
-// ---- two-pass form with the diagonal H0 of adaQN -----------------------------------------------------
-// r_0 = H0 .* q_0 makes the forward loop need H0-weighted inner products: u_i = sum y_i H0 g and
-// W_ij = sum y_i H0 y_j.  H0 changes every step, so they are recomputed every step -- in the same pass
-// over S and Y that yields [S;Y]g and applies adaQN's side effects on the raw gradient
-// (G <- update, H0 <- g/sqrt(G+eps), Fisher row <- g; reference src/stochqn.c:738-781,1174).
-struct GramH0Args {
-	RowSet s_rows, y_rows;     // the k pairs in use, logical order
-	const real* g;
-	real* G;
-	real* H0_out;
-	real* frow_out;          // nullable
-	double rmsprop_weight, scal_reg;
-};
-// quantities: [0,k) s_i'g, [k,2k) y_i'g, [2k,3k) u_i, then W_ij for i <= j row by row
-Partials launch_gram_h0(const Scratch& sc, size_t n, const GramH0Args& a);
-void launch_coef_h0(const Scratch& sc, Partials b, const CoefArgs& a);
 
 // reduce `nsums` partial arrays to scalars: out[j] = sum_b parts[j*stride+b]
 void launch_fin(const Scratch& sc, Partials in, int nsums, double* out);

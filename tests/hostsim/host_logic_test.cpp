@@ -1,0 +1,625 @@
+// host_logic_test.cpp -- scenarios that drive the product's host logic on the CPU (TEST INFRASTRUCTURE ONLY).
+//
+//   host_logic_{asan,tsan} <scenario> [lazy]
+//
+// Linked against the unchanged runtime.cpp / machines.cpp / group.cpp, the malloc-backed HIP stand-in (fake_hip.cpp), the
+// launcher stand-ins (fake_launch.cpp: x -= step * grad, the scalars of the recursion scripted) and, through
+// STOCHQN_HIP_RCCL_LIB, the rendezvous stand-in for RCCL.  Every scenario goes through the C ABI of include/stochqn.h the
+// way a profile-B caller does (R / Cython: every array the caller's, structs rebuilt per call, counters copied back) or a
+// profile-A caller (initialize_* / dealloc_*), checks the iterate against x0 - sum step * grad after every call, and ends
+// with a leak check of the fake runtime (no device allocation, stream, event or pinned range left behind).
+// Exit code 0 = the scenario passed; the sanitizers add their own verdict.
+#include "fake_hip.hpp"
+#include "fake_launch.hpp"
+
+#include "stochqn.h"
+#include "stochqn_hip.h"
+
+#include <dlfcn.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+int g_failures = 0;
+#define CHECK(cond, ...)                                                                                    \
+	do {                                                                                                    \
+		if (!(cond)) {                                                                                      \
+			std::fprintf(stderr, "CHECK FAILED %s:%d: %s -- ", __FILE__, __LINE__, #cond);                  \
+			std::fprintf(stderr, __VA_ARGS__);                                                              \
+			std::fprintf(stderr, "\n");                                                                     \
+			g_failures++;                                                                                   \
+		}                                                                                                   \
+	} while (0)
+
+void opt(const char* name, double v)
+{
+	if (stochqn_hip_set_option(name, v) != 0) { std::fprintf(stderr, "unknown option %s\n", name); g_failures++; }
+}
+long long stat(const char* name) { return stochqn_hip_stat(name); }
+
+enum Kind { OLBFGS, SQN, ADAQN };
+
+// A profile-B optimiser object: the caller owns every array (host memory), rebuilds the structs on its stack for every call
+// and copies the counters back (reference src/Rwrapper.c:98-196, stochqn/pywrapper.pxi:161-207).
+struct Opt {
+	Kind kind;
+	int n;
+	size_t m, L, fsize;
+	bool grad_diff;
+	double min_curv, max_incr;
+	int check_nan = 1;
+	std::vector<double> S, Y, rho, alpha, sbak, ybak, gprev, xsum, xprev, H0, G, F, fy;
+	std::vector<double> x, grad, hv, x_ref;
+	size_t mem_used = 0, st = 0, niter = 0, f_used = 0, f_st = 0;
+	int section = 0;
+	double f_prev = 0, f = 1.0;
+	double *req = nullptr, *req_vec = nullptr;
+	task_enum task = calc_grad;
+	info_enum info = no_problems_encountered;
+	int calls = 0, accepted = 0, failed = 0;
+	bool check_x = true;
+
+	Opt(Kind k, int n_, size_t m_, size_t L_, bool gd = false, double mc = 0.0, size_t fs = 0, double mi = 0.0)
+		: kind(k), n(n_), m(m_), L(L_), fsize(fs), grad_diff(gd), min_curv(mc), max_incr(mi)
+	{
+		const size_t N = (size_t) n;
+		S.assign(m * N, 0.0); Y.assign(m * N, 0.0); rho.assign(m, 0.0); alpha.assign(m, 0.0);
+		sbak.assign(mc > 0 ? N : 1, 0.0); ybak.assign(mc > 0 ? N : 1, 0.0);
+		gprev.assign((k == OLBFGS || gd) ? N : 1, 0.0);
+		xsum.assign(N, 0.0); xprev.assign(N, 0.0);
+		if (k == ADAQN) { H0.assign(N, 0.0); G.assign(N, 0.0); F.assign(gd ? 1 : (fs ? fs : 1) * N, 0.0); fy.assign(fs ? fs : 1, 0.0); }
+		x.resize(N); grad.assign(N, 0.0); hv.assign(gd ? 1 : N, 0.0);
+		for (size_t i = 0; i < N; i++) x[i] = 1.0 + 0.001 * (double) (i % 97);
+		x_ref = x;
+		req = x.data();
+	}
+
+	const void* key() const { return S.data(); }
+
+	// the caller's side of the protocol: what the library asked for at *req, on the host
+	void answer()
+	{
+		const size_t N = (size_t) n;
+		if (task == calc_grad || task == calc_grad_same_batch || task == calc_grad_big_batch)
+			for (size_t i = 0; i < N; i++) grad[i] = 0.25 * req[i] + 0.01;
+		else if (task == calc_hess_vec)
+			for (size_t i = 0; i < N; i++) hv[i] = 2.0 * req_vec[i];
+		else if (task == calc_fun_val_batch) { f = 0; for (size_t i = 0; i < N; i++) f += req[i] * req[i]; }
+	}
+
+	int call(double step)
+	{
+		bfgs_mem b{S.data(), Y.data(), rho.data(), alpha.data(), sbak.data(), ybak.data(), m, mem_used, st, kind == OLBFGS ? 1 : L, 0.0, min_curv};
+		int rc = -1000;
+		const bool takes_step = section == 1;
+		std::vector<double> g_in = takes_step ? grad : std::vector<double>();
+		if (kind == OLBFGS) {
+			workspace_oLBFGS w{&b, gprev.data(), 0.0, niter, section, 1, check_nan, n};
+			rc = run_oLBFGS(step, x.data(), grad.data(), &req, &task, &w, &info);
+			niter = w.niter; section = w.section;
+		} else if (kind == SQN) {
+			workspace_SQN w{&b, gprev.data(), xsum.data(), xprev.data(), grad_diff, niter, section, 1, check_nan, n};
+			rc = run_SQN(step, x.data(), grad.data(), hv.data(), &req, &req_vec, &task, &w, &info);
+			niter = w.niter; section = w.section;
+		} else {
+			fisher_mem fm{F.data(), fy.data(), fsize, f_used, f_st};
+			workspace_adaQN w{&b, grad_diff ? nullptr : &fm, H0.data(), gprev.data(), xsum.data(), xprev.data(), G.data(), f_prev, max_incr, 1e-4, 0.9,
+			                  grad_diff, niter, section, 1, check_nan, n};
+			rc = run_adaQN(step, x.data(), f, grad.data(), &req, &task, &w, &info);
+			niter = w.niter; section = w.section; f_prev = w.f_prev;
+			f_used = fm.mem_used; f_st = fm.mem_st_ix;
+		}
+		mem_used = b.mem_used; st = b.mem_st_ix;
+		calls++;
+		if (rc == -1000) { failed++; return rc; }
+		if (takes_step && rc == 1 && info != func_increased) {
+			accepted++;
+			for (size_t i = 0; i < (size_t) n; i++) x_ref[i] -= step * g_in[i];      // the stand-in's direction is the gradient
+		}
+		if (info == func_increased) x_ref = x;                                       // x <- x_avg_prev (not followed here)
+		if (check_x) {
+			double worst = 0;
+			for (size_t i = 0; i < (size_t) n; i++) worst = std::fmax(worst, std::fabs(x[i] - x_ref[i]));
+			CHECK(worst <= 1e-12, "call %d (kind %d, section -> %d): the caller's x is %.3g away from x0 - sum step * grad", calls, (int) kind, section, worst);
+		}
+		return rc;
+	}
+
+	// `count` calls of the reverse-communication loop; returns the last return code
+	int drive(int count, double step = 0.01)
+	{
+		int rc = 0;
+		for (int k = 0; k < count; k++) {
+			answer();
+			rc = call(step);
+			if (rc == -1000) break;
+		}
+		return rc;
+	}
+};
+
+void leak_check(const char* where, long pinned_allowed = 1)
+{
+	stochqn_hip_release_all();
+	const fakehip::Live l = fakehip::live();
+	CHECK(l.device_allocs == 0, "%s: %ld device allocations (%ld bytes) left behind", where, l.device_allocs, l.device_bytes);
+	CHECK(l.streams == 0 && l.events == 0, "%s: %ld streams, %ld events left behind", where, l.streams, l.events);
+	CHECK(l.registered_ranges == 0, "%s: %ld host ranges still pinned", where, l.registered_ranges);
+	CHECK(l.pinned_allocs <= pinned_allowed, "%s: %ld pinned allocations left behind (the bounce buffer of the reclaim path may stay)", where, l.pinned_allocs);
+	CHECK(fakehip::violations() == 0, "%s: %ld violations of the runtime's rules, last: %s", where, fakehip::violations(), fakehip::last_violation());
+}
+
+void defaults()
+{
+	fakehip::reset();
+	fakehip::set_devices(1);
+	fakehip::set_capacity(0);
+	fakelaunch::script() = fakelaunch::Script{};
+	opt("devices", 0); opt("virtual_devices", 0); opt("devices_min_n", 1 << 20); opt("max_mirror_bytes", 0);
+	opt("register_host", 1); opt("register_min_bytes", 4 << 20); opt("x_upload", 1); opt("x_prefetch", 0);
+	opt("upload_slices", 8); opt("apply_chunks", 8); opt("spec_x", 1); opt("strict_grad", 0); opt("threepass", 1);
+	opt("fail_alloc_after", -1); opt("reducer_patience_s", 120);
+	stochqn_hip_stats_reset();
+}
+
+// ---- scenarios ----------------------------------------------------------------------------------------------------------
+// context registry: create / look up / release, another object at the same address, section 0 after a restart, export
+void sc_registry()
+{
+	Opt a(SQN, 3000, 4, 3), b(OLBFGS, 2000, 3, 1), c(ADAQN, 1500, 3, 4, false, 1e-4, 6, 1.01);
+	a.drive(25); b.drive(30); c.drive(40);
+	CHECK(stat("contexts_created") == 3, "contexts_created = %lld", stat("contexts_created"));
+	CHECK(a.accepted >= 10 && b.accepted >= 10 && c.accepted >= 10, "steps taken: %d %d %d", a.accepted, b.accepted, c.accepted);
+	CHECK(a.mem_used == 4 && b.mem_used == 3, "rings: %zu %zu", a.mem_used, b.mem_used);
+	CHECK(stochqn_hip_export(a.key()) == 0 && stochqn_hip_export(b.key()) == 0 && stochqn_hip_export(c.key()) == 0, "export");
+	stochqn_hip_invalidate(a.key());
+	a.drive(8);
+	// a brand-new object in the same arrays (R / Python never call dealloc_*): section 0 drops the old context
+	a.section = 0; a.niter = 0; a.mem_used = 0; a.st = 0; a.x_ref = a.x;
+	a.drive(12);
+	CHECK(stat("contexts_created") == 4, "a restart makes a new context: %lld", stat("contexts_created"));
+	// the same address with another shape
+	Opt d(SQN, 1000, 4, 3);
+	d.S.swap(a.S);                                   // d now lives at a's old s_mem address, with another n
+	d.S.resize(4 * 1000);
+	d.drive(10);
+	stochqn_hip_release(b.key());
+	b.drive(6);                                      // released in mid-flight: re-imported from the caller's arrays, goes on
+	CHECK(stochqn_hip_export((const void*) 0x10) == -1000, "export of nothing");
+	leak_check("registry");
+}
+
+// least-recently-used reclaim under memory pressure -> spill -> the object comes back -> resume from the library's own copy
+void sc_reclaim_resume()
+{
+	const int n = 4000;
+	const size_t m = 5;
+	Opt a(SQN, n, m, 1000), b(SQN, n, m, 1000);       // L = 1000: no pair is built, S and Y stay what was imported
+	for (size_t i = 0; i < a.S.size(); i++) { a.S[i] = 1.0 + (double) i; a.Y[i] = -2.0 - (double) i; }
+	a.mem_used = 3; a.st = 3; a.niter = 7; a.section = 1;                 // a resumed object: its arrays are imported
+	// room for one object's mirrors (2 m n + 2 n doubles) and the scratch of two contexts, not for two objects' mirrors
+	const size_t mirrors = (2 * m + 2) * (size_t) n * 8;
+	a.drive(4);
+	const fakehip::Live one = fakehip::live();
+	fakehip::set_capacity((size_t) one.device_bytes + mirrors / 2 + (one.device_bytes - mirrors));
+	const std::vector<double> S0 = a.S, Y0 = a.Y;
+	b.drive(4);                                       // needs a's memory: a is spilled to library-owned host memory and destroyed
+	CHECK(stat("contexts_reclaimed") == 1, "contexts_reclaimed = %lld", stat("contexts_reclaimed"));
+	CHECK(b.failed == 0, "the newcomer must not fail");
+	// the caller's arrays of a are stale by now (an R vector may even be gone): scribble over them
+	std::vector<double> xs = a.xsum;
+	for (double& v : a.S) v = 777.0;
+	for (double& v : a.Y) v = 777.0;
+	for (double& v : a.xsum) v = 777.0;
+	// resume under an injected failure first: the half-made context is dropped, the library's copy must survive it
+	for (long k = 0; k < 6; k++) {
+		opt("fail_alloc_after", (double) k);
+		fakehip::set_capacity(0);                    // plenty of memory now: only the injected failure is in the way
+		a.answer();
+		const int rc = a.call(0.01);
+		opt("fail_alloc_after", -1);
+		if (rc != -1000) break;
+		a.failed = 0;
+	}
+	CHECK(a.failed == 0, "a resumed in the end");
+	a.drive(3);
+	CHECK(stochqn_hip_export(a.key()) == 0, "export");
+	size_t bad = 0;
+	for (size_t i = 0; i < S0.size(); i++) bad += (a.S[i] != S0[i]) + (a.Y[i] != Y0[i]);
+	CHECK(bad == 0, "%zu elements of S / Y differ from what the reclaimed context held (the stale arrays were imported?)", bad);
+	// x_sum went on from the spilled value, not from the scribble: 777 * n would show
+	double sum = 0;
+	for (double v : a.xsum) sum += v;
+	CHECK(sum < 700.0 * n, "x_sum continued from the stale caller array");
+	leak_check("reclaim_resume");
+}
+
+// option "max_mirror_bytes": idle contexts beyond the cap are spilled, everybody keeps working
+void sc_mirror_cap()
+{
+	const int n = 2000;
+	std::vector<Opt> objs;
+	for (int k = 0; k < 4; k++) objs.emplace_back(SQN, n, 4, 3);
+	opt("max_mirror_bytes", (double) ((2 * 4 + 2) * n * 8 * 2 + 100));        // two objects' worth
+	for (int round = 0; round < 5; round++)
+		for (auto& o : objs) o.drive(5);
+	CHECK(stat("contexts_reclaimed") >= 4, "contexts_reclaimed = %lld", stat("contexts_reclaimed"));
+	for (auto& o : objs) CHECK(o.failed == 0 && o.accepted >= 10, "object: failed %d accepted %d", o.failed, o.accepted);
+	opt("max_mirror_bytes", 0);
+	leak_check("mirror_cap");
+}
+
+// host callers of a large-enough problem: pinning in place, the gradient in slices, x ahead of the guard, a rejected step
+void sc_host_path()
+{
+	const int n = 1 << 22;                             // the sliced paths start at 2^21 .. 2^22 elements
+	opt("register_min_bytes", 1 << 20);
+	for (int strict = 0; strict < 2; strict++) {
+		opt("strict_grad", strict);
+		Opt a(SQN, n, 3, 4);
+		a.drive(14);
+		CHECK(a.failed == 0 && a.mem_used >= 2, "failed %d ring %zu", a.failed, a.mem_used);
+		fakelaunch::script().reject_step = true;     // the guard says no: x untouched, what went ahead is put right
+		const size_t before = a.mem_used;
+		a.drive(1);
+		fakelaunch::script().reject_step = false;
+		CHECK(a.info == search_direction_was_nan && a.mem_used == 0 && before > 0, "a rejected step flushes the ring (info %d)", (int) a.info);
+		a.drive(10);
+		stochqn_hip_release(a.key());
+	}
+	CHECK(stat("x_sent_ahead") > 0 && stat("x_sent_again") > 0, "x ahead of the guard: %lld, sent again: %lld", stat("x_sent_ahead"), stat("x_sent_again"));
+	// x_upload = 0: the caller vouches for x between calls; an edit the probes see makes the library upload it again
+	opt("x_upload", 0);
+	Opt c(OLBFGS, n, 3, 1);
+	c.drive(9);
+	for (size_t i = 0; i < (size_t) n; i++) c.x[i] *= 0.5;
+	c.x_ref = c.x;
+	c.drive(9);
+	CHECK(c.failed == 0 && stat("x_uploads_skipped") > 0, "skipped uploads: %lld", stat("x_uploads_skipped"));
+	opt("x_upload", 1);
+	leak_check("host_path");
+}
+
+// rejected pairs (rollback = bak -> slot), NaN guards off, gradient differences, Fisher pairs with the function-value check
+void sc_branches()
+{
+	Opt a(SQN, 3000, 3, 2, true, 1e-4);               // gradient differences + min_curvature
+	a.drive(15);
+	fakelaunch::script().reject_pair = true;
+	a.drive(12);
+	fakelaunch::script().reject_pair = false;
+	a.drive(10);
+	Opt b(ADAQN, 2500, 3, 3, false, 1e-4, 5, 1.01);
+	b.drive(60);
+	Opt c(ADAQN, 2500, 3, 3, true, 0.0, 0, 0.0);
+	c.drive(40);
+	Opt d(OLBFGS, 2000, 4, 1, false, 1e-3);
+	d.check_nan = 0;
+	d.drive(30);
+	opt("threepass", 0);
+	Opt e(SQN, 3000, 3, 2);
+	e.drive(20);
+	opt("threepass", 1);
+	fakelaunch::script().sy = 1e-9;                    // nearly orthogonal pairs: the kappa rule sends the step to the sweeps
+	Opt f(SQN, 3000, 3, 2);
+	f.drive(20);
+	fakelaunch::script().sy = 1.0;
+	CHECK(stat("steps_kappa_fallback") > 0, "kappa fallbacks: %lld", stat("steps_kappa_fallback"));
+	for (Opt* o : {&a, &b, &c, &d, &e, &f}) CHECK(o->failed == 0 && o->accepted > 5, "failed %d accepted %d", o->failed, o->accepted);
+	opt("verify_cache", 1);
+	Opt g(SQN, 3000, 3, 2);
+	g.drive(20);
+	opt("verify_cache", 0);
+	leak_check("branches");
+}
+
+// library-owned workspaces (profile A) and the isolated entries
+void sc_owned_and_raw()
+{
+	workspace_SQN* w = initialize_SQN(3000, 4, 3, 1e-4, 0, 0.0, 1, 1);
+	CHECK(w != nullptr, "initialize_SQN");
+	if (w) {
+		std::vector<double> x(3000, 1.0), g(3000), hv(3000);
+		double *req = x.data(), *req_vec = nullptr;
+		task_enum task = calc_grad;
+		info_enum info;
+		for (int k = 0; k < 30; k++) {
+			if (task == calc_hess_vec) for (int i = 0; i < 3000; i++) hv[(size_t) i] = req_vec[i];
+			else for (int i = 0; i < 3000; i++) g[(size_t) i] = 0.1 * req[i];
+			const int rc = run_SQN(0.01, x.data(), g.data(), hv.data(), &req, &req_vec, &task, w, &info);
+			CHECK(rc == 0 || rc == 1, "run_SQN on an owned workspace: %d", rc);
+		}
+		dealloc_SQN(w);
+	}
+	workspace_adaQN* wa = initialize_adaQN(2000, 3, 5, 3, 1.01, 1e-4, 1e-4, 0.9, 0, 0.0, 1, 1);
+	CHECK(wa != nullptr, "initialize_adaQN");
+	dealloc_adaQN(wa);
+	workspace_oLBFGS* wo = initialize_oLBFGS(2000, 3, 0.0, 0.0, 0.0, 1, 1);
+	CHECK(wo != nullptr, "initialize_oLBFGS");
+	dealloc_oLBFGS(wo);
+	// isolated two-loop / take_step / Fisher product on host arrays
+	const int n = 2000;
+	std::vector<double> S(4 * n, 1.0), Y(4 * n, 2.0), g(n, 0.5), rho(4), alpha(4), x(n, 1.0), G(n, 0.1), H0(n), F(6 * n, 0.2), t(6), y(n);
+	CHECK(stochqn_hip_two_loop(g.data(), n, nullptr, 0.0, Y.data(), S.data(), 4, 4, 1, rho.data(), alpha.data()) == 0, "two_loop");
+	opt("raw_reuse_cache", 1);
+	CHECK(stochqn_hip_two_loop(g.data(), n, nullptr, 0.0, Y.data(), S.data(), 4, 4, 1, rho.data(), alpha.data()) == 0, "two_loop, cached");
+	opt("raw_reuse_cache", 0);
+	bfgs_mem b{S.data(), Y.data(), rho.data(), alpha.data(), nullptr, nullptr, 4, 4, 2, 1, 0.0, 0.0};
+	info_enum info;
+	CHECK(stochqn_hip_take_step(0.01, n, x.data(), g.data(), &b, 0.9, H0.data(), 0.0, G.data(), 1e-4, 1, &info) == 0, "take_step");
+	CHECK(stochqn_hip_fisher_product(F.data(), 6, n, g.data(), t.data(), y.data()) == 0, "fisher_product");
+	CHECK(stochqn_hip_two_loop(nullptr, n, nullptr, 0.0, Y.data(), S.data(), 4, 4, 1, nullptr, nullptr) == -1000, "invalid input");
+	leak_check("owned_and_raw");
+}
+
+void use_fake_rccl(void** handle)
+{
+	const char* lib = std::getenv("STOCHQN_HIP_RCCL_LIB");
+	CHECK(lib && *lib, "STOCHQN_HIP_RCCL_LIB must name libfake_rccl_*.so");
+	*handle = lib ? dlopen(lib, RTLD_NOW | RTLD_GLOBAL) : nullptr;
+	CHECK(*handle != nullptr, "dlopen(%s): %s", lib ? lib : "?", dlerror());
+}
+template <class F> F sym(void* h, const char* name) { return h ? (F) dlsym(h, name) : nullptr; }
+
+// single-process multi-device mode: P shard threads, each with its own context, stream and RCCL communicator (ncclCommInitAll)
+void group_body(int P, bool virt)
+{
+	opt("devices", P); opt("devices_min_n", 1); opt("virtual_devices", virt ? 1 : 0);
+	const int n = 4001;                               // not divisible by P: ragged shards
+	{
+		Opt a(SQN, n, 3, 4), b(ADAQN, n, 3, 3, false, 1e-4, 5, 1.01), c(OLBFGS, n, 3, 1), d(SQN, n, 3, 3, true, 1e-4);
+		a.drive(30); b.drive(45); c.drive(30); d.drive(30);
+		CHECK(stochqn_hip_devices_active(a.key()) == P, "shards of a: %d", stochqn_hip_devices_active(a.key()));
+		CHECK(stochqn_hip_devices_reducer(a.key()) == (virt ? 3 : 1), "reducer kind %d", stochqn_hip_devices_reducer(a.key()));
+		for (Opt* o : {&a, &b, &c, &d}) CHECK(o->failed == 0 && o->accepted >= 10, "kind %d: failed %d accepted %d", (int) o->kind, o->failed, o->accepted);
+		CHECK(stochqn_hip_export(a.key()) == 0 && stochqn_hip_export(b.key()) == 0, "export of sharded state");
+		stochqn_hip_invalidate(a.key());
+		a.drive(10);
+		fakelaunch::script().reject_step = true;
+		a.drive(1);
+		fakelaunch::script().reject_step = false;
+		CHECK(a.info == search_direction_was_nan, "every shard rejects alike");
+		a.drive(8);
+		stochqn_hip_release(a.key());
+		a.drive(6);                                  // re-imported from the caller's arrays
+	}
+	// library-owned sharded workspace (n beyond one device in real life)
+	workspace_SQN* w = initialize_SQN(n, 3, 3, 0.0, 0, 0.0, 1, 1);
+	CHECK(w != nullptr, "initialize_SQN in group mode");
+	if (w) {
+		std::vector<double> x((size_t) n, 1.0), g((size_t) n), hv((size_t) n);
+		double *req = x.data(), *req_vec = nullptr;
+		task_enum task = calc_grad;
+		info_enum info;
+		for (int k = 0; k < 24; k++) {
+			if (task == calc_hess_vec) for (int i = 0; i < n; i++) hv[(size_t) i] = req_vec[i];
+			else for (int i = 0; i < n; i++) g[(size_t) i] = 0.1 * req[i];
+			const int rc = run_SQN(0.01, x.data(), g.data(), hv.data(), &req, &req_vec, &task, w, &info);
+			CHECK(rc == 0 || rc == 1, "run_SQN on an owned sharded workspace: %d", rc);
+		}
+		dealloc_SQN(w);
+	}
+	opt("devices", 0);
+}
+
+void sc_group_rccl()
+{
+	void* h = nullptr;
+	use_fake_rccl(&h);
+	fakehip::set_devices(4);
+	group_body(4, false);
+	auto init_all = sym<long (*)()>(h, "fake_rccl_init_all_calls");
+	auto live = sym<long (*)()>(h, "fake_rccl_live_comms");
+	auto reds = sym<long (*)()>(h, "fake_rccl_allreduces");
+	CHECK(init_all && init_all() >= 5, "ncclCommInitAll ran %ld times", init_all ? init_all() : -1);
+	CHECK(reds && reds() > 100, "all-reduces through the communicators: %ld", reds ? reds() : -1);
+	leak_check("group_rccl");
+	CHECK(live && live() == 0, "%ld communicators left behind", live ? live() : -1);
+	// P = 1 over a real communicator: option "devices_rccl_single" (the path an 8-GPU node takes, on one device)
+	fakehip::set_devices(1);
+	opt("devices_rccl_single", 1);
+	{
+		Opt a(SQN, 3000, 3, 3);
+		a.drive(25);
+		CHECK(stochqn_hip_devices_active(a.key()) == 1 && stochqn_hip_devices_reducer(a.key()) == 1, "P = 1 group over RCCL: %d shards, reducer %d",
+		      stochqn_hip_devices_active(a.key()), stochqn_hip_devices_reducer(a.key()));
+		CHECK(a.failed == 0 && a.accepted >= 10, "failed %d accepted %d", a.failed, a.accepted);
+	}
+	opt("devices_rccl_single", 0);
+	leak_check("group_rccl_single");
+	CHECK(live && live() == 0, "%ld communicators left behind", live ? live() : -1);
+}
+
+void sc_group_virtual()
+{
+	fakehip::set_devices(1);
+	group_body(3, true);
+	leak_check("group_virtual");
+}
+
+// group mode with every allocation failing in turn: NULL / -1000, never a crash, a hang or a leak; then a clean run works
+void sc_group_alloc_failures()
+{
+	void* h = nullptr;
+	use_fake_rccl(&h);
+	auto patience = sym<void (*)(int)>(h, "fake_rccl_set_patience_ms");
+	if (patience) patience(300);
+	opt("reducer_patience_s", 0.3);
+	for (int virt = 0; virt < 2; virt++) {
+		fakehip::set_devices(virt ? 1 : 4);
+		const int P = virt ? 3 : 4;
+		opt("devices", P); opt("devices_min_n", 1); opt("virtual_devices", virt);
+		long k = 0, failed_runs = 0;
+		int clean_in_a_row = 0;                       // some allocations may fail without harm (a pinned landing zone falls back to malloc)
+		for (; clean_in_a_row < 10; k++) {
+			opt("fail_alloc_after", (double) k);
+			int worst = 1;
+			{
+				Opt a(SQN, 2003, 3, 3);
+				a.check_x = false;                    // a failed call leaves x as it was handed in, the reference's contract for -1000
+				worst = a.drive(12);
+				stochqn_hip_release(a.key());
+			}
+			workspace_SQN* w = initialize_SQN(2003, 3, 3, 0.0, 0, 0.0, 1, 1);
+			if (w) dealloc_SQN(w);
+			opt("fail_alloc_after", -1);
+			leak_check("group_alloc_failures");
+			const bool clean = worst != -1000 && w != nullptr;
+			clean_in_a_row = clean ? clean_in_a_row + 1 : 0;
+			failed_runs += !clean;
+			if (k > 600) { CHECK(false, "the injection never stopped firing"); break; }
+		}
+		CHECK(failed_runs >= 5, "only %ld of the injected failures were felt", failed_runs);
+		std::fprintf(stderr, "group_alloc_failures: %s reducer, P = %d: %ld injection points, %ld failed cleanly\n", virt ? "host-side" : "RCCL", P, k, failed_runs);
+	}
+	opt("devices", 0);
+}
+
+// EVERY call site of the HIP runtime failing in turn, single device: a message and -1000 (or a result), never a crash / leak
+struct SweepStats { long runs = 0, failed_calls = 0, survived = 0; };
+
+void sweep_one(const std::function<int()>& body, const char* where, SweepStats& st, long stride_after, long max_per_fn)
+{
+	// a clean run tells how often each entry point is called
+	fakehip::reset();
+	(void) body();
+	long counts[fakehip::F_COUNT];
+	for (int f = 0; f < fakehip::F_COUNT; f++) counts[f] = fakehip::calls(f);
+	leak_check(where);
+	for (int f = 0; f < fakehip::F_COUNT; f++) {
+		long tried = 0;
+		for (long nth = 1; nth <= counts[f] && tried < max_per_fn; nth += (nth < stride_after ? 1 : 1 + nth / 8), tried++) {
+			fakehip::reset();
+			fakehip::fail_nth(f, nth);
+			const int rc = body();
+			st.runs++;
+			if (rc == -1000) st.failed_calls++; else st.survived++;
+			CHECK(rc == 0 || rc == 1 || rc == -1000, "%s: %s call %ld failing: return code %d", where, fakehip::fn_name(f), nth, rc);
+			char tag[160];
+			std::snprintf(tag, sizeof tag, "%s, %s #%ld failing", where, fakehip::fn_name(f), nth);
+			fakehip::fail_nth(f, 0);
+			leak_check(tag, 2);
+		}
+	}
+}
+
+void sc_fault_sweep()
+{
+	SweepStats st;
+	opt("register_min_bytes", 1 << 12);
+	// (1) a host caller through two pair cycles, (2) the same under memory pressure: reclaim -> spill -> resume
+	sweep_one([] {
+		Opt a(SQN, 1 << 13, 3, 3);
+		a.check_x = false;
+		int rc = a.drive(14);
+		if (rc != -1000) rc = stochqn_hip_export(a.key()) == 0 ? rc : -1000;
+		stochqn_hip_release(a.key());
+		return rc;
+	}, "fault_sweep/host_caller", st, 40, 120);
+	sweep_one([] {
+		const int n = 3000;
+		Opt a(SQN, n, 4, 1000), b(SQN, n, 4, 1000);
+		a.check_x = b.check_x = false;
+		a.mem_used = 2; a.st = 2; a.niter = 5; a.section = 1;
+		int rc = a.drive(3);
+		const fakehip::Live one = fakehip::live();
+		fakehip::set_capacity((size_t) one.device_bytes + (2 * 4 + 2) * (size_t) n * 8 / 2 + (size_t) (one.device_bytes - (2 * 4 + 2) * (long) n * 8));
+		const int rb = b.drive(3);
+		fakehip::set_capacity(0);
+		const int ra = a.drive(3);
+		if (rb == -1000 || ra == -1000) rc = -1000;
+		stochqn_hip_release(a.key()); stochqn_hip_release(b.key());
+		return rc;
+	}, "fault_sweep/reclaim", st, 40, 120);
+	sweep_one([] {
+		Opt a(ADAQN, 2048, 3, 3, false, 1e-4, 4, 1.01);
+		a.check_x = false;
+		const int rc = a.drive(30);
+		stochqn_hip_release(a.key());
+		return rc;
+	}, "fault_sweep/adaqn", st, 30, 80);
+	std::fprintf(stderr, "fault_sweep: %ld runs with one failing HIP call each: %ld ended in -1000, %ld completed\n", st.runs, st.failed_calls, st.survived);
+	CHECK(st.runs > 300 && st.failed_calls > 50, "the sweep did not reach the call sites (%ld runs, %ld failed calls)", st.runs, st.failed_calls);
+}
+
+// the same with shard threads in the way: a shard that fails on its own must not leave the others waiting for ever
+void sc_fault_sweep_group()
+{
+	void* h = nullptr;
+	use_fake_rccl(&h);
+	auto patience = sym<void (*)(int)>(h, "fake_rccl_set_patience_ms");
+	if (patience) patience(250);
+	opt("reducer_patience_s", 0.25);
+	opt("register_min_bytes", 1 << 12);
+	SweepStats st;
+	for (int virt = 0; virt < 2; virt++) {
+		fakehip::set_devices(virt ? 1 : 2);
+		opt("devices", 2); opt("devices_min_n", 1); opt("virtual_devices", virt);
+		sweep_one([] {
+			Opt a(SQN, 4099, 3, 3);
+			a.check_x = false;
+			const int rc = a.drive(10);
+			stochqn_hip_release(a.key());
+			return rc;
+		}, virt ? "fault_sweep_group/virtual" : "fault_sweep_group/rccl", st, 6, 14);
+	}
+	opt("devices", 0);
+	std::fprintf(stderr, "fault_sweep_group: %ld runs: %ld ended in -1000, %ld completed\n", st.runs, st.failed_calls, st.survived);
+	CHECK(st.runs > 100, "the sweep did not reach the call sites (%ld runs)", st.runs);
+}
+
+// two caller threads, each with its own objects, while a third exports and releases: the registry under contention
+void sc_threads()
+{
+	opt("max_mirror_bytes", (double) ((2 * 3 + 2) * 2000 * 8 * 3));
+	std::vector<std::thread> ts;
+	for (int t = 0; t < 3; t++)
+		ts.emplace_back([t] {
+			Opt a(t == 1 ? OLBFGS : SQN, 2000, 3, 3), b(SQN, 2000, 3, 2);
+			for (int r = 0; r < 6; r++) {
+				a.drive(7); b.drive(5);
+				if (stochqn_hip_export(a.key()) != 0) { /* reclaimed meanwhile: its spill was exported instead */ }
+				if (r == 3) stochqn_hip_release(b.key());
+			}
+			CHECK(a.failed == 0 && b.failed == 0, "thread %d: failed %d %d", t, a.failed, b.failed);
+			stochqn_hip_release(a.key()); stochqn_hip_release(b.key());
+		});
+	for (auto& t : ts) t.join();
+	opt("max_mirror_bytes", 0);
+	leak_check("threads");
+}
+
+struct Scenario { const char* name; void (*fn)(); };
+const Scenario kScenarios[] = {
+	{"registry", sc_registry}, {"reclaim_resume", sc_reclaim_resume}, {"mirror_cap", sc_mirror_cap}, {"host_path", sc_host_path},
+	{"branches", sc_branches}, {"owned_and_raw", sc_owned_and_raw}, {"group_rccl", sc_group_rccl}, {"group_virtual", sc_group_virtual},
+	{"group_alloc_failures", sc_group_alloc_failures}, {"fault_sweep", sc_fault_sweep}, {"fault_sweep_group", sc_fault_sweep_group},
+	{"threads", sc_threads}};
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+	if (argc < 2) {
+		for (const auto& s : kScenarios) std::printf("%s\n", s.name);
+		return 0;
+	}
+	const bool lazy = argc > 2 && !std::strcmp(argv[2], "lazy");
+	for (const auto& s : kScenarios)
+		if (!std::strcmp(argv[1], s.name)) {
+			defaults();
+			fakehip::set_lazy(lazy);
+			s.fn();
+			std::fprintf(stderr, "%s (%s streams): %s\n", s.name, lazy ? "lazy" : "immediate", g_failures ? "FAILED" : "ok");
+			return g_failures ? 1 : 0;
+		}
+	std::fprintf(stderr, "unknown scenario %s\n", argv[1]);
+	return 2;
+}

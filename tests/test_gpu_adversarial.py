@@ -1,6 +1,6 @@
-"""Adversarial inputs for the two forms of the two-loop recursion (DESIGN.md 3.2 "fallback rule").
+"""Adversarial inputs for the two forms of the two-loop recursion (DESIGN.md 3.0 "fallback rule").
 
-The default two-pass form evaluates the reference's recursion (reference src/stochqn.c:671-707) from cached
+The default three-pass form evaluates the reference's recursion (reference src/stochqn.c:671-707) from cached
 inner products instead of from the running vector.  Same formula, other association -- so the question is
 not "equal to the oracle on nice inputs" but "as accurate as the reference's own arithmetic on nasty ones".
 Yardstick: the sequential recursion evaluated in extended precision (numpy longdouble, 64-bit mantissa) on
@@ -122,7 +122,7 @@ def gpu_two_loop(lib, g, S, Y, m, used, st, form, kappa_max=None, h0=0.0):
     dS, dY, dg = (torch.as_tensor(a.reshape(-1), device="cuda") for a in (S, Y, g))
     set_form(lib, form)
     if kappa_max is not None:
-        lib.stochqn_hip_set_option(b"twopass_kappa_max", kappa_max)
+        lib.stochqn_hip_set_option(b"kappa_max", kappa_max)
     lib.stochqn_hip_profile_enable(1)
     lib.stochqn_hip_profile_reset()
     try:
@@ -131,12 +131,12 @@ def gpu_two_loop(lib, g, S, Y, m, used, st, form, kappa_max=None, h0=0.0):
     finally:
         lib.stochqn_hip_profile_enable(0)
         reset_form(lib)
-        lib.stochqn_hip_set_option(b"twopass_kappa_max", 1e6)
+        lib.stochqn_hip_set_option(b"kappa_max", 1e6)
         lib.stochqn_hip_release(C.c_void_p(dS.data_ptr()))
     return dg.cpu().numpy(), ran
 
 
-RAN = {"threepass": "sadd", "twopass": "combine", "sweeps": "mid"}        # the kernel that only this form launches
+RAN = {"threepass": "sadd", "sweeps": "mid"}        # the kernel that only this form launches
 
 
 ACCURATE = ["benign", "hessian_cond_1e8", "collinear_1e-8", "collinear_1e-4", "inconsistent_curvature", "negative_curvature",
@@ -157,7 +157,7 @@ def test_both_forms_are_as_accurate_as_fp64_allows(name, n, k, st, hip_backend):
     if name == "orthogonal_1e-3" and k > 24 and e_oracle > 1e-12:
         pytest.skip("48 pairs at kappa = 1e3 each: the oracle itself is %.1e from the yardstick, not an accurate class any more" % e_oracle)
     assert e_oracle <= 1e-12, e_oracle                       # the class is one fp64 handles
-    for form in (("threepass", "twopass", "sweeps") if k <= 24 else ("threepass", "sweeps")):      # the two-pass form stops at 24 pairs
+    for form in ("threepass", "sweeps"):
         got, ran = gpu_two_loop(lib, g, S, Y, k, k, st, form)
         assert [f for f in RAN if RAN[f] in ran] == [form], ran      # the form asked for is the form that ran
         e_gpu = err(got, truth)
@@ -167,7 +167,7 @@ def test_both_forms_are_as_accurate_as_fp64_allows(name, n, k, st, hip_backend):
 
 @pytest.mark.parametrize("eps", [1e-8, 1e-10, 1e-12])
 def test_nearly_orthogonal_pairs_take_the_sweep_form(eps, hip_backend):
-    """kappa = |s||y|/|s'y| = 1/eps beyond twopass_kappa_max: every fp64 evaluation loses digits (the oracle too);
+    """kappa = |s||y|/|s'y| = 1/eps beyond kappa_max: every fp64 evaluation loses digits (the oracle too);
     the default must run the reference's own chain of sweeps and be as good as the oracle up to a small factor.
     The expanded form, forced, is allowed its measured extra loss (reported, bounded)."""
     from oracle import oracle
@@ -180,11 +180,11 @@ def test_nearly_orthogonal_pairs_take_the_sweep_form(eps, hip_backend):
     oracle.two_loop(want, None, 0.0, Y.reshape(-1), S.reshape(-1), k, k, st)
     e_oracle = err(want, truth)
     got, ran = gpu_two_loop(lib, g, S, Y, k, k, st, "threepass")         # default rule: falls back to the sweeps
-    assert "sadd" not in ran and "combine" not in ran and "mid" in ran, ran
+    assert "sadd" not in ran and "mid" in ran, ran
     e_default = err(got, truth)
     assert e_default <= 50 * e_oracle + 1e-13, (e_default, e_oracle)
     report = "eps %g: oracle %.2e  sweeps (default) %.2e" % (eps, e_oracle, e_default)
-    for form in ("threepass", "twopass"):
+    for form in ("threepass",):
         forced, ran = gpu_two_loop(lib, g, S, Y, k, k, st, form, kappa_max=float("inf"))
         assert RAN[form] in ran
         e_forced = err(forced, truth)
@@ -193,9 +193,9 @@ def test_nearly_orthogonal_pairs_take_the_sweep_form(eps, hip_backend):
     print(report)
 
 
-@pytest.mark.parametrize("twopass", ["threepass", "twopass", "sweeps"])
+@pytest.mark.parametrize("which", ["threepass", "sweeps"])
 @pytest.mark.parametrize("check_nan", [1, 0])
-def test_zero_curvature_pair_is_rejected_like_the_oracle(twopass, check_nan, hip_backend):
+def test_zero_curvature_pair_is_rejected_like_the_oracle(which, check_nan, hip_backend):
     """s'y == 0 exactly (disjoint supports): rho = inf, the direction is non-finite.  With the guard: flagged,
     memory flushed, x untouched -- as the oracle; without it x becomes non-finite in both."""
     torch = torch_cuda()
@@ -213,7 +213,7 @@ def test_zero_curvature_pair_is_rejected_like_the_oracle(twopass, check_nan, hip
     want = oracle_take_step(0.05, xw, gw, S.reshape(-1), Y.reshape(-1), m, m, 0, 0.0, None, 0.0, None, 0.0, check_nan)
     dx, dg, dS, dY = (torch.as_tensor(a.reshape(-1), device="cuda") for a in (x, g, S, Y))
     from test_gpu_parity import reset_form, set_form
-    set_form(lib, twopass)
+    set_form(lib, which)
     try:
         got = hip_take_step(lib, 0.05, dx, dg, dS, dY, m, m, 0, 0.0, None, 0.0, None, 0.0, check_nan)
     finally:
@@ -227,9 +227,9 @@ def test_zero_curvature_pair_is_rejected_like_the_oracle(twopass, check_nan, hip
         assert not np.isfinite(xw).any() and not np.isfinite(dx.cpu().numpy()).any()
 
 
-@pytest.mark.parametrize("twopass", ["threepass", "twopass", "sweeps"])
+@pytest.mark.parametrize("which", ["threepass", "sweeps"])
 @pytest.mark.parametrize("scale", [1e150, 1e-150])
-def test_extreme_gradient_scales_get_the_oracles_verdict(scale, twopass, hip_backend):
+def test_extreme_gradient_scales_get_the_oracles_verdict(scale, which, hip_backend):
     """|g| ~ 1e150: sum r^2 overflows where the reference's dnrm2 does not -- the verdict (norm > 1e3 n: rejected)
     is the same; |g| ~ 1e-150: the squares underflow, the step is taken, x moves by exactly the oracle's amount."""
     torch = torch_cuda()
@@ -244,7 +244,7 @@ def test_extreme_gradient_scales_get_the_oracles_verdict(scale, twopass, hip_bac
     want = oracle_take_step(0.05, xw, gw, S.reshape(-1), Y.reshape(-1), m, m, 2, 0.0, None, 0.0, None, 0.0, 1)
     dx, dg, dS, dY = (torch.as_tensor(a.reshape(-1), device="cuda") for a in (x, g, S, Y))
     from test_gpu_parity import reset_form, set_form
-    set_form(lib, twopass)
+    set_form(lib, which)
     try:
         got = hip_take_step(lib, 0.05, dx, dg, dS, dY, m, m, 2, 0.0, None, 0.0, None, 0.0, 1)
     finally:
@@ -311,7 +311,7 @@ STOCH = {
 def test_stochastic_nonquadratic_run_keeps_parity_and_reports_the_fallback_rate(optname, hip_backend, oracle_backend):
     """min_curvature = 0 (nothing filters the pairs), ~300 optimiser steps on a stochastic logistic loss, lock-step against
     the oracle at 1e-10 on every call.  Reported (gpurun_out/ and stdout) and bounded: how many of the steps with pairs in
-    memory the kappa rule (|s||y|/|s'y| > twopass_kappa_max = 1e6) sent to the reference's chain of sweeps."""
+    memory the kappa rule (|s||y|/|s'y| > kappa_max = 1e6) sent to the reference's chain of sweeps."""
     import json
     import os
     import stochqn_amd
@@ -377,7 +377,7 @@ def test_kappa_threshold_follows_from_the_kernels_own_error(k, hip_backend):
         want = g.copy()
         oracle.two_loop(want, None, 0.0, Y.reshape(-1), S.reshape(-1), k, k, st)
         row = {"kappa": kappa, "oracle": err(want, truth)}
-        for form in ("threepass", "twopass", "sweeps"):
+        for form in ("threepass", "sweeps"):
             got, ran = gpu_two_loop(lib, g, S, Y, k, k, st, form, kappa_max=float("inf"))
             assert RAN[form] in ran
             row[form] = err(got, truth)
@@ -385,11 +385,11 @@ def test_kappa_threshold_follows_from_the_kernels_own_error(k, hip_backend):
         table.append(row)
         if kappa <= 1e6:
             floor = max(row["oracle"], row["sweeps"], 1e-15)
-            assert row["threepass"] <= 30 * floor and row["twopass"] <= 30 * floor, row
+            assert row["threepass"] <= 30 * floor, row
         if kappa <= 1e4:
-            assert row["threepass_vs_oracle"] <= TOL and row["twopass_vs_oracle"] <= TOL, row
+            assert row["threepass_vs_oracle"] <= TOL, row
     print("kappa sweep (k = %d):" % k, json.dumps(table))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, "r03_kappa_sweep_k%d.json" % k), "w") as fh:
+    with open(os.path.join(out_dir, "r04_kappa_sweep_k%d.json" % k), "w") as fh:
         json.dump(table, fh)

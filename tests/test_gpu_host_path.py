@@ -251,13 +251,13 @@ def test_step_counters_name_the_form_that_ran(hip_backend):
     plain, three = stat(lib, "steps_plain"), stat(lib, "steps_three_pass")
     assert plain == 1 and three == 9 and stat(lib, "steps_sweeps") == 0, (plain, three)
     try:
-        lib.stochqn_hip_set_option(b"twopass", 0.0)
+        lib.stochqn_hip_set_option(b"threepass", 0.0)
         lib.stochqn_hip_stats_reset()
         x = torch.as_tensor(P.x0(), device="cuda:0")
         run_trace(OPTIMIZERS["oLBFGS"](backend=hip_backend, space="device", device="cuda:0", mem_size=3), P, x, 0.05, 21)
         assert stat(lib, "steps_sweeps") == 9 and stat(lib, "steps_three_pass") == 0 and stat(lib, "steps_kappa_fallback") == 0
     finally:
-        lib.stochqn_hip_set_option(b"twopass", 1.0)
+        lib.stochqn_hip_set_option(b"threepass", 1.0)
     assert lib.stochqn_hip_stat(b"no_such_counter") == -1
     lib.stochqn_hip_release_all()
 

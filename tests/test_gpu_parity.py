@@ -16,19 +16,17 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-FORMS = {"threepass": (1.0, 1.0), "twopass": (1.0, 0.0), "sweeps": (0.0, 1.0)}      # name -> options (twopass, threepass)
+FORMS = {"threepass": 1.0, "sweeps": 0.0}      # name -> option "threepass"
 
 
 def set_form(lib, name):
-    """Select the implementation of the two-loop recursion: the three-pass form (default: S twice, Y once), the
-    two-pass (Gram) form, or the reference's chain of dependent sweeps.  The isolated entry points only use a cached
-    form when the caller vouches for the arrays (raw_reuse_cache); the tests release their contexts after every call."""
+    """Select the implementation of the two-loop recursion: the three-pass form (default: S twice, Y once) or the
+    reference's chain of dependent sweeps.  The isolated entry points only use the cached form when the caller
+    vouches for the arrays (raw_reuse_cache); the tests release their contexts after every call."""
     lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
-    tw, th = FORMS[name]
-    assert lib.stochqn_hip_set_option(b"twopass", tw) == 0
-    assert lib.stochqn_hip_set_option(b"twopass_h0", tw) == 0
+    th = FORMS[name]
     assert lib.stochqn_hip_set_option(b"threepass", th) == 0
-    assert lib.stochqn_hip_set_option(b"raw_reuse_cache", 1.0 if tw else 0.0) == 0
+    assert lib.stochqn_hip_set_option(b"raw_reuse_cache", th) == 0
 
 
 def reset_form(lib):
@@ -39,16 +37,6 @@ def reset_form(lib):
 @pytest.fixture(params=["threepass", "sweeps"])
 def form(request, hip_backend):
     """Run a test once per implementation of the two-loop: the default three-pass form and the chain of sweeps."""
-    import stochqn_amd
-    lib = stochqn_amd.cdll()
-    set_form(lib, request.param)
-    yield request.param
-    reset_form(lib)
-
-
-@pytest.fixture(params=["threepass", "twopass", "sweeps"])
-def form3(request, hip_backend):
-    """All three implementations (the two-pass form stays selectable with option threepass = 0)."""
     import stochqn_amd
     lib = stochqn_amd.cdll()
     set_form(lib, request.param)
@@ -67,7 +55,7 @@ def torch_cuda():
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("space", ["host", "device"])
 @pytest.mark.parametrize("case", ["oLBFGS_rosen2d", "SQN_rosen2d", "adaQN_rosen2d"])
-def test_known_answers(case, space, form3, hip_backend):
+def test_known_answers(case, space, form, hip_backend):
     # chaotic Rosenbrock trajectories amplify last-bit differences; 1e3 x the oracle's own pin
     check_known_answer(case, hip_backend, space=space, tol_scale=1e3)
 
@@ -106,8 +94,8 @@ CONFIGS = [
     ("adaqn_nonan_check", "adaQN", dict(mem_size=3, fisher_size=6, bfgs_upd_freq=4, check_nan=False), 0.05, 70, {}),
     # a Fisher ring larger than any fixed-size scalar buffer in the library (and never full in this run)
     ("adaqn_fisher500", "adaQN", dict(mem_size=3, fisher_size=500, bfgs_upd_freq=4, max_incr=None), 0.05, 40, {}),
-    # rings of 25 .. 48 pairs: the three-pass form still applies (the two-pass form stops at 24 and falls back to the
-    # sweeps); beyond 48 every form does (sqn_ring50).  (The adaQN ring
+    # rings of 25 .. 48 pairs: the three-pass form still applies; beyond 48 the step runs as the sweeps (sqn_ring50).
+    # (The adaQN ring
     # configs stop after ~30 calls: later the iterates jitter around the optimum, s = x_avg - x_avg_prev
     # has mixed signs and F s cancels to ~1e-6 of its terms, so ANY two summation orders differ by
     # ~1e-10 in y -- a property of the instance, not of the kernel.)
@@ -187,17 +175,6 @@ def test_lockstep_parity_full_grids(cfgname, form, hip_backend, oracle_backend):
     run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 20), TOL, on_sync=inval)
 
 
-def test_lockstep_parity_full_grids_two_pass_form(hip_backend, oracle_backend):
-    """The two-pass form (option threepass = 0) at the same size: the 20-pair ring of SQN (its adaQN kernels at full
-    launch shape are covered by test_adaqn_step_matches_the_oracle_at_full_size)."""
-    import stochqn_amd
-    lib = stochqn_amd.cdll()
-    set_form(lib, "twopass")
-    try:
-        test_lockstep_parity_full_grids("sqn_ring20", "twopass", hip_backend, oracle_backend)
-    finally:
-        reset_form(lib)
-
 
 @pytest.mark.parametrize("n", [2, 65, 1000])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
@@ -207,7 +184,7 @@ def test_trace_parity_host_arrays(cfg, n, form, hip_backend, oracle_backend):
     compare_traces(got, want, FREE_RUN_TOL.get(cfg[0], TOL))
 
 
-def test_golden_traces(form3, hip_backend):
+def test_golden_traces(form, hip_backend):
     """Committed regression vectors (tests/golden/traces.json, made by tests/golden/make_traces.py)."""
     path = os.path.join(os.path.dirname(__file__), "golden", "traces.json")
     gold = json.load(open(path))
@@ -249,7 +226,7 @@ TWO_LOOP_SHAPES = [(1, 1, 0), (5, 5, 3), (5, 2, 0), (5, 3, 4), (20, 20, 7), (20,
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 4096, 1000003])
 @pytest.mark.parametrize("m,used,st", TWO_LOOP_SHAPES)
 @pytest.mark.parametrize("mode", ["gamma", "h0"])
-def test_two_loop_matches_oracle(n, m, used, st, mode, form3, hip_backend):
+def test_two_loop_matches_oracle(n, m, used, st, mode, form, hip_backend):
     """Scalar H0 (gamma from the newest pair, or h0 > 0): both forms of the recursion."""
     check_two_loop(n, m, used, st, mode)
 
@@ -257,8 +234,7 @@ def test_two_loop_matches_oracle(n, m, used, st, mode, form3, hip_backend):
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 4096, 1000003])
 @pytest.mark.parametrize("m,used,st", TWO_LOOP_SHAPES)
 def test_two_loop_with_a_given_diagonal_matches_oracle(n, m, used, st, form, hip_backend):
-    """A caller-supplied diagonal H0: the three-pass form scales q0 by it in pass 2; the two-pass form has no kernel for
-    a GIVEN diagonal (its H0-weighted Gram entries are fused with building H0: adaQN's step, stochqn_hip_take_step)."""
+    """A caller-supplied diagonal H0: the three-pass form scales q0 by it in pass 2 (k_qdot, MODE 1)."""
     check_two_loop(n, m, used, st, "H0")
 
 
@@ -309,8 +285,8 @@ def test_two_loop_host_pointers(hip_backend):
 
 
 # ---------------------------------------------------------------------------------------------
-# take_step on its own (reference src/stochqn.c:802-840): the entry that reaches adaQN's diagonal-H0
-# kernels of the two-pass form (k_gram_h0 / k_coef_h0 / k_combine<H0V>) with a state of the caller's choice
+# take_step on its own (reference src/stochqn.c:802-840): the entry that reaches adaQN's step (pass 2 in its
+# adaQN mode, or the sweeps with the diagonal H0) with a state of the caller's choice
 # ---------------------------------------------------------------------------------------------
 def take_step_args(lib):
     from stochqn_amd import _abi
@@ -348,10 +324,9 @@ def hip_take_step(lib, step, x, g, S, Y, m, used, st_ix, w, H0, h0, G, eps, chec
 @pytest.mark.parametrize("n", [1, 65, 4096, 1000003])
 @pytest.mark.parametrize("m,used,st_ix", [(5, 5, 3), (5, 2, 2), (20, 20, 7), (20, 20, 0), (3, 0, 0), (1, 1, 0)])
 @pytest.mark.parametrize("mode", ["rmsprop", "adagrad", "gamma", "h0"])
-def test_take_step_matches_oracle(n, m, used, st_ix, mode, form3, hip_backend):
-    """Direction, x, G, H0, rho, alpha and the verdict of one isolated step; `form` = twopass really selects
-    k_gram_h0 / k_coef_h0 / k_combine<H0V> for the two diagonal modes (and rows-dot / coef / combine for the
-    scalar ones), `sweeps` the chain of dependent sweeps."""
+def test_take_step_matches_oracle(n, m, used, st_ix, mode, form, hip_backend):
+    """Direction, x, G, H0, rho, alpha and the verdict of one isolated step, in the three-pass form (k_qdot in its adaQN
+    mode for the two diagonal modes) and as the chain of dependent sweeps."""
     import stochqn_amd
     torch = torch_cuda()
     lib = stochqn_amd.cdll()
@@ -379,7 +354,7 @@ def test_take_step_matches_oracle(n, m, used, st_ix, mode, form3, hip_backend):
         assert np.allclose(got[3][:used], want[3][:used], rtol=1e-9, atol=1e-13 * np.abs(want[3][:used]).max())
 
 
-def test_take_step_guard_rejects_like_the_oracle(form3, hip_backend):
+def test_take_step_guard_rejects_like_the_oracle(form, hip_backend):
     """A non-finite gradient entry: x untouched, memory flushed, search_direction_was_nan -- in both forms."""
     import stochqn_amd
     torch = torch_cuda()
@@ -432,7 +407,7 @@ def test_take_step_host_pointers(mode, form, hip_backend):
 def test_adaqn_step_matches_the_oracle_at_full_size(hip_backend):
     """adaQN's step at the headline shape, n = 1e8, m = 20, ring full and wrapped, RMSProp diagonal: direction,
     x, G and H0 to 1e-10 against the oracle, for the default three-pass kernels (pass 2 builds H0 and applies the
-    side effects), the two-pass kernels (k_gram_h0, k_coef_h0, k_combine<H0V>) and the sweep form.  (BASELINE config 4's per-step path; the oracle needs 32 GB of host
+    side effects) and the sweep form.  (BASELINE config 4's per-step path; the oracle needs 32 GB of host
     memory and a few seconds per call.)"""
     import stochqn_amd
     torch = torch_cuda()
@@ -448,14 +423,14 @@ def test_adaqn_step_matches_the_oracle_at_full_size(hip_backend):
     want = oracle_take_step(0.01, x_w, g_w, S_h, Y_h, m, m, st_ix, 0.9, H0_w, 0.0, G_w, 1e-4, 1)
     del S_h, Y_h
     try:
-        for twopass in ("threepass", "twopass", "sweeps"):
-            set_form(lib, twopass)
+        for which in ("threepass", "sweeps"):
+            set_form(lib, which)
             xq, gq, Gq, H0q = x.clone(), g.clone(), G.clone(), torch.zeros_like(g)
             got = hip_take_step(lib, 0.01, xq, gq, S, Y, m, m, st_ix, 0.9, H0q, 0.0, Gq, 1e-4, 1)
             assert got[:2] == want[:2] == (200, m)
             for name, a, b in (("direction", gq, g_w), ("x", xq, x_w), ("G", Gq, G_w), ("H0", H0q, H0_w)):
                 e = rel_err(a.cpu().numpy(), b)
-                assert e <= TOL, (name, twopass, e)
+                assert e <= TOL, (name, which, e)
             assert np.allclose(got[2], want[2], rtol=TOL, atol=0)
             assert np.allclose(got[3], want[3], rtol=1e-9, atol=1e-13 * np.abs(want[3]).max())
             del xq, gq, Gq, H0q
@@ -611,8 +586,7 @@ def test_two_loop_properties_at_baseline_size(n, m, form, hip_backend):
 def test_two_loop_matches_the_oracle_at_full_size(hip_backend):
     """The headline shape itself against the oracle: n = 1e8, m = 20, ring full and wrapped, fp64.  The oracle
     needs the 32 GB of S and Y in host memory and ~4 s per two-loop on the box's 16 CPUs, so this is done once,
-    for all three forms of the recursion with the scalar H0; with a caller-supplied diagonal for the three-pass and
-    the sweep form (the two-pass form has no kernel for a GIVEN diagonal).  adaQN's step at this size:
+    for both forms of the recursion, with the scalar H0 and with a caller-supplied diagonal.  adaQN's step at this size:
     test_adaqn_step_matches_the_oracle_at_full_size."""
     import stochqn_amd
     from oracle import oracle
@@ -628,12 +602,12 @@ def test_two_loop_matches_the_oracle_at_full_size(hip_backend):
         for H0_d in (None, H0):
             want = g.cpu().numpy().copy()
             rho_w, alpha_w = oracle.two_loop(want, None if H0_d is None else H0_d.cpu().numpy(), 0.0, Y_h, S_h, m, m, st)
-            for twopass in (("threepass", "twopass", "sweeps") if H0_d is None else ("threepass", "sweeps")):
-                set_form(lib, twopass)
+            for which in ("threepass", "sweeps"):
+                set_form(lib, which)
                 q = g.clone()
                 rho, alpha = hip_two_loop(lib, q, H0_d, 0.0, Y, S, n, m, m, st)
                 got = q.cpu().numpy()
-                assert rel_err(got, want) <= TOL, (H0_d is not None, twopass, rel_err(got, want))
+                assert rel_err(got, want) <= TOL, (H0_d is not None, which, rel_err(got, want))
                 assert np.allclose(rho, rho_w, rtol=TOL, atol=0)
                 assert np.allclose(alpha, alpha_w, rtol=1e-9, atol=1e-13 * np.abs(alpha_w).max())
                 del q, got
@@ -692,7 +666,7 @@ def test_steps_match_the_oracle_at_full_size(optname, n, kw, iters, step, tol, h
      26, 0.002, 1e-7),
 ])
 def test_full_size_steps_agree_between_the_two_forms(optname, kw, iters, step, tol, hip_backend):
-    """n = 1e8, m = 20 (BASELINE size), whole optimiser steps: the two-pass (Gram) form and the chain of
+    """n = 1e8, m = 20 (BASELINE size), whole optimiser steps: the three-pass form and the chain of
     dependent sweeps are two independent implementations of the same recursion, each held to the oracle at
     test sizes; here they are held to each other where the oracle is too slow -- 30 iterations from the
     same start (ring filling up, then wrapping), x equal to 1e-10, every discrete output identical."""
@@ -707,8 +681,8 @@ def test_full_size_steps_agree_between_the_two_forms(optname, kw, iters, step, t
     dn = d * (1 + 0.01 * (2 * torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) - 1))
     x0 = 1 + torch.rand(n, dtype=torch.float64, device="cuda", generator=gen)
 
-    def run(twopass):
-        set_form(lib, twopass)
+    def run(which):
+        set_form(lib, which)
         opt = OPTIMIZERS[optname](backend=hip_backend, space="device", **kw)
         x = x0.clone()
         log = []
@@ -1156,7 +1130,7 @@ def hip_backend_f32():
     return be
 
 
-@pytest.fixture(params=["threepass", "twopass", "sweeps"])
+@pytest.fixture(params=["threepass", "sweeps"])
 def form_f32(request, hip_backend_f32):
     import stochqn_amd
     lib = stochqn_amd.cdll(use_float=True)
@@ -1742,8 +1716,8 @@ def test_bench_headline_workload_runs_clean(config, n):
     assert d["two_loop"]["form"] == "three-pass" and d["two_loop"]["bytes_moved"] == (3 * 20 + 5) * n * 8
     assert d["reference_form"]["two_loop_alg_bytes"] == 64 * 20 * n and d["reference_form"]["two_loop_frac_of_8TBps"] > 0.6
     micro = d["two_loop_micro"]
-    assert micro["three_pass"]["median_ms"] < micro["two_pass"]["median_ms"] < micro["sweeps"]["median_ms"]
-    assert d["forms"] == dict(d["forms"], three_pass=20, two_pass=0, sweeps=0, sweeps_because_of_kappa=0) and d["allreduces_per_step"] == 0
+    assert micro["three_pass"]["median_ms"] < micro["sweeps"]["median_ms"]
+    assert d["forms"] == dict(d["forms"], three_pass=20, sweeps=0, sweeps_because_of_kappa=0) and d["allreduces_per_step"] == 0
     assert d["sustained"]["steps"] % 10 == 0 and d["sustained"]["seconds"] > 0.5
     assert abs(d["sustained"]["value"] / d["value"] - 1) < 0.15          # the K = 20 steps are representative of a second of the same
     if config == "c5":
