@@ -86,6 +86,10 @@ def parse():
     ap.add_argument("--sustain-seconds", type=float, default=6.0,
                     help="after the K timed steps: the same workload for about this long (whole steps, profiler off), reported as "
                          "`sustained` -- the rate over seconds instead of a fraction of one; 0 = skip")
+    ap.add_argument("--value-runs", type=int, default=3,
+                    help="the K-step region this many times in all (the first one is `value`; before each further one the gradient array is "
+                         "freed and allocated again): `value_runs` = every value, minimum / median / maximum -- the run-to-run spread of "
+                         "5-8 %% that comes with where the arrays land (DESIGN.md 3.3), next to the one draw")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, RCCL communicator) even with one rank")
     ap.add_argument("--rehearse", action="store_true",
@@ -488,6 +492,26 @@ def run(args):
     if args.dump_x:
         np.save("%s.%d.npy" % (args.dump_x, rank), x.cpu().numpy())
 
+    # ---- the K-step region again, on a gradient array that was freed and allocated anew (another placement): the spread ----
+    value_runs = None
+    if args.value_runs > 1:
+        vals = [args.steps / elapsed * n_total / 1e8]
+        for _ in range(args.value_runs - 1):
+            wl.grad = None
+            torch.cuda.empty_cache()
+            wl.pad = torch.empty(int(7 + 64 * len(vals)) << 18, dtype=f64, device=dev)     # shifts where the new array lands
+            wl.grad = torch.empty(n, dtype=f64, device=dev)
+            wl.steps(L)
+            barrier(ctx)
+            tv = time.perf_counter()
+            wl.steps(args.steps)
+            barrier(ctx)
+            vals.append(args.steps / max_over_ranks(ctx, time.perf_counter() - tv) * n_total / 1e8)
+        wl.pad = None
+        sv = sorted(vals)
+        value_runs = {"values": [round(v, 3) for v in vals], "min": round(sv[0], 3), "median": round(sv[len(sv) // 2], 3), "max": round(sv[-1], 3),
+                      "note": "`value` is values[0]; before each later repetition the caller's gradient array was re-allocated"}
+
     # ---- the same workload over seconds (K is the driver's choice and may last a quarter of a second): every rank
     # derives the same number of steps from the max-over-ranks time of the K steps above ---------------------------------
     sustained = None
@@ -628,6 +652,10 @@ def run(args):
                        "calls": timed_counters["calls"], "hess_vec_requests": timed_counters["hv"],
                        "rejected_steps": timed_counters["bad"], "rejected_pairs": timed_counters["rejected"],
                        "options": args.opt,
+                       "deviation_from_survey_8d": "Hessian mini-batch: the 32 sample vectors have disjoint supports (a_k,i = sqrt(32 d_i) for "
+                                                   "i = k mod 32, else 0; stored dense, streamed in full) so that A'A/32 = diag(d) is the exact "
+                                                   "Hessian of the objective; SURVEY 8d writes a_k,i = sqrt(d_i)(1 + 0.1(2u - 1)) for every i, whose "
+                                                   "A'A/32 is a rank-32 matrix unrelated to it.  Same storage, same traffic (PMC: 27.2 GB per pass).",
                        "f_start": f0, "f_end": f1},
             "rccl_nranks": 0 if (reducer or "").startswith("gloo (the library") else rccl_nranks,      # ranks of the communicator the reductions used
             "reducer": reducer,
@@ -635,6 +663,7 @@ def run(args):
             "steps_per_s_unnormalised": round(steps_per_s, 3),
             "profiled_pass": None if prof_elapsed is None else {"steps": prof_steps, "ms_per_step": round(1e3 * prof_elapsed / prof_steps, 3)},
             "sustained": sustained,
+            "value_runs": value_runs,
             "roofline": roof,
             "two_loop": two_loop,
             "two_loop_micro": micro,
@@ -653,27 +682,42 @@ def run(args):
     want_legs = world > 1 and not args.no_extra_legs and args.config == "c3" and args.n <= 0 and not args.strong
     emitted, emit_lock, legs_done, stage = threading.Event(), threading.Lock(), threading.Event(), {"name": None}
 
-    def emit(extra_failed=()):
+    def emit(extra_failed=(), watchdog_fired=False):
         """THE line (once).  Normally at the very end; from the watchdog when an auxiliary leg hangs, with what there is."""
         with emit_lock:
             if emitted.is_set():
                 return
             out = build_out()
+            # a reader who looks at `value` alone must see at a glance when RCCL did not produce it: the reductions of a multi-rank
+            # run went over gloo (RCCL could not be brought up, or a rehearsal), or an auxiliary leg hung and was cut off
+            why = []
+            if reducer is not None and reducer != "rccl":
+                why.append("the reductions of this run did not go over RCCL: %s" % reducer)
+                out["rccl_nranks"] = 0
+            if watchdog_fired:
+                why.append("the watchdog cut an auxiliary leg off: the legs are incomplete")
+            out["degraded"] = bool(why)
+            if why:
+                out["degraded_because"] = why
             if want_legs:
                 out["legs"] = legs
                 out["legs_failed"] = legs_failed + list(extra_failed)
             if args.config == "c5" or n_gpu == CONFIGS["c5"]:
-                out["shard_reference_1gpu"] = shard_reference(world, steps_per_s)
+                out["shard_reference_1gpu"] = shard_reference(world, steps_per_s, None)
             os.write(real_stdout, (json.dumps(out) + "\n").encode())
             emitted.set()
 
     def watchdog(limit):
         # the primary result is in hand; a collective of an auxiliary leg that never completes (first contact with RCCL on N > 1
-        # ranks happens on the driver's node) must not take it along: every rank leaves at the limit, rank 0 prints first
+        # ranks happens on the driver's node) must not take it along: every rank leaves at the limit, rank 0 prints first -- the
+        # line says "degraded": true.  With --strict-legs there is no line and every rank leaves with code 3.
         if legs_done.wait(limit):
             return
+        if args.strict_legs:
+            sys.stderr.write("bench.py: rank %d: leg '%s' had not finished after %g s (--strict-legs: no result line)\n" % (rank, stage["name"], limit))
+            os._exit(3)
         if rank == 0:
-            emit(["watchdog: leg '%s' had not finished after %g s; nothing after it was run" % (stage["name"], limit)])
+            emit(["watchdog: leg '%s' had not finished after %g s; nothing after it was run" % (stage["name"], limit)], watchdog_fired=True)
         else:
             time.sleep(3.0)
         os._exit(0)
@@ -701,12 +745,6 @@ def run(args):
 
         attempt("c5", lambda: timed_leg(ctx, config_n("c5"), m, L, bs, leg_steps, args.warmup,
                                         "BASELINE config 5's weak-scaling point: n = 1.25e8 per GPU (n_total = 1e9 on 8 GPUs)"))
-        if "c5" not in legs_failed:
-            ref = shard_reference(world, legs["c5"]["steps_per_s"]) if not args.rehearse else None
-            legs["c5"]["shard_reference_1gpu"] = ref
-            if ref:
-                legs["c5"]["this_run_over_reference"] = ref.get("this_run_over_reference")
-                legs["c5"]["within_15pct_of_linear"] = bool(legs["c5"]["steps_per_s"] >= ref["within_15pct_means_at_least"])
         attempt("strong", lambda: timed_leg(ctx, config_n("c3") // world, m, L, bs, leg_steps, args.warmup,
                                             "SURVEY 8e strong scaling: the n = 1e8 problem split over the GPUs"))
         attempt("allreduce_us", lambda: allreduce_latency(ctx))
@@ -733,6 +771,19 @@ def run(args):
         except Exception as e:
             legs["in_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
             legs_failed.append("in_process")
+        # C5's yardstick -- ONE GPU at the same per-GPU shard -- measured on THIS node, now that the ranks are gone: the
+        # "within 15 % of linear" verdict compares two numbers of the same box and the same minute (boxes differ by 5-8 %)
+        if "c5" in legs and "c5" not in legs_failed:
+            here = None
+            try:
+                here = c5_yardstick_here(args, config_n("c5"), max(20, args.steps))
+            except Exception as e:
+                here = {"error": "%s: %s" % (type(e).__name__, e)}
+            ref = shard_reference(world, legs["c5"]["steps_per_s"], here)
+            legs["c5"]["shard_reference_1gpu"] = ref
+            if ref and "steps_per_s" in ref:
+                legs["c5"]["this_run_over_reference"] = ref.get("this_run_over_reference")
+                legs["c5"]["within_15pct_of_linear"] = bool(legs["c5"]["steps_per_s"] >= ref["within_15pct_means_at_least"])
 
     # ---- N = 1: the dominant kernel's HBM traffic counted now (PMC), not looked up ------------------------------
     if world == 1 and roof and not args.no_live_pmc and not args.rehearse:
@@ -750,6 +801,25 @@ def run(args):
         sys.stderr.write("bench.py: leg(s) %s failed: %s\n" % (", ".join(legs_failed), json.dumps({k: legs[k] for k in legs_failed})))
         raise SystemExit(3)
     emit()
+
+
+def c5_yardstick_here(args, n_gpu, steps):
+    """`bench.py --gpus 1` at config 5's per-GPU shard as a fresh child on this node's GPU 0 (timed region only: no profiler
+    pass, no PMC, no host legs): the 1-GPU point of the weak-scaling curve, from the same box as the N-GPU point."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--vars-per-gpu", str(n_gpu), "--steps", str(steps), "--warmup", str(args.warmup),
+           "--mem", str(args.mem), "--upd-freq", str(args.upd_freq), "--bsize", str(args.bsize), "--no-cpu-baseline", "--no-host-caller",
+           "--no-live-pmc", "--no-reference-form", "--no-profile", "--sustain-seconds", "0", "--value-runs", "1"]
+    for kv in args.opt:
+        cmd += ["--opt", kv]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                             "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("exit code %d: %s" % (r.returncode, r.stderr[-600:].replace("\n", " | ")))
+    d = json.loads(lines[0])
+    return {"steps_per_s": d["steps_per_s_unnormalised"], "ms_per_step": d["ms_per_step"], "n_per_gpu": n_gpu, "steps": d["steps"]}
 
 
 def in_process_leg(args, world, n_gpu, steps):
@@ -1054,17 +1124,23 @@ def analyse_kernels(kern, n_gpu, m, bs, prof_steps, shards):
     return detail, roof, two_loop, what
 
 
-def shard_reference(n_gpus, steps_per_s):
-    """C5's yardstick: one GPU at the same per-GPU shard, n = 1.25e8, m = 20.  With one
-    GPU this run IS that measurement; with more it is quoted from the newest committed 1-GPU profile."""
+def shard_reference(n_gpus, steps_per_s, here):
+    """C5's yardstick: one GPU at the same per-GPU shard, n = 1.25e8, m = 20.  With one GPU this run IS that
+    measurement; with more it is `here` -- a 1-GPU child run on this very node (c5_yardstick_here) -- and only when that
+    could not be had the newest committed 1-GPU profile (another box: 5-8 % either way), labelled as the fallback it is."""
     import glob
     if n_gpus == 1:
         return {"steps_per_s": round(steps_per_s, 3), "source": "this run", "within_15pct_means_at_least": round(0.85 * steps_per_s, 3)}
+    if here and "steps_per_s" in here:
+        sps = here["steps_per_s"]
+        return {"steps_per_s": round(sps, 3), "source": "this node", "measured": here, "within_15pct_means_at_least": round(0.85 * sps, 3),
+                "this_run_over_reference": round(steps_per_s / sps, 4)}
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c5_shard_1gpu.json")), reverse=True):
         try:
             ref = json.load(open(f))
             sps = ref.get("steps_per_s_unnormalised") or ref["value"] / 1.25
-            return {"steps_per_s": round(sps, 3), "source": os.path.relpath(f, ROOT),
+            return {"steps_per_s": round(sps, 3), "source": "FALLBACK, another box: " + os.path.relpath(f, ROOT),
+                    "same_node_attempt": here,
                     "within_15pct_means_at_least": round(0.85 * sps, 3),
                     "this_run_over_reference": round(steps_per_s / sps, 4)}
         except (OSError, ValueError, KeyError):
@@ -1092,7 +1168,7 @@ def live_pmc(args, kernel):
     tmp = tempfile.mkdtemp(prefix="sqn_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--config", args.config, "--mem", str(args.mem),
              "--upd-freq", str(args.upd_freq), "--bsize", str(args.bsize), "--no-profile", "--no-cpu-baseline", "--no-host-caller",
-             "--no-reference-form", "--sustain-seconds", "0", "--no-live-pmc"]
+             "--no-reference-form", "--sustain-seconds", "0", "--no-live-pmc", "--value-runs", "1"]
     if args.n > 0:
         child += ["--vars-per-gpu", str(args.n)]
     for kv in args.opt:
@@ -1257,13 +1333,23 @@ def host_caller_leg(args, lib, be, hostc, gpu, n, m, L, step_size, two_loop):
            "pcie_probe_pinned_0.8GB" if nc == 100_000_000 else "pcie_probe_pinned": pcie_probe(nc * 8)}
     lib.stochqn_hip_stat.argtypes = [C.c_char_p]
     lib.stochqn_hip_stat.restype = C.c_longlong
-    for strict in (0, 1):
+    lib.stochqn_hip_pin_host.argtypes = [C.c_void_p, C.c_size_t]
+    lib.stochqn_hip_unpin_host.argtypes = [C.c_void_p]
+    # (name, strict_grad, the caller pins its arrays, options): the first two are what a binding that owns its arrays gets with
+    # the library's defaults (stochqn_amd/free.py pins through stochqn_hip_pin_host); `pageable` is a raw C caller that pins
+    # nothing; `vouched` a caller that also promises not to touch x while *req designates it (round 3's default)
+    variants = (("strict_grad_0", 0, True, {}), ("strict_grad_1", 1, True, {}), ("pageable", 0, False, {}),
+                ("vouched", 0, True, {"x_upload": 0.0, "x_prefetch": 1.0}))
+    for vname, strict, pin, opts in variants:
         lib.stochqn_hip_release_all()
         lib.stochqn_hip_stats_reset()
         assert lib.stochqn_hip_set_option(b"strict_grad", float(strict)) == 0
+        for k, v in opts.items():
+            assert lib.stochqn_hip_set_option(k.encode(), v) == 0
         x = hostc.x0.copy()
         grad, hv = np.empty(nc), np.empty(nc)
         x_sum, x_avg_prev = np.zeros(nc), x.copy()
+        pinned = [a for a in (x, grad, hv, x_sum, x_avg_prev) if pin and lib.stochqn_hip_pin_host(a.ctypes.data, a.nbytes) == 0]
         rho_h, alpha_h, dummy = np.zeros(m), np.zeros(m), np.zeros(1)
         b = _abi.bfgs_mem(S.ctypes.data, Y.ctypes.data, rho_h.ctypes.data, alpha_h.ctypes.data,
                           dummy.ctypes.data, dummy.ctypes.data, m, m, 3 % m, L, 0.0, 0.0)
@@ -1308,7 +1394,8 @@ def host_caller_leg(args, lib, be, hostc, gpu, n, m, L, step_size, two_loop):
         up = 8 * nc * (1 + x_every_step)            # grad (+ x when it is uploaded every step)
         down = 8 * nc * (1 + strict)
         dev_ms = two_loop["ms"] + 0.75 if two_loop else None
-        res["strict_grad_%d" % strict] = {
+        res[vname] = {
+            "arrays_pinned_by_the_caller": len(pinned), "options": opts,
             "ms_per_step": round(cycle_ms / L, 2), "steps_per_s": round(1e3 * L / cycle_ms * nc / 1e8, 3),
             "ordinary_step_ms": round(ord_ms, 2), "step_after_a_pair_ms": round(after_pair, 2), "pair_step_ms": round(pair, 2),
             "per_step_ms": [round(v, 2) for v in per],
@@ -1319,14 +1406,21 @@ def host_caller_leg(args, lib, be, hostc, gpu, n, m, L, step_size, two_loop):
             "host_ranges_pinned": int(lib.stochqn_hip_stat(b"host_ranges_registered")),
             "x_sent_ahead_of_the_guard": int(lib.stochqn_hip_stat(b"x_sent_ahead")), "x_sent_again": int(lib.stochqn_hip_stat(b"x_sent_again")),
             "x_prefetched": int(lib.stochqn_hip_stat(b"x_prefetched"))}
+        lib.stochqn_hip_release_all()
+        for a in pinned:
+            lib.stochqn_hip_unpin_host(a.ctypes.data)
+        for k in opts:
+            lib.stochqn_hip_set_option(k.encode(), {"x_upload": 1.0, "x_prefetch": 0.0}[k])
     lib.stochqn_hip_set_option(b"strict_grad", 0.0)
     lib.stochqn_hip_release_all()
-    res["note"] = ("strict_grad = 0 is the library's default (the reference documents `grad` as an input that is clobbered, no shipped caller "
-                   "reads it back); ms_per_step = one whole L-cycle on the clock (the pair-building step and the step after it included: "
-                   "x has to go up again after a request at x_avg, which the library starts in the background when the call before "
-                   "returns -- x_prefetched; the caller here spends its time in between on a numpy gradient); link_GBps = (bytes up + down) / "
-                   "(ordinary step - the device-resident step's kernels). Round 2 measured 91.6 ms per step on this path (pageable "
-                   "copies, x and the direction moved on every call).")
+    res["note"] = ("strict_grad_0 / strict_grad_1: the library's defaults (x goes up on every step like the reference's *req = x; the library "
+                   "pins nothing by itself) with the caller's five per-call arrays page-locked by their owner through stochqn_hip_pin_host, "
+                   "which is what stochqn_amd/free.py does for numpy arrays; strict_grad = 0 is the default (the reference documents `grad` "
+                   "as an input that is clobbered, no shipped caller reads it back). pageable: the same with nothing pinned (a raw C caller). "
+                   "vouched: the caller also promises not to touch x while *req designates it (x_upload = 0, x_prefetch = 1: round 3's "
+                   "default, 36.6 ms there). ms_per_step = one whole L-cycle on the clock (the pair-building step and the step after it "
+                   "included); link_GBps = (bytes up + down) / (ordinary step - the device-resident step's kernels). Round 2 measured "
+                   "91.6 ms per step on this path (pageable copies, x and the direction moved on every call in one piece).")
     return res
 
 

@@ -72,6 +72,18 @@ void stochqn_hip_release_all(void);
  * support).  No-op for arrays the caller already keeps in device memory.  Returns 0 or -1000. */
 int stochqn_hip_export(const void *s_mem);
 
+/* ---- host arrays pinned by their owner --------------------------------------------------------------
+ * A host caller's x / grad / hess_vec (and the x_sum / x_avg_prev it reads requests from) cross PCIe on every step.  Pinned
+ * (page-locked) arrays move at link speed, in slices, under the kernels; pageable ones through the runtime's staged copies.
+ * The library pins nothing behind the caller's back by default: it cannot know when an array is freed, and a range that is
+ * freed and mapped again while still registered faults the GPU at the next copy.  Whoever OWNS an array for a known lifetime
+ * pins it here and unpins it before freeing it (a binding's optimiser object for the arrays it allocates; a finaliser on the
+ * user's x: stochqn_amd/free.py does both).  Calls nest (a count per address).  Equivalent to the caller's own
+ * hipHostRegister(p, bytes, hipHostRegisterPortable) / hipHostUnregister(p) for callers that do not link HIP.
+ * pin: 0 = pinned now (or once more), 1 = already page-locked by other means, -1 = refused.  unpin: 0 or -1. */
+int stochqn_hip_pin_host(void *p, size_t bytes);
+int stochqn_hip_unpin_host(void *p);
+
 /* ---- options -------------------------------------------------------------------------------------
  * "nontemporal" (default 1)  stream pair / Fisher rows with non-temporal loads
  * "grid_cap"    (default 0 = one workgroup per compute unit) maximum workgroups per sweep
@@ -96,17 +108,22 @@ int stochqn_hip_export(const void *s_mem);
  *                            first -- stored with the default cache policy; the rest streams out (sc1 nt)
  * "fuse_apply"  (default 0)  three-pass form with check_nan = 0: the position update inside pass 3 (measured slower: DESIGN.md 3.0)
  * -- host callers (arrays of R / numpy / malloc crossing the ABI; INTEGRATION.md "host callers") --
- * "register_host" (default 1), "register_min_bytes" (default 4 MiB)  the caller's x / grad / hess_vec / x_sum / x_avg_prev are
- *                            pinned in place with hipHostRegister the first time they are seen (kept until the context goes),
- *                            so that their copies are DMA transfers at link speed; refused registrations fall back to staged copies
- * "x_upload"    (default 0)  0: x is uploaded only when the device copy may be out of date -- first call, another array,
- *                            after a request that was not at x, or when any of 256 spread-out probe values differs from
- *                            what the library handed back (the reference forbids modifying *req, reference
- *                            include/stochqn.h:364-366, and *req is x after an ordinary step); 1: on every call
+ * "register_host" (default 0), "register_min_bytes" (default 4 MiB)  1: the library pins the caller's x / grad / hess_vec /
+ *                            x_sum / x_avg_prev in place by itself (hipHostRegister) once an array has been seen at the same
+ *                            address in two consecutive calls, and keeps it pinned until the context goes.  Only for callers
+ *                            that vouch for the lifetime of their arrays (see stochqn_hip_pin_host above for why it is off);
+ *                            arrays below register_min_bytes are never worth pinning
+ * "x_upload"    (default 1)  1: a host caller's x is uploaded on every call that uses it (the reference's semantics: *req
+ *                            aliases x, an edit between calls moves the iterate); for a large pinned x the upload rides under
+ *                            the update, slice by slice.  0: only when the device copy may be out of date -- first call,
+ *                            another array, after a request that was not at x, or when any of 256 spread-out probe values
+ *                            differs from what the library handed back -- for callers that vouch they do not touch x while
+ *                            *req designates it (reference include/stochqn.h:364-366)
  * "upload_slices" (default 8)  three-pass form: pass 1 runs in this many slices, each as soon as its part of `grad` has landed
  *                            (bit-identical to one launch: the lanes' accumulators are carried between the launches); 0 / 1: off
+ * "host_slice_min" (default 2^21)  vectors of fewer elements than this cross the link in one piece (no slices, nothing sent ahead)
  * "apply_chunks" (default 8) the update pass runs in this many slices so that the download of x overlaps it (bit-identical)
- * "x_prefetch"  (default 1)  a call that returns with *req == x while the device copy of x is out of date (the request before was at
+ * "x_prefetch"  (default 0)  with "x_upload" = 0: a call that returns with *req == x while the device copy of x is out of date (the request before was at
  *                            x_avg) starts the upload of x on a side stream and returns: it runs while the caller evaluates its
  *                            gradient; the next call orders itself behind it and still compares the probe values ("x_prefetched")
  * "spec_x"      (default 1)  three-pass form, n >= ~4e6: pass 3 runs in `apply_chunks` slices and x - step r of each finished

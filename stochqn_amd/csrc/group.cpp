@@ -251,6 +251,7 @@ Group* create_group(const Shape& sp, int P, bool owned, bool resumed)
 	g->kind = sp.kind; g->n = sp.n; g->P = P; g->m = sp.b->mem_size; g->fsize = sp.f ? sp.f->mem_size : 0;
 	g->owned = owned;
 	const int phys = physical_devices();
+	if (phys < 1) return nullptr;
 	g->virt = P > phys || options().virtual_devices;
 	int dev_single = 0;                                    // one shard ("devices_rccl_single"): on the device the caller is on
 	(void) hipGetDevice(&dev_single);

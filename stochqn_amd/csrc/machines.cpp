@@ -48,6 +48,7 @@ struct Call {
 	bool fresh = false;             // the device context was created by this call
 	bool x_down = false, g_down = false;   // the update pass already sent x / the direction to the host, slice by slice
 	bool g_pending = false;                // host gradient not uploaded yet: pass 1 of the three-pass form takes it in slices
+	bool x_pending = false;                // host x not uploaded yet: the update takes it in slices, each just ahead of the slice of the update that reads it
 	bool dev_requests = false;             // shard of a multi-device group: *req / *req_vec stay device pointers, the group copies them out
 	bool x_spec = false;                   // slices of x went to the host before the guard had spoken (step_was_bad puts a rejected step right)
 };
@@ -160,10 +161,23 @@ bool open_call(Call& io, int kind, int n, bfgs_mem* b, size_t fsize, bool resume
 void stage_xg(Call& io, bool need_x, bool need_g, bool may_defer = false)
 {
 	DevCtx* c = io.c;
-	if (need_x) io.x = io.host_caller ? stage_x(c, io.x_caller, N(c)) : io.x_caller;
+	if (need_x) {
+		// A large host x that has to go up (always, by default: the reference's *req aliases x) does not go up front: nothing
+		// before the update reads it, so its slices travel while the two-loop runs and land just ahead of the slices of the
+		// update -- whose results start their way down at once, on a stream of their own (the link is full duplex).
+		if (io.host_caller && may_defer && options().apply_chunks >= 2 && N(c) >= (size_t) options().host_slice_min && ensure_stage(c, 0) &&
+		    ensure_copy_stream(c, options().apply_chunks + 1)) {
+			io.x = c->stage[0];
+			if (!x_is_current(c, io.x_caller, N(c))) {
+				(void) ensure_registered(c, io.x_caller, N(c) * sizeof(real));
+				io.x_pending = true;
+			}
+		}
+		else io.x = io.host_caller ? stage_x(c, io.x_caller, N(c)) : io.x_caller;
+	}
 	if (!need_g) return;
 	const int slices = options().upload_slices;
-	if (may_defer && io.g_host && slices >= 2 && N(c) >= ((size_t) 1 << 21) && ensure_stage(c, 1) &&
+	if (may_defer && io.g_host && slices >= 2 && N(c) >= (size_t) options().host_slice_min && ensure_stage(c, 1) &&
 	    ensure_upload_slices(c, slices, sdot_carry_count(c->sc, N(c), (int) c->m))) {
 		(void) ensure_registered(c, io.g_caller, N(c) * sizeof(real));
 		io.g = c->stage[1];
@@ -178,6 +192,23 @@ void flush_g(Call& io)
 	if (!io.g_pending) return;
 	SQN_HIP_OK(hipMemcpyAsync(io.g, io.g_caller, N(io.c) * sizeof(real), hipMemcpyHostToDevice, io.c->sc.stream));
 	io.g_pending = false;
+}
+
+void flush_x(Call& io)                      // whoever reads x in one piece asks for it here first
+{
+	if (!io.x_pending) return;
+	SQN_HIP_OK(hipMemcpyAsync(io.x, io.x_caller, N(io.c) * sizeof(real), hipMemcpyHostToDevice, io.c->sc.stream));
+	io.x_pending = false;
+}
+
+// elements [lo, hi) of a pending host x go up on the side stream; the main stream waits for them (event `slot` of xup_ev)
+void x_slice_up(Call& io, size_t lo, size_t hi, int slot)
+{
+	DevCtx* c = io.c;
+	SQN_HIP_OK(hipMemcpyAsync(io.x + lo, io.x_caller + lo, (hi - lo) * sizeof(real), hipMemcpyHostToDevice, c->copy_stream));
+	SQN_HIP_OK(hipEventRecord(c->xup_ev[(size_t) slot], c->copy_stream));
+	SQN_HIP_OK(hipStreamWaitEvent(c->sc.stream, c->xup_ev[(size_t) slot], 0));
+	c->copy_busy = true;
 }
 
 // SliceFeed::arrive of a pending host gradient: elements [lo, hi) go up on the side stream, the main stream waits for them
@@ -219,7 +250,7 @@ void close_call(Call& io, bool x_changed, bool g_changed)
 	DevCtx* c = io.c;
 	// a reduction that failed while the call was being enqueued (c->fault: the call is going to return -1000) left the update
 	// working on un-reduced sums: the caller's arrays are not touched with that
-	if (x_changed && io.host_caller && io.x && !io.x_down && !c->fault) vec_to_host(c, io.x_caller, io.x, N(c));
+	if (x_changed && io.host_caller && io.x && !io.x_down && !io.x_pending && !c->fault) vec_to_host(c, io.x_caller, io.x, N(c));
 	if (g_changed && io.g_host && io.g && options().strict_grad && !io.g_down && !c->fault) vec_to_host(c, io.g_caller, io.g, N(c));
 	sync(c);
 	if (io.host_caller && io.x) x_handed_back(c, io.x_caller, N(c));      // device and host copies of x agree from here on
@@ -235,11 +266,14 @@ void apply_step(Call& io, Partials guard, const real* r_in, real* grad_out, cons
 	const size_t n = N(c);
 	const bool want_x = io.host_caller && io.x == ap.x, want_g = io.g_host && options().strict_grad && io.g == grad_out;
 	const int chunks = options().apply_chunks;
-	const size_t min_chunk = (size_t) 1 << 20;               // elements: below this a slice is all launch overhead
-	if ((!want_x && !want_g) || c->fault || chunks < 2 || n < 2 * min_chunk || !ensure_copy_stream(c, chunks)) {
+	const size_t min_chunk = (size_t) options().host_slice_min / 2;     // elements: below this a slice is all launch overhead
+	if ((!want_x && !want_g) || c->fault || chunks < 2 || n < 2 * min_chunk || !ensure_copy_stream(c, chunks + 1)) {
+		flush_x(io);
 		launch_apply(sc, n, c->n_global, guard, r_in, grad_out, ap, guarded);
 		return;
 	}
+	const bool x_up = io.x_pending && io.x == ap.x;          // x itself still has to come up: slice by slice, just ahead of the update
+	if (!x_up) flush_x(io);
 	(void) ensure_registered(c, io.x_caller, n * sizeof(real));
 	if (want_g) (void) ensure_registered(c, io.g_caller, n * sizeof(real));
 	size_t per = (n + (size_t) chunks - 1) / (size_t) chunks;
@@ -252,12 +286,14 @@ void apply_step(Call& io, Partials guard, const real* r_in, real* grad_out, cons
 		a.x = ap.x + off;
 		if (ap.x_sum) a.x_sum = ap.x_sum + off;
 		if (ap.s_slot) a.s_slot = ap.s_slot + off;
+		if (x_up) x_slice_up(io, off, off + cnt, j);
 		launch_apply(sc, cnt, c->n_global, guard, r_in + off, grad_out + off, a, guarded);
 		SQN_HIP_OK(hipEventRecord(c->chunk_ev[(size_t) j], sc.stream));
-		SQN_HIP_OK(hipStreamWaitEvent(c->copy_stream, c->chunk_ev[(size_t) j], 0));
-		if (want_x) SQN_HIP_OK(hipMemcpyAsync(io.x_caller + off, ap.x + off, cnt * sizeof(real), hipMemcpyDeviceToHost, c->copy_stream));
-		if (want_g) SQN_HIP_OK(hipMemcpyAsync(io.g_caller + off, grad_out + off, cnt * sizeof(real), hipMemcpyDeviceToHost, c->copy_stream));
+		SQN_HIP_OK(hipStreamWaitEvent(c->down_stream, c->chunk_ev[(size_t) j], 0));
+		if (want_x) SQN_HIP_OK(hipMemcpyAsync(io.x_caller + off, ap.x + off, cnt * sizeof(real), hipMemcpyDeviceToHost, c->down_stream));
+		if (want_g) SQN_HIP_OK(hipMemcpyAsync(io.g_caller + off, grad_out + off, cnt * sizeof(real), hipMemcpyDeviceToHost, c->down_stream));
 	}
+	if (x_up) io.x_pending = false;
 	c->copy_busy = true;
 	io.x_down = want_x;
 	io.g_down = want_g;
@@ -527,13 +563,14 @@ void direction_slice_done(void* user, size_t lo, size_t hi, int slice)
 	SpecDrain& d = *static_cast<SpecDrain*>(user);
 	Call& io = *d.io;
 	DevCtx* c = io.c;
+	if (io.x_pending) x_slice_up(io, lo, hi, slice);      // the caller's x[lo, hi) comes up now, right ahead of what reads it (the slices cover x once)
 	if (c->fault) return;                    // a reduction of this call failed: nothing of it reaches the caller's arrays (close_call)
 	launch_spec_x(c->sc, hi - lo, d.r + lo, d.x + lo, d.step, d.xs + lo);
 	SQN_HIP_OK(hipEventRecord(c->chunk_ev[(size_t) slice], c->sc.stream));
-	SQN_HIP_OK(hipStreamWaitEvent(c->copy_stream, c->chunk_ev[(size_t) slice], 0));
-	SQN_HIP_OK(hipMemcpyAsync(io.x_caller + lo, d.xs + lo, (hi - lo) * sizeof(real), hipMemcpyDeviceToHost, c->copy_stream));
+	SQN_HIP_OK(hipStreamWaitEvent(c->down_stream, c->chunk_ev[(size_t) slice], 0));
+	SQN_HIP_OK(hipMemcpyAsync(io.x_caller + lo, d.xs + lo, (hi - lo) * sizeof(real), hipMemcpyDeviceToHost, c->down_stream));
 	if (d.want_g) {
-		SQN_HIP_OK(hipMemcpyAsync(io.g_caller + lo, d.r + lo, (hi - lo) * sizeof(real), hipMemcpyDeviceToHost, c->copy_stream));
+		SQN_HIP_OK(hipMemcpyAsync(io.g_caller + lo, d.r + lo, (hi - lo) * sizeof(real), hipMemcpyDeviceToHost, c->down_stream));
 		io.g_down = true;
 	}
 	c->copy_busy = true;
@@ -547,7 +584,7 @@ bool spec_x_ready(Call& io, const StepIn& in)
 	const size_t n = N(c);
 	const int chunks = options().apply_chunks;
 	// oLBFGS with strict_grad: what goes back in grad is -step r, written by the update itself -- the plain path does that
-	if (!options().spec_x || !io.host_caller || io.x != in.x || (io.g_host && options().strict_grad && in.s_slot) || chunks < 2 || n < ((size_t) 2 << 20))
+	if (!options().spec_x || !io.host_caller || io.x != in.x || (io.g_host && options().strict_grad && in.s_slot) || chunks < 2 || n < (size_t) options().host_slice_min)
 		return false;
 	if (!ensure_upload_slices(c, 1, (size_t) 2 * kMaxGrid * kBlock) || !ensure_copy_stream(c, chunks + 1)) return false;   // + 1: the odd tail
 	if (!c->spec && !device_alloc((void**) &c->spec, n * sizeof(real))) { c->spec = nullptr; return false; }
@@ -590,12 +627,14 @@ void enqueue_step(Call& io, const StepIn& in)
 			if (in.G) { qs.G = in.G; qs.H0_out = in.H0; qs.frow_out = in.frow_out; qs.rmsprop_weight = in.w; qs.scal_reg = in.eps; }
 			// check_nan == 0: nothing waits for a verdict, the update rides in pass 3 (as in the sweep form below, reference :825-838)
 			const bool fuse = !in.check_nan && options().fuse_apply;
+			if (fuse) flush_x(io);
 			SpecDrain sd{&io, in.g, in.x, c->spec, in.step, io.g_host && options().strict_grad && io.g == in.g};
 			const bool ahead = !fuse && spec_x_ready(io, in);
 			sd.xs = c->spec;
 			const SliceFeed drain{options().apply_chunks, c->carry, c->carry_count, direction_slice_done, &sd};
 			Partials guard = enqueue_three_pass(c, in.g, in.used, st, in.h0, in.gprev_out, qs, fuse ? &ap : nullptr, &io, ahead ? &drain : nullptr);
 			if (io.x_spec) {                                          // every slice of x is on its way already: the update in one launch, no copies
+				io.x_pending = false;                                 // (and every slice of the caller's x came up with the slice that read it)
 				launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
 				io.x_down = true;
 				stat_add(ST_X_AHEAD);
@@ -604,6 +643,7 @@ void enqueue_step(Call& io, const StepIn& in)
 			stat_add(ST_STEP_THREE_PASS);
 		} else {
 			flush_g(io);
+			if (!in.check_nan) flush_x(io);                               // the update rides in the last sweep
 			stat_add(ST_STEP_SWEEPS);
 			// was a cached form configured for this ring, and only the kappa rule said no?  (kappa is cached per row: no extra work)
 			if (!raw_cold && options().threepass && (!in.G || in.H0) && c->m <= (size_t) kPairsMax3 && !pairs_tame(c, st, in.used))
@@ -1390,7 +1430,7 @@ static int two_loop_impl(real_t grad[], int n, real_t H0[], real_t h0, real_t y_
 	to_host(c, c->pin, c->sc.report, 8 + 2 * c->m);
 	if (g_host) vec_to_host(c, grad, g, nn);
 	sync(c);
-	if (c->fault | take_hip_failure()) { c->fault = false; return -1000; }
+	if (const bool hip_failed = take_hip_failure(); c->fault || hip_failed) { c->fault = false; return -1000; }
 	hand_back(buffer_rho, c->pin + 8, mem_used);
 	hand_back(buffer_alpha, c->pin + 8 + c->m, mem_used);
 	return 0;
@@ -1442,7 +1482,7 @@ static int take_step_impl(real_t step_size, int n, real_t x[], real_t grad[], bf
 	if (c->G.mirror) export_view(c, c->G);
 	if (c->H0.mirror && b->mem_used > 0) export_view(c, c->H0);
 	close_call(io, true, true);
-	if (c->fault | take_hip_failure()) { c->fault = false; return -1000; }
+	if (const bool hip_failed = take_hip_failure(); c->fault || hip_failed) { c->fault = false; return -1000; }
 	if (step_was_bad(io, b, b->mem_used, check_nan)) {
 		ring_reset(b);                                         // :831
 		if (iter_info) *iter_info = search_direction_was_nan;
@@ -1480,7 +1520,7 @@ static int fisher_product_impl(real_t F[], size_t fu, int n, real_t s[], real_t 
 	to_host(c, c->pin + 8 + 2 * c->m, c->fisher_t, fu);
 	if (y_host) vec_to_host(c, y, yd, nn);
 	sync(c);
-	if (c->fault | take_hip_failure()) { c->fault = false; return -1000; }
+	if (const bool hip_failed = take_hip_failure(); c->fault || hip_failed) { c->fault = false; return -1000; }
 	hand_back(buffer_y, c->pin + 8 + 2 * c->m, fu);
 	return 0;
 }

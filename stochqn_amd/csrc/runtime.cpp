@@ -189,7 +189,9 @@ bool loop_barrier(Loopback& lp)
 		lp.cv.notify_all();
 		return true;
 	}
-	if (!lp.cv.wait_for(lk, std::chrono::duration<double>(lp.patience_s), [&] { return lp.generation != gen || lp.broken; }) || lp.broken) {
+	// (a deadline on the system clock: pthread_cond_timedwait, which every sanitizer runtime knows; the wait is seconds long and coarse)
+	const auto deadline = std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::system_clock::duration>(std::chrono::duration<double>(lp.patience_s));
+	if (!lp.cv.wait_until(lk, deadline, [&] { return lp.generation != gen || lp.broken; }) || lp.broken) {
 		lp.broken = true;
 		lp.cv.notify_all();
 		return false;
@@ -221,9 +223,12 @@ void loopback_hook(void* user, double* buf, int count, hipStream_t stream)
 	}
 }
 
-void free_view(View& v)
+void free_view(DevCtx* c, View& v)
 {
-	if (v.mirror && v.dev) SQN_HIP_OK(hipFree(v.dev));
+	if (v.mirror && v.dev) {
+		SQN_HIP_OK(hipFree(v.dev));
+		c->mirrored.fetch_sub(v.count * sizeof(real));
+	}
 	v = View{};
 }
 
@@ -244,7 +249,7 @@ void destroy(DevCtx* c, bool keep_spill = false)
 	for (auto& p : c->prof.pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
 	for (auto e : c->prof.pool) (void) hipEventDestroy(e);
 	View* vs[] = {&c->S, &c->Y, &c->sbak, &c->ybak, &c->gprev, &c->xsum, &c->xprev, &c->H0, &c->G, &c->F};
-	for (View* v : vs) free_view(*v);
+	for (View* v : vs) free_view(c, *v);
 	if (c->pool) SQN_HIP_OK(hipFree(c->pool));
 	if (c->sc.fisher_part) SQN_HIP_OK(hipFree(c->sc.fisher_part));
 	if (c->fisher_t) SQN_HIP_OK(hipFree(c->fisher_t));
@@ -255,12 +260,13 @@ void destroy(DevCtx* c, bool keep_spill = false)
 	}
 	if (c->pin) SQN_HIP_OK(hipHostFree(c->pin));
 	if (c->copy_stream) { (void) hipStreamSynchronize(c->copy_stream); (void) hipStreamDestroy(c->copy_stream); }
+	if (c->down_stream) { (void) hipStreamSynchronize(c->down_stream); (void) hipStreamDestroy(c->down_stream); }
+	for (hipEvent_t e : c->xup_ev) (void) hipEventDestroy(e);
 	for (hipEvent_t e : c->chunk_ev) (void) hipEventDestroy(e);
 	for (hipEvent_t e : c->up_ev) (void) hipEventDestroy(e);
 	if (c->carry) SQN_HIP_OK(hipFree(c->carry));
 	if (c->spec) SQN_HIP_OK(hipFree(c->spec));
 	if (c->x_pre_ev) (void) hipEventDestroy(c->x_pre_ev);
-	if (c->copy_done) (void) hipEventDestroy(c->copy_done);
 	for (auto& r : c->regs)
 		if (r.p) { if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError(); }   // the caller may have freed it already
 	if (c->own_stream) SQN_HIP_OK(hipStreamDestroy(c->own_stream));
@@ -312,14 +318,7 @@ void views_of(DevCtx* c, View** out)
 	for (int i = 0; i < 10; i++) out[i] = vs[i];
 }
 
-size_t mirror_bytes(DevCtx* c)
-{
-	View* vs[10];
-	views_of(c, vs);
-	size_t b = 0;
-	for (View* v : vs) if (v->mirror && v->dev) b += v->count * sizeof(real);
-	return b;
-}
+size_t mirror_bytes(DevCtx* c) { return c->mirrored.load(); }
 
 void drop_spill(const void* key)
 {
@@ -641,12 +640,17 @@ bool prepare_context(const void* key, int kind, int n, size_t m, size_t fsize, i
 	if (!c) return false;
 	bool ok = true;
 	for (int i = 0; i < stages && i < 3 && ok; i++) ok = ensure_stage(c, i);
-	c->in_call = false;
+	end_use(c);
 	if (!ok) { release(key); return false; }
 	return true;
 }
 
-void end_use(DevCtx* c) { if (c) c->in_call = false; }
+void end_use(DevCtx* c)
+{
+	if (!c) return;
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
+	c->in_call = false;
+}
 
 // The state a reclaimed context left in host memory, if it is this object's: same shape, and the counters continue where
 // that context stopped.  Anything else at this address is a different object: the spill is dropped.
@@ -706,10 +710,12 @@ bool note_state(const void* key, size_t niter, int section, bool req_is_x, const
 	// include/stochqn.h:364-366); a request at x_avg leaves the caller free to edit x
 	if (!req_is_x) it->second->x_valid = false;
 	else if (x && !it->second->fault) prefetch_x(it->second, x);
+	it->second->call_index++;
 	it->second->has_last = true;
 	it->second->last_niter = niter;
 	it->second->last_section = section;
-	const bool fault = it->second->fault | take_hip_failure();
+	const bool hip_failed = take_hip_failure();       // always taken: the flag must not outlive the call
+	const bool fault = it->second->fault || hip_failed;
 	it->second->fault = false;
 	return fault;
 }
@@ -745,7 +751,7 @@ void release_all()
 bool bind(DevCtx* c, View& v, real* caller, size_t count, bool import)
 {
 	if (caller == v.caller && count == v.count && (v.dev || count == 0)) return true;
-	free_view(v);
+	free_view(c, v);
 	v.caller = caller;
 	v.count = count;
 	if (!caller || count == 0) return true;
@@ -756,6 +762,7 @@ bool bind(DevCtx* c, View& v, real* caller, size_t count, bool import)
 		return false;
 	}
 	v.mirror = true;
+	c->mirrored.fetch_add(count * sizeof(real));
 	{
 		std::lock_guard<std::recursive_mutex> lk(g_mu);
 		ensure_bounce();                         // reclaim_one is going to need it when memory is short
@@ -764,19 +771,19 @@ bool bind(DevCtx* c, View& v, real* caller, size_t count, bool import)
 	if (Spill* sp = static_cast<Spill*>(c->spill)) {
 		for (auto& pc : sp->pieces)
 			if (pc.caller == caller && pc.count == count && pc.data) {
-					hipError_t e;
-					{
-						std::lock_guard<std::recursive_mutex> lk(g_mu);      // one bounce buffer for the process
-						e = bounced_copy(v.dev, pc.data, count * sizeof(real), false);
-					}
-					if (e != hipSuccess) {                                   // the mirror holds garbage: the call fails, the host copy stays (abandon_context)
-						(void) hipGetLastError();
-						std::fprintf(stderr, "stochqn: could not bring a reclaimed array back to the device: %s\n", hipGetErrorString(e));
-						free_view(v);
-						return false;
-					}
-					enforce_mirror_cap();                                    // the host copy stays until the call has completed (detach_spill)
-					return true;
+				hipError_t e;
+				{
+					std::lock_guard<std::recursive_mutex> lk(g_mu);      // one bounce buffer for the process
+					e = bounced_copy(v.dev, pc.data, count * sizeof(real), false);
+				}
+				if (e != hipSuccess) {                                   // the mirror holds garbage: the call fails, the host copy stays (abandon_context)
+					(void) hipGetLastError();
+					std::fprintf(stderr, "stochqn: could not bring a reclaimed array back to the device: %s\n", hipGetErrorString(e));
+					free_view(c, v);
+					return false;
+				}
+				enforce_mirror_cap();                                    // the host copy stays until the call has completed (detach_spill)
+				return true;
 			}
 	}
 	// without `import` the mirror starts with indeterminate contents, like the reference's malloc
@@ -820,17 +827,29 @@ real* host_landing(DevCtx* c, int slot)
 bool ensure_registered(DevCtx* c, const void* p, size_t bytes)
 {
 	const Options& o = options();
-	if (!o.register_host || !p || (long) bytes < o.register_min_bytes) return false;
+	if (!p || (long) bytes < o.register_min_bytes) return false;
 	for (auto& r : c->regs)
 		if (r.p == p) {
 			if (r.bytes >= bytes) return true;
 			if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError();
 			r = DevCtx::HostRange{};
 		}
-	// pinned already by somebody else (hipHostMalloc, a caller's own hipHostRegister)?  then it is as fast as it gets
+	// pinned by its owner (hipHostMalloc, the caller's own hipHostRegister, stochqn_hip_pin_host)?  then it is as fast as it gets
 	hipPointerAttribute_t a;
 	if (hipPointerGetAttributes(&a, p) == hipSuccess) { if (a.type == hipMemoryTypeHost) return true; }
 	else (void) hipGetLastError();
+	if (!o.register_host) return false;          // the library pins nothing by itself unless told to (runtime.hpp: register_host)
+	// ... and then only an array that was already there, at this address, in an earlier call: a caller that hands over a fresh
+	// array every time would pay a registration of n words per call for nothing
+	DevCtx::Seen* mine = nullptr;
+	DevCtx::Seen* oldest = &c->seen[0];
+	for (auto& s : c->seen) {
+		if (s.p == p) mine = &s;
+		if (s.call < oldest->call) oldest = &s;
+	}
+	if (!mine) { *oldest = DevCtx::Seen{p, c->call_index}; return false; }
+	if (mine->call == c->call_index) return false;             // first sighting was in this very call
+	mine->call = c->call_index;
 	DevCtx::HostRange& slot = c->regs[c->reg_turn++ % (int) (sizeof(c->regs) / sizeof(c->regs[0]))];
 	if (slot.p) { if (hipHostUnregister(const_cast<void*>(slot.p)) != hipSuccess) (void) hipGetLastError(); slot = DevCtx::HostRange{}; }
 	if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
@@ -857,10 +876,11 @@ static inline size_t probe_index(int j, size_t count)
 	return count <= 1 ? 0 : (size_t) (((unsigned __int128) j * (count - 1)) / (DevCtx::kProbe - 1));
 }
 
-real* stage_x(DevCtx* c, real* caller, size_t count)
+// Option "x_upload" = 0 (the caller vouches that it does not touch x while *req designates it): is the device copy of x still
+// what the caller holds?  Orders the stream behind an upload of x that was started when the last call returned.
+bool x_is_current(DevCtx* c, const real* caller, size_t count)
 {
-	if (!ensure_stage(c, 0)) return nullptr;
-	if (c->x_pre_pending) {                  // an upload of x that started when the last call returned: whatever touches the staging vector comes after it
+	if (c->x_pre_pending) {                  // whatever touches the staging vector comes after that upload
 		SQN_HIP_OK(hipStreamWaitEvent(c->sc.stream, c->x_pre_ev, 0));
 		c->x_pre_pending = false;
 	}
@@ -873,9 +893,15 @@ real* stage_x(DevCtx* c, real* caller, size_t count)
 			current = std::memcmp(&v, &c->x_probe[j], sizeof v) == 0;
 		}
 	}
-	if (current) { stat_add(ST_X_UPLOAD_SKIPPED); return c->stage[0]; }
-	c->x_valid = false;
-	stat_add(ST_X_UPLOAD);
+	if (current) stat_add(ST_X_UPLOAD_SKIPPED);
+	else { c->x_valid = false; stat_add(ST_X_UPLOAD); }
+	return current;
+}
+
+real* stage_x(DevCtx* c, real* caller, size_t count)
+{
+	if (!ensure_stage(c, 0)) return nullptr;
+	if (x_is_current(c, caller, count)) return c->stage[0];
 	(void) ensure_registered(c, caller, count * sizeof(real));
 	SQN_HIP_OK(hipMemcpyAsync(c->stage[0], caller, count * sizeof(real), hipMemcpyHostToDevice, c->sc.stream));
 	return c->stage[0];
@@ -908,16 +934,15 @@ bool ensure_upload_slices(DevCtx* c, int slices, size_t carry_count)
 
 bool ensure_copy_stream(DevCtx* c, int chunks)
 {
-	if (!c->copy_stream) {
-		if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); c->copy_stream = nullptr; return false; }
-		if (hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); c->copy_done = nullptr; return false; }
-	}
-	while ((int) c->chunk_ev.size() < chunks) {
-		hipEvent_t e;
-		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); return false; }
-		c->chunk_ev.push_back(e);
-	}
-	return c->copy_done != nullptr;
+	if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); c->copy_stream = nullptr; return false; }
+	if (!c->down_stream && hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); c->down_stream = nullptr; return false; }
+	for (std::vector<hipEvent_t>* evs : {&c->chunk_ev, &c->xup_ev})
+		while ((int) evs->size() < chunks) {
+			hipEvent_t e;
+			if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); return false; }
+			evs->push_back(e);
+		}
+	return true;
 }
 
 void sync(DevCtx* c)
@@ -932,8 +957,11 @@ void sync(DevCtx* c)
 	}
 	hipError_t e = hipStreamSynchronize(c->sc.stream);
 	if (c->copy_busy) {                                  // slices of x still on their way to the host
-		const hipError_t e2 = hipStreamSynchronize(c->copy_stream);
-		if (e == hipSuccess) e = e2;
+		for (hipStream_t s : {c->copy_stream, c->down_stream}) {
+			if (!s) continue;
+			const hipError_t e2 = hipStreamSynchronize(s);
+			if (e == hipSuccess) e = e2;
+		}
 		c->copy_busy = false;
 	}
 	hipError_t l = hipGetLastError();
@@ -1013,6 +1041,50 @@ using namespace sqn;
 extern "C" {
 
 int stochqn_hip_available(void) { return device_ready() ? 1 : 0; }
+
+// ---- host arrays pinned by whoever owns them ------------------------------------------------------------
+namespace {
+struct Pin { size_t bytes = 0; int refs = 0; };
+std::mutex g_pin_mu;
+std::unordered_map<const void*, Pin> g_pins;
+}
+
+int stochqn_hip_pin_host(void* p, size_t bytes)
+{
+	if (!p || bytes == 0 || !device_ready()) return -1;
+	std::lock_guard<std::mutex> lk(g_pin_mu);
+	auto it = g_pins.find(p);
+	if (it != g_pins.end() && it->second.bytes >= bytes) { it->second.refs++; return 0; }
+	if (it != g_pins.end()) {                                  // the same array, longer now: pinned anew
+		if (hipHostUnregister(p) != hipSuccess) (void) hipGetLastError();
+		const int refs = it->second.refs;
+		g_pins.erase(it);
+		if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); return -1; }
+		g_pins[p] = Pin{bytes, refs + 1};
+		return 0;
+	}
+	hipPointerAttribute_t a;                                   // ordinary memory: an error (older runtimes) or "unregistered" (ROCm 6+)
+	if (hipPointerGetAttributes(&a, p) == hipSuccess) {
+		if (a.type == hipMemoryTypeHost) return 1;             // page-locked by other means
+		if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) return -1;
+	} else (void) hipGetLastError();
+	if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); return -1; }
+	g_pins[p] = Pin{bytes, 1};
+	stat_add(ST_HOST_REGISTERED);
+	return 0;
+}
+
+int stochqn_hip_unpin_host(void* p)
+{
+	if (!p) return -1;
+	std::lock_guard<std::mutex> lk(g_pin_mu);
+	auto it = g_pins.find(p);
+	if (it == g_pins.end()) return -1;
+	if (--it->second.refs > 0) return 0;
+	g_pins.erase(it);
+	if (hipHostUnregister(p) != hipSuccess) { (void) hipGetLastError(); return -1; }
+	return 0;
+}
 
 void stochqn_hip_invalidate(const void* s_mem)
 {
@@ -1105,6 +1177,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "x_upload")) g_opt.x_upload = (int) value;
 	else if (!std::strcmp(name, "upload_slices")) g_opt.upload_slices = value < 0 ? 0 : (value > 64 ? 64 : (int) value);
 	else if (!std::strcmp(name, "apply_chunks")) g_opt.apply_chunks = value < 1 ? 1 : (value > 64 ? 64 : (int) value);
+	else if (!std::strcmp(name, "host_slice_min")) g_opt.host_slice_min = value < 2 ? 2 : (long) value;
 	else if (!std::strcmp(name, "max_mirror_bytes")) g_opt.max_mirror_bytes = value < 0 ? 0 : (long) value;
 	else if (!std::strcmp(name, "devices")) options().devices = value < 0 ? 0 : (int) value;
 	else if (!std::strcmp(name, "virtual_devices")) options().virtual_devices = value != 0;

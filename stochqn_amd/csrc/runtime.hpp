@@ -4,6 +4,7 @@
 #include "sqn_device.hpp"
 #include "stochqn.h"
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <mutex>
@@ -46,7 +47,7 @@ struct Options {
 	// three-pass form: fraction of r0 / r stored with the default (cacheable) policy -- the part the next pass, which walks
 	// the other way, reads first; the rest leaves with sc1 nt.  0.25-0.5 measured 1 % ahead of 0 and of 1 (profiles/r03_ab_fold_tail.jsonl)
 	double keep_tail = 0.35;
-	bool x_prefetch = true;       // host callers: when a call hands *req == x back and the device copy of x is stale, x starts its way up on a side stream while the caller evaluates its gradient
+	bool x_prefetch = false;      // with x_upload = 0: when a call hands *req == x back and the device copy of x is stale, x starts its way up on a side stream while the caller evaluates its gradient (reads the caller's x after the call has returned: opt-in)
 	bool spec_x = true;           // host callers, three-pass form: slices of x start their way down while pass 3 is still running
 	bool stream_stores = true;   // pass 2 / pass 3: sc1 nt stores (kernels.hip: st_stream)
 	double kappa_max = 1e6;      // three-pass form only while every pair in use has |s||y|/|s'y| <= this (else: sweeps)
@@ -62,11 +63,21 @@ struct Options {
 	bool devices_rccl_single = false;
 	long devices_min_n = 1 << 20;   // problems smaller than this stay on one device (SURVEY.md 8e "no-shard fallback")
 	double reducer_patience_s = 120;   // host-side rendezvous reducer: how long a shard waits for the others before the reduction fails
-	// host callers (R / numpy / malloc arrays crossing the ABI): PCIe is what a step costs, so
-	int register_host = 1;          // pin the caller's x / grad / hess_vec in place (hipHostRegister, once per array) so that their copies are DMA at link speed
+	// host callers (R / numpy / malloc arrays crossing the ABI): PCIe is what a step costs.  Arrays that are PINNED -- by the
+	// caller (hipHostMalloc / hipHostRegister) or through stochqn_hip_pin_host by a binding that owns them -- move at link speed
+	// and in slices under the kernels; anything else goes through the runtime's staged copies.
+	// 1: the library pins what it is handed by itself (an array seen at the same address in two consecutive calls), and keeps it
+	// pinned until the context goes.  OFF by default: the library cannot know when the caller frees an array, and a range that was
+	// freed and mapped again while still registered takes the process down at the next copy (GPU memory access fault, measured:
+	// profiles/r04_host_link_probes.log -- round 3's one unexplained abort).  For callers that vouch for the lifetime of their arrays.
+	int register_host = 0;
 	long register_min_bytes = 4l << 20;   // ... for arrays of at least this many bytes (below, the runtime's staged copy is as fast)
-	int x_upload = 0;               // 0: x is not uploaded when the device copy is what the library handed back and the caller kept its hands off
-	                                //    (reference include/stochqn.h:364-366: "*req ... do NOT modify"); 1: always upload
+	// 1 (default): a host caller's x goes up on every call that uses it, like the reference, where *req aliases x and an edit
+	// between two calls simply moves the iterate (for large pinned x the upload rides under the update, slice by slice);
+	// 0: not when the device copy is what the library handed back and 256 probe values still agree -- for callers that vouch
+	// they keep their hands off x while *req designates it (reference include/stochqn.h:364-366)
+	int x_upload = 1;
+	long host_slice_min = 1l << 21; // host callers: vectors of fewer elements cross the link in one piece (a slice below ~8 MB is all launch overhead)
 	int upload_slices = 8;          // host callers, three-pass form: pass 1 runs in this many slices, each as soon as its part of the gradient has arrived
 	int apply_chunks = 8;           // host callers: the update pass runs in this many slices so that the download of x overlaps it
 	long max_mirror_bytes = 0;      // > 0: cap on the device memory held by mirrors of host arrays (least recently used contexts are exported and dropped)
@@ -121,6 +132,9 @@ struct DevCtx {
 	double n_global = 0;
 
 	View S, Y, sbak, ybak, gprev, xsum, xprev, H0, G, F;
+	// bytes of device memory the mirrors above hold: what the registry reads of a context that another thread may be inside of
+	// (the views themselves belong to the thread that is inside the call)
+	std::atomic<size_t> mirrored{0};
 	Scratch sc{};
 	Profiler prof;
 	int buf = 0;                       // ping-pong index of the next partial buffer
@@ -134,15 +148,18 @@ struct DevCtx {
 	// host-caller path: the caller's arrays pinned in place, the side stream the download of x runs on while the
 	// update pass is still working on later slices, and what is known about the device copy of x
 	struct HostRange { const void* p = nullptr; size_t bytes = 0; };
-	HostRange regs[6];
+	HostRange regs[6];                 // option "register_host": ranges this context pinned by itself
 	int reg_turn = 0;
+	struct Seen { const void* p = nullptr; unsigned long long call = 0; };
+	Seen seen[8];                      // large host arrays of the recent calls: only one that has been there before is worth pinning
+	unsigned long long call_index = 1; // API calls on this context (note_state)
 	hipStream_t own_stream = nullptr;  // the context's own (blocking-flavour) stream; sc.stream is this or the NULL stream (option "null_stream")
-	hipStream_t copy_stream = nullptr;
-	std::vector<hipEvent_t> chunk_ev, up_ev;
+	hipStream_t copy_stream = nullptr; // host -> device: slices of the gradient and of x on their way up
+	hipStream_t down_stream = nullptr; // device -> host: slices of x (and of the direction) on their way down -- a stream of its own: the link is full duplex
+	std::vector<hipEvent_t> chunk_ev, up_ev, xup_ev;
 	double* carry = nullptr;           // accumulators of a sliced pass 1 between its launches (kernels.hip: Slice)
 	size_t carry_count = 0;
-	hipEvent_t copy_done = nullptr;
-	bool copy_busy = false;            // work was enqueued on copy_stream during this call
+	bool copy_busy = false;            // work was enqueued on copy_stream / down_stream during this call
 	const void* x_host = nullptr;      // the host array stage[0] mirrors
 	bool x_valid = false;              // stage[0] holds the caller's current x (the library wrote both; *req == x went back)
 	static constexpr int kProbe = 256;
@@ -232,6 +249,7 @@ void export_view(DevCtx* c, View& v);                  // mirror -> caller's hos
 bool ensure_registered(DevCtx* c, const void* p, size_t bytes);
 // x of a host caller: upload unless the device copy is known to be current (option "x_upload"); stage[0] on return
 real* stage_x(DevCtx* c, real* caller, size_t count);
+bool x_is_current(DevCtx* c, const real* caller, size_t count);    // option "x_upload" = 0 and the device copy is what the caller still holds
 void x_handed_back(DevCtx* c, const real* caller, size_t count);     // after the download of x has completed
 bool ensure_copy_stream(DevCtx* c, int chunks);
 bool ensure_upload_slices(DevCtx* c, int slices, size_t carry_count);      // side stream, events and carry scratch of a sliced pass 1

@@ -15,6 +15,7 @@ The arithmetic is done by whatever library `backend` wraps: `stochqn_amd.lib()` 
 default) or, in the test-suite only, the CPU oracle.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -24,11 +25,53 @@ from . import _abi
 # ----------------------------------------------------------------------------------------------
 # array spaces
 # ----------------------------------------------------------------------------------------------
+def _unpin(lib, ptr):
+    try:
+        lib.stochqn_hip_unpin_host(C.c_void_p(ptr))
+    except Exception:                                   # interpreter shutdown: the process is going away anyway
+        pass
+
+
 class _HostSpace:
+    """numpy arrays.  Arrays that cross PCIe on every call -- the object's own gradient / hess_vec / x_sum / x_avg_prev and
+    the user's x -- are page-locked through stochqn_hip_pin_host for exactly as long as the array object lives: a
+    `weakref.finalize` on the ndarray unpins the range when the array is collected, BEFORE numpy frees its memory
+    (weak-reference callbacks run at the start of deallocation).  That is the guarantee the library cannot give itself
+    behind the C ABI (stochqn_hip.h: "host arrays pinned by their owner"), and what makes pinning safe here."""
     name = "host"
+    PIN_MIN_BYTES = 4 << 20                             # below, the runtime's staged copies are as fast
 
     def __init__(self, use_float=False):
         self.dtype = np.float32 if use_float else np.float64
+        self._lib = None
+        self._pins = {}                                 # address -> (weak reference to the array, its finaliser)
+
+    def attach(self, backend):
+        lib = getattr(backend, "lib", None)
+        if lib is not None and not getattr(backend, "prefix", "") and hasattr(lib, "stochqn_hip_pin_host"):
+            lib.stochqn_hip_pin_host.argtypes = [C.c_void_p, C.c_size_t]
+            lib.stochqn_hip_unpin_host.argtypes = [C.c_void_p]
+            self._lib = lib
+
+    def pin(self, a):
+        """Page-lock `a` for its lifetime (no-op for small, non-contiguous or foreign arrays, and without the HIP library)."""
+        if self._lib is None or not isinstance(a, np.ndarray) or a.nbytes < self.PIN_MIN_BYTES or not a.flags.c_contiguous:
+            return
+        ptr = a.ctypes.data
+        for p, (ref, fin) in list(self._pins.items()):  # an array that was resized in place sits elsewhere now: let the old range go
+            obj = ref()
+            if obj is None or obj.ctypes.data != p:
+                fin()
+                del self._pins[p]
+        if ptr in self._pins:
+            return
+        if self._lib.stochqn_hip_pin_host(C.c_void_p(ptr), C.c_size_t(a.nbytes)) == 0:
+            self._pins[ptr] = (weakref.ref(a), weakref.finalize(a, _unpin, self._lib, ptr))
+
+    def unpin_all(self):
+        for _, fin in self._pins.values():
+            fin()
+        self._pins = {}
 
     def empty(self, n):
         # the reference uses np.empty; zeros keeps runs reproducible and is a legal instance of it
@@ -49,6 +92,15 @@ class _HostSpace:
 
 class _DeviceSpace:
     name = "device"
+
+    def attach(self, backend):
+        pass
+
+    def pin(self, a):
+        pass
+
+    def unpin_all(self):
+        pass
 
     def __init__(self, device=None, use_float=False):
         import torch
@@ -150,6 +202,7 @@ class _StochQN_free:
             backend = lib(use_float=self.use_float)
         assert bool(getattr(backend, "use_float", False)) == self.use_float, "backend precision mismatch"
         self._be = backend
+        self._sp.attach(backend)
         self.initialized = False
 
     def update_gradient(self, gradient):
@@ -185,6 +238,8 @@ class _StochQN_free:
         self.__dict__.update(state)
         self._sp = _space("host", None, self.use_float)
         self._be = lib(use_float=self.use_float)
+        self._sp.attach(self._be)
+        self._pin_own()
 
     def _order_streams(self):
         """Device space: the library's stream is ordered after the NULL stream only (stochqn_hip.h).  A caller
@@ -201,6 +256,15 @@ class _StochQN_free:
         if getattr(self, "initialized", False) and hasattr(self._be.lib, "stochqn_hip_release"):
             import ctypes
             self._be.lib.stochqn_hip_release(ctypes.c_void_p(self._sp.ptr(self.BFGS_mem.s_mem)))
+        if getattr(self, "_sp", None) is not None:
+            self._sp.unpin_all()
+
+    def _pin_own(self):
+        """The arrays of this object that travel on every call (host space): page-locked while they live."""
+        for name in ("gradient", "hess_vec", "x_sum", "x_avg_prev"):
+            a = getattr(self, name, None)
+            if a is not None:
+                self._sp.pin(a)
 
     def __del__(self):
         try:
@@ -214,6 +278,8 @@ class _StochQN_free:
             raise ValueError("'x' has wrong dtype or lives in the wrong memory space.")
         if not self.initialized:
             self._initialize(int(x.shape[0]))
+        self._pin_own()
+        self._sp.pin(x)
 
     def _resolve(self, ptr, x, candidates):
         """Map a returned `*req` address back onto the array it aliases."""

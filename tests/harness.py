@@ -296,3 +296,31 @@ def run_lockstep(ref, opt, problem, x_ref, x_dev, step, ncalls, tol, on_sync=Non
             f = problem.f(np.asarray(req_r).copy(), call)
             ref.update_function(f)
             opt.update_function(f)
+
+
+class library_options:
+    """`with library_options(lib, x_upload=0, register_host=1): ...` -- stochqn_hip_set_option for the block, the library's
+    defaults (include/stochqn_hip.h) back afterwards."""
+    DEFAULTS = {"x_upload": 1.0, "x_prefetch": 0.0, "register_host": 0.0, "register_min_bytes": float(4 << 20), "spec_x": 1.0,
+                "apply_chunks": 8.0, "upload_slices": 8.0, "host_slice_min": float(1 << 21), "threepass": 1.0, "kappa_max": 1e6}
+
+    def __init__(self, lib, **kw):
+        import ctypes as C
+        self.lib, self.kw = lib, kw
+        lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+        for k in kw:
+            assert k in self.DEFAULTS, k
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            assert self.lib.stochqn_hip_set_option(k.encode(), float(v)) == 0, k
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            self.lib.stochqn_hip_set_option(k.encode(), self.DEFAULTS[k])
+        return False
+
+
+# the caller vouches: it keeps its hands off x while *req designates it, and its arrays outlive the optimiser
+VOUCHED = dict(x_upload=0, x_prefetch=1, register_host=1)

@@ -370,8 +370,8 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p)
 	if (enter(F_PointerGetAttributes)) return err(hipErrorInvalidValue);
 	std::lock_guard<std::mutex> lk(g_mu);
 	const Range* r = find_locked(p);
-	if (!r) return err(hipErrorInvalidValue);          // ordinary host memory
 	std::memset(a, 0, sizeof *a);
+	if (!r) { a->type = hipMemoryTypeUnregistered; a->device = -1; return hipSuccess; }      // ordinary host memory, as ROCm 6+ reports it
 	a->type = r->kind == DEV ? hipMemoryTypeDevice : hipMemoryTypeHost;
 	a->device = r->device;
 	return hipSuccess;

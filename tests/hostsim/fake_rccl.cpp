@@ -40,7 +40,8 @@ bool barrier(Clique& q)
 		q.cv.notify_all();
 		return true;
 	}
-	if (!q.cv.wait_for(lk, std::chrono::milliseconds(g_patience_ms), [&] { return q.generation != gen || q.broken; }) || q.broken) {
+	// (system clock: pthread_cond_timedwait, which gcc 11's libtsan intercepts -- it does not know pthread_cond_clockwait)
+	if (!q.cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(g_patience_ms), [&] { return q.generation != gen || q.broken; }) || q.broken) {
 		q.broken = true;
 		q.cv.notify_all();
 		return false;

@@ -28,10 +28,11 @@
 namespace {
 
 int g_failures = 0;
+std::string g_tag;                                 // what the fault sweeps are injecting right now
 #define CHECK(cond, ...)                                                                                    \
 	do {                                                                                                    \
 		if (!(cond)) {                                                                                      \
-			std::fprintf(stderr, "CHECK FAILED %s:%d: %s -- ", __FILE__, __LINE__, #cond);                  \
+			std::fprintf(stderr, "CHECK FAILED %s:%d: [%s] %s -- ", __FILE__, __LINE__, g_tag.c_str(), #cond);  \
 			std::fprintf(stderr, __VA_ARGS__);                                                              \
 			std::fprintf(stderr, "\n");                                                                     \
 			g_failures++;                                                                                   \
@@ -118,7 +119,7 @@ struct Opt {
 		}
 		mem_used = b.mem_used; st = b.mem_st_ix;
 		calls++;
-		if (rc == -1000) { failed++; return rc; }
+		if (rc == -1000) { failed++; check_x = false; return rc; }      // after a failed call nothing is promised about x any more
 		if (takes_step && rc == 1 && info != func_increased) {
 			accepted++;
 			for (size_t i = 0; i < (size_t) n; i++) x_ref[i] -= step * g_in[i];      // the stand-in's direction is the gradient
@@ -163,9 +164,9 @@ void defaults()
 	fakehip::set_capacity(0);
 	fakelaunch::script() = fakelaunch::Script{};
 	opt("devices", 0); opt("virtual_devices", 0); opt("devices_min_n", 1 << 20); opt("max_mirror_bytes", 0);
-	opt("register_host", 1); opt("register_min_bytes", 4 << 20); opt("x_upload", 1); opt("x_prefetch", 0);
+	opt("register_host", 0); opt("register_min_bytes", 4 << 20); opt("x_upload", 1); opt("x_prefetch", 0);
 	opt("upload_slices", 8); opt("apply_chunks", 8); opt("spec_x", 1); opt("strict_grad", 0); opt("threepass", 1);
-	opt("fail_alloc_after", -1); opt("reducer_patience_s", 120);
+	opt("fail_alloc_after", -1); opt("reducer_patience_s", 120); opt("host_slice_min", 1 << 21);
 	stochqn_hip_stats_reset();
 }
 
@@ -259,12 +260,14 @@ void sc_mirror_cap()
 // host callers of a large-enough problem: pinning in place, the gradient in slices, x ahead of the guard, a rejected step
 void sc_host_path()
 {
-	const int n = 1 << 22;                             // the sliced paths start at 2^21 .. 2^22 elements
-	opt("register_min_bytes", 1 << 20);
+	const int n = (1 << 16) + 3;                       // the sliced paths, at a size the sanitizers get through quickly
+	opt("host_slice_min", 1 << 12);
+	opt("register_min_bytes", 1 << 12);
 	for (int strict = 0; strict < 2; strict++) {
 		opt("strict_grad", strict);
-		Opt a(SQN, n, 3, 4);
-		a.drive(14);
+		Opt a(SQN, n, 3, 3);
+		a.drive(22);
+		while (a.section != 1) a.drive(1);           // the next call takes a step
 		CHECK(a.failed == 0 && a.mem_used >= 2, "failed %d ring %zu", a.failed, a.mem_used);
 		fakelaunch::script().reject_step = true;     // the guard says no: x untouched, what went ahead is put right
 		const size_t before = a.mem_used;
@@ -275,6 +278,32 @@ void sc_host_path()
 		stochqn_hip_release(a.key());
 	}
 	CHECK(stat("x_sent_ahead") > 0 && stat("x_sent_again") > 0, "x ahead of the guard: %lld, sent again: %lld", stat("x_sent_ahead"), stat("x_sent_again"));
+	// who pins what.  By default the library registers nothing by itself; the owner of an array pins it (and unpins it)
+	{
+		CHECK(fakehip::live().registered_ranges == 0, "the library pinned %ld ranges on its own", fakehip::live().registered_ranges);
+		Opt p(SQN, n, 3, 3);
+		const size_t bytes = (size_t) n * sizeof(double);
+		CHECK(stochqn_hip_pin_host(p.x.data(), bytes) == 0 && stochqn_hip_pin_host(p.grad.data(), bytes) == 0, "pin");
+		CHECK(stochqn_hip_pin_host(p.x.data(), bytes) == 0, "pins nest");
+		p.drive(12);
+		CHECK(fakehip::is_registered(p.x.data()) && fakehip::is_registered(p.grad.data()) && !fakehip::is_registered(p.hv.data()), "pinned: x, grad; not hess_vec");
+		stochqn_hip_release(p.key());
+		CHECK(stochqn_hip_unpin_host(p.x.data()) == 0 && fakehip::is_registered(p.x.data()), "one of two pins of x released");
+		CHECK(stochqn_hip_unpin_host(p.x.data()) == 0 && stochqn_hip_unpin_host(p.grad.data()) == 0 && stochqn_hip_unpin_host(p.grad.data()) == -1, "unpin");
+		CHECK(fakehip::live().registered_ranges == 0, "ranges left pinned: %ld", fakehip::live().registered_ranges);
+	}
+	// register_host = 1 (the caller vouches for the lifetime of its arrays): the library pins what it saw at the same address twice
+	opt("register_host", 1);
+	{
+		Opt q(OLBFGS, n, 3, 1);
+		q.drive(2);                                  // section 0, then the first step: x and grad seen once
+		CHECK(!fakehip::is_registered(q.x.data()), "an array seen once is not pinned");
+		q.drive(4);
+		CHECK(fakehip::is_registered(q.x.data()) && fakehip::is_registered(q.grad.data()), "x and grad pinned after the second sighting");
+	}
+	CHECK(fakehip::live().registered_ranges >= 2, "the context keeps its registrations until it goes");
+	stochqn_hip_release_all();
+	CHECK(fakehip::live().registered_ranges == 0, "ranges left pinned: %ld", fakehip::live().registered_ranges);
 	// x_upload = 0: the caller vouches for x between calls; an edit the probes see makes the library upload it again
 	opt("x_upload", 0);
 	Opt c(OLBFGS, n, 3, 1);
@@ -283,7 +312,7 @@ void sc_host_path()
 	c.x_ref = c.x;
 	c.drive(9);
 	CHECK(c.failed == 0 && stat("x_uploads_skipped") > 0, "skipped uploads: %lld", stat("x_uploads_skipped"));
-	opt("x_upload", 1);
+	opt("x_upload", 1); opt("register_host", 0);
 	leak_check("host_path");
 }
 
@@ -382,6 +411,7 @@ void group_body(int P, bool virt)
 		CHECK(stochqn_hip_export(a.key()) == 0 && stochqn_hip_export(b.key()) == 0, "export of sharded state");
 		stochqn_hip_invalidate(a.key());
 		a.drive(10);
+		while (a.section != 1) a.drive(1);
 		fakelaunch::script().reject_step = true;
 		a.drive(1);
 		fakelaunch::script().reject_step = false;
@@ -498,6 +528,7 @@ void sweep_one(const std::function<int()>& body, const char* where, SweepStats& 
 		for (long nth = 1; nth <= counts[f] && tried < max_per_fn; nth += (nth < stride_after ? 1 : 1 + nth / 8), tried++) {
 			fakehip::reset();
 			fakehip::fail_nth(f, nth);
+			g_tag = std::string(fakehip::fn_name(f)) + " #" + std::to_string(nth);
 			const int rc = body();
 			st.runs++;
 			if (rc == -1000) st.failed_calls++; else st.survived++;
@@ -506,6 +537,7 @@ void sweep_one(const std::function<int()>& body, const char* where, SweepStats& 
 			std::snprintf(tag, sizeof tag, "%s, %s #%ld failing", where, fakehip::fn_name(f), nth);
 			fakehip::fail_nth(f, 0);
 			leak_check(tag, 2);
+			g_tag.clear();
 		}
 	}
 }
@@ -517,7 +549,7 @@ void sc_fault_sweep()
 	// (1) a host caller through two pair cycles, (2) the same under memory pressure: reclaim -> spill -> resume
 	sweep_one([] {
 		Opt a(SQN, 1 << 13, 3, 3);
-		a.check_x = false;
+		// (x is checked after every call that did not fail: a HIP failure that goes unnoticed would show here)
 		int rc = a.drive(14);
 		if (rc != -1000) rc = stochqn_hip_export(a.key()) == 0 ? rc : -1000;
 		stochqn_hip_release(a.key());
@@ -526,7 +558,7 @@ void sc_fault_sweep()
 	sweep_one([] {
 		const int n = 3000;
 		Opt a(SQN, n, 4, 1000), b(SQN, n, 4, 1000);
-		a.check_x = b.check_x = false;
+
 		a.mem_used = 2; a.st = 2; a.niter = 5; a.section = 1;
 		int rc = a.drive(3);
 		const fakehip::Live one = fakehip::live();
@@ -540,7 +572,7 @@ void sc_fault_sweep()
 	}, "fault_sweep/reclaim", st, 40, 120);
 	sweep_one([] {
 		Opt a(ADAQN, 2048, 3, 3, false, 1e-4, 4, 1.01);
-		a.check_x = false;
+		// (x is checked after every call that did not fail: a HIP failure that goes unnoticed would show here)
 		const int rc = a.drive(30);
 		stochqn_hip_release(a.key());
 		return rc;

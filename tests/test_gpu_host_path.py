@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from harness import NoisyQuadratic, OPTIMIZERS, compare_traces, rel_err, run_trace, to_np
+from harness import NoisyQuadratic, OPTIMIZERS, VOUCHED, compare_traces, library_options, rel_err, run_trace, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -38,18 +38,25 @@ KW = {
 }
 
 
+@pytest.mark.parametrize("policy", ["default", "vouched"])
 @pytest.mark.parametrize("kind", ["oLBFGS", "SQN", "adaQN"])
 @pytest.mark.parametrize("n", [1000, 2_500_001])
-def test_host_and_device_callers_agree_bit_for_bit(kind, n, hip_backend):
+def test_host_and_device_callers_agree_bit_for_bit(kind, n, policy, hip_backend):
     """The same calls with the same inputs through numpy arrays and through torch tensors: every x, every request,
-    every counter identical to the last bit.  n = 2,500,001 is past the thresholds of both host-side mechanisms (arrays of
-    20 MB are pinned in place; the update pass runs in slices) and odd, so every second ring row is off the 16-byte grid."""
+    every counter identical to the last bit.  n = 2,500,001 is past the thresholds of the host-side mechanisms (20 MB arrays
+    are page-locked by their owner, stochqn_amd/free.py; the gradient comes up and x goes up and down in slices under the
+    kernels) and odd, so every second ring row is off the 16-byte grid.  Twice: with the library's defaults (x goes up on every
+    step, the library pins nothing by itself) and for a caller that vouches for its arrays (x_upload = 0, register_host = 1)."""
     import torch
     lib = _lib()
     lib.stochqn_hip_stats_reset()
     P = NoisyQuadratic(n, seed=5)
     calls = 26
-    host = run_trace(OPTIMIZERS[kind](backend=hip_backend, space="host", **KW[kind]), P, P.x0(), 0.05, calls)
+    with library_options(lib, **(VOUCHED if policy == "vouched" else {})):
+        opt = OPTIMIZERS[kind](backend=hip_backend, space="host", **KW[kind])
+        host = run_trace(opt, P, P.x0(), 0.05, calls)
+        steps = sum(1 for t in host if t["changed"] == 1 or t["info"] == "search_direction_was_nan")
+        opt.release()
     skipped, uploads, pinned = stat(lib, "x_uploads_skipped"), stat(lib, "x_uploads"), stat(lib, "host_ranges_registered")
     x = torch.as_tensor(P.x0(), device="cuda:0")
     dev = run_trace(OPTIMIZERS[kind](backend=hip_backend, space="device", device="cuda:0", **KW[kind]), P, x, 0.05, calls)
@@ -59,15 +66,110 @@ def test_host_and_device_callers_agree_bit_for_bit(kind, n, hip_backend):
         for k in ("x", "req", "req_vec"):
             if k in h:
                 assert np.array_equal(h[k], d[k]), "call %d: %s differs between the host and the device caller" % (i, k)
-    # x goes up on the first step and again only after a request that was not at x (x_avg every L steps: the caller may
-    # legally have touched x meanwhile); every other step reuses the device copy
-    assert uploads >= 1 and skipped >= 5, (uploads, skipped)
-    if kind == "oLBFGS":
-        assert uploads == 1, uploads             # every request of oLBFGS is at x
+    if policy == "vouched":
+        # x goes up on the first step and again only after a request that was not at x (x_avg every L steps: the caller may
+        # legally have touched x meanwhile); every other step reuses the device copy
+        assert uploads >= 1 and skipped >= 5, (uploads, skipped)
+        if kind == "oLBFGS":
+            assert uploads == 1, uploads         # every request of oLBFGS is at x
+    else:
+        assert skipped == 0 and uploads >= steps >= 8, (uploads, skipped, steps)       # every step brings the caller's x up
     if n > 1_000_000:
-        assert pinned >= 2                       # x and grad (at least) were pinned in place
+        assert pinned >= 2                       # x and the gradient (at least) were page-locked: by their owner, or by the library when told to
     else:
         assert pinned == 0                       # small arrays: not worth pinning
+    lib.stochqn_hip_release_all()
+
+
+@pytest.mark.parametrize("n", [50_000, 4_500_001])
+def test_an_edit_of_one_coordinate_between_two_calls_moves_the_iterate(n, hip_backend, oracle_backend):
+    """The reference's *req aliases x: a caller that clips or resets a FEW coordinates between two ordinary steps has simply
+    moved the iterate.  256 probe values would miss such an edit; with the library's defaults (x_upload = 1) x goes up on
+    every step -- for the large n in slices under the update -- and the trajectory equals the oracle's."""
+    lib = _lib()
+    P = NoisyQuadratic(n, seed=13)
+    kw = dict(mem_size=3, bfgs_upd_freq=4)
+    where = [n // 3 + 1, n // 2 + 7, n - 2]           # none of them a probe position
+
+    def drive(backend):
+        opt = OPTIMIZERS["SQN"](backend=backend, space="host", **kw)
+        x = P.x0()
+        xs = []
+        for call in range(22):
+            r = opt.run_optimizer(x, 0.05)
+            xs.append(x.copy())
+            if r["task"] == "calc_hess_vec":
+                rx, rv = r["requested_on"]
+                opt.update_hess_vec(P.hess_vec(to_np(rx), to_np(rv)))
+            else:
+                if call in (6, 7, 13) and r["task"] == "calc_grad":
+                    x[where] = 0.25                              # a projection of three coordinates, between two calls
+                opt.update_gradient(P.grad(to_np(r["requested_on"]), call))
+        opt.release()
+        return xs
+
+    got, want = drive(hip_backend), drive(oracle_backend)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert rel_err(g, w) <= TOL, i
+        assert np.array_equal(g[where] == 0.25, w[where] == 0.25), i
+    lib.stochqn_hip_release_all()
+
+
+def test_the_library_pins_nothing_behind_the_callers_back(hip_backend):
+    """Raw C-ABI callers (plain numpy arrays through ctypes, no binding that owns them): with the defaults no host range is
+    registered by the library -- a caller may free and re-allocate its arrays between calls -- and arrays that the CALLER
+    pins (stochqn_hip_pin_host) are used as pinned.  With register_host = 1 the library pins an array by itself, but only one
+    it has seen at the same address in two consecutive calls."""
+    from stochqn_amd import _abi
+    lib = _lib()
+    lib.stochqn_hip_pin_host.argtypes = [C.c_void_p, C.c_size_t]
+    lib.stochqn_hip_unpin_host.argtypes = [C.c_void_p]
+    n, m, L = 1_200_000, 3, 4
+    rng = np.random.default_rng(2)
+    d = 0.5 + rng.random(n)
+
+    def run(calls, fresh_arrays, pin):
+        S, Y = np.zeros(m * n), np.zeros(m * n)
+        x, grad, hv = 1.0 + rng.random(n), np.zeros(n), np.zeros(n)
+        x_sum, x_avg_prev, rho, alpha, dummy = np.zeros(n), np.zeros(n), np.zeros(m), np.zeros(m), np.zeros(1)
+        if pin:
+            for a in (x, grad, hv):
+                assert lib.stochqn_hip_pin_host(a.ctypes.data, a.nbytes) == 0
+        b = _abi.bfgs_mem(S.ctypes.data, Y.ctypes.data, rho.ctypes.data, alpha.ctypes.data, dummy.ctypes.data, dummy.ctypes.data, m, 0, 0, L, 0.0, 0.0)
+        w = _abi.workspace_SQN(C.pointer(b), dummy.ctypes.data, x_sum.ctypes.data, x_avg_prev.ctypes.data, 0, 0, 0, 1, 1, n)
+        req, req_vec, task, info = C.c_void_p(x.ctypes.data), C.c_void_p(), C.c_int(101), C.c_int(200)
+        view = lambda p: np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), (n,))
+        keep = []
+        for _ in range(calls):
+            if fresh_arrays:                                     # a caller that hands over a new gradient array every time
+                grad = np.zeros(n)
+                keep.append(grad)
+            if task.value == 104:
+                np.multiply(d, view(req_vec.value), out=hv)
+            else:
+                np.multiply(d, view(req.value), out=grad)
+            rc = hip_backend.run_SQN(0.05, x.ctypes.data, grad.ctypes.data, hv.ctypes.data, C.byref(req), C.byref(req_vec), C.byref(task), C.byref(w), C.byref(info))
+            assert rc in (0, 1)
+        lib.stochqn_hip_release(C.c_void_p(S.ctypes.data))
+        if pin:
+            for a in (x, grad, hv):
+                assert lib.stochqn_hip_unpin_host(a.ctypes.data) == 0
+        return x
+
+    lib.stochqn_hip_stats_reset()
+    x_plain = run(14, False, False)
+    assert stat(lib, "host_ranges_registered") == 0
+    x_pinned = run(14, False, True)
+    assert stat(lib, "host_ranges_registered") == 3              # the caller's three, through the API
+    assert np.array_equal(x_plain, x_pinned)
+    with library_options(lib, register_host=1, register_min_bytes=1 << 20):
+        lib.stochqn_hip_stats_reset()
+        run(14, True, False)
+        fresh = stat(lib, "host_ranges_registered")
+        lib.stochqn_hip_stats_reset()
+        run(14, False, False)
+        stable = stat(lib, "host_ranges_registered")
+    assert stable >= 2 and fresh <= stable - 1, (fresh, stable)  # the ever-new gradient array is never pinned, x and the stable ones are
     lib.stochqn_hip_release_all()
 
 
@@ -97,24 +199,26 @@ def test_x_edited_by_the_caller_between_calls_is_seen(hip_backend, oracle_backen
         return xs
 
     lib.stochqn_hip_stats_reset()
-    got, want = drive(hip_backend), drive(oracle_backend)
+    with library_options(lib, **VOUCHED):
+        got = drive(hip_backend)
+    want = drive(oracle_backend)
     for i, (g, w) in enumerate(zip(got, want)):
         assert rel_err(g, w) <= TOL, i
     assert stat(lib, "x_uploads") >= 3                           # the first step and the two edits
     lib.stochqn_hip_release_all()
 
 
-def test_x_upload_option_always(hip_backend):
+def test_x_upload_is_the_default(hip_backend):
     lib = _lib()
     P = NoisyQuadratic(3000, seed=1)
-    try:
-        assert lib.stochqn_hip_set_option(b"x_upload", 1.0) == 0
+    lib.stochqn_hip_stats_reset()
+    run_trace(OPTIMIZERS["oLBFGS"](backend=hip_backend, space="host", mem_size=3), P, P.x0(), 0.05, 12)
+    assert stat(lib, "x_uploads_skipped") == 0 and stat(lib, "x_uploads") >= 5
+    with library_options(lib, x_upload=0):
         lib.stochqn_hip_stats_reset()
         run_trace(OPTIMIZERS["oLBFGS"](backend=hip_backend, space="host", mem_size=3), P, P.x0(), 0.05, 12)
-        assert stat(lib, "x_uploads_skipped") == 0 and stat(lib, "x_uploads") >= 5
-    finally:
-        lib.stochqn_hip_set_option(b"x_upload", 0.0)
-        lib.stochqn_hip_release_all()
+        assert stat(lib, "x_uploads_skipped") >= 4 and stat(lib, "x_uploads") == 1
+    lib.stochqn_hip_release_all()
 
 
 @pytest.mark.parametrize("kind", ["SQN", "oLBFGS", "adaQN"])
@@ -191,7 +295,7 @@ def test_x_sent_ahead_of_the_guard_leaves_the_same_bits(kind, strict, odd, hip_b
 
 @pytest.mark.parametrize("kind", ["SQN", "adaQN"])
 def test_x_sent_up_while_the_caller_computes_changes_nothing(kind, hip_backend):
-    """Option x_prefetch (default): a call that returns with *req == x while the device copy of x is stale (the request before was
+    """Option x_prefetch (with x_upload = 0; both opt-in): a call that returns with *req == x while the device copy of x is stale (the request before was
     at x_avg: Hessian-vector product, big-batch gradient, function value) starts the upload of x on a side stream and returns;
     the copy runs while the caller evaluates its gradient, the next call orders itself behind it.  Same bits as with the upload
     inside the next call -- also when the caller, against the contract, edits x while it is on its way (the probe values catch
@@ -224,17 +328,14 @@ def test_x_sent_up_while_the_caller_computes_changes_nothing(kind, hip_backend):
         return xs
 
     out = {}
-    try:
-        for mode in (1.0, 0.0):
-            assert lib.stochqn_hip_set_option(b"x_prefetch", mode) == 0
+    for mode in (1.0, 0.0):
+        with library_options(lib, x_upload=0, register_host=1, x_prefetch=mode):
             for edit_at in EDITS:
                 lib.stochqn_hip_stats_reset()
                 out[mode, edit_at] = drive(edit_at)
                 pre = stat(lib, "x_prefetched")
                 assert (pre >= 2) if mode else (pre == 0), (mode, edit_at, pre)
                 lib.stochqn_hip_release_all()
-    finally:
-        lib.stochqn_hip_set_option(b"x_prefetch", 1.0)
     for edit_at in EDITS:
         for i, (a, b) in enumerate(zip(out[1.0, edit_at], out[0.0, edit_at])):
             assert np.array_equal(a, b), "x after call %d differs (caller's edit at call %d)" % (i, edit_at)

@@ -1,0 +1,50 @@
+"""The product's host logic under sanitizers, on the CPU (SURVEY.md section 5 "race detection / sanitizers").
+
+`tests/hostsim` compiles stochqn_amd/csrc/{runtime,machines,group}.cpp UNCHANGED with g++ against the real HIP headers and
+links them with a malloc-backed stand-in for the 29 HIP runtime entry points they call (fake_hip.cpp), stand-ins for the
+kernel launchers (fake_launch.cpp: no numerics of the recursion, the memory footprint of every kernel touched) and a
+rendezvous stand-in for RCCL (libfake_rccl_*.so, through STOCHQN_HIP_RCCL_LIB).  No kernel, no oracle, nothing that ships.
+
+Every scenario of host_logic_test.cpp runs twice per build -- streams that execute at once and streams that execute only
+when something synchronises (the two ends of what the real runtime may do) -- under -fsanitize=address,undefined and
+under -fsanitize=thread:
+  registry / reclaim_resume / mirror_cap / host_path / branches / owned_and_raw / threads: the context registry, the LRU
+      reclaim -> spill -> resume cycle (incl. a resume that fails half-way and must not lose the state), the cap on mirrors,
+      pinning bookkeeping, sliced transfers, x sent ahead of the guard and put right, every branch of the state machines;
+  group_rccl / group_virtual: the single-process multi-device mode with 4 worker threads over ncclCommInitAll, and over
+      the host-side reducer; one shard over a real communicator (option devices_rccl_single);
+  group_alloc_failures: every allocation of that mode failing in turn (NULL / -1000, no hang, no leak);
+  fault_sweep / fault_sweep_group: EVERY call site of the HIP runtime failing in turn, ~600 runs: a message and -1000 or
+      a correct result, never an abort, a wrong x or a leak -- the bound on round 3's unexplained abort.
+"""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIM = os.path.join(ROOT, "tests", "hostsim")
+SCENARIOS = ["registry", "reclaim_resume", "mirror_cap", "host_path", "branches", "owned_and_raw", "threads",
+             "group_rccl", "group_virtual", "group_alloc_failures", "fault_sweep", "fault_sweep_group"]
+
+
+@pytest.fixture(scope="module")
+def built():
+    out = subprocess.run(["make", "-C", SIM, "-j2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-4000:]
+    return os.path.join(SIM, "build")
+
+
+@pytest.mark.parametrize("streams", ["immediate", "lazy"])
+@pytest.mark.parametrize("scenario", SCENARIOS)
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_host_logic(san, scenario, streams, built):
+    env = dict(os.environ, STOCHQN_HIP_RCCL_LIB=os.path.join(built, "libfake_rccl_%s.so" % san),
+               ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
+               TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
+    cmd = [os.path.join(built, "host_logic_%s" % san), scenario] + (["lazy"] if streams == "lazy" else [])
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
+    tail = "\n".join(l for l in out.stdout.splitlines() if not l.startswith(("stochqn:", "Error: Could not", "SQN got", "oLBFGS got", "adaQN got")))[-6000:]
+    assert out.returncode == 0, tail
+    assert "%s (%s streams): ok" % (scenario, streams) in out.stdout, tail
+    assert "ERROR: AddressSanitizer" not in out.stdout and "WARNING: ThreadSanitizer" not in out.stdout and "runtime error:" not in out.stdout, tail
