@@ -81,6 +81,7 @@ def parse():
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="N > 1: only the primary weak-scaling leg (default: also config 5's n = 1.25e8 per GPU, the strong-scaling "
                          "split of n = 1e8, the all-reduce latency and the one-process / N-devices mode, all in the same JSON line)")
+    ap.add_argument("--host-n", type=int, default=0, help="--in-process: total problem size of the host-caller leg (0 = 1e8; 4e6 per shard with --virtual-devices)")
     ap.add_argument("--cpu-n", type=int, default=0, help="CPU baseline: problem size (0 = n when host memory allows, else the largest that fits)")
     ap.add_argument("--no-profile", action="store_true", help="skip the second, HIP-event-profiled pass (no roofline object)")
     ap.add_argument("--sustain-seconds", type=float, default=6.0,
@@ -830,6 +831,8 @@ def in_process_leg(args, world, n_gpu, steps):
            "--bsize", str(args.bsize), "--no-cpu-baseline"]
     if args.rehearse:
         cmd.append("--virtual-devices")
+    if args.no_host_caller:
+        cmd.append("--no-host-caller")
     for kv in args.opt:
         cmd += ["--opt", kv]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
@@ -845,7 +848,7 @@ def in_process_leg(args, world, n_gpu, steps):
             "steps_per_s": d["steps_per_s_unnormalised"], "value_normalised_to_1e8": d["value"], "rccl_nranks": d["rccl_nranks"],
             "device_shards": d["device_shards"], "hess_vec_requests": d["config"]["hess_vec_requests"],
             "rejected_steps": d["config"]["rejected_steps"], "allreduces_per_step": d.get("allreduces_per_step"),
-            "allreduce_us": d.get("allreduce_us")}
+            "allreduce_us": d.get("allreduce_us"), "host_caller": d.get("host_caller")}
 
 
 def run_in_process(args):
@@ -1028,6 +1031,23 @@ def run_in_process(args):
     if lib.stochqn_hip_devices_foreach(key, probe_cb, None) == 0 and len(probe) == P and all(v[0] == 0 for v in probe.values()):
         allreduce_us = {"median_us": round(max(v[1] for v in probe.values()), 2), "min_us": round(max(v[2] for v in probe.values()), 2),
                         "doubles": 20, "reps": 200}
+    # ---- the same process model with a HOST caller (R / numpy arrays, the reference's real callers): n cut over the shards, every
+    # shard moves ITS slice of grad / x over ITS link -- what one link cannot give (36 ms per step at n = 1e8) P links may ----
+    host_leg = None
+    if args.dump_x:
+        np.save("%s.0.npy" % args.dump_x, np.concatenate([sh["x"].cpu().numpy() for sh in shards]))
+    if not args.no_host_caller:
+        be.dealloc_SQN(w)
+        w = None
+        lib.stochqn_hip_release_all()
+        for sh in shards:
+            for name in ("A", "d", "x", "grad", "hv"):
+                sh[name] = None
+        torch.cuda.empty_cache()
+        try:
+            host_leg = in_process_host_leg(args, lib, be, P, [sh["dev"] for sh in shards], m, L)
+        except Exception as e:                           # a leg of its own: it must not cost the line its primary result
+            host_leg = {"error": "%s: %s" % (type(e).__name__, e)}
     out = {
         "metric": "optimizer steps/sec + achieved HBM GB/s, two-loop at n=10^8 m=20 fp64",
         "value": round(steps_per_s * n_total / 1e8, 3),
@@ -1056,12 +1076,99 @@ def run_in_process(args):
         "profiled_pass": None if prof_elapsed is None else {"steps": prof_steps, "ms_per_step": round(1e3 * prof_elapsed / prof_steps, 3)},
         "roofline": roof, "two_loop": two_loop, "two_loop_micro": None, "reference_form": None,
         "kernels": detail, "cpu_baseline": None,
+        "host_caller": host_leg,
     }
-    if args.dump_x:
-        np.save("%s.0.npy" % args.dump_x, np.concatenate([sh["x"].cpu().numpy() for sh in shards]))
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    be.dealloc_SQN(w)
+    if w is not None:
+        be.dealloc_SQN(w)
     lib.stochqn_hip_release_all()
+
+
+def in_process_host_leg(args, lib, be, P, devices, m, L):
+    """ONE host process, every array in host memory (numpy: the R / Cython protocol, reference src/Rwrapper.c:98-125,
+    stochqn/pywrapper.pxi:161-207), the library's single-process multi-device mode: shard p moves its slice of grad and x over
+    device p's own link.  Reported: what a pinned transfer gives per device (one at a time, and all devices at once), and per
+    ordinary step the bytes each shard moved and the rate that makes per link.  n_total = 1e8 (the headline problem), the five
+    per-call arrays page-locked by their owner (stochqn_hip_pin_host, as stochqn_amd/free.py does); a short run: 3 L-cycles
+    from an empty ring -- the link, not the two-loop, is what is being measured."""
+    import numpy as np
+    import torch
+    from stochqn_amd import _abi
+    n = args.host_n if args.host_n > 0 else (100_000_000 if not args.virtual_devices else 4_000_000 * P)
+    per_dev = {}
+    for p, dev in enumerate(devices if not args.virtual_devices else devices[:1]):
+        torch.cuda.set_device(dev)
+        per_dev[str(dev)] = pcie_probe(n // P * 8, dev)
+    # all links at once: one thread per device
+    together = None
+    if not args.virtual_devices and P > 1:
+        res = [None] * P
+
+        def probe(p):
+            torch.cuda.set_device(devices[p])
+            res[p] = pcie_probe(n // P * 8, devices[p])
+        ths = [threading.Thread(target=probe, args=(p,)) for p in range(P)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if all(res):
+            together = {"h2d_GBps_sum": round(sum(r["h2d_GBps"] for r in res), 1), "d2h_GBps_sum": round(sum(r["d2h_GBps"] for r in res), 1),
+                        "per_device": res}
+    torch.cuda.set_device(devices[0])
+    lib.stochqn_hip_pin_host.argtypes = [C.c_void_p, C.c_size_t]
+    lib.stochqn_hip_unpin_host.argtypes = [C.c_void_p]
+    lib.stochqn_hip_stat.argtypes = [C.c_char_p]
+    lib.stochqn_hip_stat.restype = C.c_longlong
+    d = 0.5 + np.random.default_rng(SEED).random(n)
+    S, Y = np.zeros(m * n), np.zeros(m * n)              # an empty ring: nothing is imported, the pages are touched by nobody
+    x, grad, hv = 1.0 + d, np.empty(n), np.empty(n)
+    x_sum, x_avg_prev, rho_h, alpha_h, dummy = np.zeros(n), np.zeros(n), np.zeros(m), np.zeros(m), np.zeros(1)
+    pinned = [a for a in (x, grad, hv, x_sum, x_avg_prev) if lib.stochqn_hip_pin_host(a.ctypes.data, a.nbytes) == 0]
+    b = _abi.bfgs_mem(S.ctypes.data, Y.ctypes.data, rho_h.ctypes.data, alpha_h.ctypes.data, dummy.ctypes.data, dummy.ctypes.data, m, 0, 0, L, 0.0, 0.0)
+    w = _abi.workspace_SQN(C.pointer(b), dummy.ctypes.data, x_sum.ctypes.data, x_avg_prev.ctypes.data, 0, 0, 0, 1, 1, n)
+    req, req_vec, task, info = C.c_void_p(x.ctypes.data), C.c_void_p(), C.c_int(101), C.c_int(200)
+    view = lambda ptr: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), (n,))
+    clock = {"lib": 0.0}
+
+    def one_step():
+        target = w.niter + 1
+        while w.niter < target or task.value != 101:
+            if task.value == 104:
+                np.multiply(d, view(req_vec.value), out=hv)
+            else:
+                np.multiply(d, view(req.value), out=grad)
+            t0 = time.perf_counter()
+            rc = be.run_SQN(0.05, x.ctypes.data, grad.ctypes.data, hv.ctypes.data, C.byref(req), C.byref(req_vec), C.byref(task), C.byref(w), C.byref(info))
+            clock["lib"] += time.perf_counter() - t0
+            assert rc in (0, 1), rc
+    try:
+        rc = be.run_SQN(0.05, x.ctypes.data, grad.ctypes.data, hv.ctypes.data, C.byref(req), C.byref(req_vec), C.byref(task), C.byref(w), C.byref(info))
+        assert rc == 0
+        lib.stochqn_hip_stats_reset()
+        for _ in range(2 * L):
+            one_step()
+        assert lib.stochqn_hip_devices_active(C.c_void_p(S.ctypes.data)) == P
+        per = []
+        for _ in range(L):
+            clock["lib"] = 0.0
+            one_step()
+            per.append(1e3 * clock["lib"])
+        ordinary = sorted(per[1:-1])
+        ord_ms = ordinary[len(ordinary) // 2]
+        up = down = 8 * n                                   # grad and x up, x down; x rides under the update (full duplex)
+        out = {"what": "ONE host process, numpy arrays, %d device shards behind the plain ABI; n_total=%g, m=%d (ring of %d pairs so far), L=%d" % (P, n, m, b.mem_used, L),
+               "pcie_probe_per_device_alone": per_dev, "pcie_probe_all_devices_at_once": together,
+               "ms_per_step": round(sum(per) / L, 2), "ordinary_step_ms": round(ord_ms, 2), "per_step_ms": [round(v, 2) for v in per],
+               "bytes_up_per_shard": 2 * up // P, "bytes_down_per_shard": down // P,
+               "link_GBps_per_shard_up": round(2 * up / P / (ord_ms * 1e-3) / 1e9, 1), "link_GBps_per_shard_down": round(down / P / (ord_ms * 1e-3) / 1e9, 1),
+               "note": "rates are bytes / the WHOLE ordinary step (kernels included): a lower bound of what each link carried",
+               "arrays_pinned_by_the_caller": len(pinned), "x_sent_ahead_of_the_guard": int(lib.stochqn_hip_stat(b"x_sent_ahead"))}
+    finally:
+        lib.stochqn_hip_release_all()
+        for a in pinned:
+            lib.stochqn_hip_unpin_host(a.ctypes.data)
+    return out
 
 
 def kernel_table(lib):
@@ -1294,7 +1401,7 @@ class HostCopies:
         self.seconds = time.perf_counter() - t0
 
 
-def pcie_probe(nbytes):
+def pcie_probe(nbytes, device="cuda"):
     """What the link gives a plain pinned transfer of `nbytes` in each direction (torch, hipHostMalloc'ed memory): the
     yardstick for the host-caller leg."""
     import torch
@@ -1303,15 +1410,15 @@ def pcie_probe(nbytes):
         h = torch.empty(count, dtype=torch.float64).pin_memory()
     except RuntimeError:
         return None
-    dv = torch.empty(count, dtype=torch.float64, device="cuda")
+    dv = torch.empty(count, dtype=torch.float64, device=device)
     out = {}
     for name, (dst, src) in (("h2d", (dv, h)), ("d2h", (h, dv))):
         ts = []
         for _ in range(3):
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(dv.device)
             t0 = time.perf_counter()
             dst.copy_(src, non_blocking=True)
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(dv.device)
             ts.append(time.perf_counter() - t0)
         out[name + "_GBps"] = round(nbytes / min(ts) / 1e9, 1)
     return out

@@ -1,4 +1,4 @@
-// scratch/hostcost.hip -- cost of the host-side pieces of one API call (not product)
+// profiles/src/hostcost.hip -- cost of the host-side pieces of one API call (not product)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <chrono>

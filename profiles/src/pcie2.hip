@@ -1,4 +1,4 @@
-// scratch/pcie2.hip -- does a second copy stream raise the rate of ONE direction over PCIe?  0.8 GB in 8 slices, pinned host memory
+// profiles/src/pcie2.hip -- does a second copy stream raise the rate of ONE direction over PCIe?  0.8 GB in 8 slices, pinned host memory
 // (hipHostRegister'ed malloc, like a caller's array), one stream against two alternating streams, H2D and D2H.  Not product.
 #include <hip/hip_runtime.h>
 #include <chrono>

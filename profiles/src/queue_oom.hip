@@ -1,4 +1,4 @@
-// scratch/queue_oom.hip -- what does the HIP runtime do when a stream is first used while the device is (almost) full?
+// profiles/src/queue_oom.hip -- what does the HIP runtime do when a stream is first used while the device is (almost) full?
 // Fill HBM up to `leave_mb`, then create streams one by one and launch a trivial kernel on each.  Not product.
 #include <hip/hip_runtime.h>
 #include <cstdio>

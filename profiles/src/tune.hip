@@ -1,5 +1,5 @@
-// scratch/tune.hip -- access-pattern sweep for the fused backward kernel (not part of the product).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off scratch/tune.hip -o gpurun_out/tune && gpurun_out/tune
+// profiles/src/tune.hip -- access-pattern sweep for the fused backward kernel (not part of the product).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off profiles/src/tune.hip -o gpurun_out/tune && gpurun_out/tune
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

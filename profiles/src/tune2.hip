@@ -1,4 +1,4 @@
-// scratch/tune2.hip -- grid / unroll sweep per kernel SHAPE (reads x writes); not part of the product.
+// profiles/src/tune2.hip -- grid / unroll sweep per kernel SHAPE (reads x writes); not part of the product.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,4 +1,4 @@
-// scratch/tune3.hip -- sweep of the two-pass kernels' shape (rows-dot / combine); not part of the product.
+// profiles/src/tune3.hip -- sweep of the two-pass kernels' shape (rows-dot / combine); not part of the product.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

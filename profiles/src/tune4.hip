@@ -1,4 +1,4 @@
-// scratch/tune4.hip -- phase ablation of the diagonal-H0 Gram pass (k_gram_h0); not part of the product.
+// profiles/src/tune4.hip -- phase ablation of the diagonal-H0 Gram pass (k_gram_h0); not part of the product.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

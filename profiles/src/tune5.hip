@@ -1,4 +1,4 @@
-// scratch/tune5.hip -- 16-byte loads/stores at 8-byte alignment (odd n: every other ring row is misaligned); not product.
+// profiles/src/tune5.hip -- 16-byte loads/stores at 8-byte alignment (odd n: every other ring row is misaligned); not product.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

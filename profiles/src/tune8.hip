@@ -1,4 +1,4 @@
-// scratch/tune8.hip -- shapes of the three-pass kernels: pass 1 (k rows of S . g: read-only, k accumulators per lane)
+// profiles/src/tune8.hip -- shapes of the three-pass kernels: pass 1 (k rows of S . g: read-only, k accumulators per lane)
 // and pass 2 (q0 = g - sum alpha_j y_j; r0 = gamma q0; v_j = y_j'r0; write r0).  Not part of the product.
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -22,7 +22,7 @@ _cdll = {}
 
 def _share_hip_runtime_with_torch():
     """One ROCm runtime per process.  torch's wheels bundle their own libamdhip64.so, libhsa-runtime64.so and
-    librccl.so (same SONAMEs as /opt/rocm's).  Measured on the GPU box (scratch/probe_order.py):
+    librccl.so (same SONAMEs as /opt/rocm's).  Measured on the GPU box (profiles/src/probe_order.py):
       * libstochqn.so loaded first brings in /opt/rocm's HIP; a later `import torch` adds the bundled one --
         two runtimes, torch.cuda then reports no device and torch's device pointers mean nothing to the library;
       * any librccl.so loaded before torch (libstochqn dlopen()s RCCL when a communicator is asked for; even

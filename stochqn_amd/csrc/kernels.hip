@@ -47,7 +47,7 @@ typedef real rvec __attribute__((ext_vector_type(kVec)));     // one 16-byte pac
 // global_load / global_store_dwordx4 at any element alignment (the compiler emits them for these
 // types); measured on the rows-dot pass at n = 1e8: 5.39 ms with every other row misaligned against
 // 5.15 ms aligned -- and 13.8 ms for the element-wise path that alignment gating used to fall back
-// to (scratch/tune5.hip).
+// to (profiles/src/tune5.hip).
 typedef rvec rvec_u __attribute__((aligned(sizeof(real))));
 
 // W elements of a vector, widened to double for the arithmetic.  W = kVec: one 16-byte access per
@@ -109,7 +109,7 @@ template <int W> __device__ __forceinline__ void st_nt(real* p, uint32_t i, cons
 }
 
 // The single store stream of pass B (1 of 2k+2 streams): agent-scope, non-temporal cache policy on the store
-// (gfx942 / gfx950 "sc1 nt").  Measured on the pass-B micro-benchmark (scratch/tune7.hip,
+// (gfx942 / gfx950 "sc1 nt").  Measured on the pass-B micro-benchmark (profiles/src/tune7.hip,
 // profiles/r02_tune_store_policy.log, n = 1e8, k = 20): 6.01 ms plain, 5.98 ms nt, 5.84 ms sc1, 5.75 ms sc1 nt
 // (no store at all: 4.77 ms).  There is no builtin for the sc bits, hence the one line of assembly.
 template <int W> __device__ __forceinline__ void st_stream(real* p, uint32_t i, const Pack<W>& a)

@@ -84,6 +84,55 @@ hipError_t bounced_copy(void* dst, const void* src, size_t bytes, bool to_host)
 	return hipSuccess;
 }
 
+// ---- experiment (round 4): the library's own scratch from ONE arena reserved at the first API call ------
+// STOCHQN_HIP_ARENA_MB=N in the environment: N MB of device memory are reserved the first time the library is asked whether a
+// device exists -- before the caller has made its big arrays -- and the per-context scratch pools (partials, landing zones of
+// the reductions, cached inner products) are carved from it (same-size blocks are reused, nothing is coalesced; a pool that
+// does not fit comes from hipMalloc as always).  The question: does where the library's own buffers land move the 5-8 %
+// run-to-run spread of the headline step?  Answer (profiles/r04_placement_arena.jsonl): see there.  Off by default.
+struct Arena {
+	char* base = nullptr;
+	size_t size = 0, used = 0;
+	std::vector<std::pair<void*, size_t>> free_blocks;
+} g_arena;
+std::mutex g_arena_mu;
+
+void arena_reserve()
+{
+	const char* e = std::getenv("STOCHQN_HIP_ARENA_MB");
+	const long mb = e ? std::atol(e) : 0;
+	if (mb <= 0) return;
+	std::lock_guard<std::mutex> lk(g_arena_mu);
+	if (g_arena.base) return;
+	if (hipMalloc((void**) &g_arena.base, (size_t) mb << 20) != hipSuccess) { (void) hipGetLastError(); g_arena.base = nullptr; return; }
+	g_arena.size = (size_t) mb << 20;
+}
+
+void* arena_alloc(size_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_arena_mu);
+	if (!g_arena.base || std::getenv("STOCHQN_HIP_ARENA_UNUSED")) return nullptr;      // _UNUSED: reserved, never carved (control of the experiment)
+	bytes = (bytes + 4095) & ~(size_t) 4095;
+	for (size_t i = 0; i < g_arena.free_blocks.size(); i++)
+		if (g_arena.free_blocks[i].second == bytes) {
+			void* p = g_arena.free_blocks[i].first;
+			g_arena.free_blocks.erase(g_arena.free_blocks.begin() + (long) i);
+			return p;
+		}
+	if (g_arena.used + bytes > g_arena.size) return nullptr;
+	void* p = g_arena.base + g_arena.used;
+	g_arena.used += bytes;
+	return p;
+}
+
+bool arena_free(void* p, size_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_arena_mu);
+	if (!g_arena.base || (char*) p < g_arena.base || (char*) p >= g_arena.base + g_arena.size) return false;
+	g_arena.free_blocks.emplace_back(p, (bytes + 4095) & ~(size_t) 4095);
+	return true;
+}
+
 bool alloc_should_fail()
 {
 	long left = g_fail_alloc_after.load();
@@ -250,7 +299,7 @@ void destroy(DevCtx* c, bool keep_spill = false)
 	for (auto e : c->prof.pool) (void) hipEventDestroy(e);
 	View* vs[] = {&c->S, &c->Y, &c->sbak, &c->ybak, &c->gprev, &c->xsum, &c->xprev, &c->H0, &c->G, &c->F};
 	for (View* v : vs) free_view(c, *v);
-	if (c->pool) SQN_HIP_OK(hipFree(c->pool));
+	if (c->pool && !arena_free(c->pool, c->pool_bytes)) SQN_HIP_OK(hipFree(c->pool));
 	if (c->sc.fisher_part) SQN_HIP_OK(hipFree(c->sc.fisher_part));
 	if (c->fisher_t) SQN_HIP_OK(hipFree(c->fisher_t));
 	for (real* p : c->stage) if (p) SQN_HIP_OK(hipFree(p));
@@ -522,6 +571,7 @@ bool device_ready()
 		int count = 0;
 		const hipError_t e = hipGetDeviceCount(&count);
 		if (e != hipSuccess || count <= 0) { (void) hipGetLastError(); return false; }
+		arena_reserve();
 		return true;
 	}();
 	return ready;
@@ -594,7 +644,9 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	const size_t rows_part = (size_t) kRedMax * kMaxGrid;
 	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + m * m + (2 + 2 * kPairsMax3) + 3 * m;
 	c->pin_count = 16 + 2 * m + fsize + 3 * m + 8;
-	if (!device_alloc((void**) &c->pool, total * sizeof(double)) ||
+	c->pool_bytes = total * sizeof(double);
+	c->pool = (double*) arena_alloc(c->pool_bytes);
+	if ((!c->pool && !device_alloc((void**) &c->pool, c->pool_bytes)) ||
 	    !pinned_alloc((void**) &c->pin, c->pin_count * sizeof(double)) ||
 	    (fsize > 0 && (!device_alloc((void**) &c->sc.fisher_part, fsize * kMaxGrid * sizeof(double)) ||
 	                   !device_alloc((void**) &c->fisher_t, fsize * sizeof(double))))) {

@@ -140,6 +140,7 @@ struct DevCtx {
 	int buf = 0;                       // ping-pong index of the next partial buffer
 	int phase = 1;                     // sweep parity inside the current API call (reset by begin_call)
 	double* pool = nullptr;            // one allocation behind sc.part/red/sy/yy/alpha/rho/report
+	size_t pool_bytes = 0;
 	double* fisher_t = nullptr;        // [fsize] F*s on device
 	hipEvent_t x_pre_ev = nullptr;                    // option "x_prefetch": the upload of x that was started when the last call returned
 	bool x_pre_pending = false;

@@ -37,14 +37,20 @@ def test_roofline_object_of_the_dominant_kernel():
     assert tl2["form"] == "sweeps" and tl2["bytes_moved"] == 8 * m * n * 8
 
 
-def test_c5_yardstick_comes_from_the_newest_committed_profile():
+def test_c5_yardstick_is_this_nodes_own_and_a_committed_profile_only_as_the_labelled_fallback():
     b = _bench()
-    one = b.shard_reference(1, 80.0)
+    one = b.shard_reference(1, 80.0, None)
     assert one["source"] == "this run" and abs(one["within_15pct_means_at_least"] - 68.0) < 1e-9
-    ref = b.shard_reference(8, 70.0)
-    assert ref and ref["source"].startswith("profiles/r") and ref["source"].endswith("_c5_shard_1gpu.json")
+    # N > 1: the 1-GPU child run on the same node is the yardstick ...
+    here = b.shard_reference(8, 70.0, {"steps_per_s": 77.0, "ms_per_step": 12.99, "n_per_gpu": 125_000_000, "steps": 20})
+    assert here["source"] == "this node" and here["steps_per_s"] == 77.0 and abs(here["this_run_over_reference"] - 70.0 / 77.0) < 1e-3
+    assert abs(here["within_15pct_means_at_least"] - 0.85 * 77.0) < 1e-2
+    # ... and only when that could not be had (child failed: an error record) the newest committed profile, labelled as what it is
+    ref = b.shard_reference(8, 70.0, {"error": "RuntimeError: exit code 1"})
+    assert ref and ref["source"].startswith("FALLBACK, another box: profiles/r") and ref["source"].endswith("_c5_shard_1gpu.json")
+    assert ref["same_node_attempt"] == {"error": "RuntimeError: exit code 1"}
     newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_c5_shard_1gpu.json"))[-1]
-    assert ref["source"] == "profiles/" + newest
+    assert ref["source"].endswith("profiles/" + newest)
     assert abs(ref["this_run_over_reference"] - 70.0 / ref["steps_per_s"]) < 1e-3
     assert abs(ref["within_15pct_means_at_least"] - 0.85 * ref["steps_per_s"]) < 1e-2
 

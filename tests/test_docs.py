@@ -1,10 +1,10 @@
-"""The documents cite files as evidence (profiles/, scratch/, tools/, tests/ ...): every cited path must exist."""
+"""The documents cite files as evidence (profiles/, profiles/src/, tools/, tests/ ...): every cited path must exist."""
 import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOCS = ["DESIGN.md", "INTEGRATION.md", "README.md", "profiles/README.md"]
-PREFIXES = ("profiles/", "scratch/", "tools/", "tests/", "oracle/", "include/", "stochqn_amd/")
+PREFIXES = ("profiles/", "tools/", "tests/", "oracle/", "include/", "stochqn_amd/")
 
 
 def cited_paths(text):
@@ -20,8 +20,8 @@ def test_every_path_cited_in_the_documents_exists():
         text = open(os.path.join(ROOT, doc)).read()
         for path in cited_paths(text):
             full = os.path.join(ROOT, path)
-            # built artefacts are not in the tree until build() has run; binaries of scratch tools likewise
-            if path.endswith(".so") or path in ("tools/latency", "scratch/tune", "scratch/hostcost", "oracle/_ref"):
+            # built artefacts are not in the tree until build() has run; binaries of the measurement tools likewise
+            if path.endswith(".so") or path in ("tools/latency", "tools/host_link_probes", "profiles/src/tune", "profiles/src/hostcost", "oracle/_ref") or path.startswith("tests/hostsim/build"):
                 continue
             if not os.path.exists(full):
                 missing.append((doc, path))

@@ -69,6 +69,49 @@ def test_host_caller_on_P_devices_equals_unsharded_oracle(name, n, devices, hip_
     opt.release()
 
 
+@pytest.fixture
+def one_shard_over_rccl(hip_backend):
+    """Option devices_rccl_single: the multi-device mode with ONE shard on the current device over a REAL communicator --
+    ncclCommInitAll of one device, the shard's worker thread, ncclAllReduce on the shard's stream for every reduction,
+    ncclCommDestroy -- i.e. every line of group.cpp / runtime.cpp that an 8-GPU node runs and a one-GPU box can."""
+    lib = _lib()
+    assert lib.stochqn_hip_set_option(b"devices", 0.0) == 0 and lib.stochqn_hip_set_option(b"virtual_devices", 0.0) == 0
+    assert lib.stochqn_hip_set_option(b"devices_min_n", 1.0) == 0
+    assert lib.stochqn_hip_set_option(b"devices_rccl_single", 1.0) == 0
+    yield 1
+    lib.stochqn_hip_release_all()
+    lib.stochqn_hip_set_option(b"devices_rccl_single", 0.0)
+    lib.stochqn_hip_set_option(b"devices_min_n", float(1 << 20))
+
+
+@pytest.mark.parametrize("name", ["olbfgs_default", "olbfgs_nan_grad", "sqn_hessvec", "sqn_graddiff", "sqn_reject", "adaqn_fisher_rms",
+                                  "adaqn_func_increased", "sqn_ring20"])
+def test_one_shard_over_a_real_rccl_communicator(name, one_shard_over_rccl, hip_backend, oracle_backend):
+    """SQN / oLBFGS / adaQN through the group mode's RCCL path on one device, against the oracle: every reduction of every
+    step is a real ncclAllReduce on the communicator that ncclCommInitAll made."""
+    lib = _lib()
+    lib.stochqn_hip_stat.argtypes = [C.c_char_p]
+    lib.stochqn_hip_stat.restype = C.c_longlong
+    cfg = [c for c in CONFIGS if c[0] == name][0]
+    _, optname, kw, step, calls, pkw = cfg
+    n = 3001
+    P = NoisyQuadratic(n, seed=7, **pkw)
+    want = run_trace(OPTIMIZERS[optname](backend=oracle_backend, space="host", **kw), P, P.x0(), step, calls)
+    lib.stochqn_hip_stats_reset()
+    opt = OPTIMIZERS[optname](backend=hip_backend, space="host", **kw)
+    got = run_trace(opt, P, P.x0(), step, calls)
+    key = C.c_void_p(opt.BFGS_mem.s_mem.ctypes.data)
+    assert lib.stochqn_hip_devices_active(key) == 1 and lib.stochqn_hip_devices_reducer(key) == RCCL
+    assert lib.stochqn_hip_stat(b"allreduces") >= calls // 2
+    compare_traces(got, want, FREE_RUN_TOL.get(name, TOL))
+    opt.release()
+
+
+def test_library_owned_workspace_on_one_shard_over_rccl(one_shard_over_rccl, hip_backend, oracle_backend):
+    test_library_owned_sharded_workspaces("SQN-hessvec", 1, hip_backend, oracle_backend)
+    test_library_owned_sharded_workspaces("adaQN-fisher", 1, hip_backend, oracle_backend)
+
+
 @pytest.mark.parametrize("kind,kw", [("SQN", dict(mem_size=3, bfgs_upd_freq=3)), ("oLBFGS", dict(mem_size=3)),
                                      ("adaQN", dict(mem_size=3, fisher_size=5, bfgs_upd_freq=3, max_incr=1.01, rmsprop_weight=0.9))])
 def test_host_path_of_the_multi_device_mode(kind, kw, devices, hip_backend, oracle_backend):
@@ -128,7 +171,7 @@ def test_large_shards_run_the_overlaps_of_the_host_path(hip_backend, oracle_back
     assert lib.stochqn_hip_set_option(b"virtual_devices", 1.0) == 0
     assert lib.stochqn_hip_set_option(b"devices_min_n", 1.0) == 0
     assert lib.stochqn_hip_set_option(b"devices", 3.0) == 0
-    n = 13_000_001
+    n = 7_000_001                                       # 2.33e6 per shard: past host_slice_min = 2^21
     P = NoisyQuadratic(n, seed=8, nan_calls=(10, 11))
     kw = dict(mem_size=3, bfgs_upd_freq=3)
     from harness import VOUCHED, library_options
@@ -559,6 +602,13 @@ def test_bench_in_process_mode_is_shard_invariant(tmp_path):
     assert outs[2][1].shape == outs[3][1].shape == (3_000_000,)
     assert rel_err(outs[2][1], outs[3][1]) <= TOL
     assert outs[2][0]["config"]["calls"] == outs[3][0]["config"]["calls"]
+    # the same process model with a HOST caller (numpy arrays, each shard moving its slice over its own link): reported per shard
+    for P in (2, 3):
+        h = outs[P][0]["host_caller"]
+        assert "error" not in h, h
+        assert h["arrays_pinned_by_the_caller"] == 5 and h["ordinary_step_ms"] > 0 and len(h["per_step_ms"]) == 3
+        assert h["bytes_up_per_shard"] == 2 * 8 * 4_000_000 and h["link_GBps_per_shard_up"] > 0 and h["link_GBps_per_shard_down"] > 0
+        assert h["pcie_probe_per_device_alone"]["cuda:0"]["h2d_GBps"] > 5
 
 
 def test_c5_shard_size_through_the_single_process_mode():
@@ -567,7 +617,7 @@ def test_c5_shard_size_through_the_single_process_mode():
     filled by the run itself, the 32-row Hessian product reduced over the shards, full-size kernels."""
     import json
     from test_gpu_parity import _bench
-    r = _bench(["--gpus", "2", "--in-process", "--virtual-devices", "--config", "c5", "--steps", "10", "--warmup", "2"], timeout=900)
+    r = _bench(["--gpus", "2", "--in-process", "--virtual-devices", "--config", "c5", "--steps", "10", "--warmup", "2", "--no-host-caller"], timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["device_shards"] == 2 and "n_total=2.5e+08" in d["config"]["workload"]

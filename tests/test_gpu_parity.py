@@ -496,13 +496,10 @@ def _chunked_fisher_reference(torch, F, fu, n, s, chunk=4_000_000):
     return t, y
 
 
-def test_adaqn_at_the_c4_shape_builds_its_pairs_from_all_128_fisher_rows(hip_backend):
+@pytest.fixture(scope="class")
+def c4_run(hip_backend):
     """BASELINE config 4 as stated: adaQN, n = 1e8, m = 20, fisher_size = 128 (102.4 GB ring), RMSProp H0, L = 20,
-    min_curvature = 1e-4.  141 iterations fill the Fisher ring; the pair built at iteration 140 must be
-    y = F'(F s)/128 over ALL 128 rows -- checked on the device against chunked torch fp64 products -- and satisfy
-    s'y = |F s|^2 / 128.  (The oracle would need the 102 GB ring on the host; the per-step kernels at this size
-    are held to the oracle by test_adaqn_step_matches_the_oracle_at_full_size, the product at 32 rows by
-    test_fisher_product_matches_the_oracle_at_full_size.)"""
+    min_curvature = 1e-4.  141 iterations fill the Fisher ring; stops right after the call that built the pair of iteration 140."""
     torch = torch_cuda()
     n, m, f, L = 100_000_000, 20, 128, 20
     gen = torch.Generator(device="cuda").manual_seed(4)
@@ -520,19 +517,63 @@ def test_adaqn_at_the_c4_shape_builds_its_pairs_from_all_128_fisher_rows(hip_bac
         t += 1
         if opt.niter == 140 and opt.section == 1 and opt.Fisher_mem.mem_used == f:
             break                                               # right after the call that built the pair of iteration 140
-    assert infos == {"no_problems_encountered"}
-    assert opt.Fisher_mem.mem_used == f and opt.BFGS_mem.mem_used == 6          # pairs at 40, 60, ..., 140
+    del d, dn, x
     row = (opt.BFGS_mem.mem_st_ix - 1) % m
-    s = opt.BFGS_mem.s_mem[row * n:(row + 1) * n]
-    y = opt.BFGS_mem.y_mem[row * n:(row + 1) * n]
-    t_ref, y_ref = _chunked_fisher_reference(torch, opt.Fisher_mem.F, f, n, s)
-    err = float(torch.linalg.norm(y - y_ref) / torch.linalg.norm(y_ref))
-    assert err <= TOL, err
-    assert rel_err(opt.Fisher_mem.buffer_y, t_ref.cpu().numpy()) <= TOL
-    sy, tt = float(torch.dot(s, y)), float(torch.dot(t_ref, t_ref)) / f
-    assert abs(sy - tt) <= 1e-9 * abs(tt), (sy, tt)
-    assert float(torch.linalg.norm(s)) > 0
+    yield {"opt": opt, "n": n, "m": m, "f": f, "infos": infos,
+           "s": opt.BFGS_mem.s_mem[row * n:(row + 1) * n], "y": opt.BFGS_mem.y_mem[row * n:(row + 1) * n]}
     opt.release()
+
+
+class TestAdaqnAtTheC4Shape:
+    def test_adaqn_at_the_c4_shape_builds_its_pairs_from_all_128_fisher_rows(self, c4_run):
+        """The pair built at iteration 140 must be y = F'(F s)/128 over ALL 128 rows -- checked on the device against chunked
+        torch fp64 products (an independent implementation) -- and satisfy s'y = |F s|^2 / 128."""
+        torch = torch_cuda()
+        opt, n, m, f, s, y = (c4_run[k] for k in ("opt", "n", "m", "f", "s", "y"))
+        assert c4_run["infos"] == {"no_problems_encountered"}
+        assert opt.Fisher_mem.mem_used == f and opt.BFGS_mem.mem_used == 6          # pairs at 40, 60, ..., 140
+        t_ref, y_ref = _chunked_fisher_reference(torch, opt.Fisher_mem.F, f, n, s)
+        err = float(torch.linalg.norm(y - y_ref) / torch.linalg.norm(y_ref))
+        assert err <= TOL, err
+        assert rel_err(opt.Fisher_mem.buffer_y, t_ref.cpu().numpy()) <= TOL
+        sy, tt = float(torch.dot(s, y)), float(torch.dot(t_ref, t_ref)) / f
+        assert abs(sy - tt) <= 1e-9 * abs(tt), (sy, tt)
+        assert float(torch.linalg.norm(s)) > 0
+
+    def test_the_128_row_pair_of_the_c4_shape_matches_the_oracle(self, c4_run):
+        """The same pair against the ORACLE (reference src/stochqn.c:936-952 restated): the whole 102.4 GB Fisher ring is
+        brought to the host (the GPU boxes have ~260 GB of it; skipped, visibly, where the host is smaller), the oracle forms
+        t = F s and y = F't/128 from the library's own s, and t (buffer_y) and y must agree to 1e-10 -- C4's pair at C4's size."""
+        from oracle import oracle
+        torch = torch_cuda()
+        opt, n, f, s, y = (c4_run[k] for k in ("opt", "n", "f", "s", "y"))
+        need = (f + 4) * n * 8
+        avail = 0
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                avail = int(line.split()[1]) * 1024
+        try:
+            lim = open("/sys/fs/cgroup/memory.max").read().strip()
+            if lim != "max":
+                avail = min(avail, int(lim) - int(open("/sys/fs/cgroup/memory.current").read()))
+        except (OSError, ValueError):
+            pass
+        if avail < 1.35 * need:
+            pytest.skip("the host has %.0f GB available, the 128-row Fisher ring needs %.0f GB there" % (avail / 1e9, 1.35 * need / 1e9))
+        olib = oracle.cdll()
+        oracle.set_threads(oracle.usable_cpus())
+        F_h = np.empty(f * n)
+        if hasattr(olib, "oracle_first_touch"):
+            olib.oracle_first_touch(F_h.ctypes.data, f * n)
+        for k in range(f):                                                # device -> the numpy buffer itself, row by row
+            torch.from_numpy(F_h[k * n:(k + 1) * n]).copy_(opt.Fisher_mem.F[k * n:(k + 1) * n])
+        s_h = s.cpu().numpy()
+        t_w, y_w = np.zeros(f), np.empty(n)
+        olib.oracle_fisher_product(F_h.ctypes.data, f, n, s_h.ctypes.data, t_w.ctypes.data, y_w.ctypes.data)
+        del F_h
+        e_y, e_t = rel_err(y.cpu().numpy(), y_w), rel_err(np.asarray(opt.Fisher_mem.buffer_y), t_w)
+        print("C4 pair at fisher_size = 128, n = 1e8 against the oracle: y %.2e, t %.2e" % (e_y, e_t))
+        assert e_y <= TOL and e_t <= TOL, (e_y, e_t)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -617,7 +658,7 @@ def test_two_loop_matches_the_oracle_at_full_size(hip_backend):
 
 
 @pytest.mark.parametrize("optname,n,kw,iters,step,tol", [
-    ("SQN", 100_000_000, dict(mem_size=20, bfgs_upd_freq=1, min_curvature=None), 26, 0.05, TOL),
+    ("SQN", 100_000_000, dict(mem_size=20, bfgs_upd_freq=1, min_curvature=None), 23, 0.05, TOL),
     ("oLBFGS", 10_000_000, dict(mem_size=10, min_curvature=None), 40, 0.05, TOL),           # the C2 shape
 ])                                                                                          # (adaQN: the lock-step test below)
 def test_steps_match_the_oracle_at_full_size(optname, n, kw, iters, step, tol, hip_backend, oracle_backend):
@@ -667,7 +708,7 @@ def test_adaqn_trajectory_at_full_size_in_lockstep_with_the_oracle(hip_backend, 
     import stochqn_amd
     torch = torch_cuda()
     lib = stochqn_amd.cdll()
-    n, iters, step, K = 100_000_000, 22, 0.002, 5
+    n, iters, step, K = 100_000_000, 22, 0.002, int(os.environ.get("SQN_TEST_K", "5"))
     kw = dict(mem_size=20, fisher_size=16, bfgs_upd_freq=1, max_incr=None, min_curvature=None, rmsprop_weight=0.9)
     gen = torch.Generator(device="cuda").manual_seed(99)
     d_d = 0.5 + torch.rand(n, dtype=torch.float64, device="cuda", generator=gen)
@@ -681,11 +722,30 @@ def test_adaqn_trajectory_at_full_size_in_lockstep_with_the_oracle(hip_backend, 
     x_ref, x_lock, x_free = x0_h.copy(), x0_d.clone(), x0_d.clone()
     t, syncs, worst = 0, 0, 0.0
 
+    bound = {}                                      # ring row -> what the cancellation in s = x_avg - x_avg_prev allows
+
     def close(what, got, want):
+        """x, G, H0, the averages and the Fisher rows at 1e-10 (measured: 1e-17 -- they are bit-identical but for single ulps).
+        s = x_avg - x_avg_prev is a difference of two vectors that agree to 7-8 digits at this step size (|s| / |x| ~ 3e-8):
+        one ulp of x is eps |x| / |s| ~ 4e-9 of s in ANY fp64 evaluation, the reference's included, and y = F'(F s)/fu is
+        linear in s.  So the rows of S and Y are held to what that allows, 16 eps |x| / |s| (measured: up to 1.1e-9, at the
+        last sync point), and -- like everything else here -- to 1e-10 of the vectors they were computed FROM (|x|)."""
         nonlocal worst
-        e = rel_err(got.cpu().numpy(), want)
-        worst = max(worst, e)
-        assert e <= TOL, "iteration %d: %s is %.3e from the oracle's" % (ref.niter, what, e)
+        w = np.asarray(want)
+        e = rel_err(got.cpu().numpy(), w)
+        tol = TOL
+        if what.startswith(("s_mem", "y_mem")):
+            row = int(what.split()[-1])
+            if what.startswith("s_mem"):
+                bound[row] = max(TOL, 16 * np.finfo(np.float64).eps * float(np.linalg.norm(x_ref)) / float(np.linalg.norm(w)))
+                assert e * float(np.linalg.norm(w)) <= TOL * float(np.linalg.norm(x_ref)), (what, e)      # absolute error against |x|: 1e-10
+            tol = bound[row]
+        else:
+            worst = max(worst, e)
+        if os.environ.get("SQN_TEST_REPORT_ONLY"):
+            print("iteration %d: %-16s %.3e (held to %.1e)" % (ref.niter, what, e, tol))
+            return
+        assert e <= tol, "iteration %d: %s is %.3e from the oracle's (held to %.1e)" % (ref.niter, what, e, tol)
 
     def rows(mem, size, st, used, name):
         a_r, a_l = getattr(getattr(ref, mem), name), getattr(getattr(lock, mem), name)
@@ -694,7 +754,7 @@ def test_adaqn_trajectory_at_full_size_in_lockstep_with_the_oracle(hip_backend, 
             yield "%s row %d" % (name, r), a_l[r * n:(r + 1) * n], a_r[r * n:(r + 1) * n]
 
     try:
-        while ref.niter < iters:
+        while (ref.niter if ref.initialized else 0) < iters:
             rs = [o.run_optimizer(x, step) for o, x in ((ref, x_ref), (lock, x_lock), (free, x_free))]
             assert rs[0]["task"] == rs[1]["task"] == rs[2]["task"] == "calc_grad" and rs[0]["info"] == rs[1]["info"] == rs[2]["info"]
             for o in (lock, free):
@@ -721,7 +781,7 @@ def test_adaqn_trajectory_at_full_size_in_lockstep_with_the_oracle(hip_backend, 
         e_free = rel_err(x_free.cpu().numpy(), x_ref)
         assert e_free <= 1e-7, e_free                                        # free-running: FREE_RUN_TOL
         assert rel_err(x_ref, x0_h) > 1e-4                                   # and the run went somewhere
-        print("adaQN at n = 1e8 in lock-step every %d iterations: worst relative error at a sync point %.2e; free-running %.2e" % (K, worst, e_free))
+        print("adaQN at n = 1e8 in lock-step every %d iterations: worst relative error of x / G / H0 / F at a sync point %.2e; free-running %.2e" % (K, worst, e_free))
     finally:
         for o in (lock, free, ref):
             o.release()
@@ -1676,7 +1736,8 @@ def test_bench_starts_its_own_ranks_and_shards_one_problem(tmp_path):
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith('{"metric"'), out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 3 and d["rccl_nranks"] == 3 and len(d["per_rank_ms_per_step"]) == 3
+    assert d["n_gpus"] == 3 and len(d["per_rank_ms_per_step"]) == 3
+    assert d["rccl_nranks"] == 0 and d["degraded"] is True          # a rehearsal: the reductions went over gloo, and the line says so
     assert d["steps"] == 12 and d["value"] > 0 and d["config"]["hess_vec_requests"] >= 1
     one = _bench(["--gpus", "1", "--vars-per-gpu", str(3 * per), "--dump-x", str(tmp_path / "x1")] + common)
     assert one.returncode == 0, one.stderr[-3000:]
@@ -1756,7 +1817,7 @@ def test_bench_keeps_its_primary_result_when_an_auxiliary_leg_hangs():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(BENCH_TEST_HANG_LEG="c5", BENCH_WATCHDOG_S="10")
+    env.update(BENCH_TEST_HANG_LEG="c5", BENCH_WATCHDOG_S="7")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rehearse"], capture_output=True, text=True,
                          timeout=600, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
