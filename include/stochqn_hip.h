@@ -94,7 +94,7 @@ int stochqn_hip_unpin_host(void *p);
  *                            used for m > 48 and for ill-conditioned pairs, "kappa_max").  (Round 1's two-pass form -- [S;Y]g,
  *                            a recursion over Gram blocks, one combine pass: (4m+3)n words -- was retired in round 4 together
  *                            with its options: the three-pass form dominated it on bytes, time and accuracy.)
- * "rows_grid", "rows_split", "rows_waves", "combine_batch", "stream_stores", "qdot_stream", "sdot_per_cu",
+ * "rows_split", "combine_batch", "stream_stores", "sdot_per_cu",
  * "sdot2_per_cu", "qdot_per_cu", "sadd_per_cu": kernel-shape knobs (grid sizes in workgroups per compute unit, packs a lane
  *                            finishes before it stores, store policy of r0 / r); the defaults are the measured optima, DESIGN.md 3.0
  * "strict_grad" (default 0)  host callers: copy the search direction back into `grad` (n words over PCIe per step).  The
@@ -102,11 +102,8 @@ int stochqn_hip_unpin_host(void *p);
  *                            include/stochqn.h:356-358), and none of its callers reads it afterwards (src/Rwrapper.c:98-196,
  *                            stochqn/pywrapper.pxi:161-207, example/c_rosen.c:103-118): off unless asked for.  Device
  *                            callers always find the direction in `grad` (it is computed there).
- * "fold_coef"   (default 1)  three-pass form: the scalar recursions run in the prologues of pass 2 / pass 3 (every
- *                            workgroup) instead of in two one-workgroup kernels between the passes
  * "keep_tail"   (default 0.35)  three-pass form: fraction of r0 / r -- the part written last, which the next pass reads
  *                            first -- stored with the default cache policy; the rest streams out (sc1 nt)
- * "fuse_apply"  (default 0)  three-pass form with check_nan = 0: the position update inside pass 3 (measured slower: DESIGN.md 3.0)
  * -- host callers (arrays of R / numpy / malloc crossing the ABI; INTEGRATION.md "host callers") --
  * "register_host" (default 0), "register_min_bytes" (default 4 MiB)  1: the library pins the caller's x / grad / hess_vec /
  *                            x_sum / x_avg_prev in place by itself (hipHostRegister) once an array has been seen at the same

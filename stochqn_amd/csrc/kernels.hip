@@ -892,13 +892,13 @@ __global__ void __launch_bounds__(kBlock) k_store_column(const double* a, int a_
 // (round 1's two-pass form kept y_i'g, y_i'y_j and adaQN's H0-weighted W_ij, and read Y twice; retired in round 4):
 // y_i'r0 is a direct dot with the vector it belongs to.  Reference: src/stochqn.c:663-708.
 // ------------------------------------------------------------------------------------------------
-// The scalar recursions of the three-pass form inside the prologues of pass 2 and pass 3 (option "fold_coef"): every
-// workgroup totals the previous pass's partials and runs the recursion itself -- the same functions in the same order as
-// k_coef3a / k_coef3b below, so the same bits -- instead of waiting for a one-workgroup kernel between the passes (two
-// launches and two dependent kernel boundaries less per step).  Workgroup 0 also stores what later kernels / the host
-// read: the new column of the cached block, alpha, rho, the coefficients.
+// The scalar recursions of the three-pass form run inside the prologues of pass 2 and pass 3: every workgroup totals the
+// previous pass's partials and runs the O(k^2) recursion itself, instead of waiting for a one-workgroup kernel between the
+// passes (round 2 had two: k_coef3a / k_coef3b -- two launches and two dependent kernel boundaries more per step, the same
+// bits; retired in round 4).  Workgroup 0 also stores what later kernels / the host read: the new column of the cached
+// block, alpha, rho.
 struct Fold3 {
-	const double* parts;        // previous pass's partials (NULL: coefficients come from k_coef3a / k_coef3b through `coef`)
+	const double* parts;        // previous pass's partials
 	int count, stride;
 	CoefArgs a;
 	int fresh_row;              // pass 2 only: ring row whose column s_i'y_fresh the previous pass produced (quantities k..2k-1), or -1
@@ -924,7 +924,7 @@ __device__ __forceinline__ void fold_load_sy(const Fold3& f, const double* col, 
 	}
 }
 
-// pass 2's prologue = k_coef3a: cf[0] = scale, cf[1 + i] = alpha_i
+// pass 2's prologue: totals of pass 1, the new pair's column, the backward recursion.  cf[0] = scale, cf[1 + i] = alpha_i
 __device__ __forceinline__ void fold_backward(const Fold3& f, double* SY, double* bS, double* col, double* cf)
 {
 	const int k = f.a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -962,7 +962,7 @@ __device__ __forceinline__ void fold_backward(const Fold3& f, double* SY, double
 	__syncthreads();
 }
 
-// pass 3's prologue = k_coef3b: cf[i] = c_i = alpha_i - beta_i
+// pass 3's prologue: totals of pass 2 (v_i = y_i'r0), the forward recursion.  cf[i] = c_i = alpha_i - beta_i
 __device__ __forceinline__ void fold_forward(const Fold3& f, double* SY, double* V, double* cf)
 {
 	const int k = f.a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -996,18 +996,15 @@ struct DiagArgs {               // how pass 2 scales q0
 };
 
 template <int W, int NG, bool NT, int MODE /*0 scalar, 1 given diagonal, 2 adaQN*/, bool SS>
-__global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, const double* coef, Fold3 fo, real* g, DiagArgs dg, uint32_t n, int rev,
+__global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, Fold3 fo, real* g, DiagArgs dg, uint32_t n, int rev,
                                                  uint32_t keep_from, double* parts)
 {
 	__shared__ double sh[NG * 8 * kWaves];
 	__shared__ double cf[1 + kPairsMax3];
 	const int k = ys.count;
-	if (fo.parts != nullptr) {
+	{
 		__shared__ double SY[kPairsMax3 * kPairsMax3], bS[kPairsMax3], col[kPairsMax3];
 		fold_backward(fo, SY, bS, col, cf);
-	} else {
-		for (int e = threadIdx.x; e < 1 + k; e += kBlock) cf[e] = coef[e];
-		__syncthreads();
 	}
 	double acc[NG * 8];
 	#pragma unroll
@@ -1094,23 +1091,19 @@ __global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, const double* coef, 
 }
 
 // pass 3: r = r0 + sum_j c_j s_j, oldest pair first (:702-707); guard sums (sum r^2, #non-finite).
-// FUSE (check_nan == 0: the update does not wait for a verdict, reference :825-838): x -= step r, x_sum += x and
-// oLBFGS's s-slot / grad <- -step r in the same pass, as the sweep form's last forward sweep does -- no guard sums, no apply pass.
+// (Folding the position update into this pass for check_nan == 0 was built in round 3 and measured slower -- 3.68 ms against
+// 2.79 + 0.73: two more store streams among 21 read streams -- and removed in round 4; profiles/r03_ab_fuse_apply.jsonl.)
 // SL: the pass in slices of the traversal (whole rounds of T packs per lane), the two guard sums carried from slice to slice
 // per lane exactly like the accumulators of pass 1 (k_rows_dot_all): same terms, same order, same bits as one launch.
-template <int W, bool NT, int T, bool SS, bool FUSE, bool SL>
-__global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, Fold3 fo, real* r, ApplyArgs ap, uint32_t n, int rev,
-                                                 uint32_t keep_from, double* parts, Slice sl)
+template <int W, bool NT, int T, bool SS, bool SL>
+__global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, Fold3 fo, real* r, uint32_t n, int rev, uint32_t keep_from, double* parts, Slice sl)
 {
 	__shared__ double sh[kWaves];
 	__shared__ double cf[kPairsMax3];
 	const int k = ss.count;
-	if (fo.parts != nullptr) {
+	{
 		__shared__ double SY[kPairsMax3 * kPairsMax3], V[kPairsMax3];
 		fold_forward(fo, SY, V, cf);
-	} else {
-		for (int e = threadIdx.x; e < k; e += kBlock) cf[e] = coef[e];
-		__syncthreads();
 	}
 	double acc0 = 0, acc1 = 0;
 	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
@@ -1120,18 +1113,13 @@ __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, 
 	}
 	const uint32_t p_end = SL ? sl.p_end : packs;
 	for (uint32_t p0 = (SL ? sl.p_begin : 0u) + gtid; p0 < p_end; p0 += T * stride) {
-		Pack<W> out[T], xo[T], xso[T];
+		Pack<W> out[T];
 		#pragma unroll
 		for (int t = 0; t < T; t++) {
 			const uint32_t p = p0 + t * stride;
 			if (p < packs) {
 				const uint32_t i = (rev ? last - p : p) * W;
 				Pack<W> v = ld<W, false>(r, i);
-				Pack<W> xv, xs;
-				if constexpr (FUSE) {
-					xv = ld<W, false>(ap.x, i);
-					if (ap.x_sum) xs = ld<W, false>(ap.x_sum, i);
-				}
 				for (int j0 = 0; j0 < k; j0 += 8) {
 					RPack<W> fs[8];
 					#pragma unroll
@@ -1144,17 +1132,8 @@ __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, 
 							for (int e = 0; e < W; e++) v.v[e] = fma(cf[j0 + u], (double) fs[u].v[e], v.v[e]);
 						}
 				}
-				if constexpr (FUSE) {
-					#pragma unroll
-					for (int e = 0; e < W; e++) {
-						xo[t].v[e] = fma(-ap.step, v.v[e], xv.v[e]);                  // :838
-						if (ap.x_sum) xso[t].v[e] = xs.v[e] + (double) (real) xo[t].v[e];     // :283, x as stored
-						if (ap.s_slot) v.v[e] = (-ap.step) * v.v[e];                  // :1006: grad <- -step r (and the s-slot)
-					}
-				} else {
-					#pragma unroll
-					for (int e = 0; e < W; e++) { acc0 = fma(v.v[e], v.v[e], acc0); acc1 += (isfinite(v.v[e]) ? 0.0 : 1.0); }
-				}
+				#pragma unroll
+				for (int e = 0; e < W; e++) { acc0 = fma(v.v[e], v.v[e], acc0); acc1 += (isfinite(v.v[e]) ? 0.0 : 1.0); }
 				out[t] = v;
 			}
 		}
@@ -1163,12 +1142,7 @@ __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, 
 			const uint32_t p = p0 + t * stride;
 			if (p < packs) {
 				const uint32_t i = (rev ? last - p : p) * W;
-				if constexpr (FUSE) {
-					st<W>(ap.x, i, xo[t]);
-					if (ap.x_sum) st<W>(ap.x_sum, i, xso[t]);
-					if (ap.s_slot) st_nt<W>(ap.s_slot, i, out[t]);
-					st<W>(r, i, out[t]);
-				} else if constexpr (SS) {
+				if constexpr (SS) {
 					if (p >= keep_from) st<W>(r, i, out[t]); else st_stream<W>(r, i, out[t]);     // see k_qdot: the tail stays cacheable for the apply pass
 				} else st<W>(r, i, out[t]);
 			}
@@ -1182,83 +1156,12 @@ __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, const double* coef, 
 		if (blockIdx.x == gridDim.x - 1 && i < n) {
 			double v = (double) r[i];
 			for (int j = 0; j < k; j++) v = fma(cf[j], (double) ss.row[j][i], v);
-			if constexpr (FUSE) {
-				const double xn = fma(-ap.step, v, (double) ap.x[i]);
-				ap.x[i] = (real) xn;
-				if (ap.x_sum) ap.x_sum[i] = (real) ((double) ap.x_sum[i] + (double) (real) xn);
-				if (ap.s_slot) { v = (-ap.step) * v; ap.s_slot[i] = (real) v; }
-			} else { acc0 = fma(v, v, acc0); acc1 += (isfinite(v) ? 0.0 : 1.0); }
+			acc0 = fma(v, v, acc0); acc1 += (isfinite(v) ? 0.0 : 1.0);
 			r[i] = (real) v;
 		}
 	}
-	if constexpr (!FUSE) {
-		const double t0 = block_sum(acc0, sh), t1 = block_sum(acc1, sh);
-		if (threadIdx.x == 0) { parts[blockIdx.x] = t0; parts[kMaxGrid + blockIdx.x] = t1; }
-	}
-}
-
-// coef a: totals of pass 1, the new pair's column of the cached s_old'y_new block (fresh_row >= 0: quantities
-// k..2k-1 are s_i'y_fresh), the backward recursion.  sy / yy: s'y and y'y of every physical row (rho, gamma).
-__global__ void __launch_bounds__(kCoefBlock) k_coef3a(const double* bparts, int count, int stride, CoefArgs a, int fresh_row,
-                                                       double* gsy, const double* sy, const double* yy, double* alpha_out, double* rho_out, double* coef)
-{
-	__shared__ double SY[kPairsMax3 * kPairsMax3], bS[kPairsMax3];
-	const int k = a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	if (fresh_row >= 0) {
-		for (int i = wave; i < k; i += kCoefWaves) {
-			const double t = wave_total_of(bparts + (size_t) (k + i) * stride, count);          // s_i'y_fresh
-			if (lane == 0) gsy[(size_t) a.rows[i] * a.m + fresh_row] = t;
-		}
-		__threadfence_block();
-		__syncthreads();
-	}
-	for (int e = threadIdx.x; e < k * k; e += kCoefBlock) {
-		const int i = e / k, j = e % k;
-		SY[e] = (i == j) ? sy[a.rows[i]] : gsy[(size_t) a.rows[i] * a.m + a.rows[j]];               // used for i <= j only
-	}
-	for (int q = wave; q < k; q += kCoefWaves) {
-		const double t = wave_total_of(bparts + (size_t) q * stride, count);
-		if (lane == 0) bS[q] = t;
-	}
-	__syncthreads();
-	if (wave != 0) return;
-	const bool mine = lane < k;
-	double al = 0;
-	for (int i = k - 1; i >= 0; i--) {                       // alpha_i = rho_i s_i'q_{i+1}  (:676-677)
-		const double t = (mine && lane > i) ? al * SY[i * k + lane] : 0.0;
-		const double sq = bS[i] - wave_sum_all(t);
-		const double rho_i = 1.0 / SY[i * k + i];
-		if (lane == i) { al = rho_i * sq; alpha_out[i] = al; rho_out[i] = rho_i; }
-	}
-	if (lane == 0) coef[0] = (a.h0 > 0) ? a.h0 : SY[(k - 1) * k + (k - 1)] / yy[a.rows[k - 1]];   // :683-689 / :698
-	if (mine) coef[1 + lane] = al;
-}
-
-// coef b: totals of pass 2 (v_i = y_i'r0), the forward recursion; c_i -> coef[1 + kPairsMax3 + i]
-__global__ void __launch_bounds__(kCoefBlock) k_coef3b(const double* vparts, int count, int stride, CoefArgs a, const double* gsy,
-                                                       const double* sy, const double* alpha, double* coef)
-{
-	__shared__ double SY[kPairsMax3 * kPairsMax3], V[kPairsMax3];
-	const int k = a.k, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	for (int e = threadIdx.x; e < k * k; e += kCoefBlock) {
-		const int i = e / k, j = e % k;
-		SY[e] = (i == j) ? sy[a.rows[i]] : gsy[(size_t) a.rows[i] * a.m + a.rows[j]];
-	}
-	for (int q = wave; q < k; q += kCoefWaves) {
-		const double t = wave_total_of(vparts + (size_t) q * stride, count);
-		if (lane == 0) V[q] = t;
-	}
-	__syncthreads();
-	if (wave != 0) return;
-	const bool mine = lane < k;
-	const double al = mine ? alpha[lane] : 0.0;
-	double c = 0;
-	for (int i = 0; i < k; i++) {                            // beta_i = rho_i y_i'r_i, r_i = r0 + sum_{j<i} c_j s_j  (:705-706)
-		const double t = (lane < i) ? c * SY[lane * k + i] : 0.0;
-		const double yr = V[i] + wave_sum_all(t);
-		if (lane == i) c = al - (1.0 / SY[i * k + i]) * yr;
-	}
-	if (mine) coef[1 + kPairsMax3 + lane] = c;
+	const double t0 = block_sum(acc0, sh), t1 = block_sum(acc1, sh);
+	if (threadIdx.x == 0) { parts[blockIdx.x] = t0; parts[kMaxGrid + blockIdx.x] = t1; }
 }
 
 // out[j] = sum of partial array j (one workgroup per quantity)
@@ -1388,7 +1291,7 @@ const char* kernel_name(int id)
 {
 	static const char* names[K_COUNT] = {
 		"first", "bwd", "mid", "fwd", "fwd_last", "apply", "pair_s", "pair_y_diff", "pair_y_hv",
-		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy", "coef", "sdot", "sdot2", "qdot", "sadd"};
+		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy", "sdot", "sdot2", "qdot", "sadd"};
 	return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
@@ -1551,23 +1454,24 @@ template <class K> static int resident_per_cu(K kernel, int threads)
 	return blocks > 8 ? 8 : blocks;
 }
 
-template <int W, int NW>
+constexpr int kSplitWaves = 8;    // waves of a workgroup that split the rows: 4.94 ms against 5.10 for the all-rows form and for 4 waves (n = 1e8, 40 rows)
+
+template <int W>
 static int rows_dot_dispatch(const Scratch& sc, size_t max_grid, int rpw, const RowSet& rows, const real* probe, real* copy_out, uint32_t n, int rev)
 {
 	int grid = 1;
 	#define SQN_RD(RPW)                                                                                                  \
 		{                                                                                                                \
-			static const int per_cu = resident_per_cu(k_rows_dot<W, RPW, true, NW>, 64 * NW);                             \
-			size_t g = sc.rows_grid > 0 ? (size_t) sc.rows_grid : (size_t) sc.grid_cap * per_cu;                          \
+			static const int per_cu = resident_per_cu(k_rows_dot<W, RPW, true, kSplitWaves>, 64 * kSplitWaves);             \
+			size_t g = (size_t) sc.grid_cap * per_cu;                                                                    \
 			if (g > max_grid) g = max_grid;                                                                              \
 			if (g > (size_t) kMaxGrid) g = kMaxGrid;                                                                     \
 			grid = (int) g;                                                                                              \
-			hipLaunchKernelGGL((k_rows_dot<W, RPW, true, NW>), dim3(grid), dim3(64 * NW), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[0]); \
+			hipLaunchKernelGGL((k_rows_dot<W, RPW, true, kSplitWaves>), dim3(grid), dim3(64 * kSplitWaves), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[0]); \
 		}
 	if (rpw <= 2) SQN_RD(2)
 	else if (rpw <= 4) SQN_RD(4)
-	else if (rpw <= 6) SQN_RD(6)
-	else if constexpr (NW == 4) { if (rpw <= 8) SQN_RD(8) else if (rpw <= 10) SQN_RD(10) else SQN_RD(12) }
+	else SQN_RD(6)                                   // k <= 48 rows over 8 waves
 	#undef SQN_RD
 	return grid;
 }
@@ -1598,14 +1502,10 @@ static int sdot_row_split(const Scratch& sc, size_t n, const RowSet& rows, const
 	const bool vec = rows_aligned(rows) && all_aligned(probe, copy_out);
 	size_t max_grid = (n / (vec ? kVec : 1) + 63) / 64;
 	if (max_grid < 1) max_grid = 1;
-	// waves of a workgroup that split the rows; measured: 8 (4.94 vs 5.10 ms of the all-rows form, n = 1e8, 40 rows)
-	const int nw = sc.rows_waves == 4 ? kWaves : 8;
-	const int rpw = (rows.count + nw - 1) / nw;             // rows per wave
+	const int rpw = (rows.count + kSplitWaves - 1) / kSplitWaves;      // rows per wave
 	ProfScope ps(sc, K_SDOT);
-	#define SQN_GO(WW) (nw == 8 ? rows_dot_dispatch<WW, 8>(sc, max_grid, rpw, rows, probe, copy_out, (uint32_t) n, rev) \
-	                            : rows_dot_dispatch<WW, 4>(sc, max_grid, rpw, rows, probe, copy_out, (uint32_t) n, rev))
-	return vec ? SQN_GO(kVec) : SQN_GO(1);
-	#undef SQN_GO
+	return vec ? rows_dot_dispatch<kVec>(sc, max_grid, rpw, rows, probe, copy_out, (uint32_t) n, rev)
+	           : rows_dot_dispatch<1>(sc, max_grid, rpw, rows, probe, copy_out, (uint32_t) n, rev);
 }
 
 // ---- three-pass form ---------------------------------------------------------------------------------
@@ -1677,13 +1577,6 @@ Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows, const re
 	return Partials{sc.red[0], 1, 1};
 }
 
-void launch_coef3a(const Scratch& sc, Partials b, const CoefArgs& a, int fresh_row)
-{
-	ProfScope ps(sc, K_COEF);
-	hipLaunchKernelGGL(k_coef3a, dim3(1), dim3(kCoefBlock), 0, sc.stream, b.parts, b.count, b.stride, a, fresh_row, sc.gsy, sc.sy, sc.yy,
-	                   sc.alpha, sc.rho, sc.coef);
-}
-
 static uint32_t keep_from_pack(const Scratch& sc, size_t n, bool vec)
 {
 	// first pack (in traversal order) that is stored with the default cache policy; the packs before it stream past the caches
@@ -1694,19 +1587,18 @@ static uint32_t keep_from_pack(const Scratch& sc, size_t n, bool vec)
 	return (uint32_t) (packs - (size_t) ((double) packs * f));
 }
 
-static Fold3 fold_args(const Scratch& sc, const Partials* in, const CoefArgs* a, int fresh_row)
+static Fold3 fold_args(const Scratch& sc, const Partials& in, const CoefArgs& a, int fresh_row)
 {
 	Fold3 f{};
-	if (!in || !a) return f;                                   // parts == NULL: coefficients come from the coef kernels
-	f.parts = in->parts; f.count = in->count; f.stride = in->stride;
-	f.a = *a;
+	f.parts = in.parts; f.count = in.count; f.stride = in.stride;
+	f.a = a;
 	f.fresh_row = fresh_row;
 	f.gsy = sc.gsy; f.sy = sc.sy; f.yy = sc.yy; f.alpha = sc.alpha; f.rho_out = sc.rho;
 	return f;
 }
 
-Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g, const QdotScale& q, const Partials* fold_in,
-                     const CoefArgs* fold_a, int fresh_row)
+Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g, const QdotScale& q, const Partials& pass1,
+                     const CoefArgs& a, int fresh_row)
 {
 	const int grid = sweep_grid(sc, n, sc.qdot_per_cu > 0 ? sc.qdot_per_cu : 1);
 	const bool vec = rows_aligned(y_rows) && all_aligned(g, q.H0_in, q.G, q.H0_out, q.frow_out);
@@ -1714,12 +1606,12 @@ Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g,
 	const int ng = (y_rows.count + 7) / 8;
 	const int mode = q.G ? 2 : (q.H0_in ? 1 : 0);
 	DiagArgs dg{q.H0_in, q.G, q.H0_out, q.frow_out, q.rmsprop_weight, 1 - q.rmsprop_weight, q.scal_reg, q.rmsprop_weight > 0 && q.rmsprop_weight < 1};
-	const Fold3 fo = fold_args(sc, fold_in, fold_a, fresh_row);
+	const Fold3 fo = fold_args(sc, pass1, a, fresh_row);
 	const uint32_t keep = keep_from_pack(sc, n, vec);
 	{
 		ProfScope ps(sc, K_QDOT);
-		#define SQN_QD3(WW, NG, MODE) { if (sc.stream_stores && sc.qdot_stream) hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, true>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, sc.coef, fo, g, dg, (uint32_t) n, rev, keep, sc.rows_part[1]); \
-		                                else hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, false>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, sc.coef, fo, g, dg, (uint32_t) n, rev, keep, sc.rows_part[1]); }
+		#define SQN_QD3(WW, NG, MODE) { if (sc.stream_stores) hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, true>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, fo, g, dg, (uint32_t) n, rev, keep, sc.rows_part[1]); \
+		                                else hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, false>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, fo, g, dg, (uint32_t) n, rev, keep, sc.rows_part[1]); }
 		#define SQN_QD2(WW, NG) { if (mode == 2) SQN_QD3(WW, NG, 2) else if (mode == 1) SQN_QD3(WW, NG, 1) else SQN_QD3(WW, NG, 0) }
 		#define SQN_QD1(WW) { if (ng <= 1) SQN_QD2(WW, 1) else if (ng == 2) SQN_QD2(WW, 2) else if (ng == 3) SQN_QD2(WW, 3) else if (ng == 4) SQN_QD2(WW, 4) else if (ng == 5) SQN_QD2(WW, 5) else SQN_QD2(WW, 6) }
 		if (vec) SQN_QD1(kVec) else SQN_QD1(1)
@@ -1734,17 +1626,11 @@ Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g,
 	return Partials{sc.red[1], 1, 1};
 }
 
-void launch_coef3b(const Scratch& sc, Partials v, const CoefArgs& a)
-{
-	ProfScope ps(sc, K_COEF);
-	hipLaunchKernelGGL(k_coef3b, dim3(1), dim3(kCoefBlock), 0, sc.stream, v.parts, v.count, v.stride, a, sc.gsy, sc.sy, sc.alpha, sc.coef);
-}
-
 // pass 3 can run in slices when the lanes work on packs (the elements beyond the last pack are written by the last launch,
 // wherever the traversal ends: they are reported on their own when that is not where the last slice lies)
-bool sadd_can_slice(const Scratch& sc, size_t n, const RowSet& s_rows, const real* r, const ApplyArgs* fuse, const SliceFeed* drain)
+bool sadd_can_slice(const Scratch& sc, size_t n, const RowSet& s_rows, const real* r, const SliceFeed* drain)
 {
-	if (!drain || fuse || drain->slices < 2 || !rows_aligned(s_rows) || !all_aligned(r)) return false;
+	if (!drain || drain->slices < 2 || !rows_aligned(s_rows) || !all_aligned(r)) return false;
 	const int grid = sweep_grid(sc, n, sc.sadd_per_cu > 0 ? sc.sadd_per_cu : 2);
 	if (!drain->carry || drain->carry_count < 2 * (size_t) grid * kBlock) return false;
 	const int T = sc.combine_batch;
@@ -1760,22 +1646,20 @@ void launch_spec_x(const Scratch& sc, size_t n, const real* r, const real* x, do
 	run_sweep<0>(local, K_APPLY, n, all_aligned(r, x, out), SpecXOp{r, x, out, step}, nullptr, grid);
 }
 
-Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r, const Partials* fold_in, const CoefArgs* fold_a,
-                     const ApplyArgs* fuse, const SliceFeed* drain)
+Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r, const Partials& pass2, const CoefArgs& a,
+                     const SliceFeed* drain)
 {
 	const int grid = sweep_grid(sc, n, sc.sadd_per_cu > 0 ? sc.sadd_per_cu : 2);
-	const bool vec = rows_aligned(s_rows) && all_aligned(r) && (!fuse || all_aligned(fuse->x, fuse->x_sum, fuse->s_slot));
+	const bool vec = rows_aligned(s_rows) && all_aligned(r);
 	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
-	const Fold3 fo = fold_args(sc, fold_in, fold_a, -1);
+	const Fold3 fo = fold_args(sc, pass2, a, -1);
 	const uint32_t keep = keep_from_pack(sc, n, vec);
-	const ApplyArgs ap = fuse ? *fuse : ApplyArgs{};
-	const double* cf = sc.coef + 1 + kPairsMax3;
 	{
 		ProfScope ps(sc, K_SADD);
-		#define SQN_SA2(WW, T, SS, FU) hipLaunchKernelGGL((k_sadd<WW, true, T, SS, FU, false>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, cf, fo, r, ap, (uint32_t) n, rev, keep, sc.part[buf], Slice{})
-		#define SQN_SA(WW, T) { if (fuse) SQN_SA2(WW, (T > 4 ? 4 : T), false, true); else if (sc.stream_stores) SQN_SA2(WW, T, true, false); else SQN_SA2(WW, T, false, false); }
+		#define SQN_SA2(WW, T, SS) hipLaunchKernelGGL((k_sadd<WW, true, T, SS, false>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, fo, r, (uint32_t) n, rev, keep, sc.part[buf], Slice{})
+		#define SQN_SA(WW, T) { if (sc.stream_stores) SQN_SA2(WW, T, true); else SQN_SA2(WW, T, false); }
 		const int T = sc.combine_batch;
-		if (sadd_can_slice(sc, n, s_rows, r, fuse, drain)) {
+		if (sadd_can_slice(sc, n, s_rows, r, drain)) {
 			// the pass in slices of whole rounds (T packs per lane and round); after the launch of slice s its part of r is final
 			// and drain->arrive is told: a host caller's x is sent on its way from there (machines.cpp: enqueue_step)
 			const size_t packs = n / kVec, round = (size_t) grid * kBlock * (size_t) (T >= 8 ? 8 : (T >= 4 ? 4 : 1));
@@ -1789,7 +1673,7 @@ Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows,
 				size_t hi = rev ? (last - pb + 1) * kVec : pe * kVec;
 				if (!rev && pe == packs) hi = n;                  // forward: the odd elements lie next to the last slice
 				const Slice sl{(uint32_t) pb, (uint32_t) pe, drain->carry, pb == 0, pe == packs};
-				#define SQN_SAS(T, SS) hipLaunchKernelGGL((k_sadd<kVec, true, T, SS, false, true>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, cf, fo, r, ap, (uint32_t) n, rev, keep, sc.part[buf], sl)
+				#define SQN_SAS(T, SS) hipLaunchKernelGGL((k_sadd<kVec, true, T, SS, true>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, fo, r, (uint32_t) n, rev, keep, sc.part[buf], sl)
 				if (T >= 8) { if (sc.stream_stores) SQN_SAS(8, true); else SQN_SAS(8, false); }
 				else if (T >= 4) { if (sc.stream_stores) SQN_SAS(4, true); else SQN_SAS(4, false); }
 				else { if (sc.stream_stores) SQN_SAS(1, true); else SQN_SAS(1, false); }
@@ -1803,7 +1687,6 @@ Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows,
 		#undef SQN_SA
 		#undef SQN_SA2
 	}
-	if (fuse) return Partials{nullptr, 0, 0};
 	return finish(sc, buf, 2, grid);
 }
 

@@ -453,7 +453,7 @@ bool threepass_ok(DevCtx* c, size_t st, size_t used)
 // Returns the guard partials (sum r^2, nonfinite); the direction replaces g.  `qs` says how q0 is scaled:
 // all-NULL = scalar (gamma of the newest pair, or h0 > 0), H0_in = a given diagonal, G = adaQN's step.
 Partials enqueue_three_pass(DevCtx* c, real* g, size_t used, size_t st, double h0, real* gprev_out, const QdotScale& qs,
-                            const ApplyArgs* fuse = nullptr, Call* pending = nullptr, const SliceFeed* drain = nullptr)
+                            Call* pending = nullptr, const SliceFeed* drain = nullptr)
 {
 	const size_t m = c->m, k = used;
 	RowSet ss{}, ys{};
@@ -476,14 +476,8 @@ Partials enqueue_three_pass(DevCtx* c, real* g, size_t used, size_t st, double h
 	if (pending && !sliced) flush_g(*pending);
 	Partials b = launch_sdot(c->sc, N(c), ss, g, gprev_out, probe, sliced ? &feed : nullptr);
 	if (fresh >= 0) c->sy_ok[(size_t) fresh] = 1;             // stored by the coefficient kernel, ahead of the recursion
-	if (c->sc.fold_coef) {                                    // the recursions in the prologues of the passes themselves
-		Partials v = launch_qdot(c->sc, N(c), ys, g, qs, &b, &a, fresh);
-		return launch_sadd(c->sc, c->next_buf(), N(c), ss, g, &v, &a, fuse, drain);
-	}
-	launch_coef3a(c->sc, b, a, fresh);
-	Partials v = launch_qdot(c->sc, N(c), ys, g, qs);
-	launch_coef3b(c->sc, v, a);
-	return launch_sadd(c->sc, c->next_buf(), N(c), ss, g, nullptr, nullptr, fuse, drain);
+	Partials v = launch_qdot(c->sc, N(c), ys, g, qs, b, a, fresh);          // the scalar recursions run in the prologues of the passes
+	return launch_sadd(c->sc, c->next_buf(), N(c), ss, g, v, a, drain);
 }
 
 // Option "verify_cache" (debugging aid for DEVICE callers).  The library caches s'y, y'y and the products
@@ -625,21 +619,18 @@ void enqueue_step(Call& io, const StepIn& in)
 		if (!raw_cold && (!in.G || in.H0) && threepass_ok(c, st, in.used)) {
 			QdotScale qs{};
 			if (in.G) { qs.G = in.G; qs.H0_out = in.H0; qs.frow_out = in.frow_out; qs.rmsprop_weight = in.w; qs.scal_reg = in.eps; }
-			// check_nan == 0: nothing waits for a verdict, the update rides in pass 3 (as in the sweep form below, reference :825-838)
-			const bool fuse = !in.check_nan && options().fuse_apply;
-			if (fuse) flush_x(io);
 			SpecDrain sd{&io, in.g, in.x, c->spec, in.step, io.g_host && options().strict_grad && io.g == in.g};
-			const bool ahead = !fuse && spec_x_ready(io, in);
+			const bool ahead = spec_x_ready(io, in);
 			sd.xs = c->spec;
 			const SliceFeed drain{options().apply_chunks, c->carry, c->carry_count, direction_slice_done, &sd};
-			Partials guard = enqueue_three_pass(c, in.g, in.used, st, in.h0, in.gprev_out, qs, fuse ? &ap : nullptr, &io, ahead ? &drain : nullptr);
+			Partials guard = enqueue_three_pass(c, in.g, in.used, st, in.h0, in.gprev_out, qs, &io, ahead ? &drain : nullptr);
 			if (io.x_spec) {                                          // every slice of x is on its way already: the update in one launch, no copies
 				io.x_pending = false;                                 // (and every slice of the caller's x came up with the slice that read it)
 				launch_apply(sc, n, c->n_global, guard, in.g, in.g, ap, in.check_nan != 0);
 				io.x_down = true;
 				stat_add(ST_X_AHEAD);
 			}
-			else if (!fuse) apply_step(io, guard, in.g, in.g, ap, in.check_nan != 0);
+			else apply_step(io, guard, in.g, in.g, ap, in.check_nan != 0);
 			stat_add(ST_STEP_THREE_PASS);
 		} else {
 			flush_g(io);

@@ -511,15 +511,11 @@ void begin_call(DevCtx* c)
 	c->sc.stream = (g_opt.null_stream == 1 || g_opt.async_device) ? nullptr : c->own_stream;      // the automatic rule: open_call
 	c->sc.nontemporal = g_opt.nontemporal;
 	c->sc.grid_cap = g_opt.grid_cap > 0 ? g_opt.grid_cap : default_grid_cap();
-	c->sc.rows_grid = g_opt.rows_grid;
 	c->sc.reverse = g_opt.reverse;
 	c->sc.rows_split = g_opt.rows_split;
-	c->sc.rows_waves = g_opt.rows_waves;
 	c->sc.combine_batch = g_opt.combine_batch;
 	c->sc.fisher_rows = g_opt.fisher_rows;
 	c->sc.stream_stores = g_opt.stream_stores;
-	c->sc.qdot_stream = g_opt.qdot_stream;
-	c->sc.fold_coef = g_opt.fold_coef;
 	c->sc.keep_tail = g_opt.keep_tail;
 	c->sc.qdot_per_cu = g_opt.qdot_per_cu; c->sc.sadd_per_cu = g_opt.sadd_per_cu; c->sc.sdot2_per_cu = g_opt.sdot2_per_cu; c->sc.sdot_per_cu = g_opt.sdot_per_cu;
 	c->sc.prof = g_profile ? &c->prof : nullptr;
@@ -639,10 +635,10 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 		return nullptr;
 	}
 	c->sc.stream = c->own_stream;
-	// pool layout: part0 | part1 | red0 | red1 | sy | yy | report | rho | alpha | rows_part x2 | gsy | coef | kap
+	// pool layout: part0 | part1 | red0 | red1 | sy | yy | report | rho | alpha | rows_part x2 | gsy | kap
 	const size_t part = (size_t) kMaxSums * kMaxGrid;
 	const size_t rows_part = (size_t) kRedMax * kMaxGrid;
-	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + m * m + (2 + 2 * kPairsMax3) + 3 * m;
+	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + m * m + 3 * m;
 	c->pin_count = 16 + 2 * m + fsize + 3 * m + 8;
 	c->pool_bytes = total * sizeof(double);
 	c->pool = (double*) arena_alloc(c->pool_bytes);
@@ -668,7 +664,6 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	c->sc.rows_part[0] = p; p += rows_part;
 	c->sc.rows_part[1] = p; p += rows_part;
 	c->sc.gsy = p; p += m * m;
-	c->sc.coef = p; p += 2 + 2 * kPairsMax3;
 	c->kap_dev = p;
 	c->forget_rows();
 	begin_call(c);
@@ -1199,20 +1194,10 @@ int stochqn_hip_set_option(const char* name, double value)
 		if (g > kMaxGrid) g = kMaxGrid;
 		g_opt.grid_cap = g;
 	}
-	else if (!std::strcmp(name, "rows_grid")) {
-		int g = (int) value;
-		if (g < 0) g = 0;
-		if (g > kMaxGrid) g = kMaxGrid;
-		g_opt.rows_grid = g;
-	}
 	else if (!std::strcmp(name, "rows_split")) g_opt.rows_split = value != 0;
-	else if (!std::strcmp(name, "rows_waves")) g_opt.rows_waves = (int) value;
 	else if (!std::strcmp(name, "combine_batch")) g_opt.combine_batch = (int) value;
 	else if (!std::strcmp(name, "fisher_rows")) g_opt.fisher_rows = (int) value;
 	else if (!std::strcmp(name, "stream_stores")) g_opt.stream_stores = value != 0;
-	else if (!std::strcmp(name, "qdot_stream")) g_opt.qdot_stream = value != 0;
-	else if (!std::strcmp(name, "fold_coef")) g_opt.fold_coef = value != 0;
-	else if (!std::strcmp(name, "fuse_apply")) g_opt.fuse_apply = value != 0;
 	else if (!std::strcmp(name, "spec_x")) g_opt.spec_x = value != 0;
 	else if (!std::strcmp(name, "x_prefetch")) g_opt.x_prefetch = value != 0;
 	else if (!std::strcmp(name, "keep_tail")) g_opt.keep_tail = value < 0 ? 0 : (value > 1 ? 1 : value);

@@ -26,11 +26,9 @@ struct View {
 struct Options {
 	bool nontemporal = true;
 	int grid_cap = 0;            // 0 = one workgroup per compute unit (measured optimum)
-	int rows_grid = 0;           // 0 = as many workgroups of the row-split rows-dot pass as are resident per compute unit
 	// pass 1 without a second probe: every lane keeps all rows (fp64: 5.1-5.2 ms; the row-split form is within
 	// +-3 % of it depending on the device) or the waves of a workgroup split the rows (fp32: 2.5 vs 5.9 ms)
 	bool rows_split = sizeof(real) == 4;
-	int rows_waves = 0;          // waves per workgroup of the row-split rows-dot kernel (0 = 8)
 	int combine_batch = 8;       // packs a lane finishes in pass 3 before it stores them
 	bool reverse = true;
 	// 1: the three-pass form (S twice, Y once: (3k+5) n words) when the ring has <= kPairsMax3 pairs and every pair in use is
@@ -38,12 +36,6 @@ struct Options {
 	bool threepass = true;
 	int fisher_rows = 16;        // Fisher rows per workgroup pass (8, 16, 32)
 	int qdot_per_cu = 0, sadd_per_cu = 0, sdot2_per_cu = 0, sdot_per_cu = 0;
-	bool qdot_stream = true;
-	bool fold_coef = true;       // three-pass form: coefficient recursions inside the prologues of pass 2 / pass 3 (two launches less per step)
-	// three-pass form with check_nan = 0: the position update inside pass 3 (no apply pass).  Measured at n = 1e8, k = 20
-	// (profiles/r03_ab_fuse_apply.jsonl): 3.68 ms fused against 2.79 + 0.73 ms -- two more store streams among 21 read
-	// streams cost more than the pass they save, as for the guarded case in round 2.  Off.
-	bool fuse_apply = false;
 	// three-pass form: fraction of r0 / r stored with the default (cacheable) policy -- the part the next pass, which walks
 	// the other way, reads first; the rest leaves with sc1 nt.  0.25-0.5 measured 1 % ahead of 0 and of 1 (profiles/r03_ab_fold_tail.jsonl)
 	double keep_tail = 0.35;

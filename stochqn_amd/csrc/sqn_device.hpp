@@ -21,8 +21,6 @@ typedef double real;
 constexpr int kVec = 16 / (int) sizeof(real);    // elements per 16-byte pack: 2 doubles or 4 floats
 
 constexpr int kBlock = 256;       // threads per workgroup (4 wave64)
-constexpr int kCoefBlock = 1024;  // the one-workgroup coefficient kernels: 16 waves to total the partials of a pass
-constexpr int kCoefWaves = kCoefBlock / 64;
 constexpr int kMaxGrid = 2048;    // 256 CUs x 8 resident workgroups; also the partial-sum stride
 constexpr int kMaxSums = 3;       // sums one sweep can produce (s'y, s's, y'y)
 constexpr int kRowsMax = 48;      // rows one rows-dot launch can take (one accumulator per row and lane)
@@ -32,7 +30,7 @@ constexpr int kRedMax = 128;      // doubles per all-reduce landing zone and qua
 // Kernel ids for the built-in HIP-event profiler (stochqn_hip_profile_*).
 enum KernelId {
 	K_FIRST = 0, K_BWD, K_MID, K_FWD, K_FWD_LAST, K_APPLY, K_PAIR_S, K_PAIR_Y_DIFF, K_PAIR_Y_HV,
-	K_DOTS3, K_FISHER_T, K_FISHER_Y, K_FIN, K_SMALL, K_COPY, K_COEF, K_SDOT, K_SDOT2, K_QDOT, K_SADD, K_COUNT
+	K_DOTS3, K_FISHER_T, K_FISHER_Y, K_FIN, K_SMALL, K_COPY, K_SDOT, K_SDOT2, K_QDOT, K_SADD, K_COUNT
 };
 const char* kernel_name(int id);
 
@@ -97,17 +95,12 @@ struct Scratch {
 	double* report;       // [4]: bad flag, sum r^2, nonfinite count, spare
 	double* rows_part[2]; // two [kRedMax][kMaxGrid] partial buffers of the rows-dot passes (pass 1, pass 2)
 	double* gsy;          // [m][m] cached block  gsy[i*m+j] = s_i'y_j   (physical rows; pair i older than pair j)
-	double* coef;         // [2 + 2*kPairsMax3]: the scale of q0, then alpha (pass 2), then c at 1 + kPairsMax3 (pass 3)
 	int grid_cap;         // max workgroups per sweep (<= kMaxGrid); default = one per CU
-	int rows_grid;        // workgroups of a row-split rows-dot pass; 0 = CUs x resident workgroups per CU
 	bool rows_split;      // pass 1 without a second probe as the row-split rows-dot kernel (float build)
-	int rows_waves;       // waves per workgroup of the row-split kernel: 4 or 8
 	int combine_batch;    // packs a lane finishes in pass 3 before storing them (1, 4, 8)
 	int fisher_rows;      // Fisher rows one workgroup accumulates per pass over its columns: 8, 16 or 32
 	int qdot_per_cu, sadd_per_cu, sdot2_per_cu, sdot_per_cu;   // workgroups per CU of the three-pass kernels (0 = default)
-	bool fold_coef;       // three-pass form: the scalar recursions run in the prologues of pass 2 / pass 3 instead of in kernels of their own
 	double keep_tail;     // three-pass form: fraction of r0 / r (the part written last) stored with the default policy instead of sc1 nt
-	bool qdot_stream;     // pass 2 of the three-pass form stores r0 with the streaming policy too
 	bool stream_stores;   // pass 2 / pass 3 store their result with the agent-scope non-temporal policy (sc1 nt)
 	bool nontemporal;     // stream S/Y/F rows with nt loads
 	bool reverse;         // alternate the traversal direction from sweep to sweep (Infinity-Cache reuse of q / r)
@@ -213,8 +206,6 @@ bool sdot_can_slice(const Scratch& sc, const RowSet& s_rows, const real* g, real
 size_t sdot_carry_count(const Scratch& sc, size_t n, int k);
 Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows /*logical order*/, const real* g, real* copy_out, const real* probe_y,
                      const SliceFeed* feed = nullptr);
-// totals, (fresh_row >= 0) the new column of the cached s_old'y_new block, backward recursion -> alpha (coef[1..k]), scale (coef[0])
-void launch_coef3a(const Scratch& sc, Partials b, const CoefArgs& a, int fresh_row);
 struct QdotScale {
 	const real* H0_in;      // caller-supplied diagonal, or NULL
 	real* G;                // adaQN: grad_sum_sq (in/out), or NULL
@@ -222,18 +213,16 @@ struct QdotScale {
 	real* frow_out;         // adaQN: Fisher row <- raw gradient, nullable
 	double rmsprop_weight, scal_reg;
 };
-// pass 2: q0, r0 (replaces g), v_i = y_i'r0 -> quantities [0,k)
-// With fold_in / fold_a the backward recursion of coef3a runs in the pass's own prologue (every workgroup; option "fold_coef")
-// on the partials of pass 1 -- fresh_row as for launch_coef3a -- and launch_coef3a is not called.
+// pass 2: q0, r0 (replaces g), v_i = y_i'r0 -> quantities [0,k).  The backward recursion -- totals of pass 1, (fresh_row >= 0) the
+// new column of the cached s_old'y_new block, alpha_i, the scale of q0 -- runs in the pass's own prologue, in every workgroup.
 Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows /*logical order*/, real* g, const QdotScale& q,
-                     const Partials* fold_in = nullptr, const CoefArgs* fold_a = nullptr, int fresh_row = -1);
-void launch_coef3b(const Scratch& sc, Partials v, const CoefArgs& a);
-// pass 3: r = r0 + sum c_j s_j; returns the guard partials (sum r^2, nonfinite).  fold_in / fold_a: the forward recursion of
-// coef3b in the prologue, on the partials of pass 2.  `fuse` (check_nan == 0): the position update in the same pass, no partials.
-// `drain`: the pass in slices (sadd_can_slice), drain->arrive(user, lo, hi, slice) right after the launch that makes r[lo, hi) final.
-bool sadd_can_slice(const Scratch& sc, size_t n, const RowSet& s_rows, const real* r, const ApplyArgs* fuse, const SliceFeed* drain);
-Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r, const Partials* fold_in = nullptr,
-                     const CoefArgs* fold_a = nullptr, const ApplyArgs* fuse = nullptr, const SliceFeed* drain = nullptr);
+                     const Partials& pass1, const CoefArgs& a, int fresh_row);
+// pass 3: r = r0 + sum c_j s_j; returns the guard partials (sum r^2, nonfinite).  The forward recursion (c_j from the totals of
+// pass 2) runs in the prologue.  `drain`: the pass in slices (sadd_can_slice), drain->arrive(user, lo, hi, slice) right after the
+// launch that makes r[lo, hi) final.
+bool sadd_can_slice(const Scratch& sc, size_t n, const RowSet& s_rows, const real* r, const SliceFeed* drain);
+Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r, const Partials& pass2, const CoefArgs& a,
+                     const SliceFeed* drain = nullptr);
 // out = x - step * r, the expression (and the bits) of the guarded update, without touching x
 void launch_spec_x(const Scratch& sc, size_t n, const real* r, const real* x, double step, real* out);
 void launch_store_column(const Scratch& sc, Partials in /*k: s_i'y_col*/, const CoefArgs& a, int col_row);

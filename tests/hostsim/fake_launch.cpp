@@ -96,7 +96,7 @@ const char* kernel_name(int id)
 {
 	static const char* names[K_COUNT] = {
 		"first", "bwd", "mid", "fwd", "fwd_last", "apply", "pair_s", "pair_y_diff", "pair_y_hv",
-		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy", "coef", "sdot", "sdot2", "qdot", "sadd"};
+		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy", "sdot", "sdot2", "qdot", "sadd"};
 	return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
@@ -304,41 +304,27 @@ Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows, const re
 	return finish(sc, parts, sc.red[0], nq, grid);
 }
 
-void launch_coef3a(const Scratch& sc, Partials b, const CoefArgs& a, int fresh_row)
-{
-	double *gsy = sc.gsy, *alpha = sc.alpha, *rho = sc.rho, *coef = sc.coef;
-	const double *sy = sc.sy, *yy = sc.yy;
-	run(sc, K_COEF, [=] {
-		read_partials(b, (fresh_row >= 0 ? 2 : 1) * a.k);
-		if (fresh_row >= 0) for (int i = 0; i < a.k; i++) gsy[(size_t) a.rows[i] * a.m + fresh_row] = 1.0;
-		for (int i = 0; i < a.k; i++) { rdd(sy + a.rows[i], 1); rdd(yy + a.rows[i], 1); alpha[i] = 1; rho[i] = 1; coef[1 + i] = 1; }
-		coef[0] = 1;
-	});
-}
-
 namespace {
-// the prologue recursions of pass 2 / pass 3 (option "fold_coef") touch what the coefficient kernels touch
-void fold_a(const Scratch& sc, const Partials* in, const CoefArgs* a, int fresh_row)
+// the recursion in the prologue of pass 2: the partials of pass 1, the cached block, s'y / y'y; writes the new column, alpha, rho
+void fold_a(const Scratch& sc, const Partials& in, const CoefArgs& a, int fresh_row)
 {
-	if (!in || !a) return;
-	read_partials(*in, (fresh_row >= 0 ? 2 : 1) * a->k);
-	if (fresh_row >= 0) for (int i = 0; i < a->k; i++) sc.gsy[(size_t) a->rows[i] * a->m + fresh_row] = 1.0;
-	for (int i = 0; i < a->k; i++) { rdd(sc.sy + a->rows[i], 1); sc.alpha[i] = 1; sc.rho[i] = 1; }
+	read_partials(in, (fresh_row >= 0 ? 2 : 1) * a.k);
+	if (fresh_row >= 0) for (int i = 0; i < a.k; i++) sc.gsy[(size_t) a.rows[i] * a.m + fresh_row] = 1.0;
+	for (int i = 0; i < a.k; i++) { rdd(sc.sy + a.rows[i], 1); rdd(sc.yy + a.rows[i], 1); sc.alpha[i] = 1; sc.rho[i] = 1; }
 }
 }  // namespace
 
-Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g, const QdotScale& q, const Partials* fold_in, const CoefArgs* fa, int fresh_row)
+Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g, const QdotScale& q, const Partials& pass1, const CoefArgs& a, int fresh_row)
 {
 	const int grid = sweep_grid(sc, n, sc.qdot_per_cu > 0 ? sc.qdot_per_cu : 1);
 	(void) next_rev(sc);
 	double* parts = sc.rows_part[1];
 	const Scratch scc = sc;
 	const RowSet rows = y_rows;
-	const bool folded = fold_in && fa;
-	const Partials fin = folded ? *fold_in : Partials{nullptr, 0, 0};
-	const CoefArgs ca = folded ? *fa : CoefArgs{};
+	const Partials fin = pass1;
+	const CoefArgs ca = a;
 	run(sc, K_QDOT, [=] {
-		if (folded) fold_a(scc, &fin, &ca, fresh_row); else rdd(scc.coef, 1 + (size_t) rows.count);
+		fold_a(scc, fin, ca, fresh_row);
 		rows_rd(rows, n); rd(q.H0_in, n);
 		if (q.G) { rw(q.G, n); rw(q.H0_out, n); }
 		if (q.frow_out) for (size_t i = 0; i < n; i++) q.frow_out[i] = g[i];
@@ -348,52 +334,37 @@ Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g,
 	return finish(sc, parts, sc.red[1], y_rows.count, grid);
 }
 
-void launch_coef3b(const Scratch& sc, Partials v, const CoefArgs& a)
+bool sadd_can_slice(const Scratch& sc, size_t n, const RowSet&, const real*, const SliceFeed* drain)
 {
-	double* coef = sc.coef;
-	const double *gsy = sc.gsy, *alpha = sc.alpha;
-	run(sc, K_COEF, [=] {
-		read_partials(v, a.k);
-		for (int i = 0; i < a.k; i++) { rdd(gsy + (size_t) a.rows[i] * a.m, (size_t) a.m); rdd(alpha + i, 1); coef[1 + kPairsMax3 + i] = 0; }
-	});
-}
-
-bool sadd_can_slice(const Scratch& sc, size_t n, const RowSet&, const real*, const ApplyArgs* fuse, const SliceFeed* drain)
-{
-	if (!drain || fuse || drain->slices < 2 || n < (size_t) 2 * drain->slices) return false;
+	if (!drain || drain->slices < 2 || n < (size_t) 2 * drain->slices) return false;
 	const int grid = sweep_grid(sc, n, sc.sadd_per_cu > 0 ? sc.sadd_per_cu : 2);
 	return drain->carry && drain->carry_count >= 2 * (size_t) grid * kBlock;
 }
 
-Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r, const Partials* fold_in, const CoefArgs* fa, const ApplyArgs* fuse, const SliceFeed* drain)
+Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r, const Partials& pass2, const CoefArgs& a, const SliceFeed* drain)
 {
 	const int grid = sweep_grid(sc, n, sc.sadd_per_cu > 0 ? sc.sadd_per_cu : 2);
 	(void) next_rev(sc);
 	double* parts = sc.part[buf];
 	const Scratch scc = sc;
 	const RowSet rows = s_rows;
-	const bool folded = fold_in && fa;
-	const Partials fin = folded ? *fold_in : Partials{nullptr, 0, 0};
-	const CoefArgs ca = folded ? *fa : CoefArgs{};
-	const bool sliced = sadd_can_slice(sc, n, s_rows, r, fuse, drain);
+	const Partials fin = pass2;
+	const CoefArgs ca = a;
+	const bool sliced = sadd_can_slice(sc, n, s_rows, r, drain);
 	const int slices = sliced ? drain->slices : 1;
-	const bool fused = fuse != nullptr;
-	const ApplyArgs ap = fuse ? *fuse : ApplyArgs{};
 	for (int s = 0; s < slices; s++) {
 		const size_t lo = n * (size_t) s / (size_t) slices, hi = n * (size_t) (s + 1) / (size_t) slices;
 		double* carry = sliced ? drain->carry : nullptr;
 		const size_t lanes = (size_t) grid * kBlock;
 		run(sc, K_SADD, [=] {
-			if (folded && s == 0) { read_partials(fin, ca.k); for (int i = 0; i < ca.k; i++) rdd(scc.gsy + (size_t) ca.rows[i] * ca.m, (size_t) ca.m); }
+			if (s == 0) { read_partials(fin, ca.k); for (int i = 0; i < ca.k; i++) { rdd(scc.gsy + (size_t) ca.rows[i] * ca.m, (size_t) ca.m); rdd(scc.alpha + i, 1); } }
 			for (int j = 0; j < rows.count; j++) rd(rows.row[j] + lo, hi - lo);
 			rw(r + lo, hi - lo);
 			if (carry) for (size_t e = 0; e < 2 * lanes; e++) carry[e] = 0.0;
-			if (fused) { ApplyArgs a = ap; a.x += lo; if (a.x_sum) a.x_sum += lo; if (a.s_slot) a.s_slot += lo; do_apply(r + lo, r + lo, a, hi - lo, false); }
-			if (s == slices - 1 && !fused) { write_partials(parts, grid, 1, 1.0); write_partials(parts + kMaxGrid, grid, 1, 0.0); }
+			if (s == slices - 1) { write_partials(parts, grid, 1, 1.0); write_partials(parts + kMaxGrid, grid, 1, 0.0); }
 		});
 		if (sliced) drain->arrive(drain->user, lo, hi, s);
 	}
-	if (fuse) return Partials{nullptr, 0, 0};
 	return finish(sc, parts, sc.red[buf], 2, grid);
 }
 

@@ -171,7 +171,7 @@ def test_large_shards_run_the_overlaps_of_the_host_path(hip_backend, oracle_back
     assert lib.stochqn_hip_set_option(b"virtual_devices", 1.0) == 0
     assert lib.stochqn_hip_set_option(b"devices_min_n", 1.0) == 0
     assert lib.stochqn_hip_set_option(b"devices", 3.0) == 0
-    n = 7_000_001                                       # 2.33e6 per shard: past host_slice_min = 2^21
+    n = 13_000_001                                      # 4.33e6 per shard: the smallest shard whose pass 3 runs in slices (two rounds of its grid)
     P = NoisyQuadratic(n, seed=8, nan_calls=(10, 11))
     kw = dict(mem_size=3, bfgs_upd_freq=3)
     from harness import VOUCHED, library_options
