@@ -1121,9 +1121,19 @@ int stochqn_hip_pin_host(void* p, size_t bytes)
 	return 0;
 }
 
+// Option "x_prefetch" leaves an upload of the caller's x in flight when a call returns.  A caller that drops x right then (its
+// finaliser unpins, the allocator unmaps) would pull the pages from under that copy: the unpin waits for such uploads first.
+static void drain_prefetches()
+{
+	std::lock_guard<std::recursive_mutex> lk(g_mu);
+	for (auto& kv : g_ctx)
+		if (kv.second->x_pre_pending && kv.second->copy_stream && hipStreamSynchronize(kv.second->copy_stream) != hipSuccess) (void) hipGetLastError();
+}
+
 int stochqn_hip_unpin_host(void* p)
 {
 	if (!p) return -1;
+	drain_prefetches();
 	std::lock_guard<std::mutex> lk(g_pin_mu);
 	auto it = g_pins.find(p);
 	if (it == g_pins.end()) return -1;

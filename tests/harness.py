@@ -8,7 +8,8 @@ from stochqn_amd.free import oLBFGS_free, SQN_free, adaQN_free
 def to_np(a):
     if isinstance(a, np.ndarray):
         return a.copy()
-    return a.detach().cpu().numpy().copy()
+    a = a.detach()
+    return a.cpu().numpy() if a.is_cuda else a.numpy().copy()       # .cpu() of a device tensor is a copy already
 
 
 # ------------------------------------------------------------------------------------------------

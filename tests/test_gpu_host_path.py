@@ -246,7 +246,7 @@ def test_sliced_passes_equal_whole_launches(kind, hip_backend):
                     assert np.array_equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("kind,strict,odd", [("SQN", 0, 0), ("SQN", 1, 1), ("oLBFGS", 0, 1), ("oLBFGS", 1, 0), ("adaQN", 0, 1)])
+@pytest.mark.parametrize("kind,strict,odd", [("SQN", 1, 1), ("oLBFGS", 0, 1), ("oLBFGS", 1, 0), ("adaQN", 0, 0)])
 def test_x_sent_ahead_of_the_guard_leaves_the_same_bits(kind, strict, odd, hip_backend):
     """Option spec_x (default): pass 3 of the three-pass form in slices, each finished slice's x - step r on its way to the host
     before the guard has seen all of r, the guarded update under the transfer.  Against the plain host path (update, then the

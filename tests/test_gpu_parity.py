@@ -17,6 +17,10 @@ TOL = 1e-10
 
 
 FORMS = {"threepass": 1.0, "sweeps": 0.0}      # name -> option "threepass"
+# The chain of sweeps is element-wise (no tiles, no row split): sizes in the middle of a grid add nothing to it that the ends
+# (1, one past a wave, one past a pack, the large odd sizes) do not show; its full launch shape runs at n = 1,000,003
+# (test_lockstep_parity_full_grids).  The default form runs every size.
+SWEEPS_SKIP_N = {2, 7, 63, 64, 127, 129, 1000, 70001}
 
 
 def set_form(lib, name):
@@ -38,6 +42,9 @@ def reset_form(lib):
 def form(request, hip_backend):
     """Run a test once per implementation of the two-loop: the default three-pass form and the chain of sweeps."""
     import stochqn_amd
+    if request.param == "sweeps" and getattr(request.node, "callspec", None) is not None \
+            and request.node.callspec.params.get("n") in SWEEPS_SKIP_N:
+        pytest.skip("the fallback form runs the ends of each size grid, the default form all of it")
     lib = stochqn_amd.cdll()
     set_form(lib, request.param)
     yield request.param
@@ -160,9 +167,12 @@ def test_lockstep_parity(cfg, n, form, hip_backend, oracle_backend):
 @pytest.mark.parametrize("cfgname", ["sqn_ring20", "adaqn_ring20", "olbfgs_default"])
 def test_lockstep_parity_full_grids(cfgname, form, hip_backend, oracle_backend):
     """The same lock-step comparison at a size where every kernel runs its full launch shape: one
-    workgroup per CU in the sweeps, 768 workgroups in the row-split pass A, whole LDS tiles plus a ragged
-    last one in the diagonal-H0 Gram kernel, and -- n odd -- every other ring row off the 16-byte grid."""
+    workgroup per CU in the sweeps, the whole-rounds grid of the row-split pass 1, full grids in passes 2 and 3,
+    and -- n odd -- every other ring row off the 16-byte grid.  (The sweeps take the two configurations whose
+    operators differ, SQN's and oLBFGS's; adaQN's chain is SQN's plus the diagonal, covered at the smaller sizes.)"""
     import stochqn_amd
+    if form == "sweeps" and cfgname == "adaqn_ring20":
+        pytest.skip("the sweeps run sqn_ring20 and olbfgs_default at this size")
     name, optname, kw, step, calls, pkw = {c[0]: c for c in CONFIGS}[cfgname]
     n = 1_000_003
     P = NoisyQuadratic(n, seed=11, **pkw)
@@ -731,21 +741,25 @@ def test_adaqn_trajectory_at_full_size_in_lockstep_with_the_oracle(hip_backend, 
         linear in s.  So the rows of S and Y are held to what that allows, 16 eps |x| / |s| (measured: up to 1.1e-9, at the
         last sync point), and -- like everything else here -- to 1e-10 of the vectors they were computed FROM (|x|)."""
         nonlocal worst
-        w = np.asarray(want)
-        e = rel_err(got.cpu().numpy(), w)
+        w = torch.from_numpy(np.ascontiguousarray(want)).to("cuda")          # compared where the 0.8 GB vectors are: on the device
+        assert bool(torch.isfinite(w).all()) and bool(torch.isfinite(got).all()), what
+        nw = float(torch.linalg.vector_norm(w))
+        e = float(torch.linalg.vector_norm(got - w)) / nw if nw > 0 else float(torch.linalg.vector_norm(got))
         tol = TOL
         if what.startswith(("s_mem", "y_mem")):
             row = int(what.split()[-1])
             if what.startswith("s_mem"):
-                bound[row] = max(TOL, 16 * np.finfo(np.float64).eps * float(np.linalg.norm(x_ref)) / float(np.linalg.norm(w)))
-                assert e * float(np.linalg.norm(w)) <= TOL * float(np.linalg.norm(x_ref)), (what, e)      # absolute error against |x|: 1e-10
+                nx = float(np.linalg.norm(x_ref))
+                bound[row] = max(TOL, 16 * np.finfo(np.float64).eps * nx / nw)
+                assert e * nw <= TOL * nx, (what, e)                         # absolute error against |x|: 1e-10
             tol = bound[row]
         else:
             worst = max(worst, e)
         if os.environ.get("SQN_TEST_REPORT_ONLY"):
             print("iteration %d: %-16s %.3e (held to %.1e)" % (ref.niter, what, e, tol))
-            return
+            return w
         assert e <= tol, "iteration %d: %s is %.3e from the oracle's (held to %.1e)" % (ref.niter, what, e, tol)
+        return w
 
     def rows(mem, size, st, used, name):
         a_r, a_l = getattr(getattr(ref, mem), name), getattr(getattr(lock, mem), name)
@@ -768,8 +782,9 @@ def test_adaqn_trajectory_at_full_size_in_lockstep_with_the_oracle(hip_backend, 
                 pieces += list(rows("Fisher_mem", 16, ref.Fisher_mem.mem_st_ix, ref.Fisher_mem.mem_used, "F"))
                 for what, got, want in pieces:
                     if what not in ("x_sum",):                               # x_sum is zero between the iterations at L = 1
-                        close(what, got, want)
-                    lock._sp.assign(got, want)
+                        got.copy_(close(what, got, want))                    # ... and put on the oracle's, from the copy that is up already
+                    else:
+                        lock._sp.assign(got, want)
                 lib.stochqn_hip_invalidate(C.c_void_p(lock._sp.ptr(lock.BFGS_mem.s_mem)))
                 syncs += 1
             np.multiply(dn_h[t % 2], rs[0]["requested_on"], out=ref.gradient)
@@ -778,7 +793,8 @@ def test_adaqn_trajectory_at_full_size_in_lockstep_with_the_oracle(hip_backend, 
             t += 1
         assert syncs == iters // K and ref.BFGS_mem.mem_used == 20 and ref.Fisher_mem.mem_used == 16
         close("the final x", x_lock, x_ref)
-        e_free = rel_err(x_free.cpu().numpy(), x_ref)
+        x_ref_d = torch.from_numpy(x_ref).to("cuda")
+        e_free = float(torch.linalg.vector_norm(x_free - x_ref_d) / torch.linalg.vector_norm(x_ref_d))
         assert e_free <= 1e-7, e_free                                        # free-running: FREE_RUN_TOL
         assert rel_err(x_ref, x0_h) > 1e-4                                   # and the run went somewhere
         print("adaQN at n = 1e8 in lock-step every %d iterations: worst relative error of x / G / H0 / F at a sync point %.2e; free-running %.2e" % (K, worst, e_free))
@@ -1262,6 +1278,9 @@ def hip_backend_f32():
 @pytest.fixture(params=["threepass", "sweeps"])
 def form_f32(request, hip_backend_f32):
     import stochqn_amd
+    if request.param == "sweeps" and getattr(request.node, "callspec", None) is not None \
+            and request.node.callspec.params.get("n") in SWEEPS_SKIP_N:
+        pytest.skip("the fallback form runs the ends of each size grid, the default form all of it")
     lib = stochqn_amd.cdll(use_float=True)
     set_form(lib, request.param)
     yield request.param
@@ -1316,8 +1335,8 @@ def test_float_lockstep_parity_full_grids(name, hip_backend_f32):
         if name != "adaqn_ring20" or rname not in ("BFGS_mem.s_mem", "BFGS_mem.y_mem") or not np.any(want):
             return False
         eps = float(np.finfo(np.float32).eps)
-        s_lib = np.asarray(to_np(A_o["BFGS_mem.s_mem"]), dtype=np.float64)[row * n:(row + 1) * n]
-        s_ref = np.asarray(A_r["BFGS_mem.s_mem"], dtype=np.float64)[row * n:(row + 1) * n]
+        s_lib = np.asarray(to_np(A_o["BFGS_mem.s_mem"][row * n:(row + 1) * n]), dtype=np.float64)
+        s_ref = np.asarray(A_r["BFGS_mem.s_mem"][row * n:(row + 1) * n], dtype=np.float64)
         amplification = float(np.linalg.norm(x_ref.astype(np.float64)) / np.linalg.norm(s_ref))
         if rname == "BFGS_mem.s_mem":
             assert rel_err(got, want) <= max(F32_TOL, eps * amplification), where
@@ -1471,6 +1490,9 @@ class _GuardedSpace:
 
     def is_array(self, a):
         return self._b.is_array(a)
+
+    def __getattr__(self, name):                      # whatever else the package asks of a space (pin, unpin_all, attach ...)
+        return getattr(self._b, name)
 
     def check(self):
         for base, lo, n in self.bases:
@@ -1811,13 +1833,13 @@ def test_bench_falls_back_to_the_host_reducer_when_rccl_cannot_be_set_up():
 def test_bench_keeps_its_primary_result_when_an_auxiliary_leg_hangs():
     """First contact with RCCL on N > 1 ranks happens on the driver's node: a collective of an auxiliary leg that never
     completes must not cost the run its primary (weak-scaling) number.  With the `c5` leg made to hang (test hook) and the
-    watchdog's limit at 10 s, the ONE line still comes, with the primary result and the leg named in `legs_failed`; every rank
+    watchdog's limit at 5 s, the ONE line still comes, with the primary result and the leg named in `legs_failed`; every rank
     leaves with code 0."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(BENCH_TEST_HANG_LEG="c5", BENCH_WATCHDOG_S="7")
+    env.update(BENCH_TEST_HANG_LEG="c5", BENCH_WATCHDOG_S="5")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rehearse"], capture_output=True, text=True,
                          timeout=600, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
