@@ -1444,9 +1444,10 @@ def host_caller_leg(args, lib, be, hostc, gpu, n, m, L, step_size, two_loop):
     lib.stochqn_hip_unpin_host.argtypes = [C.c_void_p]
     # (name, strict_grad, the caller pins its arrays, options): the first two are what a binding that owns its arrays gets with
     # the library's defaults (stochqn_amd/free.py pins through stochqn_hip_pin_host); `pageable` is a raw C caller that pins
-    # nothing; `vouched` a caller that also promises not to touch x while *req designates it (round 3's default)
+    # nothing; `vouched` a caller that also promises not to touch x while *req designates it (round 3's default); `checksum`:
+    # nobody promises anything, the library compares a checksum of all of x (host threads, under the gradient's upload)
     variants = (("strict_grad_0", 0, True, {}), ("strict_grad_1", 1, True, {}), ("pageable", 0, False, {}),
-                ("vouched", 0, True, {"x_upload": 0.0, "x_prefetch": 1.0}))
+                ("vouched", 0, True, {"x_upload": 0.0, "x_prefetch": 1.0}), ("checksum", 0, True, {"x_upload": 2.0}))
     for vname, strict, pin, opts in variants:
         lib.stochqn_hip_release_all()
         lib.stochqn_hip_stats_reset()
@@ -1525,7 +1526,8 @@ def host_caller_leg(args, lib, be, hostc, gpu, n, m, L, step_size, two_loop):
                    "which is what stochqn_amd/free.py does for numpy arrays; strict_grad = 0 is the default (the reference documents `grad` "
                    "as an input that is clobbered, no shipped caller reads it back). pageable: the same with nothing pinned (a raw C caller). "
                    "vouched: the caller also promises not to touch x while *req designates it (x_upload = 0, x_prefetch = 1: round 3's "
-                   "default, 36.6 ms there). ms_per_step = one whole L-cycle on the clock (the pair-building step and the step after it "
+                   "default, 36.6 ms there). checksum: x_upload = 2 -- nobody vouches, the library takes a checksum of all of the caller's "
+                   "x on host threads of its own while the gradient travels and compares it with the device copy's. ms_per_step = one whole L-cycle on the clock (the pair-building step and the step after it "
                    "included); link_GBps = (bytes up + down) / (ordinary step - the device-resident step's kernels). Round 2 measured "
                    "91.6 ms per step on this path (pageable copies, x and the direction moved on every call in one piece).")
     return res

@@ -115,7 +115,14 @@ int stochqn_hip_unpin_host(void *p);
  *                            the update, slice by slice.  0: only when the device copy may be out of date -- first call,
  *                            another array, after a request that was not at x, or when any of 256 spread-out probe values
  *                            differs from what the library handed back -- for callers that vouch they do not touch x while
- *                            *req designates it (reference include/stochqn.h:364-366)
+ *                            *req designates it (reference include/stochqn.h:364-366).  2: nobody vouches and the library
+ *                            finds out: a checksum of ALL of the caller's x (the buffer as 64-bit words w_i: sum w_i and
+ *                            sum (2i+1) w_i mod 2^64), taken by "hash_threads" host threads while the gradient travels, against
+ *                            the same sums of the device copy, taken on the device when the last call ended.  Equal: no upload
+ *                            ("x_uploads_skipped").  A change of any one coordinate changes the first sum; large x only
+ *                            (>= "host_slice_min" elements)
+ * "hash_threads" (default 0) host threads that take the checksum of x ("x_upload" = 2); 0: 8 (half the hardware threads below 16),
+ *                            shared among the shards of a multi-device group
  * "upload_slices" (default 8)  three-pass form: pass 1 runs in this many slices, each as soon as its part of `grad` has landed
  *                            (bit-identical to one launch: the lanes' accumulators are carried between the launches); 0 / 1: off
  * "host_slice_min" (default 2^21)  vectors of fewer elements than this cross the link in one piece (no slices, nothing sent ahead)
@@ -220,6 +227,8 @@ int stochqn_hip_comm_allreduce_probe(int count, int reps, double *median_us, dou
  *   "x_uploads", "x_uploads_skipped", "host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched"   host-caller path
  *                               (INTEGRATION.md): the last two count steps whose x started its way to the host while pass 3 was still
  *                               running (option "spec_x"), and those of them that the guard then rejected (the old x was sent again).
+ *   "host_pins_live" (a gauge: ranges pinned through stochqn_hip_pin_host right now), "host_unpin_failed" (unpins the
+ *                               runtime refused: such a range stays page-locked in its books and must not be freed).
  * Returns the count, or -1 for an unknown name. */
 long long stochqn_hip_stat(const char *name);
 void stochqn_hip_stats_reset(void);

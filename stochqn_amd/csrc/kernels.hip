@@ -1291,7 +1291,7 @@ const char* kernel_name(int id)
 {
 	static const char* names[K_COUNT] = {
 		"first", "bwd", "mid", "fwd", "fwd_last", "apply", "pair_s", "pair_y_diff", "pair_y_hv",
-		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy", "sdot", "sdot2", "qdot", "sadd"};
+		"dots3", "fisher_t", "fisher_y", "fin", "small", "copy", "sdot", "sdot2", "qdot", "sadd", "xhash"};
 	return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
@@ -1636,6 +1636,49 @@ bool sadd_can_slice(const Scratch& sc, size_t n, const RowSet& s_rows, const rea
 	const int T = sc.combine_batch;
 	const size_t round = (size_t) grid * kBlock * (size_t) (T >= 8 ? 8 : (T >= 4 ? 4 : 1));
 	return n / kVec >= 2 * round;
+}
+
+// ---- checksum of a vector's bit pattern (sqn_device.hpp: XHash) ---------------------------------------------------------
+// Read-only, one pass, 16-byte loads; the sums are integers mod 2^64, so any order of accumulation gives the same two words.
+__global__ void __launch_bounds__(kBlock) k_xhash(const ulonglong2* __restrict__ w2, size_t pairs, const unsigned char* __restrict__ rest,
+                                                  int rest_bytes, unsigned long long* __restrict__ out)
+{
+	unsigned long long a = 0, b = 0;
+	const size_t stride = (size_t) gridDim.x * kBlock;
+	for (size_t p = (size_t) blockIdx.x * kBlock + threadIdx.x; p < pairs; p += stride) {
+		const ulonglong2 v = w2[p];
+		a += v.x + v.y;
+		b += (4 * p + 1) * v.x + (4 * p + 3) * v.y;          // words 2p and 2p + 1: multipliers 2i + 1
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0 && rest_bytes > 0) {      // what is left of the buffer after the last pair: up to 15 bytes
+		unsigned long long w[2] = {0, 0};
+		for (int i = 0; i < rest_bytes; i++) w[i / 8] |= (unsigned long long) rest[i] << (8 * (i % 8));
+		a += w[0];
+		b += (4 * pairs + 1) * w[0];
+		if (rest_bytes > 8) { a += w[1]; b += (4 * pairs + 3) * w[1]; }
+	}
+	for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+	__shared__ unsigned long long la[kBlock / 64], lb[kBlock / 64];
+	const int lane = threadIdx.x % 64, wave = threadIdx.x / 64;
+	if (lane == 0) { la[wave] = a; lb[wave] = b; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int i = 1; i < kBlock / 64; i++) { a += la[i]; b += lb[i]; }
+		atomicAdd(out, a);
+		atomicAdd(out + 1, b);
+	}
+}
+
+void launch_xhash(const Scratch& sc, const real* x, size_t n, double* out2)
+{
+	const size_t bytes = n * sizeof(real), pairs = bytes / 16;
+	unsigned long long* out = reinterpret_cast<unsigned long long*>(out2);      // zeroed by the caller, on this stream
+	size_t grid = (pairs + (size_t) kBlock * 8 - 1) / ((size_t) kBlock * 8);
+	if (grid < 1) grid = 1;
+	if (grid > (size_t) kMaxGrid) grid = (size_t) kMaxGrid;
+	ProfScope ps(sc, K_XHASH);
+	hipLaunchKernelGGL(k_xhash, dim3((unsigned) grid), dim3(kBlock), 0, sc.stream, reinterpret_cast<const ulonglong2*>(x), pairs,
+	                   reinterpret_cast<const unsigned char*>(x) + pairs * 16, (int) (bytes - pairs * 16), out);
 }
 
 void launch_spec_x(const Scratch& sc, size_t n, const real* r, const real* x, double step, real* out)

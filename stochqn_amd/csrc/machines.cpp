@@ -51,6 +51,11 @@ struct Call {
 	bool x_pending = false;                // host x not uploaded yet: the update takes it in slices, each just ahead of the slice of the update that reads it
 	bool dev_requests = false;             // shard of a multi-device group: *req / *req_vec stay device pointers, the group copies them out
 	bool x_spec = false;                   // slices of x went to the host before the guard had spoken (step_was_bad puts a rejected step right)
+	XHashJob* x_job = nullptr;             // option "x_upload" = 2: the checksum of the caller's x is being taken; x_pending until it says "unchanged" (resolve_x)
+	Call() = default;
+	Call(const Call&) = delete;
+	Call& operator=(const Call&) = delete;
+	~Call() { if (x_job) (void) xhash_finish(x_job); }
 };
 
 inline size_t N(const DevCtx* c) { return (size_t) c->n; }
@@ -168,11 +173,18 @@ void stage_xg(Call& io, bool need_x, bool need_g, bool may_defer = false)
 		if (io.host_caller && may_defer && options().apply_chunks >= 2 && N(c) >= (size_t) options().host_slice_min && ensure_stage(c, 0) &&
 		    ensure_copy_stream(c, options().apply_chunks + 1)) {
 			io.x = c->stage[0];
-			if (!x_is_current(c, io.x_caller, N(c))) {
+			if (options().x_upload == 2 && c->x_hash_valid && c->x_hash_count == N(c) && c->kind != KIND_RAW && !c->x_pre_pending &&
+			    (io.x_job = xhash_start(io.x_caller, N(c) * sizeof(real), xhash_threads(c))) != nullptr) {
+				// the checksum of the caller's x is on its way (threads of its own); whoever needs x first asks resolve_x
+				(void) ensure_registered(c, io.x_caller, N(c) * sizeof(real));
+				io.x_pending = true;
+				c->x_valid = false;
+			}
+			else if (!x_is_current(c, io.x_caller, N(c))) {
 				(void) ensure_registered(c, io.x_caller, N(c) * sizeof(real));
 				io.x_pending = true;
 			}
-		}
+}
 		else io.x = io.host_caller ? stage_x(c, io.x_caller, N(c)) : io.x_caller;
 	}
 	if (!need_g) return;
@@ -194,8 +206,24 @@ void flush_g(Call& io)
 	io.g_pending = false;
 }
 
+// Option "x_upload" = 2: the verdict of the checksum that stage_xg started.  Called by whoever is about to enqueue the first
+// thing that reads or overwrites x (the caller's thread has enqueued pass 1 and pass 2 meanwhile; the device is busy with the
+// upload of the gradient for longer than the checksum takes).  Equal sums: the device holds the caller's x, nothing goes up.
+void resolve_x(Call& io)
+{
+	if (!io.x_job) return;
+	DevCtx* c = io.c;
+	const XHash h = xhash_finish(io.x_job);
+	io.x_job = nullptr;
+	const bool same = c->x_hash_valid && h.a == c->x_hash.a && h.b == c->x_hash.b;
+	c->x_hash_valid = false;                // x is about to change on the device: the sum is taken anew when the call ends (close_call)
+	if (same) { io.x_pending = false; stat_add(ST_X_UPLOAD_SKIPPED); }
+	else stat_add(ST_X_UPLOAD);
+}
+
 void flush_x(Call& io)                      // whoever reads x in one piece asks for it here first
 {
+	resolve_x(io);
 	if (!io.x_pending) return;
 	SQN_HIP_OK(hipMemcpyAsync(io.x, io.x_caller, N(io.c) * sizeof(real), hipMemcpyHostToDevice, io.c->sc.stream));
 	io.x_pending = false;
@@ -248,12 +276,28 @@ real* publish(Call& io, View& v, size_t offset, int slot)
 void close_call(Call& io, bool x_changed, bool g_changed)
 {
 	DevCtx* c = io.c;
+	resolve_x(io);
 	// a reduction that failed while the call was being enqueued (c->fault: the call is going to return -1000) left the update
 	// working on un-reduced sums: the caller's arrays are not touched with that
 	if (x_changed && io.host_caller && io.x && !io.x_down && !io.x_pending && !c->fault) vec_to_host(c, io.x_caller, io.x, N(c));
 	if (g_changed && io.g_host && io.g && options().strict_grad && !io.g_down && !c->fault) vec_to_host(c, io.g_caller, io.g, N(c));
+	// option "x_upload" = 2: the checksum of x as this call leaves it on the device (large host x only: the rest goes up in one piece)
+	const bool sum = options().x_upload == 2 && io.host_caller && io.x && !c->fault && !c->async_call && c->kind != KIND_RAW &&
+	                 N(c) >= (size_t) options().host_slice_min;
+	if (sum) {
+		SQN_HIP_OK(hipMemsetAsync(c->sc.report + 4, 0, 2 * sizeof(double), c->sc.stream));
+		launch_xhash(c->sc, io.x, N(c), c->sc.report + 4);
+		to_host(c, c->pin + 4, c->sc.report + 4, 2);
+	}
+	if (io.host_caller && io.x) c->x_hash_valid = false;
 	sync(c);
 	if (io.host_caller && io.x) x_handed_back(c, io.x_caller, N(c));      // device and host copies of x agree from here on
+	if (sum && !c->fault) {
+		std::memcpy(&c->x_hash.a, c->pin + 4, sizeof(double));
+		std::memcpy(&c->x_hash.b, c->pin + 5, sizeof(double));
+		c->x_hash_count = N(c);
+		c->x_hash_valid = true;
+	}
 }
 
 // The guarded update for a HOST caller of a large problem: the pass is element-wise, so it runs slice by slice (bit-identical
@@ -264,6 +308,7 @@ void apply_step(Call& io, Partials guard, const real* r_in, real* grad_out, cons
 	DevCtx* c = io.c;
 	const Scratch& sc = c->sc;
 	const size_t n = N(c);
+	resolve_x(io);
 	const bool want_x = io.host_caller && io.x == ap.x, want_g = io.g_host && options().strict_grad && io.g == grad_out;
 	const int chunks = options().apply_chunks;
 	const size_t min_chunk = (size_t) options().host_slice_min / 2;     // elements: below this a slice is all launch overhead
@@ -477,6 +522,7 @@ Partials enqueue_three_pass(DevCtx* c, real* g, size_t used, size_t st, double h
 	Partials b = launch_sdot(c->sc, N(c), ss, g, gprev_out, probe, sliced ? &feed : nullptr);
 	if (fresh >= 0) c->sy_ok[(size_t) fresh] = 1;             // stored by the coefficient kernel, ahead of the recursion
 	Partials v = launch_qdot(c->sc, N(c), ys, g, qs, b, a, fresh);          // the scalar recursions run in the prologues of the passes
+	if (pending) resolve_x(*pending);                         // pass 3 may send slices of x up and down: is the caller's x what the device holds?
 	return launch_sadd(c->sc, c->next_buf(), N(c), ss, g, v, a, drain);
 }
 

@@ -8,12 +8,15 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
+#include <new>
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <unordered_map>
+#include <thread>
 #include <vector>
 
 namespace sqn {
@@ -49,7 +52,7 @@ std::atomic<long long> g_stats[ST_COUNT];
 const char* const kStatNames[ST_COUNT] = {
 	"steps_three_pass", "steps_sweeps", "steps_plain", "steps_kappa_fallback",
 	"allreduces", "allreduce_doubles", "contexts_created", "contexts_reclaimed", "x_uploads", "x_uploads_skipped",
-	"host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched"};
+	"host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched", "host_unpin_failed"};
 
 // Copies between device memory and ORDINARY host memory on the reclaim path, which by definition runs when the device is
 // full: through a small pinned buffer made while memory was still plentiful (with the first mirror), so that the runtime
@@ -954,6 +957,86 @@ real* stage_x(DevCtx* c, real* caller, size_t count)
 	return c->stage[0];
 }
 
+// ---- checksum of a host buffer (sqn_device.hpp: XHash) -----------------------------------------------------------------------
+void xhash_host(const void* buf, size_t bytes, size_t word_lo, size_t word_hi, XHash* out)
+{
+	const unsigned char* p = static_cast<const unsigned char*>(buf);
+	const size_t whole = bytes / 8;                      // full words; a partial last one (float vectors of odd length) is zero-extended
+	unsigned long long a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+	size_t i = word_lo;
+	const size_t hi_whole = word_hi < whole ? word_hi : whole;
+	for (; i + 1 < hi_whole; i += 2) {
+		unsigned long long w0, w1;
+		std::memcpy(&w0, p + 8 * i, 8);
+		std::memcpy(&w1, p + 8 * i + 8, 8);
+		a0 += w0; a1 += w1;
+		b0 += (2 * i + 1) * w0; b1 += (2 * i + 3) * w1;
+	}
+	for (; i < hi_whole; i++) {
+		unsigned long long w;
+		std::memcpy(&w, p + 8 * i, 8);
+		a0 += w; b0 += (2 * i + 1) * w;
+	}
+	if (word_hi > whole && word_lo <= whole && bytes > 8 * whole) {
+		unsigned long long w = 0;
+		std::memcpy(&w, p + 8 * whole, bytes - 8 * whole);       // little-endian: the low bytes
+		a0 += w; b0 += (2 * whole + 1) * w;
+	}
+	out->a = a0 + a1;
+	out->b = b0 + b1;
+}
+
+struct XHashJob {
+	std::vector<std::thread> team;
+	std::vector<XHash> part;
+};
+
+XHashJob* xhash_start(const void* buf, size_t bytes, int threads)
+{
+	const size_t words = xhash_words(bytes);
+	if (threads < 1) threads = 1;
+	if ((size_t) threads > words / 4096 + 1) threads = (int) (words / 4096 + 1);
+	XHashJob* job = new (std::nothrow) XHashJob;
+	if (!job) return nullptr;
+	try {
+		job->part.resize((size_t) threads);
+		const size_t per = ((words + (size_t) threads - 1) / (size_t) threads + 1) & ~(size_t) 1;     // even: the pairs of the inner loop stay pairs
+		for (int t = 0; t < threads; t++) {
+			const size_t lo = (size_t) t * per < words ? (size_t) t * per : words, hi = lo + per < words ? lo + per : words;
+			XHash* out = &job->part[(size_t) t];
+			job->team.emplace_back([=] { xhash_host(buf, bytes, lo, hi, out); });
+		}
+	} catch (...) {                                      // no thread to be had: whoever asked uploads x instead
+		for (auto& th : job->team) th.join();
+		delete job;
+		return nullptr;
+	}
+	return job;
+}
+
+XHash xhash_finish(XHashJob* job)
+{
+	XHash h;
+	for (auto& th : job->team) th.join();
+	for (const XHash& p : job->part) { h.a += p.a; h.b += p.b; }
+	delete job;
+	return h;
+}
+
+int xhash_threads(const DevCtx* c)
+{
+	int t = options().hash_threads;
+	if (t <= 0) {
+		const unsigned hw = std::thread::hardware_concurrency();
+		t = hw >= 16 ? 8 : (hw >= 2 ? (int) hw / 2 : 1);
+		if (c->n > 0 && c->n_global > (double) c->n) {           // a shard of a group: the shards share the team
+			const double shards = std::ceil(c->n_global / (double) c->n);
+			t = (int) ((double) t / shards);
+		}
+	}
+	return t < 1 ? 1 : (t > 64 ? 64 : t);
+}
+
 void x_handed_back(DevCtx* c, const real* caller, size_t count)
 {
 	c->x_host = caller;
@@ -1139,7 +1222,11 @@ int stochqn_hip_unpin_host(void* p)
 	if (it == g_pins.end()) return -1;
 	if (--it->second.refs > 0) return 0;
 	g_pins.erase(it);
-	if (hipHostUnregister(p) != hipSuccess) { (void) hipGetLastError(); return -1; }
+	if (hipHostUnregister(p) != hipSuccess) {               // the range stays page-locked in the runtime's books: say so, the owner is about to free it
+		std::fprintf(stderr, "stochqn: hipHostUnregister(%p) failed: %s\n", p, hipGetErrorString(hipGetLastError()));
+		stat_add(ST_HOST_UNPIN_FAILED);
+		return -1;
+	}
 	return 0;
 }
 
@@ -1221,7 +1308,8 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "strict_grad")) g_opt.strict_grad = value != 0;
 	else if (!std::strcmp(name, "register_host")) g_opt.register_host = value != 0;
 	else if (!std::strcmp(name, "register_min_bytes")) g_opt.register_min_bytes = value < 0 ? 0 : (long) value;
-	else if (!std::strcmp(name, "x_upload")) g_opt.x_upload = (int) value;
+	else if (!std::strcmp(name, "x_upload")) g_opt.x_upload = value < 0 ? 0 : (value > 2 ? 2 : (int) value);
+	else if (!std::strcmp(name, "hash_threads")) g_opt.hash_threads = value < 0 ? 0 : (int) value;
 	else if (!std::strcmp(name, "upload_slices")) g_opt.upload_slices = value < 0 ? 0 : (value > 64 ? 64 : (int) value);
 	else if (!std::strcmp(name, "apply_chunks")) g_opt.apply_chunks = value < 1 ? 1 : (value > 64 ? 64 : (int) value);
 	else if (!std::strcmp(name, "host_slice_min")) g_opt.host_slice_min = value < 2 ? 2 : (long) value;
@@ -1370,12 +1458,17 @@ long long stochqn_hip_stat(const char* name)
 	if (!name) return -1;
 	for (int i = 0; i < ST_COUNT; i++)
 		if (!std::strcmp(name, kStatNames[i])) return g_stats[i].load(std::memory_order_relaxed);
+	if (!std::strcmp(name, "host_pins_live")) {                // a gauge, not a counter: ranges pinned through stochqn_hip_pin_host right now
+		std::lock_guard<std::mutex> lk(g_pin_mu);
+		return (long long) g_pins.size();
+	}
 	return -1;
 }
 
 void stochqn_hip_stats_reset(void)
 {
-	for (int i = 0; i < ST_COUNT; i++) g_stats[i].store(0, std::memory_order_relaxed);
+	for (int i = 0; i < ST_COUNT; i++)
+		if (i != ST_HOST_UNPIN_FAILED) g_stats[i].store(0, std::memory_order_relaxed);       // that one is a fact about the process, not a rate
 }
 
 int stochqn_hip_loopback_init(int nranks)

@@ -68,7 +68,11 @@ struct Options {
 	// between two calls simply moves the iterate (for large pinned x the upload rides under the update, slice by slice);
 	// 0: not when the device copy is what the library handed back and 256 probe values still agree -- for callers that vouch
 	// they keep their hands off x while *req designates it (reference include/stochqn.h:364-366)
+	// 2: the library finds out by itself -- a checksum of ALL of the caller's x (sqn_device.hpp: XHash; `hash_threads` host threads,
+	// under the upload of the gradient) against the checksum of what the device holds, taken on the device at the end of the
+	// last call.  Equal: no upload.  Sound where the 256 probes were not: a change of any one coordinate changes the sum.
 	int x_upload = 1;
+	int hash_threads = 0;           // host threads that checksum x (x_upload = 2); 0: min(8, half the hardware threads), split among the shards of a group
 	long host_slice_min = 1l << 21; // host callers: vectors of fewer elements cross the link in one piece (a slice below ~8 MB is all launch overhead)
 	int upload_slices = 8;          // host callers, three-pass form: pass 1 runs in this many slices, each as soon as its part of the gradient has arrived
 	int apply_chunks = 8;           // host callers: the update pass runs in this many slices so that the download of x overlaps it
@@ -157,6 +161,9 @@ struct DevCtx {
 	bool x_valid = false;              // stage[0] holds the caller's current x (the library wrote both; *req == x went back)
 	static constexpr int kProbe = 256;
 	double x_probe[kProbe];            // the caller's x at kProbe spread-out positions when it was last handed back
+	XHash x_hash;                      // option "x_upload" = 2: checksum of stage[0] as the last call left it ...
+	bool x_hash_valid = false;         // ... when that call got as far as taking it
+	size_t x_hash_count = 0;
 	int device = 0;                    // the HIP device the context (its mirrors, scratch and streams) lives on
 	unsigned long long last_use = 0;   // registry clock at the last call (least-recently-used reclaim)
 	bool in_call = false;              // between acquire() and the end of the API call: never reclaimed
@@ -194,7 +201,7 @@ struct DevCtx {
 enum StatId {
 	ST_STEP_THREE_PASS = 0, ST_STEP_SWEEPS, ST_STEP_PLAIN, ST_KAPPA_FALLBACK,
 	ST_ALLREDUCE, ST_ALLREDUCE_DOUBLES, ST_CTX_CREATED, ST_CTX_RECLAIMED, ST_X_UPLOAD, ST_X_UPLOAD_SKIPPED,
-	ST_HOST_REGISTERED, ST_X_AHEAD, ST_X_RESENT, ST_X_PREFETCH, ST_COUNT
+	ST_HOST_REGISTERED, ST_X_AHEAD, ST_X_RESENT, ST_X_PREFETCH, ST_HOST_UNPIN_FAILED, ST_COUNT
 };
 void stat_add(int id, long long v = 1);
 
@@ -244,6 +251,13 @@ bool ensure_registered(DevCtx* c, const void* p, size_t bytes);
 real* stage_x(DevCtx* c, real* caller, size_t count);
 bool x_is_current(DevCtx* c, const real* caller, size_t count);    // option "x_upload" = 0 and the device copy is what the caller still holds
 void x_handed_back(DevCtx* c, const real* caller, size_t count);     // after the download of x has completed
+// Option "x_upload" = 2: the checksum of a host buffer on `threads` threads of its own, started now and collected later (the
+// caller's thread goes on enqueueing meanwhile).  xhash_start returns nullptr when no thread could be started; xhash_finish
+// joins, frees the job and returns the sum.
+struct XHashJob;
+XHashJob* xhash_start(const void* buf, size_t bytes, int threads);
+XHash xhash_finish(XHashJob* job);
+int xhash_threads(const DevCtx* c);
 bool ensure_copy_stream(DevCtx* c, int chunks);
 bool ensure_upload_slices(DevCtx* c, int slices, size_t carry_count);      // side stream, events and carry scratch of a sliced pass 1
 bool ensure_stage(DevCtx* c, int which);               // device staging vector `which` exists

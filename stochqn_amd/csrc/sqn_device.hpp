@@ -30,7 +30,7 @@ constexpr int kRedMax = 128;      // doubles per all-reduce landing zone and qua
 // Kernel ids for the built-in HIP-event profiler (stochqn_hip_profile_*).
 enum KernelId {
 	K_FIRST = 0, K_BWD, K_MID, K_FWD, K_FWD_LAST, K_APPLY, K_PAIR_S, K_PAIR_Y_DIFF, K_PAIR_Y_HV,
-	K_DOTS3, K_FISHER_T, K_FISHER_Y, K_FIN, K_SMALL, K_COPY, K_SDOT, K_SDOT2, K_QDOT, K_SADD, K_COUNT
+	K_DOTS3, K_FISHER_T, K_FISHER_Y, K_FIN, K_SMALL, K_COPY, K_SDOT, K_SDOT2, K_QDOT, K_SADD, K_XHASH, K_COUNT
 };
 const char* kernel_name(int id);
 
@@ -226,6 +226,15 @@ Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows,
 // out = x - step * r, the expression (and the bits) of the guarded update, without touching x
 void launch_spec_x(const Scratch& sc, size_t n, const real* r, const real* x, double step, real* out);
 void launch_store_column(const Scratch& sc, Partials in /*k: s_i'y_col*/, const CoefArgs& a, int col_row);
+
+// Checksum of the bit pattern of a vector (host callers, option "x_upload" = 2: is the caller's x still what the device holds?).
+// The buffer as 64-bit little-endian words w_0 .. w_{W-1} (a last partial word zero-extended): A = sum w_i, B = sum (2i+1) w_i,
+// both mod 2^64.  A change of any ONE word changes A; any other edit goes unnoticed only if both sums collide.  Integer sums:
+// the same on the device (launch_xhash, into out[0..1] viewed as two 64-bit words) and on the host (xhash_host, any partition).
+struct XHash { unsigned long long a = 0, b = 0; };
+void launch_xhash(const Scratch& sc, const real* x, size_t n, double* out2);       // ADDS into out2[0..1]: zero them first, on sc.stream
+void xhash_host(const void* buf, size_t bytes, size_t word_lo, size_t word_hi, XHash* out);    // words [lo, hi) of the buffer (runtime.cpp)
+inline size_t xhash_words(size_t bytes) { return (bytes + 7) / 8; }
 
 // reduce `nsums` partial arrays to scalars: out[j] = sum_b parts[j*stride+b]
 void launch_fin(const Scratch& sc, Partials in, int nsums, double* out);

@@ -5,11 +5,51 @@ import numpy as np
 from stochqn_amd.free import oLBFGS_free, SQN_free, adaQN_free
 
 
+_STAGE = {}
+_STAGE_BYTES = 64 << 20
+
+
+def _stage(torch, dtype):
+    """A page-locked 64 MiB staging tensor per dtype.  Large test temporaries cross the link in chunks through it: DMA at
+    link speed instead of the runtime's pageable path, which for big transfers page-locks the (about to be freed) temporary
+    on the fly."""
+    if dtype not in _STAGE:
+        _STAGE[dtype] = torch.empty(_STAGE_BYTES // torch.empty(0, dtype=dtype).element_size(), dtype=dtype, pin_memory=True)
+    return _STAGE[dtype]
+
+
 def to_np(a):
     if isinstance(a, np.ndarray):
         return a.copy()
     a = a.detach()
-    return a.cpu().numpy() if a.is_cuda else a.numpy().copy()       # .cpu() of a device tensor is a copy already
+    if not a.is_cuda:
+        return a.numpy().copy()
+    if a.numel() * a.element_size() <= _STAGE_BYTES or not a.is_contiguous():
+        return a.cpu().numpy()                                     # .cpu() of a device tensor is a copy already
+    import torch
+    flat, st = a.reshape(-1), _stage(torch, a.dtype)
+    out = np.empty(flat.numel(), dtype=st.numpy().dtype)
+    for lo in range(0, flat.numel(), st.numel()):
+        m = min(st.numel(), flat.numel() - lo)
+        st[:m].copy_(flat[lo:lo + m])
+        out[lo:lo + m] = st[:m].numpy()
+    return out.reshape(tuple(a.shape))
+
+
+def to_dev(a, device="cuda"):
+    """A numpy array as a new device tensor (large ones in chunks through the page-locked staging tensor)."""
+    import torch
+    a = np.ascontiguousarray(a)
+    if a.nbytes <= _STAGE_BYTES:
+        return torch.from_numpy(a).to(device)
+    flat = torch.from_numpy(a.reshape(-1))
+    st = _stage(torch, flat.dtype)
+    out = torch.empty(flat.numel(), dtype=flat.dtype, device=device)
+    for lo in range(0, flat.numel(), st.numel()):
+        m = min(st.numel(), flat.numel() - lo)
+        st[:m].copy_(flat[lo:lo + m])
+        out[lo:lo + m].copy_(st[:m])                                # synchronous for the host: the stage is free again
+    return out.reshape(tuple(a.shape))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -303,7 +343,7 @@ class library_options:
     """`with library_options(lib, x_upload=0, register_host=1): ...` -- stochqn_hip_set_option for the block, the library's
     defaults (include/stochqn_hip.h) back afterwards."""
     DEFAULTS = {"x_upload": 1.0, "x_prefetch": 0.0, "register_host": 0.0, "register_min_bytes": float(4 << 20), "spec_x": 1.0,
-                "apply_chunks": 8.0, "upload_slices": 8.0, "host_slice_min": float(1 << 21), "threepass": 1.0, "kappa_max": 1e6}
+                "apply_chunks": 8.0, "upload_slices": 8.0, "hash_threads": 0.0, "host_slice_min": float(1 << 21), "threepass": 1.0, "kappa_max": 1e6}
 
     def __init__(self, lib, **kw):
         import ctypes as C
@@ -325,3 +365,20 @@ class library_options:
 
 # the caller vouches: it keeps its hands off x while *req designates it, and its arrays outlive the optimiser
 VOUCHED = dict(x_upload=0, x_prefetch=1, register_host=1)
+
+
+def assert_no_host_range_left_pinned():
+    """After a test of the host-caller path: every range that was page-locked through stochqn_hip_pin_host (stochqn_amd/free.py
+    does that for the arrays it owns and for the user's x) has been unpinned by the time its array is gone, and the runtime
+    refused none of those unpins.  A range that stays registered after its owner freed it is the recipe for a GPU memory fault at
+    the next copy through that address."""
+    import ctypes
+    import gc
+    import stochqn_amd
+    gc.collect()
+    for use_float in (False, True):
+        h = stochqn_amd.cdll(use_float)
+        h.stochqn_hip_stat.argtypes, h.stochqn_hip_stat.restype = [ctypes.c_char_p], ctypes.c_longlong
+        assert h.stochqn_hip_stat(b"host_unpin_failed") == 0, "the runtime refused to unpin a host range"
+        live = h.stochqn_hip_stat(b"host_pins_live")
+        assert live == 0, "%d host range(s) still pinned after their test" % live

@@ -18,6 +18,7 @@
 
 #include "sqn_device.hpp"
 
+#include <cstring>
 #include <cmath>
 
 namespace fakelaunch {
@@ -204,6 +205,19 @@ void launch_apply(const Scratch& sc, size_t n, double n_global, Partials guard, 
 void launch_spec_x(const Scratch& sc, size_t n, const real* r, const real* x, double step, real* out)
 {
 	run(sc, K_APPLY, [=] { for (size_t i = 0; i < n; i++) out[i] = (real) ((double) x[i] - step * (double) r[i]); });
+}
+
+// the checksum of x on the "device": the host's own routine (runtime.cpp) over the device copy, added into out2[0..1]
+void launch_xhash(const Scratch& sc, const real* x, size_t n, double* out2)
+{
+	run(sc, K_XHASH, [=] {
+		XHash h;
+		xhash_host(x, n * sizeof(real), 0, xhash_words(n * sizeof(real)), &h);
+		unsigned long long w[2];
+		std::memcpy(w, out2, sizeof w);
+		w[0] += h.a; w[1] += h.b;
+		std::memcpy(out2, w, sizeof w);
+	});
 }
 
 void launch_pair_s(const Scratch& sc, size_t n, real* x_sum, double inv_L, bool scale, const real* x_avg_prev, real* s_out)

@@ -313,6 +313,33 @@ void sc_host_path()
 	c.drive(9);
 	CHECK(c.failed == 0 && stat("x_uploads_skipped") > 0, "skipped uploads: %lld", stat("x_uploads_skipped"));
 	opt("x_upload", 1); opt("register_host", 0);
+	// x_upload = 2: nobody vouches for anything; the library compares a checksum of ALL of the caller's x (threads of its own,
+	// while the caller's thread goes on enqueueing) with the one it took of the device copy when the last call ended
+	opt("x_upload", 2); opt("hash_threads", 3);
+	for (int kind = 0; kind < 3; kind++) {
+		stochqn_hip_stats_reset();
+		Opt h(kind == 0 ? OLBFGS : (kind == 1 ? SQN : ADAQN), n + kind, 3, kind == 0 ? 1 : 3, false, 0.0, kind == 2 ? 4 : 0);
+		h.drive(14);
+		const long long skipped = stat("x_uploads_skipped"), sent = stat("x_uploads");
+		CHECK(h.failed == 0 && skipped >= 3, "kind %d: uploads skipped on the strength of the checksum: %lld (sent %lld)", kind, skipped, sent);
+		while (h.section != 1) h.drive(1);
+		h.x[(size_t) n / 3] += 1e-9;                      // ONE coordinate, nowhere near a probe: the caller's own move
+		h.x_ref = h.x;
+		h.answer();
+		for (size_t i = 0; i < (size_t) h.n; i++) h.grad[i] = 0.25 * h.x[i] + 0.01;      // ... and its gradient there
+		h.call(0.01);
+		CHECK(stat("x_uploads") == sent + 1, "kind %d: an edit of one coordinate must send x up again (%lld -> %lld)", kind, sent, stat("x_uploads"));
+		h.drive(6);
+		// a rejected step: what went ahead is put right, and the sum that was taken is the untouched device x's
+		while (h.section != 1) h.drive(1);
+		fakelaunch::script().reject_step = true;
+		h.drive(1);
+		fakelaunch::script().reject_step = false;
+		h.drive(8);
+		CHECK(h.failed == 0, "kind %d: failed calls %d", kind, h.failed);
+		stochqn_hip_release(h.key());
+	}
+	opt("x_upload", 1); opt("hash_threads", 0);
 	leak_check("host_path");
 }
 

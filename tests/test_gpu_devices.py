@@ -16,6 +16,13 @@ from test_oracle_known_answers import GOLD, host_view, run_c_rosen
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _pins_go_with_their_arrays():
+    yield
+    from harness import assert_no_host_range_left_pinned
+    assert_no_host_range_left_pinned()
+
 LOOP, RCCL = 3, 1           # Reducer::Kind of runtime.hpp
 
 

@@ -12,6 +12,13 @@ from harness import NoisyQuadratic, OPTIMIZERS, VOUCHED, compare_traces, library
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _pins_go_with_their_arrays():
+    yield
+    from harness import assert_no_host_range_left_pinned
+    assert_no_host_range_left_pinned()
+
 TOL = 1e-10
 
 
@@ -38,21 +45,22 @@ KW = {
 }
 
 
-@pytest.mark.parametrize("policy", ["default", "vouched"])
+@pytest.mark.parametrize("policy", ["default", "vouched", "checksum"])
 @pytest.mark.parametrize("kind", ["oLBFGS", "SQN", "adaQN"])
 @pytest.mark.parametrize("n", [1000, 2_500_001])
 def test_host_and_device_callers_agree_bit_for_bit(kind, n, policy, hip_backend):
     """The same calls with the same inputs through numpy arrays and through torch tensors: every x, every request,
     every counter identical to the last bit.  n = 2,500,001 is past the thresholds of the host-side mechanisms (20 MB arrays
     are page-locked by their owner, stochqn_amd/free.py; the gradient comes up and x goes up and down in slices under the
-    kernels) and odd, so every second ring row is off the 16-byte grid.  Twice: with the library's defaults (x goes up on every
-    step, the library pins nothing by itself) and for a caller that vouches for its arrays (x_upload = 0, register_host = 1)."""
+    kernels) and odd, so every second ring row is off the 16-byte grid.  Three times: with the library's defaults (x goes up on
+    every step, the library pins nothing by itself), for a caller that vouches for its arrays (x_upload = 0, register_host = 1),
+    and with x_upload = 2, where nobody vouches and a checksum of all of x decides whether it goes up."""
     import torch
     lib = _lib()
     lib.stochqn_hip_stats_reset()
     P = NoisyQuadratic(n, seed=5)
     calls = 26
-    with library_options(lib, **(VOUCHED if policy == "vouched" else {})):
+    with library_options(lib, **(VOUCHED if policy == "vouched" else (dict(x_upload=2) if policy == "checksum" else {}))):
         opt = OPTIMIZERS[kind](backend=hip_backend, space="host", **KW[kind])
         host = run_trace(opt, P, P.x0(), 0.05, calls)
         steps = sum(1 for t in host if t["changed"] == 1 or t["info"] == "search_direction_was_nan")
@@ -72,6 +80,11 @@ def test_host_and_device_callers_agree_bit_for_bit(kind, n, policy, hip_backend)
         assert uploads >= 1 and skipped >= 5, (uploads, skipped)
         if kind == "oLBFGS":
             assert uploads == 1, uploads         # every request of oLBFGS is at x
+    elif policy == "checksum" and n > 1_000_000:
+        # the caller of this test never touches x: after the first step every ordinary step finds the sums equal
+        assert uploads >= 1 and skipped >= steps - 4 >= 4, (uploads, skipped, steps)
+    elif policy == "checksum":
+        assert skipped == 0 and uploads >= steps                  # small x goes up in one piece, nothing to decide
     else:
         assert skipped == 0 and uploads >= steps >= 8, (uploads, skipped, steps)       # every step brings the caller's x up
     if n > 1_000_000:
@@ -81,12 +94,14 @@ def test_host_and_device_callers_agree_bit_for_bit(kind, n, policy, hip_backend)
     lib.stochqn_hip_release_all()
 
 
-@pytest.mark.parametrize("n", [50_000, 4_500_001])
-def test_an_edit_of_one_coordinate_between_two_calls_moves_the_iterate(n, hip_backend, oracle_backend):
+@pytest.mark.parametrize("n,mode", [(50_000, 1), (4_500_001, 1), (4_500_001, 2), (4_500_002, 2)])
+def test_an_edit_of_one_coordinate_between_two_calls_moves_the_iterate(n, mode, hip_backend, oracle_backend):
     """The reference's *req aliases x: a caller that clips or resets a FEW coordinates between two ordinary steps has simply
     moved the iterate.  256 probe values would miss such an edit; with the library's defaults (x_upload = 1) x goes up on
-    every step -- for the large n in slices under the update -- and the trajectory equals the oracle's."""
+    every step -- for the large n in slices under the update -- and the trajectory equals the oracle's.  With x_upload = 2 a
+    checksum of ALL of x decides: the steps after an edit send x up, the others do not -- same trajectory."""
     lib = _lib()
+    lib.stochqn_hip_stats_reset()
     P = NoisyQuadratic(n, seed=13)
     kw = dict(mem_size=3, bfgs_upd_freq=4)
     where = [n // 3 + 1, n // 2 + 7, n - 2]           # none of them a probe position
@@ -108,10 +123,17 @@ def test_an_edit_of_one_coordinate_between_two_calls_moves_the_iterate(n, hip_ba
         opt.release()
         return xs
 
-    got, want = drive(hip_backend), drive(oracle_backend)
+    with library_options(lib, x_upload=mode):
+        got = drive(hip_backend)
+    uploads, skipped = stat(lib, "x_uploads"), stat(lib, "x_uploads_skipped")
+    want = drive(oracle_backend)
     for i, (g, w) in enumerate(zip(got, want)):
         assert rel_err(g, w) <= TOL, i
         assert np.array_equal(g[where] == 0.25, w[where] == 0.25), i
+    if mode == 2:
+        assert skipped >= 6 and 3 <= uploads <= 8, (uploads, skipped)      # the first step, the three edits, the calls that take x in one piece
+    else:
+        assert skipped == 0
     lib.stochqn_hip_release_all()
 
 

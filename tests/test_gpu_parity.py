@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from harness import OPTIMIZERS, NoisyQuadratic, compare_traces, rel_err, run_lockstep, run_trace, to_np
+from harness import OPTIMIZERS, NoisyQuadratic, compare_traces, rel_err, run_lockstep, run_trace, to_dev, to_np
 from test_oracle_known_answers import GOLD, check_known_answer, run_c_rosen, host_view
 
 pytestmark = pytest.mark.gpu
@@ -741,7 +741,7 @@ def test_adaqn_trajectory_at_full_size_in_lockstep_with_the_oracle(hip_backend, 
         linear in s.  So the rows of S and Y are held to what that allows, 16 eps |x| / |s| (measured: up to 1.1e-9, at the
         last sync point), and -- like everything else here -- to 1e-10 of the vectors they were computed FROM (|x|)."""
         nonlocal worst
-        w = torch.from_numpy(np.ascontiguousarray(want)).to("cuda")          # compared where the 0.8 GB vectors are: on the device
+        w = to_dev(want)                                                     # compared where the 0.8 GB vectors are: on the device
         assert bool(torch.isfinite(w).all()) and bool(torch.isfinite(got).all()), what
         nw = float(torch.linalg.vector_norm(w))
         e = float(torch.linalg.vector_norm(got - w)) / nw if nw > 0 else float(torch.linalg.vector_norm(got))
@@ -793,7 +793,7 @@ def test_adaqn_trajectory_at_full_size_in_lockstep_with_the_oracle(hip_backend, 
             t += 1
         assert syncs == iters // K and ref.BFGS_mem.mem_used == 20 and ref.Fisher_mem.mem_used == 16
         close("the final x", x_lock, x_ref)
-        x_ref_d = torch.from_numpy(x_ref).to("cuda")
+        x_ref_d = to_dev(x_ref)
         e_free = float(torch.linalg.vector_norm(x_free - x_ref_d) / torch.linalg.vector_norm(x_ref_d))
         assert e_free <= 1e-7, e_free                                        # free-running: FREE_RUN_TOL
         assert rel_err(x_ref, x0_h) > 1e-4                                   # and the run went somewhere
