@@ -447,6 +447,24 @@ void group_body(int P, bool virt)
 		stochqn_hip_release(a.key());
 		a.drive(6);                                  // re-imported from the caller's arrays
 	}
+	// the sliced host path per shard, each shard taking the checksum of its slice of the caller's x on threads of its own
+	{
+		opt("host_slice_min", 1 << 9); opt("x_upload", 2); opt("hash_threads", 2);
+		stochqn_hip_stats_reset();
+		Opt a(SQN, 40013, 3, 3), b(ADAQN, 40013, 3, 3, false, 0.0, 4);
+		a.drive(20); b.drive(20);
+		CHECK(a.failed == 0 && b.failed == 0 && a.accepted >= 8 && b.accepted >= 8, "failed %d %d accepted %d %d", a.failed, b.failed, a.accepted, b.accepted);
+		CHECK(stat("x_uploads_skipped") >= 4 * P, "uploads skipped per shard on the strength of the checksum: %lld", stat("x_uploads_skipped"));
+		while (a.section != 1) a.drive(1);
+		a.x[17] -= 1e-7;                                  // one coordinate, in the first shard's slice
+		a.x_ref = a.x;
+		for (size_t i = 0; i < a.x.size(); i++) a.grad[i] = 0.25 * a.x[i] + 0.01;
+		a.call(0.01);
+		a.drive(6);
+		CHECK(a.failed == 0, "after an edit: failed %d", a.failed);
+		stochqn_hip_release(a.key()); stochqn_hip_release(b.key());
+		opt("host_slice_min", 1 << 21); opt("x_upload", 1); opt("hash_threads", 0);
+	}
 	// library-owned sharded workspace (n beyond one device in real life)
 	workspace_SQN* w = initialize_SQN(n, 3, 3, 0.0, 0, 0.0, 1, 1);
 	CHECK(w != nullptr, "initialize_SQN in group mode");

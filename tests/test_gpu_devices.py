@@ -185,14 +185,18 @@ def test_large_shards_run_the_overlaps_of_the_host_path(hip_backend, oracle_back
     try:
         assert lib.stochqn_hip_set_option(b"strict_grad", 0.0) == 0
         want = run_trace(OPTIMIZERS["SQN"](backend=oracle_backend, space="host", **kw), P, P.x0(), 0.05, 20)
-        for policy in ({}, VOUCHED):                         # the defaults (x comes up with the slices of the update), and the vouching caller
+        # the defaults (x comes up with the slices of the update), the vouching caller, and x_upload = 2 (each shard takes the
+        # checksum of its slice of the caller's x)
+        for policy in ({}, VOUCHED, dict(x_upload=2)):
             with library_options(lib, **policy):
                 lib.stochqn_hip_stats_reset()
                 opt = OPTIMIZERS["SQN"](backend=hip_backend, space="host", **kw)
                 got = run_trace(opt, P, P.x0(), 0.05, 20)
                 assert lib.stochqn_hip_devices_active(C.c_void_p(opt.BFGS_mem.s_mem.ctypes.data)) == 3
                 ahead, again, pre = (lib.stochqn_hip_stat(k) for k in (b"x_sent_ahead", b"x_sent_again", b"x_prefetched"))
-                assert ahead >= 3 * 4 and again >= 3 and (pre >= 3 if policy else pre == 0), (ahead, again, pre)      # per shard
+                assert ahead >= 3 * 4 and again >= 3 and (pre >= 3 if policy is VOUCHED else pre == 0), (ahead, again, pre)      # per shard
+                if policy.get("x_upload") == 2:
+                    assert lib.stochqn_hip_stat(b"x_uploads_skipped") >= 3 * 4, lib.stochqn_hip_stat(b"x_uploads_skipped")
                 assert any(t["info"] == "search_direction_was_nan" for t in want)
                 compare_traces(got, want, 1e-9)
                 opt.release()
