@@ -622,6 +622,16 @@ void sc_fault_sweep()
 		stochqn_hip_release(a.key());
 		return rc;
 	}, "fault_sweep/adaqn", st, 30, 80);
+	// (4) the SLICED host path (gradient and x in slices on the side streams, x ahead of the guard) with the checksum of x deciding
+	// about its upload: the events, waits and copies of copy_stream / down_stream, the checksum kernel's read-back
+	opt("host_slice_min", 1 << 10); opt("x_upload", 2); opt("hash_threads", 2);
+	sweep_one([] {
+		Opt a(SQN, (1 << 13) + 1, 3, 3);
+		const int rc = a.drive(11);
+		stochqn_hip_release(a.key());
+		return rc;
+	}, "fault_sweep/host_sliced_checksum", st, 24, 48);
+	opt("host_slice_min", 1 << 21); opt("x_upload", 1); opt("hash_threads", 0);
 	std::fprintf(stderr, "fault_sweep: %ld runs with one failing HIP call each: %ld ended in -1000, %ld completed\n", st.runs, st.failed_calls, st.survived);
 	CHECK(st.runs > 300 && st.failed_calls > 50, "the sweep did not reach the call sites (%ld runs, %ld failed calls)", st.runs, st.failed_calls);
 }

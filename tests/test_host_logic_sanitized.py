@@ -14,7 +14,7 @@ under -fsanitize=thread:
   group_rccl / group_virtual: the single-process multi-device mode with 4 worker threads over ncclCommInitAll, and over
       the host-side reducer; one shard over a real communicator (option devices_rccl_single);
   group_alloc_failures: every allocation of that mode failing in turn (NULL / -1000, no hang, no leak);
-  fault_sweep / fault_sweep_group: EVERY call site of the HIP runtime failing in turn, ~600 runs: a message and -1000 or
+  fault_sweep / fault_sweep_group: EVERY call site of the HIP runtime failing in turn, ~850 runs: a message and -1000 or
       a correct result, never an abort, a wrong x or a leak -- the bound on round 3's unexplained abort.
 """
 import os
