@@ -14,6 +14,7 @@
 
 #include "stochqn.h"
 #include "stochqn_hip.h"
+#include "runtime.hpp"          // the host checksum of x (xhash_*): tested against its definition directly
 
 #include <dlfcn.h>
 #include <cmath>
@@ -341,6 +342,53 @@ void sc_host_path()
 	}
 	opt("x_upload", 1); opt("hash_threads", 0);
 	leak_check("host_path");
+}
+
+// the checksum of a host buffer (option "x_upload" = 2): any partition and any number of threads give the sums of the
+// definition (sqn_device.hpp: XHash), ragged ends included; one changed byte anywhere changes the first sum
+void sc_xhash()
+{
+	std::vector<unsigned char> buf(70000);
+	unsigned long long seed = 12345;
+	for (auto& b : buf) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; b = (unsigned char) (seed >> 56); }
+	for (size_t bytes : {(size_t) 0, (size_t) 1, (size_t) 4, (size_t) 7, (size_t) 8, (size_t) 9, (size_t) 12, (size_t) 15, (size_t) 16, (size_t) 20,
+	                     (size_t) 4096, (size_t) 4100, (size_t) 65536, (size_t) 65540, (size_t) 69996}) {
+		// the definition, word by word
+		unsigned long long a = 0, b = 0;
+		const size_t words = (bytes + 7) / 8;
+		for (size_t i = 0; i < words; i++) {
+			unsigned long long w = 0;
+			const size_t len = bytes - 8 * i < 8 ? bytes - 8 * i : 8;
+			std::memcpy(&w, buf.data() + 8 * i, len);
+			a += w;
+			b += (2 * i + 1) * w;
+		}
+		sqn::XHash whole;
+		sqn::xhash_host(buf.data(), bytes, 0, sqn::xhash_words(bytes), &whole);
+		CHECK(whole.a == a && whole.b == b, "%zu bytes in one piece: (%llx, %llx) against the definition's (%llx, %llx)", bytes, whole.a, whole.b, a, b);
+		for (size_t cut : {(size_t) 0, (size_t) 1, words / 3, words / 2 + 1, words}) {
+			if (cut > words) continue;
+			sqn::XHash lo, hi;
+			sqn::xhash_host(buf.data(), bytes, 0, cut, &lo);
+			sqn::xhash_host(buf.data(), bytes, cut, words, &hi);
+			CHECK(lo.a + hi.a == a && lo.b + hi.b == b, "%zu bytes cut at word %zu", bytes, cut);
+		}
+		for (int threads : {1, 2, 3, 7, 64}) {
+			sqn::XHashJob* job = sqn::xhash_start(buf.data(), bytes, threads);
+			CHECK(job != nullptr, "no job for %zu bytes on %d threads", bytes, threads);
+			if (!job) continue;
+			const sqn::XHash h = sqn::xhash_finish(job);
+			CHECK(h.a == a && h.b == b, "%zu bytes on %d threads: (%llx, %llx) against (%llx, %llx)", bytes, threads, h.a, h.b, a, b);
+		}
+		for (size_t at : {(size_t) 0, bytes / 2, bytes ? bytes - 1 : 0}) {
+			if (at >= bytes) continue;
+			buf[at] ^= 0x10;
+			sqn::XHash edited;
+			sqn::xhash_host(buf.data(), bytes, 0, sqn::xhash_words(bytes), &edited);
+			CHECK(edited.a != a, "%zu bytes: byte %zu changed, the first sum did not", bytes, at);
+			buf[at] ^= 0x10;
+		}
+	}
 }
 
 // rejected pairs (rollback = bak -> slot), NaN guards off, gradient differences, Fisher pairs with the function-value check
@@ -685,7 +733,7 @@ void sc_threads()
 
 struct Scenario { const char* name; void (*fn)(); };
 const Scenario kScenarios[] = {
-	{"registry", sc_registry}, {"reclaim_resume", sc_reclaim_resume}, {"mirror_cap", sc_mirror_cap}, {"host_path", sc_host_path},
+	{"registry", sc_registry}, {"reclaim_resume", sc_reclaim_resume}, {"mirror_cap", sc_mirror_cap}, {"host_path", sc_host_path}, {"xhash", sc_xhash},
 	{"branches", sc_branches}, {"owned_and_raw", sc_owned_and_raw}, {"group_rccl", sc_group_rccl}, {"group_virtual", sc_group_virtual},
 	{"group_alloc_failures", sc_group_alloc_failures}, {"fault_sweep", sc_fault_sweep}, {"fault_sweep_group", sc_fault_sweep_group},
 	{"threads", sc_threads}};

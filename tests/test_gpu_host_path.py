@@ -509,11 +509,13 @@ def test_function_increase_rolls_x_back_for_host_callers_too(hip_backend):
     lib.stochqn_hip_release_all()
 
 
-@pytest.mark.parametrize("kind", ["SQN", "adaQN"])
-def test_float_host_and_device_callers_agree_bit_for_bit(kind):
+@pytest.mark.parametrize("kind,x_upload", [("SQN", 1), ("adaQN", 1), ("SQN", 2)])
+def test_float_host_and_device_callers_agree_bit_for_bit(kind, x_upload):
     """The same for the single-precision library (libstochqn_f32.so): pinned float arrays, sliced pass 1, sliced pass 3 with x on
     its way ahead of the guard (packs of four floats: n = 9,000,003 leaves three elements beyond the last pack and is two
-    rounds of pass 3's grid)."""
+    rounds of pass 3's grid).  With x_upload = 2 the checksum of x has a ragged end in both places -- 36,000,012 bytes are a
+    half 64-bit word beyond the last whole one for the host's threads and 12 bytes beyond the last 16-byte pair for the kernel
+    -- and uploads are only ever skipped if the two agree on it."""
     import stochqn_amd
     import torch
     be = stochqn_amd.lib(use_float=True)
@@ -525,7 +527,10 @@ def test_float_host_and_device_callers_agree_bit_for_bit(kind):
     P = NoisyQuadratic(n, seed=5)
     kw = dict(KW[kind], use_float=True)
     x0 = P.x0().astype(np.float32)
-    host = run_trace(OPTIMIZERS[kind](backend=be, space="host", **kw), P, x0.copy(), 0.05, 16)
+    with library_options(lib, x_upload=x_upload):
+        host = run_trace(OPTIMIZERS[kind](backend=be, space="host", **kw), P, x0.copy(), 0.05, 16)
+    if x_upload == 2:
+        assert lib.stochqn_hip_stat(b"x_uploads_skipped") >= 4, (lib.stochqn_hip_stat(b"x_uploads_skipped"), lib.stochqn_hip_stat(b"x_uploads"))
     x = torch.as_tensor(x0.copy(), device="cuda:0")
     dev = run_trace(OPTIMIZERS[kind](backend=be, space="device", device="cuda:0", **kw), P, x, 0.05, 16)
     for i, (h, d) in enumerate(zip(host, dev)):

@@ -24,7 +24,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM = os.path.join(ROOT, "tests", "hostsim")
-SCENARIOS = ["registry", "reclaim_resume", "mirror_cap", "host_path", "branches", "owned_and_raw", "threads",
+SCENARIOS = ["registry", "reclaim_resume", "mirror_cap", "host_path", "xhash", "branches", "owned_and_raw", "threads",
              "group_rccl", "group_virtual", "group_alloc_failures", "fault_sweep", "fault_sweep_group"]
 
 
