@@ -21,7 +21,9 @@ def test_every_path_cited_in_the_documents_exists():
         for path in cited_paths(text):
             full = os.path.join(ROOT, path)
             # built artefacts are not in the tree until build() has run; binaries of the measurement tools likewise
-            if path.endswith(".so") or path in ("tools/latency", "tools/host_link_probes", "profiles/src/tune", "profiles/src/hostcost", "oracle/_ref") or path.startswith("tests/hostsim/build"):
+            if path.endswith(".so") or path == "oracle/_ref" or path.startswith("tests/hostsim/build"):
+                continue
+            if any(os.path.exists(full + ext) for ext in (".c", ".cpp", ".hip")):     # a tool cited by its binary's name
                 continue
             if not os.path.exists(full):
                 missing.append((doc, path))
