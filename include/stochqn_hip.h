@@ -94,9 +94,15 @@ int stochqn_hip_unpin_host(void *p);
  *                            used for m > 48 and for ill-conditioned pairs, "kappa_max").  (Round 1's two-pass form -- [S;Y]g,
  *                            a recursion over Gram blocks, one combine pass: (4m+3)n words -- was retired in round 4 together
  *                            with its options: the three-pass form dominated it on bytes, time and accuracy.)
- * "rows_split", "combine_batch", "stream_stores", "sdot_per_cu",
- * "sdot2_per_cu", "qdot_per_cu", "sadd_per_cu": kernel-shape knobs (grid sizes in workgroups per compute unit, packs a lane
- *                            finishes before it stores, store policy of r0 / r); the defaults are the measured optima, DESIGN.md 3.0
+ * "rows_split", "sdot_per_cu", "sdot2_per_cu", "qdot_per_cu", "sadd_per_cu": kernel-shape knobs (rows of pass 1 split over the
+ *                            waves of a workgroup; grid sizes in workgroups per compute unit); the defaults are the measured
+ *                            optima, DESIGN.md 3.0
+ * "phase_ticks" (default 8000)  three-pass form, passes 2 and 3: the lanes park their results in LDS and every wave stores what
+ *                            it has parked when the chip-wide 100 MHz clock enters a new period of this many ticks (or when
+ *                            its 32 slots are full), so that the whole chip writes at the same moment and reads the rest of
+ *                            the time: the one store stream among ~20 read streams then costs 0.18 ms instead of 0.48 ms per
+ *                            pass at n = 1e8.  Same values at the same addresses, only later.  0: every pack
+ *                            is stored as soon as it is final (rounds 2 - 3)
  * "strict_grad" (default 0)  host callers: copy the search direction back into `grad` (n words over PCIe per step).  The
  *                            reference documents `grad` as an INPUT that "will be modified in-place" (reference
  *                            include/stochqn.h:356-358), and none of its callers reads it afterwards (src/Rwrapper.c:98-196,

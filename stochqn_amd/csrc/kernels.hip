@@ -122,6 +122,86 @@ template <int W> __device__ __forceinline__ void st_stream(real* p, uint32_t i, 
 	} else p[i] = (real) a.v[0];
 }
 
+// ---- clock-phased stores (round 4) ---------------------------------------------------------------------------------------
+// One store stream among ~20 read streams costs several times its bytes when the stores trickle out between the loads
+// (DESIGN.md 3.2).  What cures it is the WHOLE CHIP writing at the same moment and reading the rest of the time: every lane
+// parks its results in LDS (kParkSlots packs per lane, 128 KB per workgroup: the passes use no LDS otherwise) and every wave
+// flushes its parked packs when the chip-wide 100 MHz counter (s_memrealtime) enters a new period of `phase_ticks` ticks --
+// or when its slots are full.  No communication, no barrier: the clock is the only thing the 1024 waves share, a wave never
+// waits for another one, and nothing but the moment of a store changes (same values, same addresses, same bits).
+// profiles/src/tune9.hip, tune10.hip: pass 2 at n = 1e8, k = 20: 2.98 ms storing at once, 2.68 ms phased (2.50 ms without
+// the store); a grid barrier instead of the clock: 2.84 ms.
+constexpr int kParkSlots = 32;
+template <int W> struct Stored { typedef real type; };
+template <> struct Stored<kVec> { typedef rvec type; };
+
+template <int W> __device__ __forceinline__ typename Stored<W>::type to_stored(const Pack<W>& a)
+{
+	if constexpr (W == kVec) {
+		rvec t;
+		#pragma unroll
+		for (int k = 0; k < W; k++) t[k] = (real) a.v[k];
+		return t;
+	} else return (real) a.v[0];
+}
+
+// a parked pack on its way out.  pol 0: the default store policy; 1: sc1 nt like st_stream; 2: non-temporal like st_nt
+template <int W> __device__ __forceinline__ void st_stored(real* p, uint32_t i, const typename Stored<W>::type& t, int pol)
+{
+	if constexpr (W == kVec) {
+		if (pol == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p + i), "v"(t) : "memory");
+		else if (pol == 2) __builtin_nontemporal_store(t, reinterpret_cast<rvec_u*>(p + i));
+		else *reinterpret_cast<rvec_u*>(p + i) = t;
+	} else {
+		if (pol == 2) __builtin_nontemporal_store(t, p + i); else p[i] = t;
+	}
+}
+
+// period number of the chip-wide clock: floor(ticks * inv / 2^32) on the low 32 bits of the counter (it wraps every 43 s: one
+// flush out of turn)
+__device__ __forceinline__ uint32_t phase_epoch(uint32_t inv) { return __umulhi((uint32_t) __builtin_amdgcn_s_memrealtime(), inv); }
+
+// The parked results of one lane, NS output vectors per pack (pass 2 of adaQN writes four: r0, G, H0 and the Fisher row): pack
+// b of stream s of lane t at slots[(b * NS + s) * kBlock + t] (a lane reads back only what it wrote itself, so no barrier is
+// involved); pack numbers p_first, p_first + stride, ...  The slots are shared out among the streams and the period shrinks
+// with them, so that the clock -- not the full slots -- is what makes the waves flush.
+template <int W, int NS = 1> struct Parked {
+	static constexpr int kCap = kParkSlots / NS;
+	typename Stored<W>::type* slots;
+	real* out[NS];                 // where stream s goes (NULL: nowhere)
+	int pol[NS];                   // 0: default store policy; 1: sc1 nt except the tail from keep_from on; 2: non-temporal
+	uint32_t p_first, epoch, inv, stride, last, keep_from;
+	bool rev;
+	int b;
+	__device__ __forceinline__ void open(typename Stored<W>::type* lds, uint32_t inv_, uint32_t stride_, bool rev_, uint32_t last_, uint32_t keep_from_)
+	{
+		slots = lds; inv = inv_ * (uint32_t) NS; stride = stride_; rev = rev_; last = last_; keep_from = keep_from_;
+		b = 0; p_first = 0; epoch = phase_epoch(inv);
+	}
+	__device__ __forceinline__ void flush()
+	{
+		#pragma unroll 1
+		for (int bb = 0; bb < b; bb++) {
+			const uint32_t p = p_first + (uint32_t) bb * stride;
+			const uint32_t i = (rev ? last - p : p) * W;
+			#pragma unroll
+			for (int s = 0; s < NS; s++)
+				if (out[s]) st_stored<W>(out[s], i, slots[(bb * NS + s) * kBlock + threadIdx.x], (pol[s] == 1 && p >= keep_from) ? 0 : pol[s]);
+		}
+		b = 0;
+	}
+	// park the results of pack p; flush when the slots are full or the clock has entered a new period
+	__device__ __forceinline__ void put(const Pack<W> (&v)[NS], uint32_t p)
+	{
+		if (b == 0) p_first = p;
+		#pragma unroll
+		for (int s = 0; s < NS; s++) slots[(b * NS + s) * kBlock + threadIdx.x] = to_stored<W>(v[s]);
+		b++;
+		const uint32_t e = phase_epoch(inv);
+		if (b == kCap || e != epoch) { epoch = e; flush(); }
+	}
+};
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 	#pragma unroll
@@ -660,14 +740,16 @@ __global__ void __launch_bounds__(kBlock) k_fisher_t(const real* F, size_t ld_, 
 }
 
 // pass 2: y_j = (1/fu) * sum_k t_k F[k][j], rows accumulated in index order; fused with the
-// curvature dots of the new pair.
-template <int W, bool NT>
+// curvature dots of the new pair.  One store stream (y) among fu + 1 read streams: PH = its stores clock-phased like those
+// of passes 2 and 3 (Parked).
+template <int W, bool NT, bool PH>
 __global__ void __launch_bounds__(kBlock) k_fisher_y(const real* F, size_t ld_, uint32_t n, uint32_t fu,
                                                      const double* t, double inv_fu, const real* s, real* y,
-                                                     double* parts_out)
+                                                     double* parts_out, uint32_t phase_inv)
 {
 	extern __shared__ double t_sh[];   // fu doubles
 	__shared__ double sh[kWaves];
+	__shared__ typename Stored<W>::type park[PH ? kParkSlots * kBlock : 1];
 	// t passes through a real_t buffer between the two products in the reference (buffer_y, src/stochqn.c:946-949): in the
 	// float build it is rounded to float on the way, and y = F't/fu -- which can cancel to 1e-4 of its terms -- follows that rounding
 	for (uint32_t k = threadIdx.x; k < fu; k += kBlock) t_sh[k] = (double) (real) t[k];
@@ -676,6 +758,8 @@ __global__ void __launch_bounds__(kBlock) k_fisher_y(const real* F, size_t ld_, 
 	const uint32_t packs = n / W;
 	const uint32_t stride = gridDim.x * kBlock;
 	constexpr int R = 8;
+	Parked<W> pk;
+	if constexpr (PH) { pk.open(park, phase_inv, stride, false, 0u, 0u); pk.out[0] = y; pk.pol[0] = 0; }
 	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
 		Pack<W> a;
 		#pragma unroll
@@ -699,8 +783,10 @@ __global__ void __launch_bounds__(kBlock) k_fisher_y(const real* F, size_t ld_, 
 		}
 		#pragma unroll
 		for (int j = 0; j < W; j++) { a.v[j] = inv_fu * a.v[j]; three_dots(sv.v[j], a.v[j], acc); }
-		st<W>(y, p * W, a);
+		if constexpr (PH) { const Pack<W> one[1] = {a}; pk.put(one, p); }
+		else st<W>(y, p * W, a);
 	}
+	if constexpr (PH) pk.flush();
 	if (W > 1) {
 		const uint32_t i = packs * W + threadIdx.x;
 		if (blockIdx.x == gridDim.x - 1 && i < n) {
@@ -995,12 +1081,14 @@ struct DiagArgs {               // how pass 2 scales q0
 	bool rms;
 };
 
-template <int W, int NG, bool NT, int MODE /*0 scalar, 1 given diagonal, 2 adaQN*/, bool SS>
+// PH: the stores of r0 clock-phased (above); otherwise each pack is stored as soon as it is final.
+template <int W, int NG, bool NT, int MODE /*0 scalar, 1 given diagonal, 2 adaQN*/, bool PH>
 __global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, Fold3 fo, real* g, DiagArgs dg, uint32_t n, int rev,
-                                                 uint32_t keep_from, double* parts)
+                                                 uint32_t keep_from, double* parts, uint32_t phase_inv)
 {
 	__shared__ double sh[NG * 8 * kWaves];
 	__shared__ double cf[1 + kPairsMax3];
+	__shared__ typename Stored<W>::type park[PH ? kParkSlots * kBlock : 1];
 	const int k = ys.count;
 	{
 		__shared__ double SY[kPairsMax3 * kPairsMax3], bS[kPairsMax3], col[kPairsMax3];
@@ -1010,6 +1098,13 @@ __global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, Fold3 fo, real* g, D
 	#pragma unroll
 	for (int j = 0; j < NG * 8; j++) acc[j] = 0;
 	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
+	constexpr int NS = (PH && MODE == 2) ? 4 : 1;          // adaQN parks G, H0 and the Fisher row next to r0
+	Parked<W, NS> pk;
+	if constexpr (PH) {
+		pk.open(park, phase_inv, stride, rev != 0, last, keep_from);
+		pk.out[0] = g; pk.pol[0] = 1;
+		if constexpr (MODE == 2) { pk.out[1] = dg.G; pk.pol[1] = 0; pk.out[2] = dg.H0_out; pk.pol[2] = 0; pk.out[3] = dg.frow_out; pk.pol[3] = 2; }
+	}
 	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
 		const uint32_t i = (rev ? last - p : p) * W;
 		const Pack<W> gv = ld<W, false>(g, i);
@@ -1017,20 +1112,21 @@ __global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, Fold3 fo, real* g, D
 		#pragma unroll
 		for (int j = 0; j < NG * 8; j++)
 			if (j < k) f[j] = ldr<W, NT>(ys.row[j], i);
-		Pack<W> h;
+		Pack<W> h, Gn;
 		if constexpr (MODE == 1) h = ld<W, false>(dg.H0_in, i);
 		if constexpr (MODE == 2) {
 			const Pack<W> Gv = ld<W, false>(dg.G, i);
-			Pack<W> Gn;
 			#pragma unroll
 			for (int e = 0; e < W; e++) {
 				const double x = gv.v[e];
 				Gn.v[e] = dg.rms ? (dg.w_old * Gv.v[e] + dg.w_new * (x * x)) : (Gv.v[e] + x * x);     // reference :738 / :745
 				h.v[e] = x / sqrt(Gn.v[e] + dg.scal_reg);                                            // :781
 			}
-			st<W>(dg.G, i, Gn);
-			st<W>(dg.H0_out, i, h);
-			if (dg.frow_out) st_nt<W>(dg.frow_out, i, gv);
+			if constexpr (!PH) {
+				st<W>(dg.G, i, Gn);
+				st<W>(dg.H0_out, i, h);
+				if (dg.frow_out) st_nt<W>(dg.frow_out, i, gv);
+			}
 		}
 		Pack<W> q = gv;
 		#pragma unroll
@@ -1049,9 +1145,13 @@ __global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, Fold3 fo, real* g, D
 			}
 		// the part of r0 this pass writes last is what pass 3 (opposite direction) reads first: those packs are stored with
 		// the default policy so that they may still sit in the Infinity Cache, the rest streams past it (keep_from)
-		if constexpr (SS) { if (p >= keep_from) st<W>(g, i, q); else st_stream<W>(g, i, q); }
-		else st<W>(g, i, q);
+		if constexpr (PH) {
+			if constexpr (MODE == 2) { const Pack<W> four[4] = {q, Gn, h, gv}; pk.put(four, p); }
+			else { const Pack<W> one[1] = {q}; pk.put(one, p); }
+		}
+		else { if (p >= keep_from) st<W>(g, i, q); else st_stream<W>(g, i, q); }
 	}
+	if constexpr (PH) pk.flush();
 	if (W > 1) {
 		const uint32_t i = packs * W + threadIdx.x;
 		if (blockIdx.x == gridDim.x - 1 && i < n) {
@@ -1090,16 +1190,19 @@ __global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, Fold3 fo, real* g, D
 	}
 }
 
-// pass 3: r = r0 + sum_j c_j s_j, oldest pair first (:702-707); guard sums (sum r^2, #non-finite).
+// pass 3: r = r0 + sum_j c_j s_j, oldest pair first (:702-707); guard sums (sum r^2, #non-finite).  The k rows of a pack sit
+// in registers like pass 2's (all their loads issued before the first fma); PH: the stores of r clock-phased like pass 2's.
 // (Folding the position update into this pass for check_nan == 0 was built in round 3 and measured slower -- 3.68 ms against
 // 2.79 + 0.73: two more store streams among 21 read streams -- and removed in round 4; profiles/r03_ab_fuse_apply.jsonl.)
-// SL: the pass in slices of the traversal (whole rounds of T packs per lane), the two guard sums carried from slice to slice
+// SL: the pass in slices of the traversal (whole rounds of the grid), the two guard sums carried from slice to slice
 // per lane exactly like the accumulators of pass 1 (k_rows_dot_all): same terms, same order, same bits as one launch.
-template <int W, bool NT, int T, bool SS, bool SL>
-__global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, Fold3 fo, real* r, uint32_t n, int rev, uint32_t keep_from, double* parts, Slice sl)
+template <int W, int NG, bool NT, bool PH, bool SL>
+__global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, Fold3 fo, real* r, uint32_t n, int rev, uint32_t keep_from, double* parts, Slice sl,
+                                                 uint32_t phase_inv)
 {
 	__shared__ double sh[kWaves];
 	__shared__ double cf[kPairsMax3];
+	__shared__ typename Stored<W>::type park[PH ? kParkSlots * kBlock : 1];
 	const int k = ss.count;
 	{
 		__shared__ double SY[kPairsMax3 * kPairsMax3], V[kPairsMax3];
@@ -1112,42 +1215,28 @@ __global__ void __launch_bounds__(kBlock) k_sadd(RowSet ss, Fold3 fo, real* r, u
 		if (!sl.first) { acc0 = sl.carry[gtid]; acc1 = sl.carry[(size_t) stride + gtid]; }
 	}
 	const uint32_t p_end = SL ? sl.p_end : packs;
-	for (uint32_t p0 = (SL ? sl.p_begin : 0u) + gtid; p0 < p_end; p0 += T * stride) {
-		Pack<W> out[T];
+	Parked<W> pk;
+	if constexpr (PH) { pk.open(park, phase_inv, stride, rev != 0, last, keep_from); pk.out[0] = r; pk.pol[0] = 1; }
+	for (uint32_t p = (SL ? sl.p_begin : 0u) + gtid; p < p_end; p += stride) {
+		const uint32_t i = (rev ? last - p : p) * W;
+		Pack<W> v = ld<W, false>(r, i);
+		RPack<W> f[NG * 8];
 		#pragma unroll
-		for (int t = 0; t < T; t++) {
-			const uint32_t p = p0 + t * stride;
-			if (p < packs) {
-				const uint32_t i = (rev ? last - p : p) * W;
-				Pack<W> v = ld<W, false>(r, i);
-				for (int j0 = 0; j0 < k; j0 += 8) {
-					RPack<W> fs[8];
-					#pragma unroll
-					for (int u = 0; u < 8; u++)
-						if (j0 + u < k) fs[u] = ldr<W, NT>(ss.row[j0 + u], i);
-					#pragma unroll
-					for (int u = 0; u < 8; u++)
-						if (j0 + u < k) {
-							#pragma unroll
-							for (int e = 0; e < W; e++) v.v[e] = fma(cf[j0 + u], (double) fs[u].v[e], v.v[e]);
-						}
-				}
+		for (int j = 0; j < NG * 8; j++)
+			if (j < k) f[j] = ldr<W, NT>(ss.row[j], i);
+		#pragma unroll
+		for (int j = 0; j < NG * 8; j++)
+			if (j < k) {
 				#pragma unroll
-				for (int e = 0; e < W; e++) { acc0 = fma(v.v[e], v.v[e], acc0); acc1 += (isfinite(v.v[e]) ? 0.0 : 1.0); }
-				out[t] = v;
+				for (int e = 0; e < W; e++) v.v[e] = fma(cf[j], (double) f[j].v[e], v.v[e]);
 			}
-		}
 		#pragma unroll
-		for (int t = 0; t < T; t++) {
-			const uint32_t p = p0 + t * stride;
-			if (p < packs) {
-				const uint32_t i = (rev ? last - p : p) * W;
-				if constexpr (SS) {
-					if (p >= keep_from) st<W>(r, i, out[t]); else st_stream<W>(r, i, out[t]);     // see k_qdot: the tail stays cacheable for the apply pass
-				} else st<W>(r, i, out[t]);
-			}
-		}
+		for (int e = 0; e < W; e++) { acc0 = fma(v.v[e], v.v[e], acc0); acc1 += (isfinite(v.v[e]) ? 0.0 : 1.0); }
+		// the tail of r stays cacheable for the apply pass (see k_qdot)
+		if constexpr (PH) { const Pack<W> one[1] = {v}; pk.put(one, p); }
+		else { if (p >= keep_from) st<W>(r, i, v); else st_stream<W>(r, i, v); }
 	}
+	if constexpr (PH) pk.flush();
 	if constexpr (SL) {
 		if (!sl.last) { sl.carry[gtid] = acc0; sl.carry[(size_t) stride + gtid] = acc1; return; }
 	}
@@ -1433,8 +1522,12 @@ Partials launch_fisher(const Scratch& sc, int buf, size_t n, const real* F, size
 		ProfScope ps(sc, K_FISHER_Y);
 		const size_t shmem = fu * sizeof(double);
 		const double inv = 1.0 / (double) fu;
-		if (vec) hipLaunchKernelGGL((k_fisher_y<kVec, true>), dim3(grid), dim3(kBlock), shmem, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, t_dev, inv, s, y_out, sc.part[buf]);
-		else     hipLaunchKernelGGL((k_fisher_y<1, true>), dim3(grid), dim3(kBlock), shmem, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, t_dev, inv, s, y_out, sc.part[buf]);
+		// the parked results take 128 KB of a workgroup's 160 KB of LDS: t has to fit beside them
+		const bool ph = sc.phase_inv != 0 && shmem <= 16384;
+		#define SQN_FY(WW, PH) hipLaunchKernelGGL((k_fisher_y<WW, true, PH>), dim3(grid), dim3(kBlock), shmem, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, t_dev, inv, s, y_out, sc.part[buf], sc.phase_inv)
+		if (vec) { if (ph) SQN_FY(kVec, true); else SQN_FY(kVec, false); }
+		else     { if (ph) SQN_FY(1, true); else SQN_FY(1, false); }
+		#undef SQN_FY
 	}
 	return finish(sc, buf, 3, grid);
 }
@@ -1608,10 +1701,11 @@ Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g,
 	DiagArgs dg{q.H0_in, q.G, q.H0_out, q.frow_out, q.rmsprop_weight, 1 - q.rmsprop_weight, q.scal_reg, q.rmsprop_weight > 0 && q.rmsprop_weight < 1};
 	const Fold3 fo = fold_args(sc, pass1, a, fresh_row);
 	const uint32_t keep = keep_from_pack(sc, n, vec);
+	const bool ph = sc.phase_inv != 0;
 	{
 		ProfScope ps(sc, K_QDOT);
-		#define SQN_QD3(WW, NG, MODE) { if (sc.stream_stores) hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, true>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, fo, g, dg, (uint32_t) n, rev, keep, sc.rows_part[1]); \
-		                                else hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, false>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, fo, g, dg, (uint32_t) n, rev, keep, sc.rows_part[1]); }
+		#define SQN_QD3(WW, NG, MODE) { if (ph) hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, true>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, fo, g, dg, (uint32_t) n, rev, keep, sc.rows_part[1], sc.phase_inv); \
+		                                else hipLaunchKernelGGL((k_qdot<WW, NG, true, MODE, false>), dim3(grid), dim3(kBlock), 0, sc.stream, y_rows, fo, g, dg, (uint32_t) n, rev, keep, sc.rows_part[1], 0u); }
 		#define SQN_QD2(WW, NG) { if (mode == 2) SQN_QD3(WW, NG, 2) else if (mode == 1) SQN_QD3(WW, NG, 1) else SQN_QD3(WW, NG, 0) }
 		#define SQN_QD1(WW) { if (ng <= 1) SQN_QD2(WW, 1) else if (ng == 2) SQN_QD2(WW, 2) else if (ng == 3) SQN_QD2(WW, 3) else if (ng == 4) SQN_QD2(WW, 4) else if (ng == 5) SQN_QD2(WW, 5) else SQN_QD2(WW, 6) }
 		if (vec) SQN_QD1(kVec) else SQN_QD1(1)
@@ -1626,16 +1720,17 @@ Partials launch_qdot(const Scratch& sc, size_t n, const RowSet& y_rows, real* g,
 	return Partials{sc.red[1], 1, 1};
 }
 
+// pass 3: one workgroup per CU (its lanes hold all k rows of a pack, and the parked results take most of a CU's LDS)
+static int sadd_grid(const Scratch& sc, size_t n) { return sweep_grid(sc, n, sc.sadd_per_cu > 0 ? sc.sadd_per_cu : 1); }
+
 // pass 3 can run in slices when the lanes work on packs (the elements beyond the last pack are written by the last launch,
 // wherever the traversal ends: they are reported on their own when that is not where the last slice lies)
 bool sadd_can_slice(const Scratch& sc, size_t n, const RowSet& s_rows, const real* r, const SliceFeed* drain)
 {
 	if (!drain || drain->slices < 2 || !rows_aligned(s_rows) || !all_aligned(r)) return false;
-	const int grid = sweep_grid(sc, n, sc.sadd_per_cu > 0 ? sc.sadd_per_cu : 2);
+	const int grid = sadd_grid(sc, n);
 	if (!drain->carry || drain->carry_count < 2 * (size_t) grid * kBlock) return false;
-	const int T = sc.combine_batch;
-	const size_t round = (size_t) grid * kBlock * (size_t) (T >= 8 ? 8 : (T >= 4 ? 4 : 1));
-	return n / kVec >= 2 * round;
+	return n / kVec >= 2 * (size_t) grid * kBlock;
 }
 
 // ---- checksum of a vector's bit pattern (sqn_device.hpp: XHash) ---------------------------------------------------------
@@ -1692,20 +1787,24 @@ void launch_spec_x(const Scratch& sc, size_t n, const real* r, const real* x, do
 Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows, real* r, const Partials& pass2, const CoefArgs& a,
                      const SliceFeed* drain)
 {
-	const int grid = sweep_grid(sc, n, sc.sadd_per_cu > 0 ? sc.sadd_per_cu : 2);
+	const int grid = sadd_grid(sc, n);
 	const bool vec = rows_aligned(s_rows) && all_aligned(r);
 	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
 	const Fold3 fo = fold_args(sc, pass2, a, -1);
 	const uint32_t keep = keep_from_pack(sc, n, vec);
+	const bool ph = sc.phase_inv != 0;
+	const int ng = (s_rows.count + 7) / 8;
 	{
 		ProfScope ps(sc, K_SADD);
-		#define SQN_SA2(WW, T, SS) hipLaunchKernelGGL((k_sadd<WW, true, T, SS, false>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, fo, r, (uint32_t) n, rev, keep, sc.part[buf], Slice{})
-		#define SQN_SA(WW, T) { if (sc.stream_stores) SQN_SA2(WW, T, true); else SQN_SA2(WW, T, false); }
-		const int T = sc.combine_batch;
+		#define SQN_SA3(WW, NG, SL, SLICE) { if (ph) hipLaunchKernelGGL((k_sadd<WW, NG, true, true, SL>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, fo, r, (uint32_t) n, rev, keep, sc.part[buf], SLICE, sc.phase_inv); \
+		                                     else hipLaunchKernelGGL((k_sadd<WW, NG, true, false, SL>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, fo, r, (uint32_t) n, rev, keep, sc.part[buf], SLICE, 0u); }
+		#define SQN_SA(WW, SL, SLICE) { if (ng <= 1) SQN_SA3(WW, 1, SL, SLICE) else if (ng == 2) SQN_SA3(WW, 2, SL, SLICE) else if (ng == 3) SQN_SA3(WW, 3, SL, SLICE) \
+		                                else if (ng == 4) SQN_SA3(WW, 4, SL, SLICE) else if (ng == 5) SQN_SA3(WW, 5, SL, SLICE) else SQN_SA3(WW, 6, SL, SLICE) }
 		if (sadd_can_slice(sc, n, s_rows, r, drain)) {
-			// the pass in slices of whole rounds (T packs per lane and round); after the launch of slice s its part of r is final
-			// and drain->arrive is told: a host caller's x is sent on its way from there (machines.cpp: enqueue_step)
-			const size_t packs = n / kVec, round = (size_t) grid * kBlock * (size_t) (T >= 8 ? 8 : (T >= 4 ? 4 : 1));
+			// the pass in slices of whole rounds of the grid; after the launch of slice s its part of r is final (a phased kernel
+			// flushes what it has parked before it ends) and drain->arrive is told: a host caller's x is sent on its way from
+			// there (machines.cpp: enqueue_step)
+			const size_t packs = n / kVec, round = (size_t) grid * kBlock;
 			size_t per = (packs + (size_t) drain->slices - 1) / (size_t) drain->slices;
 			per = (per + round - 1) / round * round;
 			const size_t last = packs - 1;
@@ -1716,19 +1815,15 @@ Partials launch_sadd(const Scratch& sc, int buf, size_t n, const RowSet& s_rows,
 				size_t hi = rev ? (last - pb + 1) * kVec : pe * kVec;
 				if (!rev && pe == packs) hi = n;                  // forward: the odd elements lie next to the last slice
 				const Slice sl{(uint32_t) pb, (uint32_t) pe, drain->carry, pb == 0, pe == packs};
-				#define SQN_SAS(T, SS) hipLaunchKernelGGL((k_sadd<kVec, true, T, SS, true>), dim3(grid), dim3(kBlock), 0, sc.stream, s_rows, fo, r, (uint32_t) n, rev, keep, sc.part[buf], sl)
-				if (T >= 8) { if (sc.stream_stores) SQN_SAS(8, true); else SQN_SAS(8, false); }
-				else if (T >= 4) { if (sc.stream_stores) SQN_SAS(4, true); else SQN_SAS(4, false); }
-				else { if (sc.stream_stores) SQN_SAS(1, true); else SQN_SAS(1, false); }
-				#undef SQN_SAS
+				SQN_SA(kVec, true, sl)
 				drain->arrive(drain->user, lo, hi, s);
 			}
 			if (rev && n > packs * kVec) drain->arrive(drain->user, packs * kVec, n, s);   // reversed: they lie at the other end
 		}
-		else if (vec) { if (T >= 8) SQN_SA(kVec, 8) else if (T >= 4) SQN_SA(kVec, 4) else SQN_SA(kVec, 1) }
-		else     { if (T >= 4) SQN_SA(1, 4) else SQN_SA(1, 1) }
+		else if (vec) SQN_SA(kVec, false, Slice{})
+		else SQN_SA(1, false, Slice{})
 		#undef SQN_SA
-		#undef SQN_SA2
+		#undef SQN_SA3
 	}
 	return finish(sc, buf, 2, grid);
 }

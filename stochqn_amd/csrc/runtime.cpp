@@ -516,9 +516,8 @@ void begin_call(DevCtx* c)
 	c->sc.grid_cap = g_opt.grid_cap > 0 ? g_opt.grid_cap : default_grid_cap();
 	c->sc.reverse = g_opt.reverse;
 	c->sc.rows_split = g_opt.rows_split;
-	c->sc.combine_batch = g_opt.combine_batch;
 	c->sc.fisher_rows = g_opt.fisher_rows;
-	c->sc.stream_stores = g_opt.stream_stores;
+	c->sc.phase_inv = g_opt.phase_ticks > 0 ? (uint32_t) (4294967296.0 / (double) g_opt.phase_ticks) : 0u;
 	c->sc.keep_tail = g_opt.keep_tail;
 	c->sc.qdot_per_cu = g_opt.qdot_per_cu; c->sc.sadd_per_cu = g_opt.sadd_per_cu; c->sc.sdot2_per_cu = g_opt.sdot2_per_cu; c->sc.sdot_per_cu = g_opt.sdot_per_cu;
 	c->sc.prof = g_profile ? &c->prof : nullptr;
@@ -1292,9 +1291,8 @@ int stochqn_hip_set_option(const char* name, double value)
 		g_opt.grid_cap = g;
 	}
 	else if (!std::strcmp(name, "rows_split")) g_opt.rows_split = value != 0;
-	else if (!std::strcmp(name, "combine_batch")) g_opt.combine_batch = (int) value;
 	else if (!std::strcmp(name, "fisher_rows")) g_opt.fisher_rows = (int) value;
-	else if (!std::strcmp(name, "stream_stores")) g_opt.stream_stores = value != 0;
+	else if (!std::strcmp(name, "phase_ticks")) g_opt.phase_ticks = value < 2 ? 0 : (value > 1e8 ? 100000000 : (int) value);
 	else if (!std::strcmp(name, "spec_x")) g_opt.spec_x = value != 0;
 	else if (!std::strcmp(name, "x_prefetch")) g_opt.x_prefetch = value != 0;
 	else if (!std::strcmp(name, "keep_tail")) g_opt.keep_tail = value < 0 ? 0 : (value > 1 ? 1 : value);

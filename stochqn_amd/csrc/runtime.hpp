@@ -29,7 +29,6 @@ struct Options {
 	// pass 1 without a second probe: every lane keeps all rows (fp64: 5.1-5.2 ms; the row-split form is within
 	// +-3 % of it depending on the device) or the waves of a workgroup split the rows (fp32: 2.5 vs 5.9 ms)
 	bool rows_split = sizeof(real) == 4;
-	int combine_batch = 8;       // packs a lane finishes in pass 3 before it stores them
 	bool reverse = true;
 	// 1: the three-pass form (S twice, Y once: (3k+5) n words) when the ring has <= kPairsMax3 pairs and every pair in use is
 	// tame ("kappa_max"); 0: always the reference's chain of dependent sweeps (8k n words)
@@ -41,7 +40,9 @@ struct Options {
 	double keep_tail = 0.35;
 	bool x_prefetch = false;      // with x_upload = 0: when a call hands *req == x back and the device copy of x is stale, x starts its way up on a side stream while the caller evaluates its gradient (reads the caller's x after the call has returned: opt-in)
 	bool spec_x = true;           // host callers, three-pass form: slices of x start their way down while pass 3 is still running
-	bool stream_stores = true;   // pass 2 / pass 3: sc1 nt stores (kernels.hip: st_stream)
+	// pass 2 / pass 3: results parked in LDS, every wave stores them when the chip-wide 100 MHz clock enters a new period of this
+	// many ticks (kernels.hip: Parked; 4000 - 10000 measured alike, 2000 and 16000 1 - 3 % behind); 0 = each pack stored at once
+	int phase_ticks = 8000;
 	double kappa_max = 1e6;      // three-pass form only while every pair in use has |s||y|/|s'y| <= this (else: sweeps)
 	// host callers: copy the search direction back into `grad` (n words over PCIe).  The reference documents `grad` as an
 	// input that "will be modified in-place" (include/stochqn.h:356-358), not as an output, and no shipped caller reads it

@@ -97,11 +97,10 @@ struct Scratch {
 	double* gsy;          // [m][m] cached block  gsy[i*m+j] = s_i'y_j   (physical rows; pair i older than pair j)
 	int grid_cap;         // max workgroups per sweep (<= kMaxGrid); default = one per CU
 	bool rows_split;      // pass 1 without a second probe as the row-split rows-dot kernel (float build)
-	int combine_batch;    // packs a lane finishes in pass 3 before storing them (1, 4, 8)
 	int fisher_rows;      // Fisher rows one workgroup accumulates per pass over its columns: 8, 16 or 32
 	int qdot_per_cu, sadd_per_cu, sdot2_per_cu, sdot_per_cu;   // workgroups per CU of the three-pass kernels (0 = default)
 	double keep_tail;     // three-pass form: fraction of r0 / r (the part written last) stored with the default policy instead of sc1 nt
-	bool stream_stores;   // pass 2 / pass 3 store their result with the agent-scope non-temporal policy (sc1 nt)
+	uint32_t phase_inv;   // pass 2 / pass 3: 2^32 / (ticks of the 100 MHz clock per store phase), 0 = every pack stored at once (kernels.hip: Parked)
 	bool nontemporal;     // stream S/Y/F rows with nt loads
 	bool reverse;         // alternate the traversal direction from sweep to sweep (Infinity-Cache reuse of q / r)
 	int* phase;           // sweep counter of the current API call (parity = direction)

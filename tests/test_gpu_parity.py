@@ -273,6 +273,49 @@ def check_two_loop(n, m, used, st, mode):
     assert np.allclose(alpha[:used], alpha_w[:used], rtol=1e-9, atol=1e-13 * np.abs(alpha_w[:used]).max())
 
 
+@pytest.mark.parametrize("n,m,grid_cap", [(200_001, 20, 4), (70_002, 33, 2), (3_000_001, 20, 0), (1000, 5, 1)])
+@pytest.mark.parametrize("mode", ["gamma", "H0"])
+def test_clock_phased_stores_change_nothing_but_the_moment(n, m, grid_cap, mode, hip_backend):
+    """Passes 2 and 3 of the three-pass form park their results in LDS and store them when the chip-wide clock enters a new
+    period (`phase_ticks`, kernels.hip: Parked).  Whatever the period -- the default, one so short that every few iterations
+    flush, one so long that only full slots do -- and with the phases off (every pack stored at once), the direction, rho and
+    alpha are the same BITS: the same values reach the same addresses, only later.  A small grid_cap gives every lane hundreds
+    of packs (its 32 slots fill many times over) at a size the test can afford; the result is also held to the oracle."""
+    import stochqn_amd
+    from oracle import oracle
+    torch = torch_cuda()
+    lib = stochqn_amd.cdll()
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    rng = np.random.default_rng(n + m)
+    S, Y = make_pairs(rng, n, m)
+    g = rng.random(n) - 0.5
+    H0 = (0.5 + rng.random(n)) if mode == "H0" else None
+    used, st = m, 3 % m
+    want = g.copy()
+    oracle.two_loop(want, H0, 0.0, Y, S, m, used, st)
+    dS, dY = (torch.as_tensor(a, device="cuda") for a in (S, Y))
+    dH0 = None if H0 is None else torch.as_tensor(H0, device="cuda")
+    got = {}
+    try:
+        assert lib.stochqn_hip_set_option(b"raw_reuse_cache", 1.0) == 0        # the isolated entry in the three-pass form
+        assert lib.stochqn_hip_set_option(b"grid_cap", float(grid_cap)) == 0
+        for ticks in (8000, 0, 3, 50, 100000000):
+            assert lib.stochqn_hip_set_option(b"phase_ticks", float(ticks)) == 0
+            dg = torch.as_tensor(g, device="cuda")
+            rho, alpha = hip_two_loop(lib, dg, dH0, 0.0, dY, dS, n, m, used, st)
+            got[ticks] = (dg.cpu().numpy(), rho, alpha)
+            lib.stochqn_hip_release(C.c_void_p(dS.data_ptr()))
+    finally:
+        lib.stochqn_hip_set_option(b"phase_ticks", 8000.0)
+        lib.stochqn_hip_set_option(b"grid_cap", 0.0)
+        lib.stochqn_hip_set_option(b"raw_reuse_cache", 0.0)
+        lib.stochqn_hip_release(C.c_void_p(dS.data_ptr()))
+    assert rel_err(got[8000][0], want) <= TOL
+    for ticks in (0, 3, 50, 100000000):
+        for a, b in zip(got[ticks], got[8000]):
+            assert np.array_equal(a, b), "phase_ticks = %d differs from the default" % ticks
+
+
 def test_two_loop_host_pointers(hip_backend):
     """Same entry point fed with plain numpy memory (staged over PCIe behind the ABI)."""
     import stochqn_amd
