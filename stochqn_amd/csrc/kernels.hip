@@ -169,7 +169,7 @@ template <int W, int NS = 1> struct Parked {
 	static constexpr int kCap = kParkSlots / NS;
 	typename Stored<W>::type* slots;
 	real* out[NS];                 // where stream s goes (NULL: nowhere)
-	int pol[NS];                   // 0: default store policy; 1: sc1 nt except the tail from keep_from on; 2: non-temporal
+	int pol[NS];                   // 0: default store policy; 1: sc1 nt (stream 0: except the tail from keep_from on); 2: non-temporal
 	uint32_t p_first, epoch, inv, stride, last, keep_from;
 	bool rev;
 	int b;
@@ -186,7 +186,7 @@ template <int W, int NS = 1> struct Parked {
 			const uint32_t i = (rev ? last - p : p) * W;
 			#pragma unroll
 			for (int s = 0; s < NS; s++)
-				if (out[s]) st_stored<W>(out[s], i, slots[(bb * NS + s) * kBlock + threadIdx.x], (pol[s] == 1 && p >= keep_from) ? 0 : pol[s]);
+				if (out[s]) st_stored<W>(out[s], i, slots[(bb * NS + s) * kBlock + threadIdx.x], (s == 0 && p >= keep_from) ? 0 : pol[s]);
 		}
 		b = 0;
 	}
@@ -759,7 +759,7 @@ __global__ void __launch_bounds__(kBlock) k_fisher_y(const real* F, size_t ld_, 
 	const uint32_t stride = gridDim.x * kBlock;
 	constexpr int R = 8;
 	Parked<W> pk;
-	if constexpr (PH) { pk.open(park, phase_inv, stride, false, 0u, 0u); pk.out[0] = y; pk.pol[0] = 0; }
+	if constexpr (PH) { pk.open(park, phase_inv, stride, false, 0u, 0xFFFFFFFFu); pk.out[0] = y; pk.pol[0] = 1; }
 	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
 		Pack<W> a;
 		#pragma unroll
@@ -1103,7 +1103,7 @@ __global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, Fold3 fo, real* g, D
 	if constexpr (PH) {
 		pk.open(park, phase_inv, stride, rev != 0, last, keep_from);
 		pk.out[0] = g; pk.pol[0] = 1;
-		if constexpr (MODE == 2) { pk.out[1] = dg.G; pk.pol[1] = 0; pk.out[2] = dg.H0_out; pk.pol[2] = 0; pk.out[3] = dg.frow_out; pk.pol[3] = 2; }
+		if constexpr (MODE == 2) { pk.out[1] = dg.G; pk.pol[1] = 1; pk.out[2] = dg.H0_out; pk.pol[2] = 1; pk.out[3] = dg.frow_out; pk.pol[3] = 1; }
 	}
 	for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += stride) {
 		const uint32_t i = (rev ? last - p : p) * W;
