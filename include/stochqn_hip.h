@@ -108,8 +108,10 @@ int stochqn_hip_unpin_host(void *p);
  *                            include/stochqn.h:356-358), and none of its callers reads it afterwards (src/Rwrapper.c:98-196,
  *                            stochqn/pywrapper.pxi:161-207, example/c_rosen.c:103-118): off unless asked for.  Device
  *                            callers always find the direction in `grad` (it is computed there).
- * "keep_tail"   (default 0.35)  three-pass form: fraction of r0 / r -- the part written last, which the next pass reads
- *                            first -- stored with the default cache policy; the rest streams out (sc1 nt)
+ * "keep_tail"   (default 0)  three-pass form: fraction of r0 / r -- the part written last, which the next pass reads
+ *                            first -- stored with the default cache policy; the rest streams out (sc1 nt).  0.35 was worth 1 % while
+ *                            every pack was stored at once (rounds 2 - 3); with "phase_ticks" on, a write-back store is a store out
+ *                            of phase and 0 measures 1 - 2 % ahead
  * -- host callers (arrays of R / numpy / malloc crossing the ABI; INTEGRATION.md "host callers") --
  * "register_host" (default 0), "register_min_bytes" (default 4 MiB)  1: the library pins the caller's x / grad / hess_vec /
  *                            x_sum / x_avg_prev in place by itself (hipHostRegister) once an array has been seen at the same

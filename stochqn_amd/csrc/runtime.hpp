@@ -36,8 +36,10 @@ struct Options {
 	int fisher_rows = 16;        // Fisher rows per workgroup pass (8, 16, 32)
 	int qdot_per_cu = 0, sadd_per_cu = 0, sdot2_per_cu = 0, sdot_per_cu = 0;
 	// three-pass form: fraction of r0 / r stored with the default (cacheable) policy -- the part the next pass, which walks
-	// the other way, reads first; the rest leaves with sc1 nt.  0.25-0.5 measured 1 % ahead of 0 and of 1 (profiles/r03_ab_fold_tail.jsonl)
-	double keep_tail = 0.35;
+	// the other way, reads first; the rest leaves with sc1 nt.  Rounds 2 - 3 (every pack stored at once): 0.25-0.5 measured 1 % ahead
+	// of 0 and of 1 (profiles/r03_ab_fold_tail.jsonl).  With the clock-phased stores a write-back store is a store out of phase:
+	// 0 measures 1 - 2 % ahead of 0.35 (profiles/r04b_keep_tail_ab.log), 1 loses the phases altogether
+	double keep_tail = 0;
 	bool x_prefetch = false;      // with x_upload = 0: when a call hands *req == x back and the device copy of x is stale, x starts its way up on a side stream while the caller evaluates its gradient (reads the caller's x after the call has returned: opt-in)
 	bool spec_x = true;           // host callers, three-pass form: slices of x start their way down while pass 3 is still running
 	// pass 2 / pass 3: results parked in LDS, every wave stores them when the chip-wide 100 MHz clock enters a new period of this

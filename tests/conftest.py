@@ -9,8 +9,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _stable_heap():
+    """glibc raises its mmap threshold to the size of the largest chunk freed so far (up to 32 MiB), so after the first tests the
+    suite's 4 - 32 MiB numpy arrays -- the ones stochqn_amd/free.py page-locks (hipHostRegister: a userptr mapping of the GPU
+    driver) and the ones the HIP runtime page-locks on the fly for pageable copies -- live in the brk heap, which grows and is
+    trimmed by gigabytes between tests (26-call traces of 20 MB vectors).  Round 4 saw two GPU memory-access faults in ~10 runs of
+    the suite, the one whose message was captured on a brk-heap address above the then-current break.  A fixed
+    threshold gives every array of 1 MiB or more a mapping of its own -- page-aligned, unmapped exactly when the array dies,
+    after its finaliser has unpinned it -- and the break never moves down again.  Test process only; nothing in the product."""
+    try:
+        libc = C.CDLL("libc.so.6")
+        M_TRIM_THRESHOLD, M_MMAP_THRESHOLD = -1, -3
+        libc.mallopt(M_MMAP_THRESHOLD, 1 << 20)
+        libc.mallopt(M_TRIM_THRESHOLD, 1 << 30)          # (mallopt takes an int)
+    except OSError:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _stable_heap()
 
 
 @pytest.fixture(scope="session")
