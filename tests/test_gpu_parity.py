@@ -316,6 +316,43 @@ def test_clock_phased_stores_change_nothing_but_the_moment(n, m, grid_cap, mode,
             assert np.array_equal(a, b), "phase_ticks = %d differs from the default" % ticks
 
 
+@pytest.mark.parametrize("kind,use_float", [("SQN", False), ("adaQN", False), ("adaQN", True), ("oLBFGS", True)])
+def test_clock_phased_stores_leave_whole_runs_bit_identical(kind, use_float, hip_backend, hip_backend_f32):
+    """The same over whole optimiser runs, device-resident, in both builds: adaQN's pass 2 parks four vectors per pack (r0, G, H0
+    and the Fisher row), its pairs come out of the Fisher product, whose second pass parks y.  Every x, every request, every
+    counter of 40 calls with the phases on, off, and at a period of a few hundred nanoseconds: identical to the last bit.
+    (grid_cap = 2: two workgroups walk the whole vector, so every lane fills its slots many times at n = 300,001.)"""
+    import stochqn_amd
+    torch = torch_cuda()
+    lib = stochqn_amd.cdll(use_float)
+    be = hip_backend_f32 if use_float else hip_backend
+    lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    n = 300_001
+    P = NoisyQuadratic(n, seed=21)
+    kw = {"SQN": dict(mem_size=9, bfgs_upd_freq=3), "oLBFGS": dict(mem_size=9),
+          "adaQN": dict(mem_size=9, fisher_size=11, bfgs_upd_freq=3, max_incr=1.01, rmsprop_weight=0.9)}[kind]
+    dt = np.float32 if use_float else np.float64
+    runs = {}
+    try:
+        assert lib.stochqn_hip_set_option(b"grid_cap", 2.0) == 0
+        for ticks in (8000, 0, 40):
+            assert lib.stochqn_hip_set_option(b"phase_ticks", float(ticks)) == 0
+            x = torch.as_tensor(P.x0().astype(dt), device="cuda")
+            runs[ticks] = run_trace(OPTIMIZERS[kind](backend=be, space="device", device="cuda", use_float=use_float, **kw), P, x, 0.05, 40)
+            lib.stochqn_hip_release_all()
+    finally:
+        lib.stochqn_hip_set_option(b"phase_ticks", 8000.0)
+        lib.stochqn_hip_set_option(b"grid_cap", 0.0)
+        lib.stochqn_hip_release_all()
+    assert max(t["mem_used"] for t in runs[8000]) >= 5, "the ring never filled far enough for the three-pass form to matter"
+    for ticks in (0, 40):
+        for i, (a, b) in enumerate(zip(runs[8000], runs[ticks])):
+            assert a.keys() == b.keys()
+            for k in a:
+                same = np.array_equal(a[k], b[k], equal_nan=True) if isinstance(a[k], np.ndarray) else (a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]))
+                assert same, "phase_ticks = %d, call %d: %s differs" % (ticks, i, k)
+
+
 def test_two_loop_host_pointers(hip_backend):
     """Same entry point fed with plain numpy memory (staged over PCIe behind the ABI)."""
     import stochqn_amd
