@@ -246,20 +246,24 @@ def test_x_upload_is_the_default(hip_backend):
 def test_sliced_passes_equal_whole_launches(kind, hip_backend):
     """The two overlaps of the host path against their plain forms: pass 1 in slices that start as their part of the gradient
     lands (upload_slices; the accumulators are carried from launch to launch) and the update in slices whose x goes down
-    while the next is computed (apply_chunks), against one launch each with the copies before / after: same bits."""
+    while the next is computed (apply_chunks), against one launch each with the copies before / after: same bits.  A sliced
+    pass 3 ends every slice by storing what its lanes have parked (clock-phased stores, `phase_ticks`): with the phases off and
+    at a period of 300 ns the bits are the same again."""
     lib = _lib()
     n = 2_200_003
     P = NoisyQuadratic(n, seed=3)
     out = []
     try:
-        for chunks, slices in ((1.0, 0.0), (8.0, 8.0), (3.0, 5.0), (1.0, 16.0)):
+        for chunks, slices, ticks in ((1.0, 0.0, 8000.0), (8.0, 8.0, 8000.0), (3.0, 5.0, 8000.0), (1.0, 16.0, 8000.0), (8.0, 8.0, 0.0), (5.0, 3.0, 30.0)):
             assert lib.stochqn_hip_set_option(b"apply_chunks", chunks) == 0
             assert lib.stochqn_hip_set_option(b"upload_slices", slices) == 0
+            assert lib.stochqn_hip_set_option(b"phase_ticks", ticks) == 0
             out.append(run_trace(OPTIMIZERS[kind](backend=hip_backend, space="host", **KW[kind]), P, P.x0(), 0.05, 16))
             lib.stochqn_hip_release_all()
     finally:
         lib.stochqn_hip_set_option(b"apply_chunks", 8.0)
         lib.stochqn_hip_set_option(b"upload_slices", 8.0)
+        lib.stochqn_hip_set_option(b"phase_ticks", 8000.0)
     for other in out[1:]:
         for a, b in zip(out[0], other):
             assert a["task"] == b["task"] and a["info"] == b["info"]
