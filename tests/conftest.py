@@ -26,9 +26,49 @@ def _stable_heap():
         pass
 
 
+_TRACE = None
+
+
+def _pin_trace():
+    """A line per page-locked range that comes and goes (stochqn_amd/free.py through stochqn_hip_pin_host) and per test (its id, the
+    program break), flushed as written, in gpurun_out/pin_trace.log: should the GPU fault of DESIGN.md 7.1 come back, the log says
+    whether its address lay in a range that was page-locked at the time, in one that had been, or in none.  GPU runs only."""
+    global _TRACE
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        _TRACE = open(os.path.join(ROOT, "gpurun_out", "pin_trace.log"), "w", buffering=1)
+    except OSError:
+        return
+    from stochqn_amd import free
+    pin0, unpin0 = free._HostSpace.pin, free._unpin
+
+    def pin(self, a):
+        before = set(self._pins)
+        pin0(self, a)
+        for p in set(self._pins) - before:
+            _TRACE.write("pin   %#x +%d\n" % (p, a.nbytes))
+
+    def unpin(lib, ptr):
+        _TRACE.write("unpin %#x\n" % ptr)
+        unpin0(lib, ptr)
+
+    free._HostSpace.pin, free._unpin = pin, unpin
+
+
+@pytest.fixture(autouse=True)
+def _trace_test(request):
+    if _TRACE is not None:
+        libc = C.CDLL(None)
+        libc.sbrk.restype, libc.sbrk.argtypes = C.c_void_p, [C.c_long]
+        _TRACE.write("test  %s brk %#x\n" % (request.node.nodeid, libc.sbrk(0) or 0))
+    yield
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     _stable_heap()
+    if "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or ""):
+        _pin_trace()
 
 
 @pytest.fixture(scope="session")
