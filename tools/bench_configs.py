@@ -27,6 +27,9 @@ lib.stochqn_hip_profile_name.restype = C.c_char_p
 lib.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
 for _name, _val in [kv.split("=") for kv in os.environ.get("SQN_OPTS", "").split(",") if kv]:     # A/B of kernel-shape knobs
     assert lib.stochqn_hip_set_option(_name.encode(), float(_val)) == 0, _name
+    _f32 = stochqn_amd.cdll(use_float=True)                                                        # the float library has options of its own
+    _f32.stochqn_hip_set_option.argtypes = [C.c_char_p, C.c_double]
+    assert _f32.stochqn_hip_set_option(_name.encode(), float(_val)) == 0, _name
 
 
 def kernels():
