@@ -193,6 +193,14 @@ int main(int argc, char** argv)
 	printf("sadd  round-3 shape T %d grid %-4d : %.3f ms  %.0f GB/s\n", T, GRID, ms, (K + 2.0) * 8.0 * n / ms / 1e6); fflush(stdout); }
 #define RE(NR, NWR, NB, PH, U, POL, GRID, TICKS, WHAT) { double ms = time_ms([&](int) { hipLaunchKernelGGL((k_ew<NR, NWR, NB, PH, U, POL>), dim3(GRID), dim3(BLOCK), 0, 0, x, xs, g, n, parts, INV(TICKS)); }); \
 	printf("%-7s %-14s NB %-3d U %d pol %d period %-6d grid %-4d : %.3f ms  %.0f GB/s\n", WHAT, PH ? "clock-phased" : "store at once", NB, U, POL, PH ? (int) (TICKS) : 0, GRID, ms, (NR + NWR) * 8.0 * n / ms / 1e6); fflush(stdout); }
+	if (argc > 2) {         // the guarded update's shape only: store policy x grid
+		for (int rep = 0; rep < 3; rep++) {
+			RE(3, 2, 16, 0, 2, 0, 2 * cus, 8000, "update"); RE(3, 2, 16, 0, 2, 1, 2 * cus, 8000, "update"); RE(3, 2, 16, 0, 2, 0, 3 * cus, 8000, "update"); RE(3, 2, 16, 0, 2, 1, 3 * cus, 8000, "update");
+			RE(3, 2, 16, 0, 2, 0, 4 * cus, 8000, "update"); RE(3, 2, 16, 0, 2, 1, 4 * cus, 8000, "update"); RE(3, 2, 16, 0, 4, 0, 2 * cus, 8000, "update"); RE(3, 2, 16, 0, 4, 1, 2 * cus, 8000, "update");
+			RE(3, 2, 16, 0, 1, 0, 4 * cus, 8000, "update"); RE(3, 2, 16, 0, 1, 1, 4 * cus, 8000, "update");
+		}
+		return 0;
+	}
 	for (int rep = 0; rep < 2; rep++) {
 		RS3(8, 2 * cus); RS(1, 0, 1, cus, 8000); RS(1, 0, 2, 2 * cus, 8000);
 		RS(32, 1, 1, cus, 4000); RS(32, 1, 1, cus, 8000); RS(16, 1, 2, 2 * cus, 4000); RS(16, 1, 2, 2 * cus, 8000);
