@@ -213,6 +213,7 @@ class Workload:
         self.ptr2t = {self.x.data_ptr(): self.x, self.x_sum.data_ptr(): self.x_sum, self.x_avg_prev.data_ptr(): self.x_avg_prev}
         self.counters = {"calls": 0, "hv": 0, "bad": 0, "rejected": 0}
         self.t_idx = 0
+        self.steps_done, self.resets, self.warm = 0, 0, 5
         # the caller's Hessian-vector routine A'(A v)/bs, checked once (on v = x0) against plain torch products over the same batch.
         # This is also where its one-time set-up happens (the product's scratch and stream: 5.8 ms on the first call, which would
         # otherwise land in whichever timed step builds the first pair -- 2.7 % of a K = 20 window)
@@ -265,6 +266,33 @@ class Workload:
     def steps(self, k):
         for _ in range(k):
             self.one_step()
+        self.steps_done += k
+
+    # The curvature pairs of this workload come from a rank-`bs` matrix (A'A/bs), not from the Hessian of f: after ~1700 steps
+    # with one optimiser state the objective stalls and near step 2800 it blows up -- in every form of the recursion alike, the
+    # reference's own sweeps included (tools/long_run_probe.sh, profiles/r04b_long_run_ladder.log).  No leg may walk into that:
+    # the direction would turn non-finite, the guard would reject the steps and a rejected step skips the update (less work).
+    STABLE_STEPS = 1500
+
+    def keep_stable(self, planned):
+        """Before a leg of `planned` steps: back to the initial state if this state would leave the stable regime during it."""
+        if self.steps_done + planned > self.STABLE_STEPS:
+            self.reset()
+
+    def reset(self):
+        """x0, the synthetic ring and empty averages again -- what the K-step region started from (then `warm` warm-up steps)."""
+        self.uniform(self.x, ST_X0, 0, 1.0, 1.0)
+        self.fill_ring()
+        self.x_sum.zero_()
+        self.x_avg_prev.copy_(self.x)
+        self.b.mem_used, self.b.mem_st_ix = self.m, 3 % self.m
+        self.w.niter, self.w.section = self.L, 1
+        self.req.value, self.req_vec.value = self.x.data_ptr(), None
+        self.task.value, self.info.value = 101, 200
+        self.ctx["lib"].stochqn_hip_invalidate(C.c_void_p(self.S.data_ptr()))      # the ring was rewritten from outside
+        self.steps_done = 0
+        self.resets += 1
+        self.steps(self.warm)
 
     def objective(self):
         import torch
@@ -467,6 +495,7 @@ def run(args):
 
     # ---- the measurement: W warm-up steps, then EXACTLY K steps, profiler off -----------------------
     f0 = wl.objective()
+    wl.warm = args.warmup
     wl.steps(args.warmup)
     lib.stochqn_hip_profile_enable(0)
     barrier(ctx)
@@ -502,6 +531,7 @@ def run(args):
             torch.cuda.empty_cache()
             wl.pad = torch.empty(int(7 + 64 * len(vals)) << 18, dtype=f64, device=dev)     # shifts where the new array lands
             wl.grad = torch.empty(n, dtype=f64, device=dev)
+            wl.keep_stable(L + args.steps)
             wl.steps(L)
             barrier(ctx)
             tv = time.perf_counter()
@@ -518,6 +548,8 @@ def run(args):
     sustained = None
     if args.sustain_seconds > 0:
         extra = max(L, int(args.sustain_seconds / (elapsed / args.steps)) // L * L)
+        extra = min(extra, wl.STABLE_STEPS - wl.warm) // L * L
+        wl.keep_stable(extra)
         barrier(ctx)
         ts = time.perf_counter()
         wl.steps(extra)
@@ -531,6 +563,7 @@ def run(args):
     kern, prof_elapsed, prof_steps = {}, None, 0
     if not args.no_profile:
         prof_steps = max(L, min(args.steps, 4 * L)) // L * L                # whole L-cycles: the pair-building calls in proportion
+        wl.keep_stable(prof_steps + 12)                                     # + the reference-form steps below
         lib.stochqn_hip_profile_enable(1)
         lib.stochqn_hip_profile_reset()
         barrier(ctx)
@@ -630,6 +663,8 @@ def run(args):
         del hostc
         gpu = None
 
+    # no leg after the timed region may have had a step rejected: a rejected step skips the update, and its time would be that of less work
+    assert wl.counters["bad"] == timed_counters["bad"], "a leg after the timed region had %d step(s) rejected" % (wl.counters["bad"] - timed_counters["bad"])
     par = ("n sharded over %d GPU(s), one process per GPU; one RCCL all-reduce per dot product" % world)
     if args.rehearse:
         par = "REHEARSAL: %d ranks sharing one GPU, all-reduce over gloo -- not a measurement" % world
@@ -654,9 +689,14 @@ def run(args):
                        "rejected_steps": timed_counters["bad"], "rejected_pairs": timed_counters["rejected"],
                        "options": args.opt,
                        "deviation_from_survey_8d": "Hessian mini-batch: the 32 sample vectors have disjoint supports (a_k,i = sqrt(32 d_i) for "
-                                                   "i = k mod 32, else 0; stored dense, streamed in full) so that A'A/32 = diag(d) is the exact "
-                                                   "Hessian of the objective; SURVEY 8d writes a_k,i = sqrt(d_i)(1 + 0.1(2u - 1)) for every i, whose "
-                                                   "A'A/32 is a rank-32 matrix unrelated to it.  Same storage, same traffic (PMC: 27.2 GB per pass).",
+                                                   "i = k mod 32, else 0; stored dense, streamed in full): A'A/32 has the diagonal d of the objective's "
+                                                   "Hessian and couples the variables of a residue class (32 rank-one blocks); SURVEY 8d writes "
+                                                   "a_k,i = sqrt(d_i)(1 + 0.1(2u - 1)) for every i, whose A'A/32 is one rank-32 matrix of norm ~ n.  Same "
+                                                   "storage, same traffic (PMC: 27.2 GB per pass).  Either way the curvature pairs come from a rank-32 matrix: "
+                                                   "one optimiser state is good for ~1500 steps (the objective stalls near step 1700 and blows up near 2800 in "
+                                                   "every form of the recursion, the reference's own sweeps included), so every leg after the timed region "
+                                                   "starts again from the initial state when it would pass that (`workload_resets`).",
+                       "workload_resets": wl.resets,
                        "f_start": f0, "f_end": f1},
             "rccl_nranks": 0 if (reducer or "").startswith("gloo (the library") else rccl_nranks,      # ranks of the communicator the reductions used
             "reducer": reducer,
