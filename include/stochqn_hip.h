@@ -96,13 +96,16 @@ int stochqn_hip_unpin_host(void *p);
  *                            with its options: the three-pass form dominated it on bytes, time and accuracy.)
  * "rows_split", "sdot_per_cu", "sdot2_per_cu", "qdot_per_cu", "sadd_per_cu": kernel-shape knobs (rows of pass 1 split over the
  *                            waves of a workgroup; grid sizes in workgroups per compute unit); the defaults are the measured
- *                            optima, DESIGN.md 3.0
+ *                            optima, DESIGN.md 3.0.  With "phase_ticks" on, passes 2 and 3 (and the second Fisher pass) hold
+ *                            ~150 KB of LDS per workgroup, so ONE workgroup is resident per compute unit whatever these say:
+ *                            "qdot_per_cu" / "sadd_per_cu" > 1 then only make the grid larger (more, shorter rounds), they do
+ *                            not put two workgroups side by side on a compute unit
  * "phase_ticks" (default 8000)  three-pass form, passes 2 and 3: the lanes park their results in LDS and every wave stores what
  *                            it has parked when the chip-wide 100 MHz clock enters a new period of this many ticks (or when
  *                            its 32 slots are full), so that the whole chip writes at the same moment and reads the rest of
  *                            the time: the one store stream among ~20 read streams then costs 0.18 ms instead of 0.48 ms per
- *                            pass at n = 1e8.  Same values at the same addresses, only later.  0: every pack
- *                            is stored as soon as it is final (rounds 2 - 3)
+ *                            pass at n = 1e8.  Same values at the same addresses, only later.  0 (or < 2): every
+ *                            pack is stored as soon as it is final (rounds 2 - 3); values from 2 to 63 are raised to 64
  * "strict_grad" (default 0)  host callers: copy the search direction back into `grad` (n words over PCIe per step).  The
  *                            reference documents `grad` as an INPUT that "will be modified in-place" (reference
  *                            include/stochqn.h:356-358), and none of its callers reads it afterwards (src/Rwrapper.c:98-196,
@@ -124,11 +127,13 @@ int stochqn_hip_unpin_host(void *p);
  *                            another array, after a request that was not at x, or when any of 256 spread-out probe values
  *                            differs from what the library handed back -- for callers that vouch they do not touch x while
  *                            *req designates it (reference include/stochqn.h:364-366).  2: nobody vouches and the library
- *                            finds out: a checksum of ALL of the caller's x (the buffer as 64-bit words w_i: sum w_i and
- *                            sum (2i+1) w_i mod 2^64), taken by "hash_threads" host threads while the gradient travels, against
- *                            the same sums of the device copy, taken on the device when the last call ended.  Equal: no upload
- *                            ("x_uploads_skipped").  A change of any one coordinate changes the first sum; large x only
- *                            (>= "host_slice_min" elements)
+ *                            finds out: a checksum of ALL of the caller's x (the buffer as 64-bit words w_i, each mixed with its
+ *                            position by a non-linear bijection of 64 bits, h_i = mix(w_i xor key_i): sum h_i and
+ *                            sum (2i+1) rot32(h_i) mod 2^64), taken by "hash_threads" host threads while the gradient travels,
+ *                            against the same sums of the device copy, taken on the device when the last call ended.  Equal: no
+ *                            upload ("x_uploads_skipped").  A change of any one coordinate changes the first sum for certain;
+ *                            any other edit (two sign flips, x -> -x, a swap: what sums of the plain words cannot see) passes
+ *                            only on a collision of two 64-bit sums of mixed values.  Large x only (>= "host_slice_min" elements)
  * "hash_threads" (default 0) host threads that take the checksum of x ("x_upload" = 2); 0: 8 (half the hardware threads below 16),
  *                            shared among the shards of a multi-device group
  * "upload_slices" (default 8)  three-pass form: pass 1 runs in this many slices, each as soon as its part of `grad` has landed
@@ -236,7 +241,11 @@ int stochqn_hip_comm_allreduce_probe(int count, int reps, double *median_us, dou
  *                               (INTEGRATION.md): the last two count steps whose x started its way to the host while pass 3 was still
  *                               running (option "spec_x"), and those of them that the guard then rejected (the old x was sent again).
  *   "host_pins_live" (a gauge: ranges pinned through stochqn_hip_pin_host right now), "host_unpin_failed" (unpins the
- *                               runtime refused: such a range stays page-locked in its books and must not be freed).
+ *                               runtime refused: such a range stays page-locked in its books and must not be freed);
+ *   "host_copies_in_flight"     the invariant of the host path, asked of the runtime (hipStreamQuery) at the return of every
+ *                               run_* call of a host caller: streams of the context that still had work on them.  Always 0 --
+ *                               the caller may free x, grad or the requested vector as soon as it has them back (the one
+ *                               upload that "x_prefetch" leaves running on purpose is not counted).
  * Returns the count, or -1 for an unknown name. */
 long long stochqn_hip_stat(const char *name);
 void stochqn_hip_stats_reset(void);

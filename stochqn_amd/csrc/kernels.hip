@@ -175,7 +175,7 @@ template <int W, int NS = 1> struct Parked {
 	int b;
 	__device__ __forceinline__ void open(typename Stored<W>::type* lds, uint32_t inv_, uint32_t stride_, bool rev_, uint32_t last_, uint32_t keep_from_)
 	{
-		slots = lds; inv = inv_ * (uint32_t) NS; stride = stride_; rev = rev_; last = last_; keep_from = keep_from_;
+		slots = lds; inv = inv_ > 0xFFFFFFFFu / (uint32_t) NS ? 0xFFFFFFFFu : inv_ * (uint32_t) NS; stride = stride_; rev = rev_; last = last_; keep_from = keep_from_;
 		b = 0; p_first = 0; epoch = phase_epoch(inv);
 	}
 	__device__ __forceinline__ void flush()
@@ -1734,7 +1734,8 @@ bool sadd_can_slice(const Scratch& sc, size_t n, const RowSet& s_rows, const rea
 }
 
 // ---- checksum of a vector's bit pattern (sqn_device.hpp: XHash) ---------------------------------------------------------
-// Read-only, one pass, 16-byte loads; the sums are integers mod 2^64, so any order of accumulation gives the same two words.
+// Read-only, one pass, 16-byte loads; every word is mixed with its position (xhash_word), the sums of the mixed words are integers
+// mod 2^64, so any order of accumulation gives the same two words.
 __global__ void __launch_bounds__(kBlock) k_xhash(const ulonglong2* __restrict__ w2, size_t pairs, const unsigned char* __restrict__ rest,
                                                   int rest_bytes, unsigned long long* __restrict__ out)
 {
@@ -1742,15 +1743,14 @@ __global__ void __launch_bounds__(kBlock) k_xhash(const ulonglong2* __restrict__
 	const size_t stride = (size_t) gridDim.x * kBlock;
 	for (size_t p = (size_t) blockIdx.x * kBlock + threadIdx.x; p < pairs; p += stride) {
 		const ulonglong2 v = w2[p];
-		a += v.x + v.y;
-		b += (4 * p + 1) * v.x + (4 * p + 3) * v.y;          // words 2p and 2p + 1: multipliers 2i + 1
+		xhash_word(v.x, 2 * p, a, b);                         // words 2p and 2p + 1
+		xhash_word(v.y, 2 * p + 1, a, b);
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0 && rest_bytes > 0) {      // what is left of the buffer after the last pair: up to 15 bytes
 		unsigned long long w[2] = {0, 0};
 		for (int i = 0; i < rest_bytes; i++) w[i / 8] |= (unsigned long long) rest[i] << (8 * (i % 8));
-		a += w[0];
-		b += (4 * pairs + 1) * w[0];
-		if (rest_bytes > 8) { a += w[1]; b += (4 * pairs + 3) * w[1]; }
+		xhash_word(w[0], 2 * pairs, a, b);
+		if (rest_bytes > 8) xhash_word(w[1], 2 * pairs + 1, a, b);
 	}
 	for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
 	__shared__ unsigned long long la[kBlock / 64], lb[kBlock / 64];

@@ -52,7 +52,7 @@ std::atomic<long long> g_stats[ST_COUNT];
 const char* const kStatNames[ST_COUNT] = {
 	"steps_three_pass", "steps_sweeps", "steps_plain", "steps_kappa_fallback",
 	"allreduces", "allreduce_doubles", "contexts_created", "contexts_reclaimed", "x_uploads", "x_uploads_skipped",
-	"host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched", "host_unpin_failed"};
+	"host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched", "host_unpin_failed", "host_copies_in_flight"};
 
 // Copies between device memory and ORDINARY host memory on the reclaim path, which by definition runs when the device is
 // full: through a small pinned buffer made while memory was still plentiful (with the first mirror), so that the runtime
@@ -85,55 +85,6 @@ hipError_t bounced_copy(void* dst, const void* src, size_t bytes, bool to_host)
 		}
 	}
 	return hipSuccess;
-}
-
-// ---- experiment (round 4): the library's own scratch from ONE arena reserved at the first API call ------
-// STOCHQN_HIP_ARENA_MB=N in the environment: N MB of device memory are reserved the first time the library is asked whether a
-// device exists -- before the caller has made its big arrays -- and the per-context scratch pools (partials, landing zones of
-// the reductions, cached inner products) are carved from it (same-size blocks are reused, nothing is coalesced; a pool that
-// does not fit comes from hipMalloc as always).  The question: does where the library's own buffers land move the 5-8 %
-// run-to-run spread of the headline step?  Answer (profiles/r04_placement_arena.jsonl): see there.  Off by default.
-struct Arena {
-	char* base = nullptr;
-	size_t size = 0, used = 0;
-	std::vector<std::pair<void*, size_t>> free_blocks;
-} g_arena;
-std::mutex g_arena_mu;
-
-void arena_reserve()
-{
-	const char* e = std::getenv("STOCHQN_HIP_ARENA_MB");
-	const long mb = e ? std::atol(e) : 0;
-	if (mb <= 0) return;
-	std::lock_guard<std::mutex> lk(g_arena_mu);
-	if (g_arena.base) return;
-	if (hipMalloc((void**) &g_arena.base, (size_t) mb << 20) != hipSuccess) { (void) hipGetLastError(); g_arena.base = nullptr; return; }
-	g_arena.size = (size_t) mb << 20;
-}
-
-void* arena_alloc(size_t bytes)
-{
-	std::lock_guard<std::mutex> lk(g_arena_mu);
-	if (!g_arena.base || std::getenv("STOCHQN_HIP_ARENA_UNUSED")) return nullptr;      // _UNUSED: reserved, never carved (control of the experiment)
-	bytes = (bytes + 4095) & ~(size_t) 4095;
-	for (size_t i = 0; i < g_arena.free_blocks.size(); i++)
-		if (g_arena.free_blocks[i].second == bytes) {
-			void* p = g_arena.free_blocks[i].first;
-			g_arena.free_blocks.erase(g_arena.free_blocks.begin() + (long) i);
-			return p;
-		}
-	if (g_arena.used + bytes > g_arena.size) return nullptr;
-	void* p = g_arena.base + g_arena.used;
-	g_arena.used += bytes;
-	return p;
-}
-
-bool arena_free(void* p, size_t bytes)
-{
-	std::lock_guard<std::mutex> lk(g_arena_mu);
-	if (!g_arena.base || (char*) p < g_arena.base || (char*) p >= g_arena.base + g_arena.size) return false;
-	g_arena.free_blocks.emplace_back(p, (bytes + 4095) & ~(size_t) 4095);
-	return true;
 }
 
 bool alloc_should_fail()
@@ -241,9 +192,15 @@ bool loop_barrier(Loopback& lp)
 		lp.cv.notify_all();
 		return true;
 	}
-	// (a deadline on the system clock: pthread_cond_timedwait, which every sanitizer runtime knows; the wait is seconds long and coarse)
+#if defined(__SANITIZE_THREAD__)
+	// tests/hostsim's TSan build only: gcc 11's libtsan does not know pthread_cond_clockwait, which a steady-clock wait compiles to
 	const auto deadline = std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::system_clock::duration>(std::chrono::duration<double>(lp.patience_s));
-	if (!lp.cv.wait_until(lk, deadline, [&] { return lp.generation != gen || lp.broken; }) || lp.broken) {
+	const bool arrived = lp.cv.wait_until(lk, deadline, [&] { return lp.generation != gen || lp.broken; });
+#else
+	// the steady clock: a step of the wall clock (NTP, an operator) neither fires the patience early nor stretches it
+	const bool arrived = lp.cv.wait_for(lk, std::chrono::duration<double>(lp.patience_s), [&] { return lp.generation != gen || lp.broken; });
+#endif
+	if (!arrived || lp.broken) {
 		lp.broken = true;
 		lp.cv.notify_all();
 		return false;
@@ -302,7 +259,7 @@ void destroy(DevCtx* c, bool keep_spill = false)
 	for (auto e : c->prof.pool) (void) hipEventDestroy(e);
 	View* vs[] = {&c->S, &c->Y, &c->sbak, &c->ybak, &c->gprev, &c->xsum, &c->xprev, &c->H0, &c->G, &c->F};
 	for (View* v : vs) free_view(c, *v);
-	if (c->pool && !arena_free(c->pool, c->pool_bytes)) SQN_HIP_OK(hipFree(c->pool));
+	if (c->pool) SQN_HIP_OK(hipFree(c->pool));
 	if (c->sc.fisher_part) SQN_HIP_OK(hipFree(c->sc.fisher_part));
 	if (c->fisher_t) SQN_HIP_OK(hipFree(c->fisher_t));
 	for (real* p : c->stage) if (p) SQN_HIP_OK(hipFree(p));
@@ -569,7 +526,6 @@ bool device_ready()
 		int count = 0;
 		const hipError_t e = hipGetDeviceCount(&count);
 		if (e != hipSuccess || count <= 0) { (void) hipGetLastError(); return false; }
-		arena_reserve();
 		return true;
 	}();
 	return ready;
@@ -643,8 +599,7 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + m * m + 3 * m;
 	c->pin_count = 16 + 2 * m + fsize + 3 * m + 8;
 	c->pool_bytes = total * sizeof(double);
-	c->pool = (double*) arena_alloc(c->pool_bytes);
-	if ((!c->pool && !device_alloc((void**) &c->pool, c->pool_bytes)) ||
+	if (!device_alloc((void**) &c->pool, c->pool_bytes) ||
 	    !pinned_alloc((void**) &c->pin, c->pin_count * sizeof(double)) ||
 	    (fsize > 0 && (!device_alloc((void**) &c->sc.fisher_part, fsize * kMaxGrid * sizeof(double)) ||
 	                   !device_alloc((void**) &c->fisher_t, fsize * sizeof(double))))) {
@@ -748,11 +703,28 @@ static void prefetch_x(DevCtx* c, const real* x)
 	stat_add(ST_X_PREFETCH);
 }
 
+// The invariant of the host path (callers whose arrays live in a garbage-collected heap: reference src/Rwrapper.c:106-123,
+// stochqn/pywrapper.pxi:161-172): when a call returns, NOTHING the library enqueued on any of the context's streams is still
+// running -- the caller may free x, grad or the requested vector the moment it has them back.  Asked of the runtime itself
+// (hipStreamQuery), not of the library's own bookkeeping; every stream found busy counts one "host_copies_in_flight".  The one
+// exception is the upload that option x_prefetch starts on purpose, after this check.
+static void count_work_in_flight(DevCtx* c)
+{
+	if (c->async_call || !(c->stage[0] || c->stage[1] || c->copy_stream)) return;      // host callers only (stream-ordered device callers leave work behind by design)
+	for (hipStream_t s : {c->own_stream, c->copy_stream, c->down_stream}) {
+		if (!s || (s == c->copy_stream && c->x_pre_pending)) continue;
+		const hipError_t e = hipStreamQuery(s);
+		if (e == hipErrorNotReady) stat_add(ST_WORK_IN_FLIGHT);
+		if (e != hipSuccess) (void) hipGetLastError();
+	}
+}
+
 bool note_state(const void* key, size_t niter, int section, bool req_is_x, const real* x)
 {
 	std::lock_guard<std::recursive_mutex> lk(g_mu);
 	auto it = g_ctx.find(key);
 	if (it == g_ctx.end()) return false;
+	count_work_in_flight(it->second);
 	it->second->in_call = false;
 	detach_spill(it->second);                        // whatever the first call after a reclaim did not pick up is not this object's
 	// x is only known to be untouched until the next call while it is what *req designates ("do NOT modify", reference
@@ -968,18 +940,18 @@ void xhash_host(const void* buf, size_t bytes, size_t word_lo, size_t word_hi, X
 		unsigned long long w0, w1;
 		std::memcpy(&w0, p + 8 * i, 8);
 		std::memcpy(&w1, p + 8 * i + 8, 8);
-		a0 += w0; a1 += w1;
-		b0 += (2 * i + 1) * w0; b1 += (2 * i + 3) * w1;
+		xhash_word(w0, i, a0, b0);
+		xhash_word(w1, i + 1, a1, b1);
 	}
 	for (; i < hi_whole; i++) {
 		unsigned long long w;
 		std::memcpy(&w, p + 8 * i, 8);
-		a0 += w; b0 += (2 * i + 1) * w;
+		xhash_word(w, i, a0, b0);
 	}
 	if (word_hi > whole && word_lo <= whole && bytes > 8 * whole) {
 		unsigned long long w = 0;
 		std::memcpy(&w, p + 8 * whole, bytes - 8 * whole);       // little-endian: the low bytes
-		a0 += w; b0 += (2 * whole + 1) * w;
+		xhash_word(w, whole, a0, b0);
 	}
 	out->a = a0 + a1;
 	out->b = b0 + b1;
@@ -1292,7 +1264,9 @@ int stochqn_hip_set_option(const char* name, double value)
 	}
 	else if (!std::strcmp(name, "rows_split")) g_opt.rows_split = value != 0;
 	else if (!std::strcmp(name, "fisher_rows")) g_opt.fisher_rows = (int) value;
-	else if (!std::strcmp(name, "phase_ticks")) g_opt.phase_ticks = value < 2 ? 0 : (value > 1e8 ? 100000000 : (int) value);
+	// 0 = off; otherwise at least 64 ticks (640 ns): the kernels multiply 2^32 / ticks by the number of output streams of the pass
+	// (up to 4, adaQN's pass 2) in 32 bits, which a period of 2 or 3 ticks would wrap to a period that never ends
+	else if (!std::strcmp(name, "phase_ticks")) g_opt.phase_ticks = value < 2 ? 0 : (value < 64 ? 64 : (value > 1e8 ? 100000000 : (int) value));
 	else if (!std::strcmp(name, "spec_x")) g_opt.spec_x = value != 0;
 	else if (!std::strcmp(name, "x_prefetch")) g_opt.x_prefetch = value != 0;
 	else if (!std::strcmp(name, "keep_tail")) g_opt.keep_tail = value < 0 ? 0 : (value > 1 ? 1 : value);
@@ -1466,7 +1440,7 @@ long long stochqn_hip_stat(const char* name)
 void stochqn_hip_stats_reset(void)
 {
 	for (int i = 0; i < ST_COUNT; i++)
-		if (i != ST_HOST_UNPIN_FAILED) g_stats[i].store(0, std::memory_order_relaxed);       // that one is a fact about the process, not a rate
+		if (i != ST_HOST_UNPIN_FAILED && i != ST_WORK_IN_FLIGHT) g_stats[i].store(0, std::memory_order_relaxed);       // those two are facts about the process, not rates
 }
 
 int stochqn_hip_loopback_init(int nranks)

@@ -73,7 +73,8 @@ struct Options {
 	// they keep their hands off x while *req designates it (reference include/stochqn.h:364-366)
 	// 2: the library finds out by itself -- a checksum of ALL of the caller's x (sqn_device.hpp: XHash; `hash_threads` host threads,
 	// under the upload of the gradient) against the checksum of what the device holds, taken on the device at the end of the
-	// last call.  Equal: no upload.  Sound where the 256 probes were not: a change of any one coordinate changes the sum.
+	// last call.  Equal: no upload.  A change of any one coordinate changes the first sum for certain (the words are mixed one-to-one
+	// before they are summed); other edits pass only on a collision of two 64-bit sums of mixed values.
 	int x_upload = 1;
 	int hash_threads = 0;           // host threads that checksum x (x_upload = 2); 0: min(8, half the hardware threads), split among the shards of a group
 	long host_slice_min = 1l << 21; // host callers: vectors of fewer elements cross the link in one piece (a slice below ~8 MB is all launch overhead)
@@ -204,7 +205,7 @@ struct DevCtx {
 enum StatId {
 	ST_STEP_THREE_PASS = 0, ST_STEP_SWEEPS, ST_STEP_PLAIN, ST_KAPPA_FALLBACK,
 	ST_ALLREDUCE, ST_ALLREDUCE_DOUBLES, ST_CTX_CREATED, ST_CTX_RECLAIMED, ST_X_UPLOAD, ST_X_UPLOAD_SKIPPED,
-	ST_HOST_REGISTERED, ST_X_AHEAD, ST_X_RESENT, ST_X_PREFETCH, ST_HOST_UNPIN_FAILED, ST_COUNT
+	ST_HOST_REGISTERED, ST_X_AHEAD, ST_X_RESENT, ST_X_PREFETCH, ST_HOST_UNPIN_FAILED, ST_WORK_IN_FLIGHT, ST_COUNT
 };
 void stat_add(int id, long long v = 1);
 

@@ -227,10 +227,33 @@ void launch_spec_x(const Scratch& sc, size_t n, const real* r, const real* x, do
 void launch_store_column(const Scratch& sc, Partials in /*k: s_i'y_col*/, const CoefArgs& a, int col_row);
 
 // Checksum of the bit pattern of a vector (host callers, option "x_upload" = 2: is the caller's x still what the device holds?).
-// The buffer as 64-bit little-endian words w_0 .. w_{W-1} (a last partial word zero-extended): A = sum w_i, B = sum (2i+1) w_i,
-// both mod 2^64.  A change of any ONE word changes A; any other edit goes unnoticed only if both sums collide.  Integer sums:
-// the same on the device (launch_xhash, into out[0..1] viewed as two 64-bit words) and on the host (xhash_host, any partition).
+// The buffer as 64-bit little-endian words w_0 .. w_{W-1} (a last partial word zero-extended).  Every word is first mixed with
+// its position by a BIJECTION of 64 bits that is not linear over the integers or over GF(2) (splitmix64's finaliser):
+// h_i = mix(w_i xor (i G + K)); then A = sum h_i and B = sum (2i+1) rot32(h_i), both mod 2^64.  A change of any ONE word changes
+// A for certain (mix is one-to-one); any other edit -- sign flips of two coordinates, x -> -x, a swap of two words: the edits a
+// plain sum of the words is blind to -- goes unnoticed only if two 64-bit sums of unrelated mixed values collide.
+// Integer sums: the same on the device (launch_xhash, into out[0..1] viewed as two 64-bit words) and on the host (xhash_host,
+// any partition, any order).
 struct XHash { unsigned long long a = 0, b = 0; };
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline unsigned long long xhash_mix(unsigned long long w, unsigned long long i)
+{
+	unsigned long long z = w ^ (i * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull);
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline void xhash_word(unsigned long long w, unsigned long long i, unsigned long long& a, unsigned long long& b)
+{
+	const unsigned long long h = xhash_mix(w, i);
+	a += h;
+	b += (2 * i + 1) * ((h << 32) | (h >> 32));
+}
 void launch_xhash(const Scratch& sc, const real* x, size_t n, double* out2);       // ADDS into out2[0..1]: zero them first, on sc.stream
 void xhash_host(const void* buf, size_t bytes, size_t word_lo, size_t word_hi, XHash* out);    // words [lo, hi) of the buffer (runtime.cpp)
 inline size_t xhash_words(size_t bytes) { return (bytes + 7) / 8; }

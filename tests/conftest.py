@@ -17,11 +17,16 @@ def _stable_heap():
     the suite, the one whose message was captured on a brk-heap address above the then-current break.  A fixed
     threshold gives every array of 1 MiB or more a mapping of its own -- page-aligned, unmapped exactly when the array dies,
     after its finaliser has unpinned it -- and the break never moves down again.  Test process only; nothing in the product."""
+    mode = os.environ.get("STOCHQN_TEST_HEAP", "stable")   # round 5 (tools/suite_soak.sh): "default" = glibc's own thresholds, "brk" = 32 MiB / trim at every free
     try:
         libc = C.CDLL("libc.so.6")
         M_TRIM_THRESHOLD, M_MMAP_THRESHOLD = -1, -3
-        libc.mallopt(M_MMAP_THRESHOLD, 1 << 20)
-        libc.mallopt(M_TRIM_THRESHOLD, 1 << 30)          # (mallopt takes an int)
+        if mode == "stable":
+            libc.mallopt(M_MMAP_THRESHOLD, 1 << 20)
+            libc.mallopt(M_TRIM_THRESHOLD, 1 << 30)          # (mallopt takes an int)
+        elif mode == "brk":
+            libc.mallopt(M_MMAP_THRESHOLD, 32 << 20)
+            libc.mallopt(M_TRIM_THRESHOLD, 0)
     except OSError:
         pass
 

@@ -1,4 +1,4 @@
-// fake_hip.cpp -- malloc-backed stand-in for the 29 HIP runtime entry points the product's host logic calls
+// fake_hip.cpp -- malloc-backed stand-in for the 30 HIP runtime entry points the product's host logic calls
 // (TEST INFRASTRUCTURE ONLY; see fake_hip.hpp).  Signatures come from the real <hip/hip_runtime_api.h>, the
 // definitions here take libamdhip64's place at link time in tests/hostsim's sanitizer builds.
 #include "fake_hip.hpp"
@@ -19,7 +19,7 @@
 #include <vector>
 
 struct ihipStream_t { int device; unsigned flags; };
-struct ihipEvent_t { bool recorded; };
+struct ihipEvent_t { bool recorded; const void* stream; long ticket; };        // (per-stream model) recorded after `ticket` operations of `stream`
 
 namespace fakehip {
 namespace {
@@ -32,7 +32,7 @@ std::map<uintptr_t, Range> g_ranges;
 std::set<const void*> g_streams, g_events;
 int g_devices = 1;
 size_t g_capacity = 0;
-bool g_lazy = false;
+int g_mode = 0;                                  // 0: work runs when enqueued; 1: one FIFO, run at any synchronisation; 2: a queue per stream
 long g_calls[F_COUNT];
 long g_fail_at[F_COUNT];                         // fails when g_calls reaches this (0 = off)
 long g_injected = 0, g_violations = 0;
@@ -40,16 +40,36 @@ std::string g_last_violation;
 thread_local int t_device = 0;
 thread_local hipError_t t_last = hipSuccess;
 
-std::mutex g_q_mu;                               // the queue of deferred work (lazy mode)
+std::mutex g_q_mu;                               // the queues of deferred work
 std::recursive_mutex g_flush_mu;                 // one flush at a time: work runs in enqueue order
-std::deque<std::function<void()>> g_queue;
+std::deque<std::function<void()>> g_queue;       // model 1: one FIFO over all streams
+
+// model 2: a queue per stream.  An operation runs only when ITS stream (or one that waits for it through an event, or the
+// device) is synchronised -- what a stream other than the one the caller waited for may legally do.  The NULL stream runs at
+// once, behind everything on the blocking streams (a legal schedule of its own).
+struct Op {
+	std::function<void()> work;                  // empty: a wait marker
+	const void* wait_stream = nullptr;
+	long wait_ticket = 0;
+	uintptr_t lo[2] = {0, 0}, hi[2] = {0, 0};    // host memory the operation touches (copies): what must not die under it
+	const char* what = "work";
+};
+struct Queue { std::deque<Op> ops; long enqueued = 0, done = 0; };
+std::map<const void*, Queue> g_sq;               // g_q_mu
+std::map<uintptr_t, size_t> g_dead;              // host ranges their owner has freed (host_range_dies), g_mu
+
+bool touches(const Op& op, uintptr_t lo, uintptr_t hi)
+{
+	for (int k = 0; k < 2; k++) if (op.hi[k] > op.lo[k] && op.lo[k] < hi && lo < op.hi[k]) return true;
+	return false;
+}
 
 const char* const kNames[F_COUNT] = {
 	"hipMalloc", "hipFree", "hipHostMalloc", "hipHostFree", "hipHostRegister", "hipHostUnregister", "hipMemcpy", "hipMemcpyAsync",
 	"hipMemcpy2D", "hipMemset", "hipMemsetAsync", "hipPointerGetAttributes", "hipStreamCreate", "hipStreamCreateWithFlags",
 	"hipStreamDestroy", "hipStreamSynchronize", "hipStreamWaitEvent", "hipEventCreate", "hipEventCreateWithFlags", "hipEventDestroy",
 	"hipEventRecord", "hipEventElapsedTime", "hipGetDevice", "hipSetDevice", "hipGetDeviceCount", "hipDeviceGetAttribute",
-	"hipDeviceSynchronize"};
+	"hipDeviceSynchronize", "hipStreamQuery"};
 
 void violation(const std::string& what)
 {
@@ -139,7 +159,8 @@ void reset()
 
 void set_devices(int count) { std::lock_guard<std::mutex> lk(g_mu); g_devices = count < 1 ? 1 : count; }
 void set_capacity(size_t bytes) { std::lock_guard<std::mutex> lk(g_mu); g_capacity = bytes; }
-void set_lazy(bool on) { flush(); std::lock_guard<std::mutex> lk(g_mu); g_lazy = on; }
+void set_lazy(bool on) { set_stream_model(on ? 1 : 0); }
+void set_stream_model(int model) { flush(); std::lock_guard<std::mutex> lk(g_mu); g_mode = model < 0 || model > 2 ? 0 : model; }
 void fail_nth(int fn, long nth)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
@@ -150,6 +171,80 @@ long injected() { std::lock_guard<std::mutex> lk(g_mu); return g_injected; }
 long violations() { std::lock_guard<std::mutex> lk(g_mu); return g_violations; }
 const char* last_violation() { std::lock_guard<std::mutex> lk(g_mu); return g_last_violation.c_str(); }
 
+namespace {
+int mode() { std::lock_guard<std::mutex> lk(g_mu); return g_mode; }
+
+// model 2: run the operations of stream s until `upto` of them are done (< 0: all that are queued now).  g_flush_mu held.
+void drain(const void* s, long upto)
+{
+	for (;;) {
+		Op op;
+		{
+			std::lock_guard<std::mutex> lk(g_q_mu);
+			auto it = g_sq.find(s);
+			if (it == g_sq.end() || it->second.ops.empty() || (upto >= 0 && it->second.done >= upto)) return;
+			op = std::move(it->second.ops.front());
+			it->second.ops.pop_front();
+		}
+		if (op.work) op.work();
+		else drain(op.wait_stream, op.wait_ticket);              // an event of another stream: that stream runs up to its record first
+		std::lock_guard<std::mutex> lk(g_q_mu);
+		auto it = g_sq.find(s);
+		if (it != g_sq.end()) it->second.done++;
+	}
+}
+
+bool is_blocking(const void* s)
+{
+	if (!s) return true;
+	std::lock_guard<std::mutex> lk(g_mu);
+	return g_streams.count(s) && !(static_cast<const ihipStream_t*>(s)->flags & hipStreamNonBlocking);
+}
+
+// what the NULL stream (and every blocking call: hipMemcpy, hipMemset) orders itself behind: the blocking streams
+void drain_blocking()
+{
+	std::lock_guard<std::recursive_mutex> fl(g_flush_mu);
+	std::vector<const void*> ss;
+	{
+		std::lock_guard<std::mutex> lk(g_q_mu);
+		for (auto& kv : g_sq) ss.push_back(kv.first);
+	}
+	for (const void* st : ss) if (is_blocking(st)) drain(st, -1);
+}
+
+void sync_stream(const void* s)
+{
+	const int m = mode();
+	if (m != 2) { flush(); return; }
+	if (!s) { drain_blocking(); return; }
+	std::lock_guard<std::recursive_mutex> fl(g_flush_mu);
+	drain(s, -1);
+}
+
+void push(const void* stream, Op op)
+{
+	const int m = mode();
+	if (m == 2 && stream) {
+		std::lock_guard<std::mutex> lk(g_q_mu);
+		Queue& q = g_sq[stream];
+		q.ops.push_back(std::move(op));
+		q.enqueued++;
+		return;
+	}
+	if (m == 2) { drain_blocking(); if (op.work) op.work(); return; }        // the NULL stream
+	if (!op.work) return;                                                    // models 0 / 1: one FIFO, waits are implied
+	if (m == 0) {
+		std::lock_guard<std::recursive_mutex> fl(g_flush_mu);      // not while another thread is half-way through the queue
+		flush();
+		op.work();
+		return;
+	}
+	std::lock_guard<std::mutex> lk(g_q_mu);
+	g_queue.push_back(std::move(op.work));
+}
+}  // namespace
+
 void flush()
 {
 	std::lock_guard<std::recursive_mutex> fl(g_flush_mu);
@@ -157,30 +252,73 @@ void flush()
 		std::function<void()> work;
 		{
 			std::lock_guard<std::mutex> lk(g_q_mu);
-			if (g_queue.empty()) return;
+			if (g_queue.empty()) break;
 			work = std::move(g_queue.front());
 			g_queue.pop_front();
 		}
 		work();
 	}
+	for (;;) {                                       // model 2: every stream, until nothing is left anywhere
+		std::vector<const void*> ss;
+		{
+			std::lock_guard<std::mutex> lk(g_q_mu);
+			for (auto& kv : g_sq) if (!kv.second.ops.empty()) ss.push_back(kv.first);
+		}
+		if (ss.empty()) return;
+		for (const void* st : ss) drain(st, -1);
+	}
 }
 
 void enqueue(void* stream, std::function<void()> work)
 {
-	(void) stream;                                   // one FIFO for all streams: enqueue order is a legal schedule
-	bool lazy;
+	Op op;
+	op.work = std::move(work);
+	op.what = "kernel";
+	push(stream, std::move(op));
+}
+
+long pending_host_ops()
+{
+	std::lock_guard<std::mutex> lk(g_q_mu);
+	long k = 0;
+	for (auto& kv : g_sq) for (const Op& op : kv.second.ops) k += (op.hi[0] > op.lo[0]) || (op.hi[1] > op.lo[1]);
+	return k;
+}
+
+long pending_ops()
+{
+	std::lock_guard<std::mutex> lk(g_q_mu);
+	long k = (long) g_queue.size();
+	for (auto& kv : g_sq) k += (long) kv.second.ops.size();
+	return k;
+}
+
+void host_range_dies(const void* p, size_t bytes)
+{
+	const uintptr_t lo = (uintptr_t) p, hi = lo + bytes;
+	std::string hit;
+	{
+		std::lock_guard<std::mutex> lk(g_q_mu);
+		for (auto& kv : g_sq) for (const Op& op : kv.second.ops) if (touches(op, lo, hi)) hit = op.what;
+	}
+	if (!hit.empty()) violation("a host range was freed by its owner while a queued " + hit + " still goes through it");
 	{
 		std::lock_guard<std::mutex> lk(g_mu);
-		lazy = g_lazy;
+		uintptr_t base = 0;
+		const Range* r = find_locked(p, &base);
+		if (r && r->kind == REGISTERED) hit = "registered";
+		g_dead[lo] = bytes;
 	}
-	if (!lazy) {
-		std::lock_guard<std::recursive_mutex> fl(g_flush_mu);      // not while another thread is half-way through the queue
-		flush();
-		work();
-		return;
-	}
-	std::lock_guard<std::mutex> lk(g_q_mu);
-	g_queue.push_back(std::move(work));
+	if (hit == "registered") violation("a host range was freed by its owner while it was still page-locked (hipHostRegister)");
+}
+
+void host_range_lives(const void* p, size_t bytes)
+{
+	const uintptr_t lo = (uintptr_t) p, hi = lo + bytes;
+	std::lock_guard<std::mutex> lk(g_mu);
+	for (auto it = g_dead.begin(); it != g_dead.end();)
+		if (it->first < hi && lo < it->first + it->second) it = g_dead.erase(it);
+		else ++it;
 }
 
 Live live()
@@ -357,6 +495,20 @@ hipError_t hipHostRegister(void* p, size_t bytes, unsigned int)
 hipError_t hipHostUnregister(void* p)
 {
 	const bool fail = enter(F_HostUnregister);
+	if (mode() == 2) {                               // the real call waits for nothing: a copy still queued through the range loses its pages
+		size_t bytes = 0;
+		{
+			std::lock_guard<std::mutex> lk(g_mu);
+			auto it = g_ranges.find((uintptr_t) p);
+			if (it != g_ranges.end() && it->second.kind == REGISTERED) bytes = it->second.bytes;
+		}
+		bool hit = false;
+		{
+			std::lock_guard<std::mutex> lk(g_q_mu);
+			for (auto& kv : g_sq) for (const Op& op : kv.second.ops) hit = hit || (bytes && touches(op, (uintptr_t) p, (uintptr_t) p + bytes));
+		}
+		if (hit) violation("hipHostUnregister of a range that a queued copy still goes through");
+	}
 	flush();
 	std::lock_guard<std::mutex> lk(g_mu);
 	auto it = g_ranges.find((uintptr_t) p);
@@ -378,16 +530,38 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p)
 }
 
 namespace {
+bool dead(const void* p, size_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	const uintptr_t lo = (uintptr_t) p, hi = lo + bytes;
+	for (auto& kv : g_dead) if (kv.first < hi && lo < kv.first + kv.second) return true;
+	return false;
+}
+
 void copy_now(void* dst, const void* src, size_t bytes)
 {
-	if (bytes) std::memmove(dst, src, bytes);
+	if (!bytes) return;
+	if (dead(dst, bytes) || dead(src, bytes)) { violation("a copy goes through a host range that its owner has freed"); return; }
+	std::memmove(dst, src, bytes);
+}
+
+// the host side(s) of a copy, for Op::lo / hi (device allocations of the fake are not the caller's to free)
+void host_sides(Op& op, const void* dst, const void* src, size_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int k = 0;
+	for (const void* p : {dst, src}) {
+		const Range* r = find_locked(p);
+		if (r && r->kind == DEV) continue;
+		op.lo[k] = (uintptr_t) p; op.hi[k] = (uintptr_t) p + bytes; k++;
+	}
 }
 }  // namespace
 
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind)
 {
 	const bool fail = enter(F_Memcpy);
-	flush();                                          // a blocking copy: everything before it has run
+	sync_stream(nullptr);                             // a blocking copy: everything before it (on the blocking streams) has run
 	if (fail) return err(hipErrorUnknown);
 	if (!span_ok(dst, bytes, "hipMemcpy dst") || !span_ok(src, bytes, "hipMemcpy src")) return err(hipErrorInvalidValue);
 	copy_now(dst, src, bytes);
@@ -402,16 +576,23 @@ hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKin
 	// pageable memory on either side makes the real call synchronous for the host: the source is read / the destination is
 	// written before it returns.  Only copies between device and PINNED memory may still be in flight afterwards.
 	if (!known(dst)) {
-		flush();
+		sync_stream(stream);
 		copy_now(dst, src, bytes);
 		return hipSuccess;
 	}
+	Op op;
+	op.what = "copy";
 	if (!known(src)) {
+		if (dead(src, bytes)) { violation("a copy reads a host range that its owner has freed"); return err(hipErrorInvalidValue); }
 		std::shared_ptr<std::vector<char>> snap(new std::vector<char>((const char*) src, (const char*) src + bytes));
-		enqueue(stream, [dst, snap, bytes] { copy_now(dst, snap->data(), bytes); });
+		op.work = [dst, snap, bytes] { copy_now(dst, snap->data(), bytes); };
+		host_sides(op, dst, nullptr, bytes);
+		push(stream, std::move(op));
 		return hipSuccess;
 	}
-	enqueue(stream, [dst, src, bytes] { copy_now(dst, src, bytes); });
+	op.work = [dst, src, bytes] { copy_now(dst, src, bytes); };
+	host_sides(op, dst, src, bytes);
+	push(stream, std::move(op));
 	return hipSuccess;
 }
 
@@ -430,7 +611,7 @@ hipError_t hipMemcpy2D(void* dst, size_t dpitch, const void* src, size_t spitch,
 hipError_t hipMemset(void* dst, int value, size_t bytes)
 {
 	const bool fail = enter(F_Memset);
-	flush();
+	sync_stream(nullptr);
 	if (fail) return err(hipErrorUnknown);
 	if (!span_ok(dst, bytes, "hipMemset")) return err(hipErrorInvalidValue);
 	if (bytes) std::memset(dst, value, bytes);
@@ -462,7 +643,8 @@ hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int flags) { return
 hipError_t hipStreamDestroy(hipStream_t s)
 {
 	const bool fail = enter(F_StreamDestroy);
-	flush();
+	sync_stream(s);                                   // (the real call lets the stream's work finish)
+	if (mode() == 2) { std::lock_guard<std::mutex> lk(g_q_mu); g_sq.erase(s); }
 	bool ok;
 	{
 		std::lock_guard<std::mutex> lk(g_mu);
@@ -477,22 +659,46 @@ hipError_t hipStreamSynchronize(hipStream_t s)
 {
 	const bool fail = enter(F_StreamSynchronize);
 	if (!stream_ok(s, "hipStreamSynchronize")) return err(hipErrorInvalidValue);
-	flush();
+	sync_stream(s);
 	return fail ? err(hipErrorLaunchFailure) : hipSuccess;
+}
+
+hipError_t hipStreamQuery(hipStream_t s)
+{
+	if (enter(F_StreamQuery)) return err(hipErrorUnknown);
+	if (!stream_ok(s, "hipStreamQuery")) return err(hipErrorInvalidValue);
+	const int m = mode();
+	std::lock_guard<std::mutex> lk(g_q_mu);
+	bool busy = m == 1 && !g_queue.empty();
+	if (m == 2) { auto it = g_sq.find(s); busy = it != g_sq.end() && !it->second.ops.empty(); }
+	return busy ? err(hipErrorNotReady) : hipSuccess;
 }
 
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned int)
 {
 	if (enter(F_StreamWaitEvent)) return err(hipErrorUnknown);
 	if (!stream_ok(s, "hipStreamWaitEvent") || !event_ok(e, "hipStreamWaitEvent")) return err(hipErrorInvalidValue);
-	return hipSuccess;                                // one FIFO: whatever was recorded earlier runs earlier
+	if (mode() == 2) {
+		Op op;
+		op.what = "wait";
+		{
+			std::lock_guard<std::mutex> lk(g_mu);
+			if (!e->recorded) return hipSuccess;      // an event never recorded holds nobody up
+			op.wait_stream = e->stream;
+			op.wait_ticket = e->ticket;
+		}
+		if (op.wait_stream == s) return hipSuccess;   // same stream: already in order
+		if (!s) { std::lock_guard<std::recursive_mutex> fl(g_flush_mu); drain(op.wait_stream, op.wait_ticket); return hipSuccess; }
+		push(s, std::move(op));
+	}
+	return hipSuccess;                                // models 0 / 1: one FIFO, whatever was recorded earlier runs earlier
 }
 
 static hipError_t make_event(int fn, hipEvent_t* e)
 {
 	*e = nullptr;
 	if (enter(fn)) return err(hipErrorOutOfMemory);
-	ihipEvent_t* ev = new ihipEvent_t{false};
+	ihipEvent_t* ev = new ihipEvent_t{false, nullptr, 0};
 	std::lock_guard<std::mutex> lk(g_mu);
 	g_events.insert(ev);
 	*e = ev;
@@ -518,8 +724,16 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
 {
 	if (enter(F_EventRecord)) return err(hipErrorUnknown);
 	if (!event_ok(e, "hipEventRecord") || !stream_ok(s, "hipEventRecord")) return err(hipErrorInvalidValue);
+	long ticket = 0;
+	{
+		std::lock_guard<std::mutex> lk(g_q_mu);
+		auto it = g_sq.find(s);
+		if (it != g_sq.end()) ticket = it->second.enqueued;
+	}
 	std::lock_guard<std::mutex> lk(g_mu);
 	e->recorded = true;
+	e->stream = s;
+	e->ticket = ticket;
 	return hipSuccess;
 }
 
@@ -527,6 +741,10 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b)
 {
 	if (enter(F_EventElapsedTime)) return err(hipErrorUnknown);
 	if (!event_ok(a, "hipEventElapsedTime") || !event_ok(b, "hipEventElapsedTime")) return err(hipErrorInvalidValue);
+	if (mode() == 2) {                                // both must have happened: the product only asks after a synchronisation
+		std::lock_guard<std::mutex> lk(g_q_mu);
+		for (hipEvent_t e : {a, b}) { auto it = g_sq.find(e->stream); if (it != g_sq.end() && it->second.done < e->ticket) return err(hipErrorNotReady); }
+	}
 	std::lock_guard<std::mutex> lk(g_mu);
 	if (!a->recorded || !b->recorded) return err(hipErrorInvalidValue);
 	*ms = 0.001f;

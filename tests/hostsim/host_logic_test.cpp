@@ -1,6 +1,6 @@
 // host_logic_test.cpp -- scenarios that drive the product's host logic on the CPU (TEST INFRASTRUCTURE ONLY).
 //
-//   host_logic_{asan,tsan} <scenario> [lazy]
+//   host_logic_{asan,tsan} <scenario> [lazy | per_stream]
 //
 // Linked against the unchanged runtime.cpp / machines.cpp / group.cpp, the malloc-backed HIP stand-in (fake_hip.cpp), the
 // launcher stand-ins (fake_launch.cpp: x -= step * grad, the scalars of the recursion scripted) and, through
@@ -17,6 +17,9 @@
 #include "runtime.hpp"          // the host checksum of x (xhash_*): tested against its definition directly
 
 #include <dlfcn.h>
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
+#endif
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -360,8 +363,13 @@ void sc_xhash()
 			unsigned long long w = 0;
 			const size_t len = bytes - 8 * i < 8 ? bytes - 8 * i : 8;
 			std::memcpy(&w, buf.data() + 8 * i, len);
-			a += w;
-			b += (2 * i + 1) * w;
+			// the definition written out (sqn_device.hpp: XHash): splitmix64's finaliser over the word xor a position key
+			unsigned long long z = w ^ ((unsigned long long) i * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull);
+			z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+			z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+			z ^= z >> 31;
+			a += z;
+			b += (2 * i + 1) * ((z << 32) | (z >> 32));
 		}
 		sqn::XHash whole;
 		sqn::xhash_host(buf.data(), bytes, 0, sqn::xhash_words(bytes), &whole);
@@ -388,6 +396,35 @@ void sc_xhash()
 			CHECK(edited.a != a, "%zu bytes: byte %zu changed, the first sum did not", bytes, at);
 			buf[at] ^= 0x10;
 		}
+	}
+	// the edits a plain sum of the words cannot see: the sign bits of an EVEN number of doubles flipped -- two
+	// coordinates, every coordinate (x -> -x, even n) -- and two words exchanged.  Bit 63 of a word adds 2^63 to a linear first
+	// sum and an odd multiple of 2^63 to a linear weighted one: two flips cancel in both.  Not here.
+	for (size_t n : {(size_t) 2, (size_t) 64, (size_t) 1000, (size_t) 8750}) {
+		std::vector<double> x(n);
+		for (size_t i = 0; i < n; i++) x[i] = 0.25 + 1e-3 * (double) ((i * 2654435761u) % 1000);
+		sqn::XHash h0;
+		sqn::xhash_host(x.data(), 8 * n, 0, n, &h0);
+		auto differs = [&](const char* what) {
+			sqn::XHash h;
+			sqn::xhash_host(x.data(), 8 * n, 0, n, &h);
+			CHECK(h.a != h0.a && h.b != h0.b, "n = %zu: %s leaves a sum unchanged (%llx %llx)", n, what, h.a, h.b);
+		};
+		x[0] = -x[0]; x[n - 1] = -x[n - 1];
+		differs("the signs of two coordinates flipped");
+		x[0] = -x[0]; x[n - 1] = -x[n - 1];
+		for (auto& v : x) v = -v;
+		differs("x -> -x");
+		for (auto& v : x) v = -v;
+		std::swap(x[0], x[n / 2]);
+		if (x[0] != x[n / 2]) differs("two coordinates exchanged");
+		std::swap(x[0], x[n / 2]);
+		for (auto& v : x) v *= 0.5;
+		differs("x scaled by 1/2");
+		for (auto& v : x) v *= 2.0;
+		sqn::XHash back;
+		sqn::xhash_host(x.data(), 8 * n, 0, n, &back);
+		CHECK(back.a == h0.a && back.b == h0.b, "n = %zu: the sums of the restored vector differ", n);
 	}
 }
 
@@ -731,12 +768,137 @@ void sc_threads()
 	leak_check("threads");
 }
 
+// A caller whose arrays live in a garbage-collected heap (reference src/Rwrapper.c:106-123: SEXPs the R collector may move or
+// free between two .Call()s; stochqn/pywrapper.pxi:161-172: numpy arrays): x, the gradient and the Hessian-vector array are
+// pinned by their owner (the binding), used for a few calls, then REPLACED -- unpinned, freed, a new array elsewhere -- between
+// two calls, as `x = x.copy()` or `optimizer$gradient <- g` do.  The invariant of the host path: when run_* returns, no
+// operation that touches the caller's memory is queued on any stream (fakehip::pending_host_ops, the per-stream model) and the
+// library's own check agrees ("host_copies_in_flight", hipStreamQuery); an array may therefore die the moment the call is back.
+// fake_hip reports a violation if a range dies under a queued copy, is freed while registered, or is copied through afterwards.
+struct Heap {
+	std::vector<std::pair<double*, size_t>> pinned, graveyard;       // dead arrays keep their addresses to themselves until the object is gone:
+	                                                                 // whoever goes through one afterwards is caught, nobody is caught by a reused address
+	double* fresh(size_t count, const double* from, bool pin)
+	{
+		double* p = static_cast<double*>(std::malloc(count * sizeof(double)));
+		fakehip::host_range_lives(p, count * sizeof(double));
+		if (from) std::memcpy(p, from, count * sizeof(double)); else std::memset(p, 0, count * sizeof(double));
+		if (pin && stochqn_hip_pin_host(p, count * sizeof(double)) == 0) pinned.emplace_back(p, count);
+		return p;
+	}
+	void drop(double* p, size_t count)
+	{
+		for (size_t i = 0; i < pinned.size(); i++)
+			if (pinned[i].first == p) { CHECK(stochqn_hip_unpin_host(p) == 0, "unpin"); pinned.erase(pinned.begin() + (long) i); break; }
+		fakehip::host_range_dies(p, count * sizeof(double));
+		std::memset(p, 0x5a, count * sizeof(double));            // what the allocator's next customer writes there
+#if defined(__SANITIZE_ADDRESS__)
+		__asan_poison_memory_region(p, count * sizeof(double));  // a read by the library's own threads (probe values, the checksum of x) shows too
+#endif
+		graveyard.emplace_back(p, count);
+	}
+	~Heap()
+	{
+		for (auto& d : graveyard) {
+#if defined(__SANITIZE_ADDRESS__)
+			__asan_unpoison_memory_region(d.first, d.second * sizeof(double));
+#endif
+			fakehip::host_range_lives(d.first, d.second * sizeof(double));
+			std::free(d.first);
+		}
+	}
+};
+
+void sc_caller_heap()
+{
+	const int n = (1 << 16) + 3;
+	const size_t N = (size_t) n;
+	opt("host_slice_min", 1 << 12);
+	opt("register_min_bytes", 1 << 12);
+	struct Policy { const char* name; int x_upload, register_host, x_prefetch, pin; };
+	const Policy policies[] = {{"defaults, arrays pinned by their owner", 1, 0, 0, 1}, {"defaults, nothing pinned", 1, 0, 0, 0},
+	                           {"checksum of x", 2, 0, 0, 1}, {"vouched + the library pins + x prefetched", 0, 1, 1, 1}};
+	for (const Policy& pol : policies)
+		for (int strict = 0; strict < 2; strict++)
+			for (int kind = 0; kind < 3; kind++) {
+				g_tag = std::string("caller_heap / ") + pol.name + (strict ? " / strict_grad" : "") + " / kind " + std::to_string(kind);
+				opt("x_upload", pol.x_upload); opt("register_host", pol.register_host); opt("x_prefetch", pol.x_prefetch); opt("strict_grad", strict);
+				opt("hash_threads", 2);
+				Heap heap;
+				Opt a(kind == 0 ? OLBFGS : (kind == 1 ? SQN : ADAQN), n, 3, kind == 0 ? 1 : 3, false, 0.0, kind == 2 ? 4 : 0, kind == 2 ? 1.01 : 0.0);
+				// the arrays that cross the link live in the caller's heap, not in the Opt object
+				double* x = heap.fresh(N, a.x.data(), pol.pin);
+				double* g = heap.fresh(N, nullptr, pol.pin);
+				double* hv = heap.fresh(N, nullptr, pol.pin);
+				double *req = x, *req_vec = nullptr;
+				std::vector<double> x_ref(a.x);
+				task_enum task = calc_grad;
+				info_enum info = no_problems_encountered;
+				size_t mem_used = 0, st = 0, niter = 0, f_used = 0, f_st = 0;
+				int section = 0, failed = 0, steps = 0, replaced = 0;
+				double f_prev = 0, f = 1.0;
+				for (int call = 0; call < 44; call++) {
+					// the caller answers the request where it was made ...
+					if (task == calc_grad || task == calc_grad_same_batch || task == calc_grad_big_batch) for (size_t i = 0; i < N; i++) g[i] = 0.25 * req[i] + 0.01;
+					else if (task == calc_hess_vec) for (size_t i = 0; i < N; i++) hv[i] = 2.0 * req_vec[i];
+					else if (task == calc_fun_val_batch) { f = 0; for (size_t i = 0; i < N; i++) f += req[i] * req[i]; }
+					// ... and its collector moves the arrays it owns: every few calls x, the gradient or hess_vec is a NEW array
+					if (call % 5 == 3) { double* nx = heap.fresh(N, x, pol.pin); if (req == x) req = nx; heap.drop(x, N); x = nx; replaced++; }
+					if (call % 7 == 2) { double* ng = heap.fresh(N, g, pol.pin); heap.drop(g, N); g = ng; replaced++; }
+					if (call % 11 == 6) { double* nh = heap.fresh(N, hv, pol.pin); heap.drop(hv, N); hv = nh; replaced++; }
+					if (call == 30) fakelaunch::script().reject_step = true;         // one step that the guard rejects: x that went ahead is put right
+					const bool takes_step = section == 1;
+					std::vector<double> g_in(g, g + (takes_step ? N : 0));
+					bfgs_mem b{a.S.data(), a.Y.data(), a.rho.data(), a.alpha.data(), a.sbak.data(), a.ybak.data(), a.m, mem_used, st, a.kind == OLBFGS ? 1 : a.L, 0.0, 0.0};
+					int rc;
+					if (a.kind == OLBFGS) {
+						workspace_oLBFGS w{&b, a.gprev.data(), 0.0, niter, section, 1, 1, n};
+						rc = run_oLBFGS(0.01, x, g, &req, &task, &w, &info);
+						niter = w.niter; section = w.section;
+					} else if (a.kind == SQN) {
+						workspace_SQN w{&b, a.gprev.data(), a.xsum.data(), a.xprev.data(), 0, niter, section, 1, 1, n};
+						rc = run_SQN(0.01, x, g, hv, &req, &req_vec, &task, &w, &info);
+						niter = w.niter; section = w.section;
+					} else {
+						fisher_mem fm{a.F.data(), a.fy.data(), a.fsize, f_used, f_st};
+						workspace_adaQN w{&b, &fm, a.H0.data(), a.gprev.data(), a.xsum.data(), a.xprev.data(), a.G.data(), f_prev, a.max_incr, 1e-4, 0.9, 0, niter, section, 1, 1, n};
+						rc = run_adaQN(0.01, x, f, g, &req, &task, &w, &info);
+						niter = w.niter; section = w.section; f_prev = w.f_prev; f_used = fm.mem_used; f_st = fm.mem_st_ix;
+					}
+					mem_used = b.mem_used; st = b.mem_st_ix;
+					fakelaunch::script().reject_step = false;
+					if (rc == -1000) { failed++; break; }
+					// THE INVARIANT: the call is back, nothing that touches the caller's memory is still queued anywhere
+					const long queued = fakehip::pending_host_ops();
+					const bool prefetching = pol.x_prefetch && stat("x_prefetched") > 0;
+					CHECK(queued == 0 || (prefetching && queued == 1), "call %d: %ld copies through host memory still queued when the call returned", call, queued);
+					if (takes_step && rc == 1 && info != func_increased) { steps++; for (size_t i = 0; i < N; i++) x_ref[i] -= 0.01 * g_in[i]; }
+					if (info == func_increased) x_ref.assign(x, x + N);
+					double worst = 0;
+					for (size_t i = 0; i < N; i++) worst = std::fmax(worst, std::fabs(x[i] - x_ref[i]));
+					CHECK(worst <= 1e-12, "call %d: the caller's x is %.3g away from x0 - sum step * grad", call, worst);
+				}
+				CHECK(failed == 0 && steps >= 8 && replaced >= 12, "failed %d, steps %d, arrays replaced %d", failed, steps, replaced);
+				CHECK(stat("host_copies_in_flight") == 0, "the library's own check found %lld busy streams at the return of a call", stat("host_copies_in_flight"));
+				// the object dies: the collector frees everything, in its own order, WITHOUT telling the library (R / Python never call dealloc_*)
+				heap.drop(g, N); heap.drop(hv, N); heap.drop(x, N);
+				CHECK(fakehip::violations() == 0, "%ld violations, last: %s", fakehip::violations(), fakehip::last_violation());
+				// a new object finds a context under the same s_mem address: section 0 drops it
+			}
+	g_tag.clear();
+	CHECK(stat("x_sent_ahead") > 0 && stat("x_sent_again") > 0 && stat("x_prefetched") > 0 && stat("x_uploads_skipped") > 0,
+	      "the paths this scenario is for: x ahead of the guard %lld, sent again %lld, prefetched %lld, uploads skipped %lld",
+	      stat("x_sent_ahead"), stat("x_sent_again"), stat("x_prefetched"), stat("x_uploads_skipped"));
+	opt("x_upload", 1); opt("register_host", 0); opt("x_prefetch", 0); opt("strict_grad", 0); opt("hash_threads", 0);
+	leak_check("caller_heap");
+}
+
 struct Scenario { const char* name; void (*fn)(); };
 const Scenario kScenarios[] = {
 	{"registry", sc_registry}, {"reclaim_resume", sc_reclaim_resume}, {"mirror_cap", sc_mirror_cap}, {"host_path", sc_host_path}, {"xhash", sc_xhash},
 	{"branches", sc_branches}, {"owned_and_raw", sc_owned_and_raw}, {"group_rccl", sc_group_rccl}, {"group_virtual", sc_group_virtual},
 	{"group_alloc_failures", sc_group_alloc_failures}, {"fault_sweep", sc_fault_sweep}, {"fault_sweep_group", sc_fault_sweep_group},
-	{"threads", sc_threads}};
+	{"threads", sc_threads}, {"caller_heap", sc_caller_heap}};
 
 }  // namespace
 
@@ -746,13 +908,14 @@ int main(int argc, char** argv)
 		for (const auto& s : kScenarios) std::printf("%s\n", s.name);
 		return 0;
 	}
-	const bool lazy = argc > 2 && !std::strcmp(argv[2], "lazy");
+	const int model = argc > 2 && !std::strcmp(argv[2], "lazy") ? 1 : (argc > 2 && !std::strcmp(argv[2], "per_stream") ? 2 : 0);
+	const char* const names[] = {"immediate", "lazy", "per_stream"};
 	for (const auto& s : kScenarios)
 		if (!std::strcmp(argv[1], s.name)) {
 			defaults();
-			fakehip::set_lazy(lazy);
+			fakehip::set_stream_model(model);
 			s.fn();
-			std::fprintf(stderr, "%s (%s streams): %s\n", s.name, lazy ? "lazy" : "immediate", g_failures ? "FAILED" : "ok");
+			std::fprintf(stderr, "%s (%s streams): %s\n", s.name, names[model], g_failures ? "FAILED" : "ok");
 			return g_failures ? 1 : 0;
 		}
 	std::fprintf(stderr, "unknown scenario %s\n", argv[1]);

@@ -94,12 +94,16 @@ def test_host_and_device_callers_agree_bit_for_bit(kind, n, policy, hip_backend)
     lib.stochqn_hip_release_all()
 
 
-@pytest.mark.parametrize("n,mode", [(50_000, 1), (4_500_001, 1), (4_500_001, 2), (4_500_002, 2)])
-def test_an_edit_of_one_coordinate_between_two_calls_moves_the_iterate(n, mode, hip_backend, oracle_backend):
+@pytest.mark.parametrize("n,mode,edit", [(50_000, 1, "project"), (4_500_001, 1, "project"), (4_500_001, 2, "project"), (4_500_002, 2, "project"),
+                                         (4_500_002, 2, "flip2"), (4_500_002, 2, "negate")])
+def test_an_edit_of_one_coordinate_between_two_calls_moves_the_iterate(n, mode, edit, hip_backend, oracle_backend):
     """The reference's *req aliases x: a caller that clips or resets a FEW coordinates between two ordinary steps has simply
     moved the iterate.  256 probe values would miss such an edit; with the library's defaults (x_upload = 1) x goes up on
     every step -- for the large n in slices under the update -- and the trajectory equals the oracle's.  With x_upload = 2 a
-    checksum of ALL of x decides: the steps after an edit send x up, the others do not -- same trajectory."""
+    checksum of ALL of x decides: the steps after an edit send x up, the others do not -- same trajectory.  The edits: a
+    projection of three coordinates; the SIGNS of two coordinates flipped; x -> -x with n even -- the last two are invisible to
+    any sum of the words of x, plain or position-weighted (bit 63 twice cancels mod 2^64): the checksum mixes every
+    word non-linearly with its position first (sqn_device.hpp: XHash)."""
     lib = _lib()
     lib.stochqn_hip_stats_reset()
     P = NoisyQuadratic(n, seed=13)
@@ -118,7 +122,12 @@ def test_an_edit_of_one_coordinate_between_two_calls_moves_the_iterate(n, mode, 
                 opt.update_hess_vec(P.hess_vec(to_np(rx), to_np(rv)))
             else:
                 if call in (6, 7, 13) and r["task"] == "calc_grad":
-                    x[where] = 0.25                              # a projection of three coordinates, between two calls
+                    if edit == "project":
+                        x[where] = 0.25                          # a projection of three coordinates, between two calls
+                    elif edit == "flip2":
+                        x[where[:2]] = -x[where[:2]]
+                    else:
+                        np.negative(x, out=x)
                 opt.update_gradient(P.grad(to_np(r["requested_on"]), call))
         opt.release()
         return xs
@@ -129,7 +138,10 @@ def test_an_edit_of_one_coordinate_between_two_calls_moves_the_iterate(n, mode, 
     want = drive(oracle_backend)
     for i, (g, w) in enumerate(zip(got, want)):
         assert rel_err(g, w) <= TOL, i
-        assert np.array_equal(g[where] == 0.25, w[where] == 0.25), i
+        if edit == "project":
+            assert np.array_equal(g[where] == 0.25, w[where] == 0.25), i
+        else:
+            assert np.array_equal(np.signbit(g[where]), np.signbit(w[where])), i
     if mode == 2:
         assert skipped >= 6 and 3 <= uploads <= 8, (uploads, skipped)      # the first step, the three edits, the calls that take x in one piece
     else:

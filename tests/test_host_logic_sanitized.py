@@ -7,7 +7,12 @@ rendezvous stand-in for RCCL (libfake_rccl_*.so, through STOCHQN_HIP_RCCL_LIB). 
 
 Every scenario of host_logic_test.cpp runs twice per build -- streams that execute at once and streams that execute only
 when something synchronises (the two ends of what the real runtime may do) -- under -fsanitize=address,undefined and
-under -fsanitize=thread:
+under -fsanitize=thread; the host-path scenarios a third time with a queue PER STREAM (what a stream other than the one the
+caller waited for may legally do):
+  caller_heap: a caller whose arrays live in a garbage-collected heap (reference src/Rwrapper.c:106-123, stochqn/pywrapper.pxi:
+      161-172) -- x, grad and hess_vec are replaced by new arrays between calls, the old ones unpinned, poisoned and kept out of
+      circulation; no copy through host memory may be queued on ANY stream when a call returns, none may ever go through a dead
+      array, the library's own hipStreamQuery check ("host_copies_in_flight") must agree;
   registry / reclaim_resume / mirror_cap / host_path / branches / owned_and_raw / threads: the context registry, the LRU
       reclaim -> spill -> resume cycle (incl. a resume that fails half-way and must not lose the state), the cap on mirrors,
       pinning bookkeeping, sliced transfers, x sent ahead of the guard and put right, every branch of the state machines;
@@ -25,7 +30,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM = os.path.join(ROOT, "tests", "hostsim")
 SCENARIOS = ["registry", "reclaim_resume", "mirror_cap", "host_path", "xhash", "branches", "owned_and_raw", "threads",
-             "group_rccl", "group_virtual", "group_alloc_failures", "fault_sweep", "fault_sweep_group"]
+             "group_rccl", "group_virtual", "group_alloc_failures", "fault_sweep", "fault_sweep_group", "caller_heap"]
+# the third stream model (round 5): a queue PER STREAM -- synchronising one stream leaves the others' work queued, hipHostUnregister
+# waits for nothing -- for the scenarios in which a copy left behind on a side stream would touch memory the caller has freed
+PER_STREAM = ["caller_heap", "host_path", "reclaim_resume", "branches", "owned_and_raw", "group_virtual", "group_rccl"]
 
 
 @pytest.fixture(scope="module")
@@ -35,14 +43,16 @@ def built():
     return os.path.join(SIM, "build")
 
 
-@pytest.mark.parametrize("streams", ["immediate", "lazy"])
-@pytest.mark.parametrize("scenario", SCENARIOS)
+CASES = [(sc, st) for sc in SCENARIOS for st in ("immediate", "lazy")] + [(sc, "per_stream") for sc in PER_STREAM]
+
+
+@pytest.mark.parametrize("scenario,streams", CASES)
 @pytest.mark.parametrize("san", ["asan", "tsan"])
 def test_host_logic(san, scenario, streams, built):
     env = dict(os.environ, STOCHQN_HIP_RCCL_LIB=os.path.join(built, "libfake_rccl_%s.so" % san),
                ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
                TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
-    cmd = [os.path.join(built, "host_logic_%s" % san), scenario] + (["lazy"] if streams == "lazy" else [])
+    cmd = [os.path.join(built, "host_logic_%s" % san), scenario] + ([streams] if streams != "immediate" else [])
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
     tail = "\n".join(l for l in out.stdout.splitlines() if not l.startswith(("stochqn:", "Error: Could not", "SQN got", "oLBFGS got", "adaQN got")))[-6000:]
     assert out.returncode == 0, tail

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 measurement session on the GPU box (run from the repository root): profiles/README.md quotes these commands.
 # Part 1 ("profile"): rocprofv3 kernel stats + the two PMC passes of the default workload, the other configurations, the plain C
-# config-5 caller.  Part 2 ("arena"): tools/placement_arena_ab.sh.
+# config-5 caller.  Part 2 ("arena"): placement_arena_ab.sh, removed in round 5 with the arena code.
 set -o pipefail
 R=$PWD
 O=$R/gpurun_out
@@ -17,5 +17,5 @@ if [ "$1" != "arena" ]; then
 	cd $R
 	ls $O/prof_stats/*/ $O/prof_fetch/*/ | head
 else
-	./tools/placement_arena_ab.sh $O/r04_placement_arena.jsonl
+	echo "the arena experiment is closed (round 5): the script and the code are gone"
 fi
