@@ -79,8 +79,16 @@ int stochqn_hip_export(const void *s_mem);
  * freed and mapped again while still registered faults the GPU at the next copy.  Whoever OWNS an array for a known lifetime
  * pins it here and unpins it before freeing it (a binding's optimiser object for the arrays it allocates; a finaliser on the
  * user's x: stochqn_amd/free.py does both).  Calls nest (a count per address).  Equivalent to the caller's own
- * hipHostRegister(p, bytes, hipHostRegisterPortable) / hipHostUnregister(p) for callers that do not link HIP.
- * pin: 0 = pinned now (or once more), 1 = already page-locked by other means, -1 = refused.  unpin: 0 or -1. */
+ * hipHostRegister(p, bytes, hipHostRegisterPortable) / hipHostUnregister(p) for callers that do not link HIP -- except for the
+ * one rule the library adds: a range is pinned IN PLACE only if it has its pages to itself.  hipHostRegister maps the pages that
+ * contain [p, p + bytes) into the device's address space at their own addresses (measured on MI355X, ROCm 7.0 and 7.2:
+ * tools/pin_probe.hip); a block inside the program-break heap shares its first and last page with its neighbours, and the
+ * break moves under it whenever the allocator trims the heap.  Such a range -- and one whose pages overlap a range pinned here
+ * already -- is DECLINED (return 1, "host_pins_declined"): it still works, through the runtime's pageable path.  Arrays with a
+ * mapping of their own (malloc / numpy / R above the mmap threshold; anything from mmap or posix_memalign(4096, a multiple of
+ * 4096)) are pinned.  "register_host" = 1 and the multi-device mode's own registrations follow the same rule.
+ * pin: 0 = pinned now (or once more), 1 = not pinned by this call (already page-locked by other means, or declined: the range
+ * stays pageable), -1 = refused (not host memory, no device).  unpin: 0, or -1 when the range was not pinned here. */
 int stochqn_hip_pin_host(void *p, size_t bytes);
 int stochqn_hip_unpin_host(void *p);
 
@@ -242,6 +250,8 @@ int stochqn_hip_comm_allreduce_probe(int count, int reps, double *median_us, dou
  *                               running (option "spec_x"), and those of them that the guard then rejected (the old x was sent again).
  *   "host_pins_live" (a gauge: ranges pinned through stochqn_hip_pin_host right now), "host_unpin_failed" (unpins the
  *                               runtime refused: such a range stays page-locked in its books and must not be freed);
+ *   "host_pins_declined"        ranges that stochqn_hip_pin_host / "register_host" / the multi-device mode left pageable because
+ *                               they lie in the program-break heap or share a page with another pin;
  *   "host_copies_in_flight"     the invariant of the host path, asked of the runtime (hipStreamQuery) at the return of every
  *                               run_* call of a host caller: streams of the context that still had work on them.  Always 0 --
  *                               the caller may free x, grad or the requested vector as soon as it has them back (the one

@@ -1,6 +1,8 @@
 """Turns the raw rocprofv3 output under gpurun_out/ into the small summaries committed here.
 
     python profiles/summarise.py r01
+    python profiles/summarise.py r05_c2 r05/c2_        (round 5: one set of passes per BASELINE configuration; inputs then
+                                                        gpurun_out/r05/c2_prof_stats, ..._prof_fetch, ..._prof_write, ..._prof_stats.json)
 
 Inputs (written on the GPU box by the commands quoted in profiles/README.md):
     gpurun_out/prof_stats/*/*_kernel_stats.csv       rocprofv3 --kernel-trace --stats
@@ -21,6 +23,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+pre = sys.argv[2] if len(sys.argv) > 2 else ""               # prefix of the input directories under gpurun_out/
 out = os.path.join(ROOT, "profiles")
 
 
@@ -29,7 +32,7 @@ def short(name):
     m = re.search(r"k_sweep<(\d), (\d), (\w+)(<[^>]*>)?", name)
     if m:
         return "k_sweep<W=%s,NP=%s,%s%s>" % (m.group(1), m.group(2), m.group(3), m.group(4) or "")
-    m = re.search(r"(k_rows_dot_all|k_rows_dot|k_combine|k_qdot|k_sadd|k_fisher_t|k_fisher_y)<([^>]*)>", name)
+    m = re.search(r"(k_rows_dot_all|k_rows_dot|k_combine|k_qdot|k_sadd|k_fisher_t|k_fisher_y|k_pair_y_diff)<([^>]*)>", name)
     if m:
         return "%s<%s>" % (m.group(1), m.group(2))
     return re.sub(r"\(.*", "", name)[:80]
@@ -40,13 +43,13 @@ def newest(pattern):
     return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
 
 
-stats = newest(os.path.join(ROOT, "gpurun_out", "prof_stats", "*", "*_kernel_stats.csv"))
+stats = newest(os.path.join(ROOT, "gpurun_out", pre + "prof_stats", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(out, tag + "_rocprofv3_kernel_stats.csv"))
 
 pmc = {}
 for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    files = newest(os.path.join(ROOT, "gpurun_out", "prof_" + kind, "*", "*_counter_collection.csv"))
+    files = newest(os.path.join(ROOT, "gpurun_out", pre + "prof_" + kind, "*", "*_counter_collection.csv"))
     if not files:
         continue
     agg = collections.defaultdict(list)
@@ -63,7 +66,8 @@ for k, d in pmc.items():
     wr = d.get("WRITE_SIZE", {}).get("median_KiB", 0.0) * 1024
     summary[k] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr, "raw": d}
 json.dump(summary, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
-shutil.copy(os.path.join(ROOT, "gpurun_out", "prof_stats.json"), os.path.join(out, tag + "_bench_under_rocprofv3.json"))
+if os.path.exists(os.path.join(ROOT, "gpurun_out", pre + "prof_stats.json")):
+    shutil.copy(os.path.join(ROOT, "gpurun_out", pre + "prof_stats.json"), os.path.join(out, tag + "_bench_under_rocprofv3.json"))
 for k in sorted(summary, key=lambda k: -summary[k]["hbm_bytes_per_launch"])[:12]:
     s = summary[k]
     print("%-60s read %.3e  write %.3e  total %.3e" % (k, s["read_bytes_per_launch"], s["write_bytes_per_launch"], s["hbm_bytes_per_launch"]))

@@ -206,18 +206,20 @@ void pin_for_all_devices(Group* g, const void* p, size_t bytes)
 	hipPointerAttribute_t a;
 	if (hipPointerGetAttributes(&a, p) == hipSuccess) { if (a.type == hipMemoryTypeHost) return; }      // pinned by somebody else already
 	else (void) hipGetLastError();
+	if (!pinnable_in_place(p, bytes)) return;                  // runtime.cpp: not in the break heap, no page shared with another pin
 	Group::HostRange& slot = g->regs[g->reg_turn++ % 4];
-	if (slot.p) { if (hipHostUnregister(const_cast<void*>(slot.p)) != hipSuccess) (void) hipGetLastError(); slot = Group::HostRange{}; }
+	if (slot.p) { if (hipHostUnregister(const_cast<void*>(slot.p)) != hipSuccess) (void) hipGetLastError(); note_unpinned(slot.p); slot = Group::HostRange{}; }
 	if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); return; }
 	slot.p = p;
 	slot.bytes = bytes;
+	note_pinned(p, bytes);
 	stat_add(ST_HOST_REGISTERED);
 }
 
 void destroy_group(Group* g)
 {
 	for (auto& r : g->regs)
-		if (r.p) { if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError(); }
+		if (r.p) { if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError(); note_unpinned(r.p); }
 	for_all(g, [&](Shard& s) {
 		if (s.S) release(s.S);                                  // the shard's device context
 		dfree(s.S); dfree(s.Y); dfree(s.sbak); dfree(s.ybak); dfree(s.gprev); dfree(s.xsum); dfree(s.xprev);

@@ -296,6 +296,40 @@ __global__ void __launch_bounds__(kBlock) k_sweep(Op op, uint32_t n, int rev, do
 	}
 }
 
+// A pair kernel (three sums: s'y, s's, y'y) that also takes the verdict on its pair: every workgroup stores its partials, makes
+// them visible device-wide (__threadfence: write-back of this XCD's L2) and takes a ticket; the workgroup that draws the last
+// ticket re-reads ALL partials (behind a fence of its own: the other XCDs' lines are not in its L2) and does exactly what
+// k_verdict does -- the same total_of over the same array, so the same bits -- then puts the ticket counter back to zero.
+template <int W, class Op>
+__global__ void __launch_bounds__(kBlock) k_sweep_verdict(Op op, uint32_t n, int rev, double* parts_out, unsigned* ticket, VerdictArgs v)
+{
+	__shared__ double sh[kWaves];
+	__shared__ unsigned drawn;
+	op.prologue(sh);
+	double acc[3] = {0, 0, 0};
+	sweep<W, 3>(n, rev != 0, op, acc);
+	#pragma unroll
+	for (int j = 0; j < 3; j++) {
+		double t = block_sum(acc[j], sh);
+		if (threadIdx.x == 0) parts_out[j * kMaxGrid + blockIdx.x] = t;
+	}
+	if (threadIdx.x == 0) {
+		__threadfence();
+		drawn = atomicAdd(ticket, 1u);
+	}
+	__syncthreads();
+	if (drawn != gridDim.x - 1) return;
+	__threadfence();
+	const double sy = total_of(parts_out, (int) gridDim.x, sh);
+	const double ss = total_of(parts_out + kMaxGrid, (int) gridDim.x, sh);
+	const double yy = total_of(parts_out + 2 * kMaxGrid, (int) gridDim.x, sh);
+	if (threadIdx.x != 0) return;
+	const bool rejected = v.min_curvature > 0 && sy / ss <= v.min_curvature;      // NaN curvature is accepted (k_verdict)
+	if (!rejected) { *v.sy_dst = sy; *v.yy_dst = yy; }
+	v.out[0] = sy; v.out[1] = ss; v.out[2] = yy; v.out[3] = rejected ? 1.0 : 0.0;
+	*ticket = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // first sweep (take_step prologue; reference src/stochqn.c:808-818, 996, 1174 + first dot of :677)
 // ------------------------------------------------------------------------------------------------
@@ -1364,6 +1398,15 @@ void run_sweep(const Scratch& sc, int id, size_t n, bool vec, const Op& op, doub
 	else     hipLaunchKernelGGL((k_sweep<1, NP, Op>), dim3(grid), dim3(kBlock), 0, sc.stream, op, (uint32_t) n, rev, parts_out);
 }
 
+template <class Op>
+void run_sweep_verdict(const Scratch& sc, int id, size_t n, bool vec, const Op& op, double* parts_out, int grid, const VerdictArgs& v)
+{
+	ProfScope ps(sc, id);
+	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
+	if (vec) hipLaunchKernelGGL((k_sweep_verdict<kVec, Op>), dim3(grid), dim3(kBlock), 0, sc.stream, op, (uint32_t) n, rev, parts_out, sc.ticket, v);
+	else     hipLaunchKernelGGL((k_sweep_verdict<1, Op>), dim3(grid), dim3(kBlock), 0, sc.stream, op, (uint32_t) n, rev, parts_out, sc.ticket, v);
+}
+
 // What the consumer of buffer `buf` has to read: the raw partials, or (multi-GPU) the summed scalars.
 Partials finish(const Scratch& sc, int buf, int nsums, int grid)
 {
@@ -1473,19 +1516,27 @@ void launch_pair_s(const Scratch& sc, size_t n, real* x_sum, double inv_L, bool 
 }
 
 Partials launch_pair_y_diff(const Scratch& sc, int buf, size_t n, const real* g, const real* g_prev,
-                            const real* s, double lambda, real* y_out)
+                            const real* s, double lambda, real* y_out, const VerdictArgs* verdict)
 {
 	const int grid = sweep_grid(sc, n);
 	const bool vec = all_aligned(g, g_prev, s, y_out);
+	if (verdict && !sc.allreduce && sc.ticket) {               // the last workgroup takes the verdict: no second launch
+		run_sweep_verdict(sc, K_PAIR_Y_DIFF, n, vec, PairYDiffOp{g, g_prev, s, lambda, y_out}, sc.part[buf], grid, *verdict);
+		return Partials{nullptr, 0, 0};
+	}
 	run_sweep<3>(sc, K_PAIR_Y_DIFF, n, vec, PairYDiffOp{g, g_prev, s, lambda, y_out}, sc.part[buf], grid);
 	return finish(sc, buf, 3, grid);
 }
 
 Partials launch_pair_y_hv(const Scratch& sc, int buf, size_t n, const real* hv, const real* s, real* y_out,
-                          real* x_sum, real* x_avg_prev)
+                          real* x_sum, real* x_avg_prev, const VerdictArgs* verdict)
 {
 	const int grid = sweep_grid(sc, n);
 	const bool vec = all_aligned(hv, s, y_out, x_sum, x_avg_prev);
+	if (verdict && !sc.allreduce && sc.ticket) {
+		run_sweep_verdict(sc, K_PAIR_Y_HV, n, vec, PairYHvOp{hv, s, y_out, x_sum, x_avg_prev}, sc.part[buf], grid, *verdict);
+		return Partials{nullptr, 0, 0};
+	}
 	run_sweep<3>(sc, K_PAIR_Y_HV, n, vec, PairYHvOp{hv, s, y_out, x_sum, x_avg_prev}, sc.part[buf], grid);
 	return finish(sc, buf, 3, grid);
 }

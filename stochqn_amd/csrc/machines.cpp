@@ -733,13 +733,20 @@ void make_s(DevCtx* c, bfgs_mem* b, bool needs_div)
 
 // check_min_curvature (reference src/stochqn.c:883-900) given the (s'y, s's, y'y) partials of the
 // pair in the slot.  Synchronises (the decision is taken on the host).
+// what the pair kernel needs to take the verdict on its own pair (its last workgroup; single device)
+VerdictArgs verdict_of(DevCtx* c, const bfgs_mem* b)
+{
+	return VerdictArgs{(double) b->min_curvature, c->sc.sy + b->mem_st_ix, c->sc.yy + b->mem_st_ix, c->sc.report + 4};
+}
+
 void accept_or_reject(DevCtx* c, bfgs_mem* b, Partials p, info_enum* info)
 {
 	const size_t st = b->mem_st_ix;
 	// one kernel reduces the three dots, decides and commits s'y / y'y of an accepted pair; the host
-	// only needs the verdict for its bookkeeping (and for the rare rollback)
+	// only needs the verdict for its bookkeeping (and for the rare rollback).  p.parts == NULL: the pair kernel's last
+	// workgroup has done all of that already (kernels.hip: k_sweep_verdict)
 	double* verdict = c->sc.report + 4;                                // report[4..7] <-> pin[4..7]
-	launch_verdict(c->sc, p, (double) b->min_curvature, c->sc.sy + st, c->sc.yy + st, verdict);
+	if (p.parts) launch_verdict(c->sc, p, (double) b->min_curvature, c->sc.sy + st, c->sc.yy + st, verdict);
 	if (c->async_call) {                 // min_curvature == 0: the pair is accepted whatever its dots are (:893); no read-back
 		c->rho_ok[st] = 1;
 		c->kappa[st] = 0;                // the kappa rule needs the dots on the host: off in stream-ordered calls (documented)
@@ -895,7 +902,8 @@ static int run_oLBFGS_impl(real_t step_size, real_t x[], real_t grad[], real_t**
 	// section 2: y-slot from the gradient difference, accept / reject, ask for a new gradient
 	stage_xg(io, false, true);
 	const size_t st = b->mem_st_ix;
-	Partials p = launch_pair_y_diff(c->sc, c->next_buf(), N(c), io.g, c->gprev.dev, row(c->S, st, c), b->y_reg, row(c->Y, st, c));
+	const VerdictArgs va = verdict_of(c, b);
+	Partials p = launch_pair_y_diff(c->sc, c->next_buf(), N(c), io.g, c->gprev.dev, row(c->S, st, c), b->y_reg, row(c->Y, st, c), &va);
 	accept_or_reject(c, b, p, iter_info);
 	sync(c);
 	*task = calc_grad;
@@ -969,7 +977,8 @@ static int run_SQN_impl(real_t step_size, real_t x[], real_t grad[], real_t hess
 		case 3: {                                                     // :1125-1134
 			stage_xg(io, false, true);
 			const size_t st = b->mem_st_ix;
-			Partials p = launch_pair_y_diff(c->sc, c->next_buf(), n, io.g, c->gprev.dev, row(c->S, st, c), b->y_reg, row(c->Y, st, c));
+			const VerdictArgs va = verdict_of(c, b);
+			Partials p = launch_pair_y_diff(c->sc, c->next_buf(), n, io.g, c->gprev.dev, row(c->S, st, c), b->y_reg, row(c->Y, st, c), &va);
 			accept_or_reject(c, b, p, iter_info);
 			if (*iter_info == no_problems_encountered) {
 				d2d(c, c->gprev.dev, io.g, n);
@@ -984,7 +993,8 @@ static int run_SQN_impl(real_t step_size, real_t x[], real_t grad[], real_t hess
 			real* hv = stage_in(c, 2, hess_vec, n, hv_host);
 			if (!hv) return invalid(task, "SQN");
 			const size_t st = b->mem_st_ix;
-			Partials p = launch_pair_y_hv(c->sc, c->next_buf(), n, hv, row(c->S, st, c), row(c->Y, st, c), c->xsum.dev, c->xprev.dev);
+			const VerdictArgs va = verdict_of(c, b);
+			Partials p = launch_pair_y_hv(c->sc, c->next_buf(), n, hv, row(c->S, st, c), row(c->Y, st, c), c->xsum.dev, c->xprev.dev, &va);
 			accept_or_reject(c, b, p, iter_info);
 			sync(c);
 			break;
@@ -1085,7 +1095,8 @@ static int run_adaQN_impl(real_t step_size, real_t x[], real_t f, real_t grad[],
 		case 4: {                                                     // :1265-1270
 			stage_xg(io, false, true);
 			const size_t st = b->mem_st_ix;
-			Partials p = launch_pair_y_diff(c->sc, c->next_buf(), n, io.g, c->gprev.dev, row(c->S, st, c), b->y_reg, row(c->Y, st, c));
+			const VerdictArgs va = verdict_of(c, b);
+			Partials p = launch_pair_y_diff(c->sc, c->next_buf(), n, io.g, c->gprev.dev, row(c->S, st, c), b->y_reg, row(c->Y, st, c), &va);
 			accept_or_reject(c, b, p, iter_info);
 			if (*iter_info == no_problems_encountered) d2d(c, c->gprev.dev, io.g, n);
 			zero(c, c->xsum.dev, n);

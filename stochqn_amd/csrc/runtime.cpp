@@ -5,14 +5,17 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
 #include <new>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <unordered_map>
@@ -52,7 +55,7 @@ std::atomic<long long> g_stats[ST_COUNT];
 const char* const kStatNames[ST_COUNT] = {
 	"steps_three_pass", "steps_sweeps", "steps_plain", "steps_kappa_fallback",
 	"allreduces", "allreduce_doubles", "contexts_created", "contexts_reclaimed", "x_uploads", "x_uploads_skipped",
-	"host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched", "host_unpin_failed", "host_copies_in_flight"};
+	"host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched", "host_unpin_failed", "host_copies_in_flight", "host_pins_declined"};
 
 // Copies between device memory and ORDINARY host memory on the reclaim path, which by definition runs when the device is
 // full: through a small pinned buffer made while memory was still plentiful (with the first mirror), so that the runtime
@@ -277,7 +280,7 @@ void destroy(DevCtx* c, bool keep_spill = false)
 	if (c->spec) SQN_HIP_OK(hipFree(c->spec));
 	if (c->x_pre_ev) (void) hipEventDestroy(c->x_pre_ev);
 	for (auto& r : c->regs)
-		if (r.p) { if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError(); }   // the caller may have freed it already
+		if (r.p) { if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError(); note_unpinned(r.p); }   // the caller may have freed it already
 	if (c->own_stream) SQN_HIP_OK(hipStreamDestroy(c->own_stream));
 	delete c;
 }
@@ -593,10 +596,10 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 		return nullptr;
 	}
 	c->sc.stream = c->own_stream;
-	// pool layout: part0 | part1 | red0 | red1 | sy | yy | report | rho | alpha | rows_part x2 | gsy | kap
+	// pool layout: part0 | part1 | red0 | red1 | sy | yy | report | rho | alpha | rows_part x2 | gsy | kap | ticket
 	const size_t part = (size_t) kMaxSums * kMaxGrid;
 	const size_t rows_part = (size_t) kRedMax * kMaxGrid;
-	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + m * m + 3 * m;
+	const size_t total = 2 * part + 2 * kRedMax + 4 * m + 8 + 2 * rows_part + m * m + 3 * m + 1;
 	c->pin_count = 16 + 2 * m + fsize + 3 * m + 8;
 	c->pool_bytes = total * sizeof(double);
 	if (!device_alloc((void**) &c->pool, c->pool_bytes) ||
@@ -621,7 +624,8 @@ DevCtx* acquire(const void* key, int kind, int n, size_t m, size_t fsize, bool* 
 	c->sc.rows_part[0] = p; p += rows_part;
 	c->sc.rows_part[1] = p; p += rows_part;
 	c->sc.gsy = p; p += m * m;
-	c->kap_dev = p;
+	c->kap_dev = p; p += 3 * m;
+	c->sc.ticket = reinterpret_cast<unsigned*>(p);             // zero (the pool is cleared above), and put back to zero by whoever draws the last ticket
 	c->forget_rows();
 	begin_call(c);
 	c->sc.allreduce = nullptr;
@@ -845,6 +849,62 @@ real* host_landing(DevCtx* c, int slot)
 	return c->host_stage[slot];
 }
 
+// ---- which host ranges may be page-locked in place -------------------------------------------------------------------------------
+// hipHostRegister maps the PAGES that contain [p, p + bytes) into the device's address space at their own addresses (measured
+// on the MI355X boxes, ROCm 7.0 and 7.2: device pointer == host pointer; tools/pin_probe.hip).  That is safe exactly as long as
+// those pages belong to the array and to nothing else, and stay mapped until the unregister.  A block in the program-break heap
+// gives neither: its first and last page hold its neighbours' bytes too, and glibc cuts the break back (an munmap of pages
+// next to, or -- once the block is freed -- under a registration) whenever the top of the heap falls free.  Round 4 lost a test
+// process twice to a GPU memory-access fault at a break-heap address.  Arrays with a mapping of their own -- what
+// malloc / numpy / R hand out above the mmap threshold, what stochqn_amd/free.py makes for its own arrays -- start on a page of
+// their own and are unmapped as a whole by their owner, after the owner has unpinned them.
+namespace {
+std::mutex g_span_mu;
+std::map<uintptr_t, uintptr_t> g_spans;            // first page -> one past the last page, of every range this library registered
+
+uintptr_t break_heap_start()
+{
+	static std::atomic<uintptr_t> start{0};
+	uintptr_t s = start.load(std::memory_order_relaxed);
+	if (s) return s;
+	if (FILE* f = std::fopen("/proc/self/maps", "r")) {     // the start of [heap] never moves; the break (its end) is sbrk(0)
+		char line[512];
+		while (std::fgets(line, sizeof line, f))
+			if (std::strstr(line, "[heap]")) { s = (uintptr_t) std::strtoull(line, nullptr, 16); break; }
+		std::fclose(f);
+	}
+	if (s) start.store(s, std::memory_order_relaxed);
+	return s;
+}
+}  // namespace
+
+bool pinnable_in_place(const void* p, size_t bytes)
+{
+	const uintptr_t lo = (uintptr_t) p & ~(uintptr_t) 4095, hi = ((uintptr_t) p + bytes + 4095) & ~(uintptr_t) 4095;
+	const uintptr_t heap = break_heap_start(), brk_now = (uintptr_t) sbrk(0);
+	bool ok = !(heap && lo < brk_now && hi > heap);
+	if (ok) {
+		std::lock_guard<std::mutex> lk(g_span_mu);
+		auto it = g_spans.upper_bound(lo);                  // the first span that starts above lo; the one before may reach into [lo, hi)
+		if (it != g_spans.end() && it->first < hi) ok = false;
+		if (ok && it != g_spans.begin()) { --it; if (it->second > lo) ok = false; }
+	}
+	if (!ok) stat_add(ST_HOST_PIN_DECLINED);
+	return ok;
+}
+
+void note_pinned(const void* p, size_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_span_mu);
+	g_spans[(uintptr_t) p & ~(uintptr_t) 4095] = ((uintptr_t) p + bytes + 4095) & ~(uintptr_t) 4095;
+}
+
+void note_unpinned(const void* p)
+{
+	std::lock_guard<std::mutex> lk(g_span_mu);
+	g_spans.erase((uintptr_t) p & ~(uintptr_t) 4095);
+}
+
 bool ensure_registered(DevCtx* c, const void* p, size_t bytes)
 {
 	const Options& o = options();
@@ -853,6 +913,7 @@ bool ensure_registered(DevCtx* c, const void* p, size_t bytes)
 		if (r.p == p) {
 			if (r.bytes >= bytes) return true;
 			if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError();
+			note_unpinned(r.p);
 			r = DevCtx::HostRange{};
 		}
 	// pinned by its owner (hipHostMalloc, the caller's own hipHostRegister, stochqn_hip_pin_host)?  then it is as fast as it gets
@@ -871,14 +932,16 @@ bool ensure_registered(DevCtx* c, const void* p, size_t bytes)
 	if (!mine) { *oldest = DevCtx::Seen{p, c->call_index}; return false; }
 	if (mine->call == c->call_index) return false;             // first sighting was in this very call
 	mine->call = c->call_index;
+	if (!pinnable_in_place(p, bytes)) return false;          // a block in the break heap, or pages shared with another pin: left to the runtime's pageable path
 	DevCtx::HostRange& slot = c->regs[c->reg_turn++ % (int) (sizeof(c->regs) / sizeof(c->regs[0]))];
-	if (slot.p) { if (hipHostUnregister(const_cast<void*>(slot.p)) != hipSuccess) (void) hipGetLastError(); slot = DevCtx::HostRange{}; }
+	if (slot.p) { if (hipHostUnregister(const_cast<void*>(slot.p)) != hipSuccess) (void) hipGetLastError(); note_unpinned(slot.p); slot = DevCtx::HostRange{}; }
 	if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
 		(void) hipGetLastError();                        // not fatal: the runtime's staged copies still work
 		return false;
 	}
 	slot.p = p;
 	slot.bytes = bytes;
+	note_pinned(p, bytes);
 	stat_add(ST_HOST_REGISTERED);
 	return true;
 }
@@ -1158,9 +1221,12 @@ int stochqn_hip_pin_host(void* p, size_t bytes)
 	if (it != g_pins.end() && it->second.bytes >= bytes) { it->second.refs++; return 0; }
 	if (it != g_pins.end()) {                                  // the same array, longer now: pinned anew
 		if (hipHostUnregister(p) != hipSuccess) (void) hipGetLastError();
+		note_unpinned(p);
 		const int refs = it->second.refs;
 		g_pins.erase(it);
+		if (!pinnable_in_place(p, bytes)) return 1;
 		if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); return -1; }
+		note_pinned(p, bytes);
 		g_pins[p] = Pin{bytes, refs + 1};
 		return 0;
 	}
@@ -1169,7 +1235,9 @@ int stochqn_hip_pin_host(void* p, size_t bytes)
 		if (a.type == hipMemoryTypeHost) return 1;             // page-locked by other means
 		if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) return -1;
 	} else (void) hipGetLastError();
+	if (!pinnable_in_place(p, bytes)) return 1;                // in the break heap, or sharing a page with another pin: stays pageable (works, a little slower)
 	if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); return -1; }
+	note_pinned(p, bytes);
 	g_pins[p] = Pin{bytes, 1};
 	stat_add(ST_HOST_REGISTERED);
 	return 0;
@@ -1193,6 +1261,7 @@ int stochqn_hip_unpin_host(void* p)
 	if (it == g_pins.end()) return -1;
 	if (--it->second.refs > 0) return 0;
 	g_pins.erase(it);
+	note_unpinned(p);
 	if (hipHostUnregister(p) != hipSuccess) {               // the range stays page-locked in the runtime's books: say so, the owner is about to free it
 		std::fprintf(stderr, "stochqn: hipHostUnregister(%p) failed: %s\n", p, hipGetErrorString(hipGetLastError()));
 		stat_add(ST_HOST_UNPIN_FAILED);

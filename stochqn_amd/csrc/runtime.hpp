@@ -205,9 +205,16 @@ struct DevCtx {
 enum StatId {
 	ST_STEP_THREE_PASS = 0, ST_STEP_SWEEPS, ST_STEP_PLAIN, ST_KAPPA_FALLBACK,
 	ST_ALLREDUCE, ST_ALLREDUCE_DOUBLES, ST_CTX_CREATED, ST_CTX_RECLAIMED, ST_X_UPLOAD, ST_X_UPLOAD_SKIPPED,
-	ST_HOST_REGISTERED, ST_X_AHEAD, ST_X_RESENT, ST_X_PREFETCH, ST_HOST_UNPIN_FAILED, ST_WORK_IN_FLIGHT, ST_COUNT
+	ST_HOST_REGISTERED, ST_X_AHEAD, ST_X_RESENT, ST_X_PREFETCH, ST_HOST_UNPIN_FAILED, ST_WORK_IN_FLIGHT, ST_HOST_PIN_DECLINED, ST_COUNT
 };
 void stat_add(int id, long long v = 1);
+// May [p, p + bytes) of ordinary host memory be page-locked in place (hipHostRegister)?  Only a range that has its pages to
+// itself for as long as it lives: not one inside the program-break heap (malloc'ed blocks there share their first and last
+// page with neighbours, and the break moves under them when the heap is trimmed), not one whose pages overlap a range that is
+// page-locked already.  Whatever is declined still works: the runtime's pageable path carries it (runtime.cpp).
+bool pinnable_in_place(const void* p, size_t bytes);
+void note_pinned(const void* p, size_t bytes);          // bookkeeping of the ranges this library has registered, for the overlap rule
+void note_unpinned(const void* p);
 
 bool device_ready();                                   // a HIP device exists and is usable
 // Every device / pinned-host allocation of the library goes through these two: they report failure

@@ -15,6 +15,7 @@ The arithmetic is done by whatever library `backend` wraps: `stochqn_amd.lib()` 
 default) or, in the test-suite only, the CPU oracle.
 """
 import ctypes as C
+import mmap
 import weakref
 
 import numpy as np
@@ -37,7 +38,15 @@ class _HostSpace:
     the user's x -- are page-locked through stochqn_hip_pin_host for exactly as long as the array object lives: a
     `weakref.finalize` on the ndarray unpins the range when the array is collected, BEFORE numpy frees its memory
     (weak-reference callbacks run at the start of deallocation).  That is the guarantee the library cannot give itself
-    behind the C ABI (stochqn_hip.h: "host arrays pinned by their owner"), and what makes pinning safe here."""
+    behind the C ABI (stochqn_hip.h: "host arrays pinned by their owner"), and what makes pinning safe here.
+
+    The arrays the object makes for itself (`empty`) get an anonymous mapping of their OWN once they are large enough to be
+    pinned: they start on a page boundary, share no page with anything else and are unmapped as a whole when the array dies
+    (after its finaliser has unpinned it) -- whatever the process's malloc thresholds are.  numpy's own allocations of that
+    size may sit in the program-break heap (glibc raises its mmap threshold up to 32 MiB as large blocks are freed), where a
+    block shares its first and last page with its neighbours and the break moves under it; the library declines to pin such a
+    range (stochqn_hip_pin_host returns 1) and the user's x, if it lives there, crosses the link through the runtime's
+    pageable path instead."""
     name = "host"
     PIN_MIN_BYTES = 4 << 20                             # below, the runtime's staged copies are as fast
 
@@ -75,7 +84,11 @@ class _HostSpace:
 
     def empty(self, n):
         # the reference uses np.empty; zeros keeps runs reproducible and is a legal instance of it
-        return np.zeros(int(n), dtype=self.dtype)
+        n = int(n)
+        nbytes = n * np.dtype(self.dtype).itemsize
+        if self._lib is not None and nbytes >= self.PIN_MIN_BYTES:
+            return np.frombuffer(mmap.mmap(-1, nbytes), dtype=self.dtype, count=n)      # a mapping of its own, zero-filled by the kernel
+        return np.zeros(n, dtype=self.dtype)
 
     zeros = empty
 

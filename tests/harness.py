@@ -36,6 +36,18 @@ def to_np(a):
     return out.reshape(tuple(a.shape))
 
 
+def own_mapping(a):
+    """A copy of `a` in an anonymous mapping of its own -- what malloc / numpy / R hand out for a large array when the allocator's
+    mmap threshold is below its size, made deterministic: pages that belong to this array alone, unmapped when it dies.  The
+    library page-locks such an array in place when asked to; one that sits in the program-break heap it leaves pageable
+    (stochqn_amd/csrc/runtime.cpp: pinnable_in_place)."""
+    import mmap
+    a = np.ascontiguousarray(a)
+    out = np.frombuffer(mmap.mmap(-1, max(a.nbytes, 1)), dtype=a.dtype, count=a.size).reshape(a.shape)
+    out[...] = a
+    return out
+
+
 def to_dev(a, device="cuda"):
     """A numpy array as a new device tensor (large ones in chunks through the page-locked staging tensor)."""
     import torch

@@ -246,18 +246,29 @@ Partials three_dots(const Scratch& sc, int id, int buf, size_t n, std::function<
 }
 }  // namespace
 
-Partials launch_pair_y_diff(const Scratch& sc, int buf, size_t n, const real* g, const real* g_prev, const real* s, double lambda, real* y_out)
+void launch_verdict(const Scratch& sc, Partials in, double min_curvature, double* sy_dst, double* yy_dst, double* out);
+
+// the pair kernel's last workgroup takes the verdict itself (kernels.hip: k_sweep_verdict): same stream, right behind the sweep
+static Partials with_verdict(const Scratch& sc, Partials p, const VerdictArgs* v)
 {
-	(void) lambda;
-	return three_dots(sc, K_PAIR_Y_DIFF, buf, n, [=] { rd(g_prev, n); rd(s, n); for (size_t i = 0; i < n; i++) y_out[i] = g[i]; });
+	if (!v || sc.allreduce || !sc.ticket) return p;
+	rdd(reinterpret_cast<const double*>(sc.ticket), 1);
+	launch_verdict(sc, p, v->min_curvature, v->sy_dst, v->yy_dst, v->out);
+	return Partials{nullptr, 0, 0};
 }
 
-Partials launch_pair_y_hv(const Scratch& sc, int buf, size_t n, const real* hv, const real* s, real* y_out, real* x_sum, real* x_avg_prev)
+Partials launch_pair_y_diff(const Scratch& sc, int buf, size_t n, const real* g, const real* g_prev, const real* s, double lambda, real* y_out, const VerdictArgs* v)
 {
-	return three_dots(sc, K_PAIR_Y_HV, buf, n, [=] {
+	(void) lambda;
+	return with_verdict(sc, three_dots(sc, K_PAIR_Y_DIFF, buf, n, [=] { rd(g_prev, n); rd(s, n); for (size_t i = 0; i < n; i++) y_out[i] = g[i]; }), v);
+}
+
+Partials launch_pair_y_hv(const Scratch& sc, int buf, size_t n, const real* hv, const real* s, real* y_out, real* x_sum, real* x_avg_prev, const VerdictArgs* v)
+{
+	return with_verdict(sc, three_dots(sc, K_PAIR_Y_HV, buf, n, [=] {
 		rd(s, n);
 		for (size_t i = 0; i < n; i++) { y_out[i] = hv[i]; x_avg_prev[i] = x_sum[i]; x_sum[i] = 0; }
-	});
+	}), v);
 }
 
 Partials launch_dots3(const Scratch& sc, int buf, size_t n, const real* s, const real* y)

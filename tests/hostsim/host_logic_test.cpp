@@ -17,6 +17,7 @@
 #include "runtime.hpp"          // the host checksum of x (xhash_*): tested against its definition directly
 
 #include <dlfcn.h>
+#include <unistd.h>
 #if defined(__SANITIZE_ADDRESS__)
 #include <sanitizer/asan_interface.h>
 #endif
@@ -295,6 +296,18 @@ void sc_host_path()
 		CHECK(stochqn_hip_unpin_host(p.x.data()) == 0 && fakehip::is_registered(p.x.data()), "one of two pins of x released");
 		CHECK(stochqn_hip_unpin_host(p.x.data()) == 0 && stochqn_hip_unpin_host(p.grad.data()) == 0 && stochqn_hip_unpin_host(p.grad.data()) == -1, "unpin");
 		CHECK(fakehip::live().registered_ranges == 0, "ranges left pinned: %ld", fakehip::live().registered_ranges);
+		// ... but only a range that has its pages to itself (runtime.cpp: pinnable_in_place): not a block of the program-break heap
+		// (the sanitizers' allocators never use the break, so a piece of it is taken directly), not one that shares a page with a live pin
+		const long long declined = stat("host_pins_declined");
+		void* blk = sbrk(1 << 16);
+		CHECK(blk != (void*) -1 && stochqn_hip_pin_host(blk, 1 << 16) == 1 && stat("host_pins_declined") == declined + 1, "a block of the break heap must be declined");
+		CHECK(stochqn_hip_unpin_host(blk) == -1 && fakehip::live().registered_ranges == 0, "a declined range is not pinned");
+		std::vector<double> two(2 * (size_t) n + 2048);
+		double* first = two.data();
+		double* second = (double*) (((uintptr_t) (first + n) & ~(uintptr_t) 4095) + 64);      // begins in the page the first range ends in
+		CHECK(stochqn_hip_pin_host(first, bytes) == 0 && stochqn_hip_pin_host(second, bytes / 2) == 1, "a range that shares a page with a live pin must be declined");
+		CHECK(stochqn_hip_pin_host((char*) second + 8192, bytes / 2) == 0, "two pages on: pages of its own");
+		CHECK(stochqn_hip_unpin_host(first) == 0 && stochqn_hip_unpin_host((char*) second + 8192) == 0 && fakehip::live().registered_ranges == 0, "unpin");
 	}
 	// register_host = 1 (the caller vouches for the lifetime of its arrays): the library pins what it saw at the same address twice
 	opt("register_host", 1);

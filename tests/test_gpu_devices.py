@@ -163,7 +163,8 @@ def test_host_path_of_the_multi_device_mode(kind, kw, devices, hip_backend, orac
     want, _ = drive(oracle_backend)
     for i, (g, w) in enumerate(zip(got, want)):
         assert rel_err(g, w) <= 1e-9, i
-    assert skipped >= 3 and uploads >= 2 and pinned >= 2, (skipped, uploads, pinned)
+    # pinned: at least the object's own gradient array (a mapping of its own, stochqn_amd/free.py); the test's x only if numpy did not put it in the break heap
+    assert skipped >= 3 and uploads >= 2 and pinned >= 1, (skipped, uploads, pinned)
     opt.release()
 
 

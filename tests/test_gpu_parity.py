@@ -1385,10 +1385,12 @@ def test_float_lockstep_parity(name, n, form_f32, hip_backend_f32):
     run_lockstep(ref, opt, P, x_ref, x_dev, step, min(calls, 50), F32_TOL, on_sync=inval)
 
 
-@pytest.mark.parametrize("name", ["sqn_ring20", "adaqn_fisher_rms", "adaqn_ring20"])
+@pytest.mark.parametrize("name", ["adaqn_ring20"])
 def test_float_lockstep_parity_full_grids(name, hip_backend_f32):
     """Single precision at full launch shapes: n = 1,000,003 puts three ring rows in four off the 16-byte grid
-    (float4 packs read at 4-byte alignment), the row-split pass A runs its whole-rounds grid.
+    (float4 packs read at 4-byte alignment), the row-split pass A runs its whole-rounds grid.  The one hard configuration
+    (rounds 2 - 4 also ran sqn_ring20 and adaqn_fisher_rms here: the same kernels at the same launch shapes, 17 s of the
+    suite's budget; in single precision they stay covered at every size of test_float_lockstep_parity's grid).
 
     adaqn_ring20 (L = 1, step 0.002) is the hard case: s = x_new - x_old cancels to ~1e-3 of x, so the ONE float rounding by
     which the library's update (fma in double, one rounding to float) and the oracle's (float product, float sum: two
@@ -1920,7 +1922,10 @@ def test_bench_keeps_its_primary_result_when_an_auxiliary_leg_hangs():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(BENCH_TEST_HANG_LEG="c5", BENCH_WATCHDOG_S="5")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rehearse"], capture_output=True, text=True,
+    # (the control flow is what is under test: a short primary leg -- the default run's 200 steps, sustained seconds, repeated
+    # regions and reference-form extras are test_bench_default_multi_gpu_run_carries_every_leg's business)
+    short = ["--steps", "20", "--warmup", "2", "--sustain-seconds", "0", "--value-runs", "1", "--no-reference-form", "--no-profile"]
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rehearse"] + short, capture_output=True, text=True,
                          timeout=600, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -1930,9 +1935,115 @@ def test_bench_keeps_its_primary_result_when_an_auxiliary_leg_hangs():
     assert d["legs"] == {} and len(d["legs_failed"]) == 1 and "watchdog" in d["legs_failed"][0] and "'c5'" in d["legs_failed"][0]
     assert d["degraded"] is True and any("watchdog" in w for w in d["degraded_because"])
     # --strict-legs: the same hang is a failed run -- no line, a non-zero exit code from every rank
-    strict = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rehearse", "--strict-legs"], capture_output=True,
+    strict = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rehearse", "--strict-legs"] + short, capture_output=True,
                             text=True, timeout=600, cwd=root, env=env)
     assert strict.returncode != 0 and not [l for l in strict.stdout.splitlines() if l.startswith('{"metric"')], strict.stdout[-1000:]
+
+
+def _host_memory_available():
+    avail = 0
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable"):
+            avail = int(line.split()[1]) * 1024
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            avail = min(avail, int(lim) - int(open("/sys/fs/cgroup/memory.current").read()))
+    except (OSError, ValueError):
+        pass
+    return avail
+
+
+def test_the_benchmarked_workload_itself_matches_the_oracle(hip_backend, oracle_backend):
+    """bench.py's headline workload EXACTLY as it is timed -- `bench.Workload`: SQN, n = 1e8, m = 20, L = 10, the ring pre-filled
+    and wrapped (mem_st_ix = 3), Hv = A'(Av)/32 over the 32-row mini-batch (stochqn_hip_fisher_product), check_nan = 1, the
+    default three-pass form -- against the CPU oracle from the same state: one whole L-cycle (ten ordinary steps), the
+    Hessian-vector request at x_avg that builds a pair from the batch (reference src/stochqn.c:1093-1115, 962-966), and the
+    step after the pair, which is the first to use it.  Identical task / info / counter sequences; x, the averages, the NEW
+    row of S and of Y, rho and alpha of the last step at 1e-10.  Both sides get their gradient from their own iterate by
+    the same expression ((d x) noise_t, noise_t from the counter-based generator: bit-identical in numpy and torch), so only
+    the library's arithmetic can differ.  (VERDICT r04 weak #4: the full-size SQN parity test uses Hv = d v at L = 1.)"""
+    import bench
+    import stochqn_amd
+    from oracle import oracle
+    from stochqn_amd import _abi
+    torch = torch_cuda()
+    n, m, L, bs = 100_000_000, 20, 10, 32
+    need = (2 * m + bs + 9) * n * 8
+    avail = _host_memory_available()
+    if avail < 1.2 * need:
+        pytest.skip("the host has %.0f GB available, the oracle's copy of the workload needs %.0f GB" % (avail / 1e9, 1.2 * need / 1e9))
+    lib = stochqn_amd.cdll()
+    bench.prototypes(lib)
+    ctx = {"lib": lib, "be": hip_backend, "dev": torch.device("cuda", 0), "dist": None, "cpu_or_dev": "cpu", "rank": 0, "world": 1}
+    wl = bench.Workload(ctx, n, 0, m, L, bs)
+    olib = oracle.cdll()
+    oracle.set_threads(oracle.usable_cpus())
+    try:
+        assert (wl.b.mem_used, wl.b.mem_st_ix, wl.w.niter, wl.w.section, wl.w.check_nan, wl.b.upd_freq) == (m, 3, L, 1, 1, L)
+        # the oracle's copy of the state the timed region starts from
+        S_h, Y_h, A_h, d_h, x_h = to_np(wl.S), to_np(wl.Y), to_np(wl.A), to_np(wl.d), to_np(wl.x)
+        g_h, hv_h, tb_h, xs_h, xp_h = np.zeros(n), np.zeros(n), np.zeros(bs), np.zeros(n), x_h.copy()
+        rho_r, alpha_r, dummy = np.zeros(m), np.zeros(m), np.zeros(1)
+        b_r = _abi.bfgs_mem(S_h.ctypes.data, Y_h.ctypes.data, rho_r.ctypes.data, alpha_r.ctypes.data, dummy.ctypes.data, dummy.ctypes.data, m, m, 3 % m, L, 0.0, 0.0)
+        w_r = _abi.workspace_SQN(C.pointer(b_r), dummy.ctypes.data, xs_h.ctypes.data, xp_h.ctypes.data, 0, L, 1, 1, 1, n)
+        at_r = {x_h.ctypes.data: x_h, xs_h.ctypes.data: xs_h, xp_h.ctypes.data: xp_h}
+        ref = {"be": oracle_backend, "b": b_r, "w": w_r, "req": C.c_void_p(x_h.ctypes.data), "req_vec": C.c_void_p(), "task": C.c_int(101), "info": C.c_int(200),
+               "x": x_h.ctypes.data, "g": g_h.ctypes.data, "hv": hv_h.ctypes.data, "log": []}
+        dev = {"be": hip_backend, "b": wl.b, "w": wl.w, "req": wl.req, "req_vec": wl.req_vec, "task": wl.task, "info": wl.info,
+               "x": wl.x.data_ptr(), "g": wl.grad.data_ptr(), "hv": wl.hv.data_ptr(), "log": []}
+        noise_d = torch.empty(n, dtype=torch.float64, device="cuda")
+
+        def gradient(side, t):
+            if side is ref:
+                np.multiply(d_h, at_r[side["req"].value], out=g_h)
+                np.multiply(g_h, noise_h[0], out=g_h)
+            else:
+                torch.mul(wl.d, wl.ptr2t[side["req"].value], out=wl.grad)
+                wl.grad.mul_(noise_d)
+
+        def hess_vec(side):
+            if side is ref:
+                olib.oracle_fisher_product(A_h.ctypes.data, bs, n, side["req_vec"].value, tb_h.ctypes.data, hv_h.ctypes.data)
+            else:
+                assert lib.stochqn_hip_fisher_product(wl.A.data_ptr(), bs, n, side["req_vec"].value, wl.t_buf.data_ptr(), wl.hv.data_ptr()) == 0
+
+        noise_h = [None]
+        t, new_row = 0, wl.b.mem_st_ix
+        while w_r.niter < 2 * L + 1:                                     # niter starts at L: 10 steps, the pair, the step after it
+            assert dev["task"].value == ref["task"].value
+            if ref["task"].value == 101:
+                wl.uniform(noise_d, bench.ST_NOISE, t, 0.99, 0.02)
+                noise_h[0] = to_np(noise_d)
+                t += 1
+            for side in (ref, dev):
+                if side["task"].value == 101:
+                    gradient(side, t)
+                elif side["task"].value == 104:
+                    hess_vec(side)
+                rc = side["be"].run_SQN(wl.step_size, side["x"], side["g"], side["hv"], C.byref(side["req"]), C.byref(side["req_vec"]),
+                                        C.byref(side["task"]), C.byref(side["w"]), C.byref(side["info"]))
+                side["log"].append((rc, side["task"].value, side["info"].value, side["w"].niter, side["w"].section, side["b"].mem_used, side["b"].mem_st_ix))
+            assert dev["log"][-1] == ref["log"][-1], (len(ref["log"]), dev["log"][-1], ref["log"][-1])
+        tasks = [e[1] for e in ref["log"]]
+        assert tasks.count(104) == 1 and b_r.mem_st_ix == (new_row + 1) % m and b_r.mem_used == m and all(e[2] == 200 for e in ref["log"])
+        assert w_r.niter == 2 * L + 1 and len(ref["log"]) == L + 2       # ten steps, the call that takes the Hessian-vector product in, the step after
+
+        def close(what, got, want, tol=TOL):
+            wd = to_dev(want)
+            e = float(torch.linalg.vector_norm(got - wd) / torch.linalg.vector_norm(wd))
+            print("benchmarked workload, %-12s %.2e from the oracle's" % (what + ":", e))
+            assert e <= tol, (what, e)
+
+        close("x", wl.x, x_h)
+        close("x_avg_prev", wl.x_avg_prev, xp_h)
+        close("new s row", wl.S[new_row * n:(new_row + 1) * n], S_h[new_row * n:(new_row + 1) * n])
+        close("new y row", wl.Y[new_row * n:(new_row + 1) * n], Y_h[new_row * n:(new_row + 1) * n])
+        assert float(torch.linalg.vector_norm(wl.x_sum - to_dev(xs_h))) <= TOL * float(np.linalg.norm(x_h))       # one step's x after the average was archived
+        assert np.allclose(wl.rho_h, rho_r, rtol=1e-9, atol=0) and np.allclose(wl.alpha_h, alpha_r, rtol=1e-7, atol=1e-12 * np.abs(alpha_r).max())
+        assert rel_err(x_h, to_np(wl.uniform(noise_d, bench.ST_X0, 0, 1.0, 1.0))) > 1e-3      # and the iterate moved
+    finally:
+        wl.free()
 
 
 @pytest.mark.parametrize("config,n", [("c3", 100_000_000), ("c5", 125_000_000)])
@@ -1966,7 +2077,7 @@ def test_bench_headline_workload_runs_clean(config, n):
     assert abs(d["sustained"]["value"] / d["value"] - 1) < 0.15          # the K = 20 steps are representative of a second of the same
     vr = d["value_runs"]                                                 # the K-step region three times, the gradient array re-allocated in between
     assert len(vr["values"]) == 3 and abs(vr["values"][0] - d["value"]) <= 1e-3 * d["value"] + 2e-3 and vr["min"] <= vr["median"] <= vr["max"]
-    assert vr["max"] / vr["min"] < 1.25 and d["degraded"] is False and "disjoint supports" in d["config"]["deviation_from_survey_8d"]
+    assert vr["max"] / vr["min"] < 1.25 and d["degraded"] is False and "disjoint supports" in d["config"]["deviation_from_survey_8d"] and d["config"]["workload_resets"] == 0
     if config == "c5":
         assert d["shard_reference_1gpu"]["source"] == "this run"
 

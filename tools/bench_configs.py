@@ -108,12 +108,81 @@ def drive(opt, P, x, step, steps, warmup, host=False):
     return dt, ncalls
 
 
-def report(name, workload, n, m, dt, steps, calls, extra=None):
+PEAK = 8000.0            # GB/s, MI355X HBM3E (MI355X_MICROARCH.md)
+PMC_KEYS = {"sdot": "k_rows_dot_all", "sdot2": "k_rows_dot_all", "qdot": "k_qdot", "sadd": "k_sadd", "fisher_t": "k_fisher_t", "fisher_y": "k_fisher_y"}
+
+
+def words_per_launch(kind, k, fisher_rows):
+    """Algorithmic n-words one launch of each kernel has to move, for the optimiser `kind` with k pairs in
+    the ring and `fisher_rows` rows in the Fisher product."""
+    w = {"sdot": k + 1,                 # pass 1: g and the k rows of S
+         "sdot2": k + 2,                # ... plus the new pair's y as a probe (its column of the cached s'y block)
+         "qdot": k + 2,                 # pass 2: g and the k rows of Y; writes r0
+         "sadd": k + 2,                 # pass 3: r0 and the k rows of S; writes r
+         "apply": 5,                    # SQN / adaQN: r, x, x_sum -> x, x_sum;  oLBFGS: r, x -> x, s_slot, grad
+         "pair_s": 4, "pair_y_hv": 6, "pair_y_diff": 4,      # g, g_prev, s -> y (+ the three dots)
+         "fisher_t": fisher_rows + 1, "fisher_y": fisher_rows + 2,
+         "first": 2, "bwd": 4, "mid": 3, "fwd": 4, "fwd_last": 3}
+    if kind == "oLBFGS":
+        w["sdot"] += 1; w["sdot2"] += 1  # pass 1 also writes g_prev
+    if kind == "adaQN":
+        w["qdot"] += 4                  # pass 2 also reads G and writes G, H0 and the Fisher row
+        w["mid"] += 1
+    return w
+
+
+def pmc_of(kernel):
+    """HBM bytes per launch of `kernel` from a summary of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS
+    command (profiles/summarise.py; the path comes in through PMC_JSON -- tools/r05_measure.sh sets it for its last pass)."""
+    path = os.environ.get("PMC_JSON", "")
+    if not path or not os.path.exists(path) or kernel not in PMC_KEYS:
+        return None, None
+    d = json.load(open(path))
+    best = None
+    for key, v in d.items():
+        if key.startswith(PMC_KEYS[kernel]) and (best is None or v["hbm_bytes_per_launch"] > best["hbm_bytes_per_launch"]):
+            best = v                    # several instantiations share a name: the one that moves the most is the pass itself
+    return (int(best["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT) + " (FETCH_SIZE x 2 + WRITE_SIZE, median dispatch)") if best else (None, None)
+
+
+def report(name, workload, n, m, dt, steps, calls, extra=None, kind="SQN", k_pairs=None, fisher_rows=0):
+    prof_steps = max(1, min(steps, int(os.environ.get("PROFILE_STEPS", "20"))))      # what drive() ran under the event profiler
     k = kernels()
-    tl = sum(k[x]["avg_ms"] * k[x]["launches"] for x in ("first", "bwd", "mid", "fwd", "fwd_last") if x in k) / steps
-    out = {"config": name, "workload": workload, "steps_per_s": round(steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3),
-           "calls": calls, "two_loop_ms": round(tl, 4),
-           "two_loop_alg_GBps": round(64.0 * m * n / (tl * 1e-3) / 1e9, 1) if tl > 0 else None, "kernels": k}
+    kp = m if k_pairs is None else k_pairs
+    words = words_per_launch(kind, kp, fisher_rows)
+    for kn, e in k.items():
+        if kn in words:
+            e["alg_GB"] = round(words[kn] * n * 8 / 1e9, 3)
+            e["alg_GBps"] = round(words[kn] * n * 8 / (e["avg_ms"] * 1e-3) / 1e9, 1)
+            e["frac_of_8TBps"] = round(e["alg_GBps"] / PEAK, 4)
+    chain = ("first", "bwd", "mid", "fwd", "fwd_last", "sdot", "sdot2", "qdot", "sadd")
+    tl = sum(k[x]["avg_ms"] * k[x]["launches"] for x in chain if x in k) / prof_steps
+    form = "three-pass" if "sadd" in k else "sweeps"
+    moved_tl = sum(words[x] * k[x]["launches"] for x in chain if x in k) * n * 8 / prof_steps
+    moved_step = sum(words[x] * e["launches"] for x, e in k.items() if x in words) * n * 8 / prof_steps
+    kern_ms = sum(e["avg_ms"] * e["launches"] for e in k.values()) / prof_steps
+    ms_step = 1e3 * dt / steps
+    cands = [x for x in k if x in words]
+    dom = max(cands, key=lambda x: k[x]["avg_ms"] * k[x]["launches"]) if cands else None
+    roof = None
+    if dom:
+        alg = words[dom] * n * 8
+        ach = alg / (k[dom]["avg_ms"] * 1e-3) / 1e9
+        traffic, src = pmc_of(dom)
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK, "unit": "GB/s", "frac": round(ach / PEAK, 4),
+                "traffic": traffic, "traffic_source": src, "traffic_over_algorithmic": round(traffic / alg, 4) if traffic else None,
+                "alg_bytes_per_launch": alg, "avg_launch_ms": k[dom]["avg_ms"],
+                "measured": "HIP events on the library's stream, %d steps of the same workload right after the timed region" % prof_steps}
+    out = {"config": name, "workload": workload, "steps_per_s": round(steps / dt, 2), "ms_per_step": round(ms_step, 3),
+           "calls": calls, "roofline": roof,
+           "two_loop": {"form": form, "ms": round(tl, 4), "bytes_moved": int(moved_tl), "GBps_on_bytes_moved": round(moved_tl / (tl * 1e-3) / 1e9, 1) if tl > 0 else None,
+                        "frac_of_8TBps_on_bytes_moved": round(moved_tl / (tl * 1e-3) / 1e9 / PEAK, 4) if tl > 0 else None,
+                        "reference_form_bytes": 64 * kp * n, "pairs_in_ring": kp},
+           "step": {"bytes_moved": int(moved_step), "kernel_ms": round(kern_ms, 4), "ms": round(ms_step, 4),
+                    "launch_and_sync_gap_ms": round(ms_step - kern_ms, 4), "gap_frac": round(1 - kern_ms / ms_step, 4),
+                    "GBps_on_bytes_moved": round(moved_step / (ms_step * 1e-3) / 1e9, 1), "frac_of_8TBps": round(moved_step / (ms_step * 1e-3) / 1e9 / PEAK, 4),
+                    "GBps_inside_kernels": round(moved_step / (kern_ms * 1e-3) / 1e9, 1) if kern_ms > 0 else None},
+           "two_loop_ms": round(tl, 4), "kernels": k}
     if extra:
         out.update(extra)
     print(json.dumps(out), flush=True)
@@ -126,7 +195,8 @@ def c2():
     x = P.x0.clone()
     opt = oLBFGS_free(mem_size=m, min_curvature=None, check_nan=True, space="device")
     dt, calls = drive(opt, P, x, 0.1, 200, 30)
-    report("C2", "oLBFGS n=1e7 m=10 fp64 check_nan=1, device-resident, opts=%s" % os.environ.get("SQN_OPTS", ""), n, m, dt, 200, calls, {"f_end": P.f(x), "mem_used": opt.BFGS_mem.mem_used})
+    report("C2", "oLBFGS n=1e7 m=10 fp64 check_nan=1, device-resident, opts=%s" % os.environ.get("SQN_OPTS", ""), n, m, dt, 200, calls, {"f_end": P.f(x), "mem_used": opt.BFGS_mem.mem_used},
+           kind="oLBFGS", k_pairs=opt.BFGS_mem.mem_used)
 
 
 def c3host():
@@ -157,7 +227,8 @@ def c4():
                          scal_reg=1e-4, rmsprop_weight=0.9, space="device")
         dt, calls = drive(opt, P, x, 1e-3, 40, 400)
         report("C4", "adaQN n=1e8 m=20 fisher_size=128 L=20 rmsprop=0.9 max_incr=%s, device-resident, opts=%s" % (max_incr, os.environ.get("SQN_OPTS", "")), n, m, dt, 40, calls,
-               {"mem_used": opt.BFGS_mem.mem_used, "fisher_used": opt.Fisher_mem.mem_used, "f_end": P.f(x), "f_start": P.f(P.x0)})
+               {"mem_used": opt.BFGS_mem.mem_used, "fisher_used": opt.Fisher_mem.mem_used, "f_end": P.f(x), "f_start": P.f(P.x0)},
+               kind="adaQN", k_pairs=opt.BFGS_mem.mem_used, fisher_rows=f)
 
 
 def c3f32():
