@@ -251,7 +251,9 @@ int stochqn_hip_comm_allreduce_probe(int count, int reps, double *median_us, dou
  *   "host_pins_live" (a gauge: ranges pinned through stochqn_hip_pin_host right now), "host_unpin_failed" (unpins the
  *                               runtime refused: such a range stays page-locked in its books and must not be freed);
  *   "host_pins_declined"        ranges that stochqn_hip_pin_host / "register_host" / the multi-device mode left pageable because
- *                               they lie in the program-break heap or share a page with another pin;
+ *                               they lie in the program-break heap or share a page with another pin; "host_pins_foreign": requests
+ *                               for ranges the runtime already reports as page-locked (by the caller's own hipHostRegister /
+ *                               hipHostMalloc); "host_pin_errors": requests that hipHostRegister itself refused;
  *   "host_copies_in_flight"     the invariant of the host path, asked of the runtime (hipStreamQuery) at the return of every
  *                               run_* call of a host caller: streams of the context that still had work on them.  Always 0 --
  *                               the caller may free x, grad or the requested vector as soon as it has them back (the one

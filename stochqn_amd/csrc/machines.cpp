@@ -277,6 +277,9 @@ void close_call(Call& io, bool x_changed, bool g_changed)
 {
 	DevCtx* c = io.c;
 	resolve_x(io);
+	// ranks of a communicator: a copy into pageable caller memory blocks INSIDE the runtime until the stream has run -- for ever if a
+	// collective on it waits for a peer that is gone.  The bounded wait comes first (runtime.cpp: wait_stream); a no-op without RCCL.
+	if (c->red.kind == Reducer::RCCL && io.host_caller && (x_changed || g_changed)) (void) wait_stream(c, c->sc.stream);
 	// a reduction that failed while the call was being enqueued (c->fault: the call is going to return -1000) left the update
 	// working on un-reduced sums: the caller's arrays are not touched with that
 	if (x_changed && io.host_caller && io.x && !io.x_down && !io.x_pending && !c->fault) vec_to_host(c, io.x_caller, io.x, N(c));

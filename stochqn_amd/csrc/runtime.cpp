@@ -55,7 +55,7 @@ std::atomic<long long> g_stats[ST_COUNT];
 const char* const kStatNames[ST_COUNT] = {
 	"steps_three_pass", "steps_sweeps", "steps_plain", "steps_kappa_fallback",
 	"allreduces", "allreduce_doubles", "contexts_created", "contexts_reclaimed", "x_uploads", "x_uploads_skipped",
-	"host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched", "host_unpin_failed", "host_copies_in_flight", "host_pins_declined"};
+	"host_ranges_registered", "x_sent_ahead", "x_sent_again", "x_prefetched", "host_unpin_failed", "host_copies_in_flight", "host_pins_declined", "host_pins_foreign", "host_pin_errors"};
 
 // Copies between device memory and ORDINARY host memory on the reclaim path, which by definition runs when the device is
 // full: through a small pinned buffer made while memory was still plentiful (with the first mirror), so that the runtime
@@ -113,8 +113,18 @@ struct Comm {
 	ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
 	ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                       // optional: present in every RCCL of ROCm 5+
+	ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr; // optional
 	const char* (*GetErrorString)(ncclResult_t) = nullptr;
 } g_comm;
+// communicators that were aborted after a reduction failed or never completed: every later reduction over them fails at once
+std::mutex g_dead_mu;
+std::vector<void*> g_dead_comms;
+bool comm_is_dead(void* comm)
+{
+	std::lock_guard<std::mutex> lk(g_dead_mu);
+	return std::find(g_dead_comms.begin(), g_dead_comms.end(), comm) != g_dead_comms.end();
+}
 
 bool load_rccl()
 {
@@ -133,6 +143,8 @@ bool load_rccl()
 	g_comm.AllReduce = (decltype(g_comm.AllReduce)) dlsym(g_comm.dl, "ncclAllReduce");
 	g_comm.CommDestroy = (decltype(g_comm.CommDestroy)) dlsym(g_comm.dl, "ncclCommDestroy");
 	g_comm.GetErrorString = (decltype(g_comm.GetErrorString)) dlsym(g_comm.dl, "ncclGetErrorString");
+	g_comm.CommAbort = (decltype(g_comm.CommAbort)) dlsym(g_comm.dl, "ncclCommAbort");
+	g_comm.CommGetAsyncError = (decltype(g_comm.CommGetAsyncError)) dlsym(g_comm.dl, "ncclCommGetAsyncError");
 	if (!g_comm.GetUniqueId || !g_comm.CommInitRank || !g_comm.CommInitAll || !g_comm.AllReduce || !g_comm.CommDestroy) {
 		std::fprintf(stderr, "stochqn: RCCL library lacks the expected symbols\n");
 		dlclose(g_comm.dl);                      // a later attempt starts over instead of calling NULL pointers
@@ -155,10 +167,18 @@ void allreduce_hook(void* user, double* buf, int count, hipStream_t stream)
 {
 	DevCtx* c = static_cast<DevCtx*>(user);
 	stat_add(ST_ALLREDUCE); stat_add(ST_ALLREDUCE_DOUBLES, count);
+	if (comm_is_dead(c->red.comm)) { reducer_failed(user, "the communicator was aborted after an earlier failure"); return; }
 	ncclResult_t r = g_comm.AllReduce(buf, buf, (size_t) count, ncclDouble, ncclSum, (ncclComm_t) c->red.comm, stream);
 	if (r != ncclSuccess) {
 		std::fprintf(stderr, "stochqn: ncclAllReduce: %s\n", g_comm.GetErrorString ? g_comm.GetErrorString(r) : "?");
 		reducer_failed(user, "ncclAllReduce failed");
+		// a communicator one of whose collectives failed is finished: the peers are waiting for a contribution that will not come,
+		// this rank must not post the next one as if nothing had happened.  Aborted here, dead for every later reduction.
+		std::lock_guard<std::mutex> lk(g_dead_mu);
+		if (std::find(g_dead_comms.begin(), g_dead_comms.end(), c->red.comm) == g_dead_comms.end()) {
+			g_dead_comms.push_back(c->red.comm);
+			if (g_comm.CommAbort) (void) g_comm.CommAbort((ncclComm_t) c->red.comm);
+		}
 	}
 }
 
@@ -880,14 +900,22 @@ uintptr_t break_heap_start()
 
 bool pinnable_in_place(const void* p, size_t bytes)
 {
+	static const bool trace = std::getenv("STOCHQN_HIP_PIN_TRACE") != nullptr;
 	const uintptr_t lo = (uintptr_t) p & ~(uintptr_t) 4095, hi = ((uintptr_t) p + bytes + 4095) & ~(uintptr_t) 4095;
 	const uintptr_t heap = break_heap_start(), brk_now = (uintptr_t) sbrk(0);
 	bool ok = !(heap && lo < brk_now && hi > heap);
+	if (!ok && trace) std::fprintf(stderr, "stochqn: pin %p +%zu declined: inside the break heap [%#lx, %#lx)\n", p, bytes, (unsigned long) heap, (unsigned long) brk_now);
 	if (ok) {
 		std::lock_guard<std::mutex> lk(g_span_mu);
 		auto it = g_spans.upper_bound(lo);                  // the first span that starts above lo; the one before may reach into [lo, hi)
-		if (it != g_spans.end() && it->first < hi) ok = false;
-		if (ok && it != g_spans.begin()) { --it; if (it->second > lo) ok = false; }
+		const std::pair<const uintptr_t, uintptr_t>* hit = nullptr;
+		if (it != g_spans.end() && it->first < hi) hit = &*it;
+		if (!hit && it != g_spans.begin()) { --it; if (it->second > lo) hit = &*it; }
+		if (hit) {
+			ok = false;
+			if (trace) std::fprintf(stderr, "stochqn: pin %p +%zu declined: its pages [%#lx, %#lx) overlap the pinned range [%#lx, %#lx)\n", p, bytes,
+			                        (unsigned long) lo, (unsigned long) hi, (unsigned long) hit->first, (unsigned long) hit->second);
+		}
 	}
 	if (!ok) stat_add(ST_HOST_PIN_DECLINED);
 	return ok;
@@ -1109,6 +1137,45 @@ bool ensure_copy_stream(DevCtx* c, int chunks)
 	return true;
 }
 
+// Waiting for a stream that carries RCCL all-reduces (one process per GPU, stochqn_hip_comm_init; or the shards of one process).
+// A collective whose peer never arrives -- a rank that failed on its own and left the call, a process that died, a fabric that
+// never came up at first contact -- does not return an error: its kernel spins on the device and hipStreamSynchronize waits
+// for it for ever.  So the wait is bounded: the stream is polled (spinning for the first two milliseconds, then every 100 us),
+// the communicator's asynchronous error state is looked at, and after "reducer_patience_s" seconds the communicator is ABORTED
+// (ncclCommAbort ends the kernels that wait), marked dead for every later reduction, and the call fails (-1000) -- on every
+// rank that was waiting for the one that is gone.  Contexts without an RCCL reducer wait with hipStreamSynchronize as before.
+hipError_t wait_stream(DevCtx* c, hipStream_t s)
+{
+	if (c->sc.allreduce != allreduce_hook || !c->red.comm) return hipStreamSynchronize(s);
+	const auto t0 = std::chrono::steady_clock::now();
+	const double patience = options().reducer_patience_s;
+	const char* why = nullptr;
+	for (long spin = 0;; spin++) {
+		const hipError_t q = hipStreamQuery(s);
+		if (q != hipErrorNotReady) return q;
+		(void) hipGetLastError();
+		const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		if (waited > 2e-3) {
+			if (g_comm.CommGetAsyncError && (spin & 63) == 0) {
+				ncclResult_t st = ncclSuccess;
+				if (g_comm.CommGetAsyncError((ncclComm_t) c->red.comm, &st) == ncclSuccess && st != ncclSuccess && st != ncclInProgress) { why = "the communicator reports an asynchronous error"; break; }
+			}
+			if (waited > patience) { why = "a reduction did not complete within reducer_patience_s"; break; }
+			std::this_thread::sleep_for(std::chrono::microseconds(100));
+		}
+	}
+	std::fprintf(stderr, "stochqn: rank %d of %d: %s -- aborting the communicator; this call and every later reduction over it fail (-1000)\n", c->red.rank, c->red.nranks, why);
+	{
+		std::lock_guard<std::mutex> lk(g_dead_mu);
+		if (std::find(g_dead_comms.begin(), g_dead_comms.end(), c->red.comm) == g_dead_comms.end()) {
+			g_dead_comms.push_back(c->red.comm);
+			if (g_comm.CommAbort) (void) g_comm.CommAbort((ncclComm_t) c->red.comm);       // ends the kernels that wait for the missing peer
+		}
+	}
+	c->fault = true;
+	return hipStreamSynchronize(s);                    // what was enqueued behind the collective drains now
+}
+
 void sync(DevCtx* c)
 {
 	// a kernel that could not be launched (or failed) leaves its outputs stale: never hand that back
@@ -1119,7 +1186,7 @@ void sync(DevCtx* c)
 		if (l0 != hipSuccess) { std::fprintf(stderr, "stochqn: device work failed: %s\n", hipGetErrorString(l0)); c->fault = true; }
 		return;
 	}
-	hipError_t e = hipStreamSynchronize(c->sc.stream);
+	hipError_t e = wait_stream(c, c->sc.stream);
 	if (c->copy_busy) {                                  // slices of x still on their way to the host
 		for (hipStream_t s : {c->copy_stream, c->down_stream}) {
 			if (!s) continue;
@@ -1172,7 +1239,7 @@ void comm_attach(DevCtx* c)
 	SQN_HIP_OK(hipMemcpyAsync(c->sc.red[0], &nn, sizeof(double), hipMemcpyHostToDevice, c->sc.stream));
 	c->sc.allreduce(c, c->sc.red[0], 1, c->sc.stream);
 	SQN_HIP_OK(hipMemcpyAsync(&nn, c->sc.red[0], sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
-	SQN_HIP_OK(hipStreamSynchronize(c->sc.stream));
+	SQN_HIP_OK(wait_stream(c, c->sc.stream));               // first contact with the peers: bounded like every later wait
 	c->n_global = nn;
 }
 
@@ -1190,9 +1257,19 @@ bool comm_init_all(int ndev, const int* devices, void** comms_out)
 	return true;
 }
 
+static bool forget_dead(void* comm)             // true: the communicator was aborted (ncclCommAbort released it): not to be destroyed again
+{
+	std::lock_guard<std::mutex> lk(g_dead_mu);
+	auto it = std::find(g_dead_comms.begin(), g_dead_comms.end(), comm);
+	if (it == g_dead_comms.end()) return false;
+	const bool aborted = g_comm.CommAbort != nullptr;
+	g_dead_comms.erase(it);
+	return aborted;
+}
+
 void comm_destroy(void* comm)
 {
-	if (comm && g_comm.CommDestroy) g_comm.CommDestroy((ncclComm_t) comm);
+	if (comm && !forget_dead(comm) && g_comm.CommDestroy) g_comm.CommDestroy((ncclComm_t) comm);
 }
 
 }  // namespace sqn
@@ -1213,34 +1290,44 @@ std::mutex g_pin_mu;
 std::unordered_map<const void*, Pin> g_pins;
 }
 
+// STOCHQN_HIP_PIN_TRACE=1: every pin / unpin request and what became of it, on stderr (which arrays of a caller got page-locked,
+// which were left pageable and why)
+static int pin_says(void* p, size_t bytes, int rc, const char* why)
+{
+	static const bool on = std::getenv("STOCHQN_HIP_PIN_TRACE") != nullptr;
+	if (on) std::fprintf(stderr, "stochqn: pin %p +%zu -> %d (%s)\n", p, bytes, rc, why);
+	return rc;
+}
+
 int stochqn_hip_pin_host(void* p, size_t bytes)
 {
 	if (!p || bytes == 0 || !device_ready()) return -1;
 	std::lock_guard<std::mutex> lk(g_pin_mu);
 	auto it = g_pins.find(p);
-	if (it != g_pins.end() && it->second.bytes >= bytes) { it->second.refs++; return 0; }
+	if (it != g_pins.end() && it->second.bytes >= bytes) { it->second.refs++; return pin_says(p, bytes, 0, "pinned here already: once more"); }
 	if (it != g_pins.end()) {                                  // the same array, longer now: pinned anew
 		if (hipHostUnregister(p) != hipSuccess) (void) hipGetLastError();
 		note_unpinned(p);
 		const int refs = it->second.refs;
 		g_pins.erase(it);
-		if (!pinnable_in_place(p, bytes)) return 1;
-		if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); return -1; }
+		if (!pinnable_in_place(p, bytes)) return pin_says(p, bytes, 1, "declined: break heap or shared pages");
+		if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); return pin_says(p, bytes, -1, "hipHostRegister failed"); }
 		note_pinned(p, bytes);
 		g_pins[p] = Pin{bytes, refs + 1};
-		return 0;
+		return pin_says(p, bytes, 0, "pinned anew, longer");
 	}
 	hipPointerAttribute_t a;                                   // ordinary memory: an error (older runtimes) or "unregistered" (ROCm 6+)
 	if (hipPointerGetAttributes(&a, p) == hipSuccess) {
-		if (a.type == hipMemoryTypeHost) return 1;             // page-locked by other means
-		if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) return -1;
+		if (a.type == hipMemoryTypeHost) { stat_add(ST_HOST_PIN_FOREIGN); return pin_says(p, bytes, 1, "page-locked by other means"); }
+		if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) return pin_says(p, bytes, -1, "not host memory");
 	} else (void) hipGetLastError();
-	if (!pinnable_in_place(p, bytes)) return 1;                // in the break heap, or sharing a page with another pin: stays pageable (works, a little slower)
-	if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); return -1; }
+	if (!pinnable_in_place(p, bytes)) return pin_says(p, bytes, 1, "declined: break heap or shared pages");                // stays pageable (works, a little slower)
+	const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+	if (e != hipSuccess) { (void) hipGetLastError(); stat_add(ST_HOST_PIN_ERRORS); return pin_says(p, bytes, -1, hipGetErrorString(e)); }
 	note_pinned(p, bytes);
 	g_pins[p] = Pin{bytes, 1};
 	stat_add(ST_HOST_REGISTERED);
-	return 0;
+	return pin_says(p, bytes, 0, "pinned");
 }
 
 // Option "x_prefetch" leaves an upload of the caller's x in flight when a call returns.  A caller that drops x right then (its
@@ -1509,7 +1596,7 @@ long long stochqn_hip_stat(const char* name)
 void stochqn_hip_stats_reset(void)
 {
 	for (int i = 0; i < ST_COUNT; i++)
-		if (i != ST_HOST_UNPIN_FAILED && i != ST_WORK_IN_FLIGHT) g_stats[i].store(0, std::memory_order_relaxed);       // those two are facts about the process, not rates
+		if (i != ST_HOST_UNPIN_FAILED && i != ST_WORK_IN_FLIGHT && i != ST_HOST_PIN_ERRORS && i != ST_HOST_PIN_FOREIGN) g_stats[i].store(0, std::memory_order_relaxed);       // those two are facts about the process, not rates
 }
 
 int stochqn_hip_loopback_init(int nranks)
@@ -1543,7 +1630,7 @@ void stochqn_hip_loopback_finalize(void)
 void stochqn_hip_comm_finalize(void)
 {
 	release_all();
-	if (g_comm.comm) { g_comm.CommDestroy(g_comm.comm); g_comm.comm = nullptr; g_comm.nranks = 1; g_comm.rank = 0; }
+	if (g_comm.comm) { if (!forget_dead(g_comm.comm)) g_comm.CommDestroy(g_comm.comm); g_comm.comm = nullptr; g_comm.nranks = 1; g_comm.rank = 0; }
 	g_custom = Custom{};
 }
 

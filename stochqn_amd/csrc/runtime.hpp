@@ -205,7 +205,7 @@ struct DevCtx {
 enum StatId {
 	ST_STEP_THREE_PASS = 0, ST_STEP_SWEEPS, ST_STEP_PLAIN, ST_KAPPA_FALLBACK,
 	ST_ALLREDUCE, ST_ALLREDUCE_DOUBLES, ST_CTX_CREATED, ST_CTX_RECLAIMED, ST_X_UPLOAD, ST_X_UPLOAD_SKIPPED,
-	ST_HOST_REGISTERED, ST_X_AHEAD, ST_X_RESENT, ST_X_PREFETCH, ST_HOST_UNPIN_FAILED, ST_WORK_IN_FLIGHT, ST_HOST_PIN_DECLINED, ST_COUNT
+	ST_HOST_REGISTERED, ST_X_AHEAD, ST_X_RESENT, ST_X_PREFETCH, ST_HOST_UNPIN_FAILED, ST_WORK_IN_FLIGHT, ST_HOST_PIN_DECLINED, ST_HOST_PIN_FOREIGN, ST_HOST_PIN_ERRORS, ST_COUNT
 };
 void stat_add(int id, long long v = 1);
 // May [p, p + bytes) of ordinary host memory be page-locked in place (hipHostRegister)?  Only a range that has its pages to
@@ -275,7 +275,10 @@ bool ensure_stage(DevCtx* c, int which);               // device staging vector 
 real* stage_in(DevCtx* c, int which, real* caller, size_t count, bool host);       // H2D if host; nullptr = out of memory
 real* host_landing(DevCtx* c, int slot);               // host landing zone for *req / *req_vec (pinned if possible)
 void begin_call(DevCtx* c);                            // refresh options, restart the sweep parity
-void sync(DevCtx* c);                                  // stream sync + profiler collection
+void sync(DevCtx* c);
+// hipStreamSynchronize, bounded when the stream carries RCCL collectives (option "reducer_patience_s": a peer that never arrives
+// gets the communicator aborted and the call failed instead of a wait for ever); plain hipStreamSynchronize otherwise
+hipError_t wait_stream(DevCtx* c, hipStream_t s);                                  // stream sync + profiler collection
 
 // One named range per API call for `rocprofv3 --marker-trace` (roctx), only with STOCHQN_HIP_ROCTX=1 in the
 // environment; the marker library is dlopen()ed then, never linked.

@@ -54,6 +54,7 @@ class _HostSpace:
         self.dtype = np.float32 if use_float else np.float64
         self._lib = None
         self._pins = {}                                 # address -> (weak reference to the array, its finaliser)
+        self._left = {}                                 # address -> (weak reference, bytes) of arrays the library left pageable: not asked again
 
     def attach(self, backend):
         lib = getattr(backend, "lib", None)
@@ -74,8 +75,14 @@ class _HostSpace:
                 del self._pins[p]
         if ptr in self._pins:
             return
+        left = self._left.get(ptr)
+        if left is not None and left[0]() is a and left[1] == a.nbytes:
+            return                                      # the same array, declined before (break heap, pages shared, pinned by its owner)
         if self._lib.stochqn_hip_pin_host(C.c_void_p(ptr), C.c_size_t(a.nbytes)) == 0:
             self._pins[ptr] = (weakref.ref(a), weakref.finalize(a, _unpin, self._lib, ptr))
+        else:
+            self._left = {p: v for p, v in self._left.items() if v[0]() is not None}
+            self._left[ptr] = (weakref.ref(a), a.nbytes)
 
     def unpin_all(self):
         for _, fin in self._pins.values():

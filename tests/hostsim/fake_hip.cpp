@@ -14,7 +14,9 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <chrono>
 #include <set>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -48,7 +50,8 @@ std::deque<std::function<void()>> g_queue;       // model 1: one FIFO over all s
 // device) is synchronised -- what a stream other than the one the caller waited for may legally do.  The NULL stream runs at
 // once, behind everything on the blocking streams (a legal schedule of its own).
 struct Op {
-	std::function<void()> work;                  // empty: a wait marker
+	std::function<void()> work;                  // empty (and no try_run): a wait marker
+	std::function<bool()> try_run;               // an operation that may not be able to complete yet (a collective whose peers have not arrived): false = ask again
 	const void* wait_stream = nullptr;
 	long wait_ticket = 0;
 	uintptr_t lo[2] = {0, 0}, hi[2] = {0, 0};    // host memory the operation touches (copies): what must not die under it
@@ -175,22 +178,43 @@ namespace {
 int mode() { std::lock_guard<std::mutex> lk(g_mu); return g_mode; }
 
 // model 2: run the operations of stream s until `upto` of them are done (< 0: all that are queued now).  g_flush_mu held.
-void drain(const void* s, long upto)
+// false: the operation at the head of the queue cannot complete yet (Op::try_run) -- it stays where it is.
+bool drain(const void* s, long upto)
 {
 	for (;;) {
 		Op op;
 		{
 			std::lock_guard<std::mutex> lk(g_q_mu);
 			auto it = g_sq.find(s);
-			if (it == g_sq.end() || it->second.ops.empty() || (upto >= 0 && it->second.done >= upto)) return;
+			if (it == g_sq.end() || it->second.ops.empty() || (upto >= 0 && it->second.done >= upto)) return true;
 			op = std::move(it->second.ops.front());
 			it->second.ops.pop_front();
 		}
-		if (op.work) op.work();
-		else drain(op.wait_stream, op.wait_ticket);              // an event of another stream: that stream runs up to its record first
+		bool done = true;
+		if (op.try_run) done = op.try_run();
+		else if (op.work) op.work();
+		else done = drain(op.wait_stream, op.wait_ticket);       // an event of another stream: that stream runs up to its record first
 		std::lock_guard<std::mutex> lk(g_q_mu);
 		auto it = g_sq.find(s);
+		if (!done) {
+			if (it != g_sq.end()) it->second.ops.push_front(std::move(op));
+			return false;
+		}
 		if (it != g_sq.end()) it->second.done++;
+	}
+}
+
+// a stream is synchronised: its operations run; one that cannot complete yet is asked again until it can (a real stream waits
+// the same way -- for ever, if the peer never comes: after two minutes the stand-in calls that a violation and moves on)
+void drain_all_of(const void* s)
+{
+	for (long spins = 0;; spins++) {
+		{
+			std::lock_guard<std::recursive_mutex> fl(g_flush_mu);
+			if (drain(s, -1)) return;
+		}
+		if (spins > 600000) { violation("a stream never finished: an operation on it waited for something that did not come"); return; }
+		std::this_thread::sleep_for(std::chrono::microseconds(200));
 	}
 }
 
@@ -210,7 +234,7 @@ void drain_blocking()
 		std::lock_guard<std::mutex> lk(g_q_mu);
 		for (auto& kv : g_sq) ss.push_back(kv.first);
 	}
-	for (const void* st : ss) if (is_blocking(st)) drain(st, -1);
+	for (const void* st : ss) if (is_blocking(st)) (void) drain(st, -1);
 }
 
 void sync_stream(const void* s)
@@ -218,8 +242,7 @@ void sync_stream(const void* s)
 	const int m = mode();
 	if (m != 2) { flush(); return; }
 	if (!s) { drain_blocking(); return; }
-	std::lock_guard<std::recursive_mutex> fl(g_flush_mu);
-	drain(s, -1);
+	drain_all_of(s);
 }
 
 void push(const void* stream, Op op)
@@ -232,7 +255,12 @@ void push(const void* stream, Op op)
 		q.enqueued++;
 		return;
 	}
-	if (m == 2) { drain_blocking(); if (op.work) op.work(); return; }        // the NULL stream
+	auto now = [](Op& o) {                              // run at once; an operation that cannot complete yet is asked until it can
+		if (o.try_run) { while (!o.try_run()) std::this_thread::sleep_for(std::chrono::microseconds(200)); }
+		else if (o.work) o.work();
+	};
+	if (m == 2) { drain_blocking(); now(op); return; }                       // the NULL stream
+	if (op.try_run && !op.work) { std::function<bool()> t = op.try_run; op.work = [t] { while (!t()) std::this_thread::sleep_for(std::chrono::microseconds(200)); }; op.try_run = nullptr; }
 	if (!op.work) return;                                                    // models 0 / 1: one FIFO, waits are implied
 	if (m == 0) {
 		std::lock_guard<std::recursive_mutex> fl(g_flush_mu);      // not while another thread is half-way through the queue
@@ -265,7 +293,7 @@ void flush()
 			for (auto& kv : g_sq) if (!kv.second.ops.empty()) ss.push_back(kv.first);
 		}
 		if (ss.empty()) return;
-		for (const void* st : ss) drain(st, -1);
+		for (const void* st : ss) drain_all_of(st);
 	}
 }
 
@@ -274,6 +302,14 @@ void enqueue(void* stream, std::function<void()> work)
 	Op op;
 	op.work = std::move(work);
 	op.what = "kernel";
+	push(stream, std::move(op));
+}
+
+void enqueue_waitable(void* stream, std::function<bool()> try_run)
+{
+	Op op;
+	op.try_run = std::move(try_run);
+	op.what = "collective";
 	push(stream, std::move(op));
 }
 
@@ -668,6 +704,11 @@ hipError_t hipStreamQuery(hipStream_t s)
 	if (enter(F_StreamQuery)) return err(hipErrorUnknown);
 	if (!stream_ok(s, "hipStreamQuery")) return err(hipErrorInvalidValue);
 	const int m = mode();
+	if (m == 2 && s) {                                 // the device works while the host asks: what can run, runs
+		std::lock_guard<std::recursive_mutex> fl(g_flush_mu);
+		(void) drain(s, -1);
+	}
+	if (m == 1) flush();                               // one FIFO: a device that is asked has had time to work its queue off
 	std::lock_guard<std::mutex> lk(g_q_mu);
 	bool busy = m == 1 && !g_queue.empty();
 	if (m == 2) { auto it = g_sq.find(s); busy = it != g_sq.end() && !it->second.ops.empty(); }
@@ -688,7 +729,7 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned int)
 			op.wait_ticket = e->ticket;
 		}
 		if (op.wait_stream == s) return hipSuccess;   // same stream: already in order
-		if (!s) { std::lock_guard<std::recursive_mutex> fl(g_flush_mu); drain(op.wait_stream, op.wait_ticket); return hipSuccess; }
+		if (!s) { std::lock_guard<std::recursive_mutex> fl(g_flush_mu); (void) drain(op.wait_stream, op.wait_ticket); return hipSuccess; }
 		push(s, std::move(op));
 	}
 	return hipSuccess;                                // models 0 / 1: one FIFO, whatever was recorded earlier runs earlier

@@ -45,6 +45,9 @@ long injected();                                // injections that fired since r
 
 // work that a "kernel launch" stands for: runs now, or at the next synchronisation in lazy mode (fake_launch.cpp)
 void enqueue(void* stream, std::function<void()> work);
+// an operation that may not be able to complete when its turn comes (a collective whose peers have not arrived yet): try_run is
+// asked again -- at every synchronisation and every hipStreamQuery of its stream -- until it returns true
+void enqueue_waitable(void* stream, std::function<bool()> try_run);
 void flush();                                   // run everything that is queued (what a synchronisation does)
 
 // what is alive (leak checks) and what went wrong (use of dead objects, copies outside allocations, double frees ...)

@@ -17,10 +17,14 @@
 #include "runtime.hpp"          // the host checksum of x (xhash_*): tested against its definition directly
 
 #include <dlfcn.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #if defined(__SANITIZE_ADDRESS__)
 #include <sanitizer/asan_interface.h>
 #endif
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -906,12 +910,92 @@ void sc_caller_heap()
 	leak_check("caller_heap");
 }
 
+// One process per GPU (stochqn_hip_comm_init -> ncclCommInitRank, the mode bench.py and every torch.distributed caller uses): three
+// ranks = three forked processes over the stand-in's shared-memory clique, whose all-reduces are operations ON THE STREAM that
+// complete only when every rank has posted -- like the real thing, a collective whose peer never comes does not return an error,
+// it waits.  The ranks' contributions arrive with rank-dependent delays, and rank 1's 17th all-reduce FAILS at the call.  Required:
+// rank 1 returns -1000 from that call; ranks 0 and 2, which are waiting on their streams for a contribution that will never be
+// posted, give up after reducer_patience_s (runtime.cpp: wait_stream aborts the communicator) and return -1000 FROM THE SAME
+// CALL; every later call of every rank fails at once (the communicator is dead); nobody hangs.
+void sc_model_a_failure()
+{
+	void* handle = nullptr;
+	use_fake_rccl(&handle);
+	auto shared_bytes = (size_t (*)(void)) dlsym(handle, "fake_rccl_shared_bytes");
+	auto shared_init = (void (*)(void*, int)) dlsym(handle, "fake_rccl_shared_init");
+	auto shared_script = (void (*)(int, int, long)) dlsym(handle, "fake_rccl_shared_script");
+	CHECK(shared_bytes && shared_init && shared_script, "the RCCL stand-in lacks its multi-process controls");
+	if (!shared_bytes || !shared_init || !shared_script) return;
+	constexpr int P = 3, kCalls = 26;
+	struct Result { int first_failure, failures_after, calls_done, check_failures; double seconds_of_failing_call, seconds_after; };
+	const size_t bytes = shared_bytes() + P * sizeof(Result);
+	char* mem = (char*) mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+	CHECK(mem != MAP_FAILED, "mmap");
+	shared_init(mem, P);
+	for (int r = 0; r < P; r++) shared_script(r, 1500 * r, r == 1 ? 17 : 0);       // rank r's contributions arrive 1.5 r ms late
+	Result* res = reinterpret_cast<Result*>(mem + shared_bytes());
+	for (int r = 0; r < P; r++) res[r] = Result{-1, 0, 0, 0, 0, 0};
+	opt("reducer_patience_s", 1.5);
+	std::fflush(nullptr);
+	pid_t kids[P];
+	for (int r = 0; r < P; r++) {
+		kids[r] = fork();
+		if (kids[r] == 0) {
+			unsigned char id[128] = {0};
+			if (stochqn_hip_comm_init(r, P, id) != 0 || stochqn_hip_comm_nranks() != P) _exit(90);
+			Opt a(SQN, 1500 + 7 * r, 3, 3);               // device-resident or host caller alike: here a host caller, its shard of the problem
+			a.check_x = true;
+			for (int call = 0; call < kCalls; call++) {
+				a.answer();
+				const auto t0 = std::chrono::steady_clock::now();
+				const int rc = a.call(0.01);
+				const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+				res[r].calls_done = call + 1;
+				if (rc == -1000 && res[r].first_failure < 0) { res[r].first_failure = call; res[r].seconds_of_failing_call = dt; }
+				else if (res[r].first_failure >= 0) { res[r].failures_after += rc == -1000; res[r].seconds_after += dt; }
+				if (res[r].first_failure >= 0 && call >= res[r].first_failure + 3) break;
+			}
+			res[r].check_failures = g_failures;
+			stochqn_hip_release_all();
+			stochqn_hip_comm_finalize();
+			_exit(fakehip::violations() ? 91 : 0);
+		}
+		CHECK(kids[r] > 0, "fork");
+	}
+	// nobody may hang: the ranks are given ten times the patience, then killed
+	const auto t0 = std::chrono::steady_clock::now();
+	int alive = P, status[P];
+	bool done[P] = {false, false, false};
+	while (alive > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 60) {
+		for (int r = 0; r < P; r++)
+			if (!done[r] && waitpid(kids[r], &status[r], WNOHANG) == kids[r]) { done[r] = true; alive--; }
+		std::this_thread::sleep_for(std::chrono::milliseconds(20));
+	}
+	for (int r = 0; r < P; r++)
+		if (!done[r]) { kill(kids[r], SIGKILL); waitpid(kids[r], &status[r], 0); CHECK(false, "rank %d HUNG (call %d): killed after 60 s", r, res[r].calls_done); }
+		else CHECK(WIFEXITED(status[r]) && WEXITSTATUS(status[r]) == 0, "rank %d ended with status %#x", r, status[r]);
+	for (int r = 0; r < P; r++) {
+		std::fprintf(stderr, "model_a_failure: rank %d: first -1000 at call %d (that call took %.2f s), %d of the %d calls after it failed too (%.3f s in all), x checks failed: %d\n",
+		             r, res[r].first_failure, res[r].seconds_of_failing_call, res[r].failures_after, res[r].calls_done - res[r].first_failure - 1, res[r].seconds_after, res[r].check_failures);
+		CHECK(res[r].first_failure >= 4, "rank %d: the run did not get going before the failure (first -1000 at call %d)", r, res[r].first_failure);
+		CHECK(res[r].first_failure == res[1].first_failure, "rank %d failed in call %d, rank 1 in call %d: not the same call", r, res[r].first_failure, res[1].first_failure);
+		CHECK(res[r].failures_after == 3 && res[r].seconds_after < 0.5, "rank %d: every later call must fail at once (%d of 3 failed, %.3f s)", r, res[r].failures_after, res[r].seconds_after);
+		CHECK(res[r].check_failures == 0, "rank %d: %d checks failed before the failure", r, res[r].check_failures);
+	}
+	CHECK(res[1].seconds_of_failing_call < 0.5, "the rank whose own all-reduce failed knows at once (%.2f s)", res[1].seconds_of_failing_call);
+	CHECK(res[0].seconds_of_failing_call > 1.0 && res[0].seconds_of_failing_call < 6.0 && res[2].seconds_of_failing_call > 1.0 && res[2].seconds_of_failing_call < 6.0,
+	      "the waiting ranks give up after the patience (1.5 s): %.2f s, %.2f s", res[0].seconds_of_failing_call, res[2].seconds_of_failing_call);
+	munmap(mem, bytes);
+	opt("reducer_patience_s", 120);
+	leak_check("model_a_failure");
+}
+
 struct Scenario { const char* name; void (*fn)(); };
 const Scenario kScenarios[] = {
 	{"registry", sc_registry}, {"reclaim_resume", sc_reclaim_resume}, {"mirror_cap", sc_mirror_cap}, {"host_path", sc_host_path}, {"xhash", sc_xhash},
 	{"branches", sc_branches}, {"owned_and_raw", sc_owned_and_raw}, {"group_rccl", sc_group_rccl}, {"group_virtual", sc_group_virtual},
 	{"group_alloc_failures", sc_group_alloc_failures}, {"fault_sweep", sc_fault_sweep}, {"fault_sweep_group", sc_fault_sweep_group},
-	{"threads", sc_threads}, {"caller_heap", sc_caller_heap}};
+	{"threads", sc_threads}, {"caller_heap", sc_caller_heap}, {"model_a_failure", sc_model_a_failure}};
 
 }  // namespace
 

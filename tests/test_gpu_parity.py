@@ -63,8 +63,15 @@ def torch_cuda():
 @pytest.mark.parametrize("space", ["host", "device"])
 @pytest.mark.parametrize("case", ["oLBFGS_rosen2d", "SQN_rosen2d", "adaQN_rosen2d"])
 def test_known_answers(case, space, form, hip_backend):
-    # chaotic Rosenbrock trajectories amplify last-bit differences; 1e3 x the oracle's own pin
-    check_known_answer(case, hip_backend, space=space, tol_scale=1e3)
+    # held to the ORACLE'S OWN pin (rtol 1e-11 / 1e-13 / 1e-12 per case; rounds 1 - 4 allowed 1e3 x that).  Measured on the MI355X in
+    # round 5, host and device callers alike: oLBFGS 3.9e-13 (three-pass form; 0 in the sweeps), SQN 1.4e-16, adaQN 1.7e-15
+    # (gpurun_out/known_answers_errors.txt of the run, quoted in DESIGN.md section 6)
+    check_known_answer(case, hip_backend, space=space, tol_scale=1.0)
+    try:                                                      # the measured error, for the record of the run (gpurun_out/ is scratch)
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "known_answers_errors.txt"), "a") as f:
+            f.write("%s %s %s %.3e\n" % (case, space, form, check_known_answer.measured[(case, space)]))
+    except OSError:
+        pass
 
 
 def test_c_rosen_protocol_host_caller(form, hip_backend):
@@ -666,6 +673,61 @@ class TestAdaqnAtTheC4Shape:
         assert e_y <= TOL and e_t <= TOL, (e_y, e_t)
 
 
+def test_adaqn_at_the_c4_shape_first_cycle_matches_the_oracle(hip_backend, oracle_backend):
+    """BASELINE config 4 AS STATED -- adaQN, n = 1e8, m = 20, fisher_size = 128, L = 20, RMSProp 0.9, scal_reg 1e-4,
+    min_curvature 1e-4 -- from its first call through one whole correction-pair cycle against the oracle: forty rescaled-gradient
+    steps that fill forty rows of the Fisher ring, the average archived at iteration 20, the pair of iteration 40 built from those
+    forty rows (y = F'(F s)/40, reference src/stochqn.c:936-952, accepted against min_curvature), and the step after it, which is
+    the first to use a pair and the diagonal H0 together.  Identical task / info / counter sequences; x, G, H0, the averages,
+    the pair and the Fisher rows at 1e-10.  (The 128-row pair is TestAdaqnAtTheC4Shape's; a whole trajectory with a pair per
+    iteration is the lock-step test's.)  The oracle's Fisher ring is 102 GB of untouched zero pages but for its 41 rows."""
+    torch = torch_cuda()
+    n, m, f, L, iters, step = 100_000_000, 20, 128, 20, 41, 0.01
+    need = (41 + 2 + 12) * n * 8                    # touched: 41 Fisher rows, one pair, the n-vectors and three gradient factors
+    avail = _host_memory_available()
+    if avail < 1.3 * need:
+        pytest.skip("the host has %.0f GB available, the oracle's side of the C4 cycle needs %.0f GB" % (avail / 1e9, 1.3 * need / 1e9))
+    kw = dict(mem_size=m, fisher_size=f, bfgs_upd_freq=L, max_incr=None, min_curvature=1e-4, rmsprop_weight=0.9, scal_reg=1e-4)
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    d = 0.5 + torch.rand(n, dtype=torch.float64, device="cuda", generator=gen)
+    dn_d = [d * (1 + 0.01 * (2 * torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) - 1)) for _ in range(3)]
+    x_d = 1 + torch.rand(n, dtype=torch.float64, device="cuda", generator=gen)
+    del d
+    dn_h, x_h = [to_np(a) for a in dn_d], to_np(x_d)
+    ref = OPTIMIZERS["adaQN"](backend=oracle_backend, space="host", **kw)
+    dev = OPTIMIZERS["adaQN"](backend=hip_backend, space="device", **kw)
+    try:
+        t = 0
+        while (ref.niter if ref.initialized else 0) < iters:
+            r_r, r_d = ref.run_optimizer(x_h, step), dev.run_optimizer(x_d, step)
+            state = lambda o: (o.niter, o.section, o.BFGS_mem.mem_used, o.BFGS_mem.mem_st_ix, o.Fisher_mem.mem_used, o.Fisher_mem.mem_st_ix)
+            assert (r_d["task"], r_d["info"], state(dev)) == (r_r["task"], r_r["info"], state(ref)), (t, r_d["task"], r_r["task"], state(dev), state(ref))
+            assert r_r["task"] == "calc_grad"
+            np.multiply(dn_h[t % 3], r_r["requested_on"], out=ref.gradient)
+            torch.mul(dn_d[t % 3], r_d["requested_on"], out=dev.gradient)
+            t += 1
+        assert ref.BFGS_mem.mem_used == 1 and ref.Fisher_mem.mem_used == 41 and ref.niter == 41
+
+        def close(what, got, want):
+            wd = to_dev(np.ascontiguousarray(want))
+            e = float(torch.linalg.vector_norm(got - wd) / torch.linalg.vector_norm(wd))
+            print("C4 first cycle, %-14s %.2e from the oracle's" % (what + ":", e))
+            assert e <= TOL, (what, e)
+
+        close("x", x_d, x_h)
+        close("grad_sum_sq", dev.grad_sum_sq, ref.grad_sum_sq)
+        close("H0", dev.H0, ref.H0)
+        close("x_avg_prev", dev.x_avg_prev, ref.x_avg_prev)
+        close("s of the pair", dev.BFGS_mem.s_mem[:n], ref.BFGS_mem.s_mem[:n])
+        close("y of the pair", dev.BFGS_mem.y_mem[:n], ref.BFGS_mem.y_mem[:n])
+        for row in (0, 20, 40):
+            close("Fisher row %d" % row, dev.Fisher_mem.F[row * n:(row + 1) * n], ref.Fisher_mem.F[row * n:(row + 1) * n])
+        assert rel_err(np.asarray(dev.Fisher_mem.buffer_y)[:40], np.asarray(ref.Fisher_mem.buffer_y)[:40]) <= TOL
+    finally:
+        dev.release()
+        ref.release()
+
+
 # ---------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE sizes (the oracle is too slow / too big there)
 # ---------------------------------------------------------------------------------------------
@@ -821,7 +883,7 @@ def test_adaqn_trajectory_at_full_size_in_lockstep_with_the_oracle(hip_backend, 
         linear in s.  So the rows of S and Y are held to what that allows, 16 eps |x| / |s| (measured: up to 1.1e-9, at the
         last sync point), and -- like everything else here -- to 1e-10 of the vectors they were computed FROM (|x|)."""
         nonlocal worst
-        w = to_dev(want)                                                     # compared where the 0.8 GB vectors are: on the device
+        w = torch.from_numpy(np.ascontiguousarray(want)).to("cuda")          # compared where the 0.8 GB vectors are: on the device
         assert bool(torch.isfinite(w).all()) and bool(torch.isfinite(got).all()), what
         nw = float(torch.linalg.vector_norm(w))
         e = float(torch.linalg.vector_norm(got - w)) / nw if nw > 0 else float(torch.linalg.vector_norm(got))
@@ -1982,7 +2044,14 @@ def test_the_benchmarked_workload_itself_matches_the_oracle(hip_backend, oracle_
     try:
         assert (wl.b.mem_used, wl.b.mem_st_ix, wl.w.niter, wl.w.section, wl.w.check_nan, wl.b.upd_freq) == (m, 3, L, 1, 1, L)
         # the oracle's copy of the state the timed region starts from
-        S_h, Y_h, A_h, d_h, x_h = to_np(wl.S), to_np(wl.Y), to_np(wl.A), to_np(wl.d), to_np(wl.x)
+        def rows_to_host(t, rows):                                     # device -> the numpy buffer itself, row by row (as the 128-row Fisher test does)
+            out = np.empty(rows * n)
+            if hasattr(olib, "oracle_first_touch"):
+                olib.oracle_first_touch(out.ctypes.data, rows * n)
+            for k in range(rows):
+                torch.from_numpy(out[k * n:(k + 1) * n]).copy_(t[k * n:(k + 1) * n])
+            return out
+        S_h, Y_h, A_h, d_h, x_h = rows_to_host(wl.S, m), rows_to_host(wl.Y, m), rows_to_host(wl.A, bs), to_np(wl.d), to_np(wl.x)
         g_h, hv_h, tb_h, xs_h, xp_h = np.zeros(n), np.zeros(n), np.zeros(bs), np.zeros(n), x_h.copy()
         rho_r, alpha_r, dummy = np.zeros(m), np.zeros(m), np.zeros(1)
         b_r = _abi.bfgs_mem(S_h.ctypes.data, Y_h.ctypes.data, rho_r.ctypes.data, alpha_r.ctypes.data, dummy.ctypes.data, dummy.ctypes.data, m, m, 3 % m, L, 0.0, 0.0)

@@ -9,6 +9,10 @@ Every scenario of host_logic_test.cpp runs twice per build -- streams that execu
 when something synchronises (the two ends of what the real runtime may do) -- under -fsanitize=address,undefined and
 under -fsanitize=thread; the host-path scenarios a third time with a queue PER STREAM (what a stream other than the one the
 caller waited for may legally do):
+  model_a_failure (per-stream model only: its collectives are operations on the stream that wait for their peers, like RCCL's):
+      one process per GPU over ncclCommInitRank -- three forked ranks, rank-dependent delays, rank 1's 17th all-reduce fails at
+      the call: every rank returns -1000 FROM THE SAME CALL (the waiting ones after reducer_patience_s: runtime.cpp wait_stream
+      aborts the communicator), every later call fails at once, nobody hangs;
   caller_heap: a caller whose arrays live in a garbage-collected heap (reference src/Rwrapper.c:106-123, stochqn/pywrapper.pxi:
       161-172) -- x, grad and hess_vec are replaced by new arrays between calls, the old ones unpinned, poisoned and kept out of
       circulation; no copy through host memory may be queued on ANY stream when a call returns, none may ever go through a dead
@@ -43,7 +47,7 @@ def built():
     return os.path.join(SIM, "build")
 
 
-CASES = [(sc, st) for sc in SCENARIOS for st in ("immediate", "lazy")] + [(sc, "per_stream") for sc in PER_STREAM]
+CASES = [(sc, st) for sc in SCENARIOS for st in ("immediate", "lazy")] + [(sc, "per_stream") for sc in PER_STREAM] + [("model_a_failure", "per_stream")]
 
 
 @pytest.mark.parametrize("scenario,streams", CASES)
