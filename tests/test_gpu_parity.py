@@ -709,7 +709,7 @@ def test_adaqn_at_the_c4_shape_first_cycle_matches_the_oracle(hip_backend, oracl
         assert ref.BFGS_mem.mem_used == 1 and ref.Fisher_mem.mem_used == 41 and ref.niter == 41
 
         def close(what, got, want):
-            wd = to_dev(np.ascontiguousarray(want))
+            wd = torch.from_numpy(np.ascontiguousarray(want)).to("cuda")
             e = float(torch.linalg.vector_norm(got - wd) / torch.linalg.vector_norm(wd))
             print("C4 first cycle, %-14s %.2e from the oracle's" % (what + ":", e))
             assert e <= TOL, (what, e)

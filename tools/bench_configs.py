@@ -89,6 +89,22 @@ def drive(opt, P, x, step, steps, warmup, host=False):
 
     advance(warmup)
     torch.cuda.synchronize()
+    # what the CALLER's own kernels cost per step (its gradient / Hessian-vector products run on the GPU too and sit inside the
+    # wall-clock step): the same element-wise product timed alone, times the number of such products per step
+    caller_ms = None
+    if not host:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        scratch = torch.empty_like(x)
+        for _ in range(5):
+            torch.mul(P.dn[0], x, out=scratch)
+        ev[0].record()
+        for _ in range(20):
+            torch.mul(P.dn[0], x, out=scratch)
+        ev[1].record()
+        torch.cuda.synchronize()
+        caller_ms = ev[0].elapsed_time(ev[1]) / 20
+        del scratch
+    drive.caller_kernel_ms = caller_ms
     # timed pass WITHOUT the library's event profiler (an event pair costs ~10 us per launch, which is
     # 8 % of a C2 step) ...
     c0 = calls
@@ -162,6 +178,8 @@ def report(name, workload, n, m, dt, steps, calls, extra=None, kind="SQN", k_pai
     moved_step = sum(words[x] * e["launches"] for x, e in k.items() if x in words) * n * 8 / prof_steps
     kern_ms = sum(e["avg_ms"] * e["launches"] for e in k.values()) / prof_steps
     ms_step = 1e3 * dt / steps
+    # the caller's own GPU kernels inside the step: one product per gradient request (oLBFGS: two per step), L-th steps one more
+    caller_per_step = (calls / steps) * drive.caller_kernel_ms if getattr(drive, "caller_kernel_ms", None) else None
     cands = [x for x in k if x in words]
     dom = max(cands, key=lambda x: k[x]["avg_ms"] * k[x]["launches"]) if cands else None
     roof = None
@@ -179,8 +197,11 @@ def report(name, workload, n, m, dt, steps, calls, extra=None, kind="SQN", k_pai
                         "frac_of_8TBps_on_bytes_moved": round(moved_tl / (tl * 1e-3) / 1e9 / PEAK, 4) if tl > 0 else None,
                         "reference_form_bytes": 64 * kp * n, "pairs_in_ring": kp},
            "step": {"bytes_moved": int(moved_step), "kernel_ms": round(kern_ms, 4), "ms": round(ms_step, 4),
-                    "launch_and_sync_gap_ms": round(ms_step - kern_ms, 4), "gap_frac": round(1 - kern_ms / ms_step, 4),
+                    "caller_kernels_ms": None if caller_per_step is None else round(caller_per_step, 4),
+                    "library_ms": None if caller_per_step is None else round(ms_step - caller_per_step, 4),
+                    "launch_and_sync_gap_ms": round(ms_step - kern_ms - (caller_per_step or 0.0), 4), "gap_frac": round((ms_step - kern_ms - (caller_per_step or 0.0)) / ms_step, 4),
                     "GBps_on_bytes_moved": round(moved_step / (ms_step * 1e-3) / 1e9, 1), "frac_of_8TBps": round(moved_step / (ms_step * 1e-3) / 1e9 / PEAK, 4),
+                    "library_GBps_on_bytes_moved": None if caller_per_step is None else round(moved_step / ((ms_step - caller_per_step) * 1e-3) / 1e9, 1),
                     "GBps_inside_kernels": round(moved_step / (kern_ms * 1e-3) / 1e9, 1) if kern_ms > 0 else None},
            "two_loop_ms": round(tl, 4), "kernels": k}
     if extra:
