@@ -252,7 +252,6 @@ void launch_verdict(const Scratch& sc, Partials in, double min_curvature, double
 static Partials with_verdict(const Scratch& sc, Partials p, const VerdictArgs* v)
 {
 	if (!v || sc.allreduce || !sc.ticket) return p;
-	rdd(reinterpret_cast<const double*>(sc.ticket), 1);
 	launch_verdict(sc, p, v->min_curvature, v->sy_dst, v->yy_dst, v->out);
 	return Partials{nullptr, 0, 0};
 }

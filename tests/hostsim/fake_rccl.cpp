@@ -234,7 +234,9 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
 ncclResult_t ncclCommAbort(ncclComm_t comm)
 {
 	if (!comm) return ncclInvalidArgument;
-	comm->aborted.store(true);                        // (the object stays: operations still queued on a stream refer to it)
+	comm->aborted.store(true);
+	if (!comm->shared) delete comm;                   // in-process clique: its collectives are synchronous, nothing queued refers to it
+	                                                  // (a rank of a multi-process clique stays: operations still queued on a stream refer to it)
 	std::lock_guard<std::mutex> lk(g_mu);
 	g_live--;
 	return ncclSuccess;
