@@ -1140,7 +1140,7 @@ bool ensure_copy_stream(DevCtx* c, int chunks)
 // Waiting for a stream that carries RCCL all-reduces (one process per GPU, stochqn_hip_comm_init; or the shards of one process).
 // A collective whose peer never arrives -- a rank that failed on its own and left the call, a process that died, a fabric that
 // never came up at first contact -- does not return an error: its kernel spins on the device and hipStreamSynchronize waits
-// for it for ever.  So the wait is bounded: the stream is polled (spinning for the first two milliseconds, then every 100 us),
+// for it for ever.  So the wait is bounded: the stream is polled (spinning like hipStreamSynchronize itself for the first 50 ms, then every 200 us),
 // the communicator's asynchronous error state is looked at, and after "reducer_patience_s" seconds the communicator is ABORTED
 // (ncclCommAbort ends the kernels that wait), marked dead for every later reduction, and the call fails (-1000) -- on every
 // rank that was waiting for the one that is gone.  Contexts without an RCCL reducer wait with hipStreamSynchronize as before.
@@ -1154,14 +1154,16 @@ hipError_t wait_stream(DevCtx* c, hipStream_t s)
 		const hipError_t q = hipStreamQuery(s);
 		if (q != hipErrorNotReady) return q;
 		(void) hipGetLastError();
+		if ((spin & 255) != 255) continue;                 // the clock is read every 256 polls (a poll is ~1 us)
 		const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-		if (waited > 2e-3) {
-			if (g_comm.CommGetAsyncError && (spin & 63) == 0) {
+		if (waited > 50e-3) {                              // no step takes this long: from here on something is slow or gone -- stop burning the core
+			if (g_comm.CommGetAsyncError) {
 				ncclResult_t st = ncclSuccess;
 				if (g_comm.CommGetAsyncError((ncclComm_t) c->red.comm, &st) == ncclSuccess && st != ncclSuccess && st != ncclInProgress) { why = "the communicator reports an asynchronous error"; break; }
 			}
 			if (waited > patience) { why = "a reduction did not complete within reducer_patience_s"; break; }
-			std::this_thread::sleep_for(std::chrono::microseconds(100));
+			std::this_thread::sleep_for(std::chrono::microseconds(200));
+			spin |= 255;                                   // ... and look at the clock after every poll
 		}
 	}
 	std::fprintf(stderr, "stochqn: rank %d of %d: %s -- aborting the communicator; this call and every later reduction over it fail (-1000)\n", c->red.rank, c->red.nranks, why);
