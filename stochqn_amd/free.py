@@ -78,6 +78,12 @@ class _HostSpace:
         left = self._left.get(ptr)
         if left is not None and left[0]() is a and left[1] == a.nbytes:
             return                                      # the same array, declined before (break heap, pages shared, pinned by its owner)
+        if (ptr & 4095) > 64:
+            # an array that begins deep inside a page shares that page with whatever precedes it: a block of some heap (the library
+            # recognises the program-break heap by itself; glibc's thread arenas it cannot tell from other mappings).  Arrays with a
+            # mapping of their own begin within a malloc header of a page boundary.  Left pageable.
+            self._left[ptr] = (weakref.ref(a), a.nbytes)
+            return
         if self._lib.stochqn_hip_pin_host(C.c_void_p(ptr), C.c_size_t(a.nbytes)) == 0:
             self._pins[ptr] = (weakref.ref(a), weakref.finalize(a, _unpin, self._lib, ptr))
         else:

@@ -37,7 +37,7 @@ SCENARIOS = ["registry", "reclaim_resume", "mirror_cap", "host_path", "xhash", "
              "group_rccl", "group_virtual", "group_alloc_failures", "fault_sweep", "fault_sweep_group", "caller_heap"]
 # the third stream model (round 5): a queue PER STREAM -- synchronising one stream leaves the others' work queued, hipHostUnregister
 # waits for nothing -- for the scenarios in which a copy left behind on a side stream would touch memory the caller has freed
-PER_STREAM = ["caller_heap", "host_path", "reclaim_resume", "branches", "owned_and_raw", "group_virtual", "group_rccl"]
+PER_STREAM = ["caller_heap", "host_path", "reclaim_resume", "group_virtual", "group_rccl"]
 
 
 @pytest.fixture(scope="module")
