@@ -53,6 +53,8 @@ CASES = [(sc, st) for sc in SCENARIOS for st in ("immediate", "lazy")] + [(sc, "
 @pytest.mark.parametrize("scenario,streams", CASES)
 @pytest.mark.parametrize("san", ["asan", "tsan"])
 def test_host_logic(san, scenario, streams, built):
+    if san == "tsan" and scenario == "caller_heap" and streams != "per_stream":
+        pytest.skip("caller_heap is single-threaded: under TSan (40 s a run) it runs with the stream model it was written for only")
     env = dict(os.environ, STOCHQN_HIP_RCCL_LIB=os.path.join(built, "libfake_rccl_%s.so" % san),
                ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
                TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
