@@ -1385,8 +1385,9 @@ template <class... P> inline bool all_aligned(P... ps) { return (elem_aligned(ps
 
 struct ProfScope {
 	const Scratch& sc;
-	ProfScope(const Scratch& s, int id) : sc(s) { if (sc.prof) sc.prof->begin(id, sc.stream); }
-	~ProfScope() { if (sc.prof) sc.prof->end(sc.stream); }
+	size_t which = 0;
+	ProfScope(const Scratch& s, int id) : sc(s) { if (sc.prof) which = sc.prof->begin(id, sc.stream); }
+	~ProfScope() { if (sc.prof) sc.prof->end(which, sc.stream); }
 };
 
 template <int NP, class Op>

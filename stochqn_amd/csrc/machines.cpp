@@ -63,16 +63,16 @@ inline real* row(View& v, size_t r, const DevCtx* c) { return v.dev + r * N(c); 
 
 void d2d(DevCtx* c, real* dst, const real* src, size_t count)
 {
-	if (c->sc.prof) c->sc.prof->begin(K_COPY, c->sc.stream);
+	const size_t pr = c->sc.prof ? c->sc.prof->begin(K_COPY, c->sc.stream) : 0;
 	SQN_HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(real), hipMemcpyDeviceToDevice, c->sc.stream));
-	if (c->sc.prof) c->sc.prof->end(c->sc.stream);
+	if (c->sc.prof) c->sc.prof->end(pr, c->sc.stream);
 }
 
 void zero(DevCtx* c, real* dst, size_t count)
 {
-	if (c->sc.prof) c->sc.prof->begin(K_COPY, c->sc.stream);
+	const size_t pr = c->sc.prof ? c->sc.prof->begin(K_COPY, c->sc.stream) : 0;
 	SQN_HIP_OK(hipMemsetAsync(dst, 0, count * sizeof(real), c->sc.stream));
-	if (c->sc.prof) c->sc.prof->end(c->sc.stream);
+	if (c->sc.prof) c->sc.prof->end(pr, c->sc.stream);
 }
 
 void to_host(DevCtx* c, void* dst, const double* src, size_t count)      // scalars of the recursion

@@ -50,18 +50,24 @@ struct Profiler {
 		(void) hipEventCreate(&e);
 		return e;
 	}
-	void begin(int id, hipStream_t st)
+	// begin returns the index of the pair it opened and end takes it: scopes NEST (a sliced pass hands each finished slice to
+	// a callback that launches kernels of its own inside the pass's scope), so "the last pair opened" is not the one to close.
+	// (Until round 5 end() closed pending.back(): the outer scope's second event was never recorded, hipEventElapsedTime on it
+	// left "invalid resource handle" behind, and the next synchronisation of a PROFILED host caller failed the call.)
+	size_t begin(int id, hipStream_t st)
 	{
 		Pending p{id, get(), get()};
 		(void) hipEventRecord(p.a, st);
 		pending.push_back(p);
+		return pending.size() - 1;
 	}
-	void end(hipStream_t st) { (void) hipEventRecord(pending.back().b, st); }
+	void end(size_t which, hipStream_t st) { if (which < pending.size()) (void) hipEventRecord(pending[which].b, st); }
 	void collect()  // call only after the stream has been synchronised
 	{
 		for (auto& p : pending) {
 			float ms = 0;
 			if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { total_ms[p.id] += ms; launches[p.id]++; }
+			else (void) hipGetLastError();           // a pair that cannot be read is not counted -- and must not fail somebody's call later
 			pool.push_back(p.a);
 			pool.push_back(p.b);
 		}

@@ -75,9 +75,9 @@ void write_partials(double* parts, int grid, int nq, double total)
 
 void run(const Scratch& sc, int id, std::function<void()> work)
 {
-	if (sc.prof) sc.prof->begin(id, sc.stream);
+	const size_t pr = sc.prof ? sc.prof->begin(id, sc.stream) : 0;
 	fakehip::enqueue(sc.stream, std::move(work));
-	if (sc.prof) sc.prof->end(sc.stream);
+	if (sc.prof) sc.prof->end(pr, sc.stream);
 }
 
 int next_rev(const Scratch& sc) { return (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0; }

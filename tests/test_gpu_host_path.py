@@ -400,6 +400,40 @@ def test_x_sent_up_while_the_caller_computes_changes_nothing(kind, hip_backend):
             assert np.array_equal(a, b), "x after call %d differs (caller's edit at call %d)" % (i, edit_at)
 
 
+def test_the_event_profiler_nests_with_the_sliced_host_path(hip_backend):
+    """STOCHQN_HIP_PROFILE / stochqn_hip_profile_enable with a HOST caller of a size whose passes run in slices: a sliced pass hands
+    every finished slice to a callback that launches kernels of its own INSIDE the pass's profiling scope.  Until round 5 the inner
+    scope's end closed the outer pair, the outer pair's second event was never recorded, and the next synchronisation failed the
+    call (-1000, "invalid resource handle") -- found by tools/bench_configs.py c3host.  Now: every call succeeds, the kernels of
+    the sliced passes are all counted, and the trajectory is the unprofiled one bit for bit."""
+    lib = _lib()
+    lib.stochqn_hip_profile_get.argtypes = [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
+    lib.stochqn_hip_profile_name.restype = C.c_char_p
+    n = 6_291_457
+    P = NoisyQuadratic(n, seed=21)
+    plain = run_trace(OPTIMIZERS["SQN"](backend=hip_backend, space="host", **KW["SQN"]), P, P.x0(), 0.05, 14)
+    lib.stochqn_hip_release_all()
+    try:
+        lib.stochqn_hip_profile_enable(1)
+        lib.stochqn_hip_profile_reset()
+        lib.stochqn_hip_stats_reset()
+        prof = run_trace(OPTIMIZERS["SQN"](backend=hip_backend, space="host", **KW["SQN"]), P, P.x0(), 0.05, 14)     # raises on -1000
+        lib.stochqn_hip_release_all()
+        seen = {}
+        for i in range(lib.stochqn_hip_profile_kernels()):
+            cnt, ms = C.c_longlong(), C.c_double()
+            lib.stochqn_hip_profile_get(i, C.byref(cnt), C.byref(ms))
+            if cnt.value:
+                seen[lib.stochqn_hip_profile_name(i).decode()] = cnt.value
+    finally:
+        lib.stochqn_hip_profile_enable(0)
+    assert stat(lib, "x_sent_ahead") >= 3                                   # the path under test ran: pass 3 in slices, x ahead of the guard
+    assert seen.get("sadd", 0) >= 3 and seen.get("apply", 0) >= 3 and seen.get("sdot", 0) + seen.get("sdot2", 0) >= 3, seen
+    for a, b in zip(plain, prof):
+        assert a["task"] == b["task"] and a["info"] == b["info"] and np.array_equal(a["x"], b["x"])
+    lib.stochqn_hip_release_all()
+
+
 def test_step_counters_name_the_form_that_ran(hip_backend):
     """stochqn_hip_stat: which form of the recursion each step took."""
     import torch

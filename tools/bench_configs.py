@@ -161,21 +161,22 @@ def pmc_of(kernel):
     return (int(best["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT) + " (FETCH_SIZE x 2 + WRITE_SIZE, median dispatch)") if best else (None, None)
 
 
-def report(name, workload, n, m, dt, steps, calls, extra=None, kind="SQN", k_pairs=None, fisher_rows=0):
+def report(name, workload, n, m, dt, steps, calls, extra=None, kind="SQN", k_pairs=None, fisher_rows=0, elem_bytes=8):
     prof_steps = max(1, min(steps, int(os.environ.get("PROFILE_STEPS", "20"))))      # what drive() ran under the event profiler
     k = kernels()
     kp = m if k_pairs is None else k_pairs
     words = words_per_launch(kind, kp, fisher_rows)
+    nb = n * elem_bytes                 # bytes per n-vector (the float build streams 4-byte elements)
     for kn, e in k.items():
         if kn in words:
-            e["alg_GB"] = round(words[kn] * n * 8 / 1e9, 3)
-            e["alg_GBps"] = round(words[kn] * n * 8 / (e["avg_ms"] * 1e-3) / 1e9, 1)
+            e["alg_GB"] = round(words[kn] * nb / 1e9, 3)
+            e["alg_GBps"] = round(words[kn] * nb / (e["avg_ms"] * 1e-3) / 1e9, 1)
             e["frac_of_8TBps"] = round(e["alg_GBps"] / PEAK, 4)
     chain = ("first", "bwd", "mid", "fwd", "fwd_last", "sdot", "sdot2", "qdot", "sadd")
     tl = sum(k[x]["avg_ms"] * k[x]["launches"] for x in chain if x in k) / prof_steps
     form = "three-pass" if "sadd" in k else "sweeps"
-    moved_tl = sum(words[x] * k[x]["launches"] for x in chain if x in k) * n * 8 / prof_steps
-    moved_step = sum(words[x] * e["launches"] for x, e in k.items() if x in words) * n * 8 / prof_steps
+    moved_tl = sum(words[x] * k[x]["launches"] for x in chain if x in k) * nb / prof_steps
+    moved_step = sum(words[x] * e["launches"] for x, e in k.items() if x in words) * nb / prof_steps
     kern_ms = sum(e["avg_ms"] * e["launches"] for e in k.values()) / prof_steps
     ms_step = 1e3 * dt / steps
     # the caller's own GPU kernels inside the step: one product per gradient request (oLBFGS: two per step), L-th steps one more
@@ -184,7 +185,7 @@ def report(name, workload, n, m, dt, steps, calls, extra=None, kind="SQN", k_pai
     dom = max(cands, key=lambda x: k[x]["avg_ms"] * k[x]["launches"]) if cands else None
     roof = None
     if dom:
-        alg = words[dom] * n * 8
+        alg = words[dom] * nb
         ach = alg / (k[dom]["avg_ms"] * 1e-3) / 1e9
         traffic, src = pmc_of(dom)
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK, "unit": "GB/s", "frac": round(ach / PEAK, 4),
@@ -195,7 +196,7 @@ def report(name, workload, n, m, dt, steps, calls, extra=None, kind="SQN", k_pai
            "calls": calls, "roofline": roof,
            "two_loop": {"form": form, "ms": round(tl, 4), "bytes_moved": int(moved_tl), "GBps_on_bytes_moved": round(moved_tl / (tl * 1e-3) / 1e9, 1) if tl > 0 else None,
                         "frac_of_8TBps_on_bytes_moved": round(moved_tl / (tl * 1e-3) / 1e9 / PEAK, 4) if tl > 0 else None,
-                        "reference_form_bytes": 64 * kp * n, "pairs_in_ring": kp},
+                        "reference_form_bytes": 8 * elem_bytes * kp * n, "pairs_in_ring": kp},
            "step": {"bytes_moved": int(moved_step), "kernel_ms": round(kern_ms, 4), "ms": round(ms_step, 4),
                     "caller_kernels_ms": None if caller_per_step is None else round(caller_per_step, 4),
                     "library_ms": None if caller_per_step is None else round(ms_step - caller_per_step, 4),
@@ -269,7 +270,7 @@ def c3f32():
     opt.niter = 10 * ((opt.niter + 9) // 10)
     dt, calls = drive(opt, P, x, 0.05, 40, 2)
     report("C3-f32", "SQN n=1e8 m=20 L=10 fp32 storage (libstochqn_f32.so), Hv = d*v, device-resident", n, m, dt, 40, calls,
-           {"mem_used": opt.BFGS_mem.mem_used, "f_end": float(0.5 * torch.sum(P.d.double() * x.double() ** 2))})
+           {"mem_used": opt.BFGS_mem.mem_used, "f_end": float(0.5 * torch.sum(P.d.double() * x.double() ** 2))}, elem_bytes=4)
     lib = lib64
 
 
