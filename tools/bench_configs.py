@@ -200,7 +200,7 @@ def report(name, workload, n, m, dt, steps, calls, extra=None, kind="SQN", k_pai
            "step": {"bytes_moved": int(moved_step), "kernel_ms": round(kern_ms, 4), "ms": round(ms_step, 4),
                     "caller_kernels_ms": None if caller_per_step is None else round(caller_per_step, 4),
                     "library_ms": None if caller_per_step is None else round(ms_step - caller_per_step, 4),
-                    "launch_and_sync_gap_ms": round(ms_step - kern_ms - (caller_per_step or 0.0), 4), "gap_frac": round((ms_step - kern_ms - (caller_per_step or 0.0)) / ms_step, 4),
+                    "launch_and_sync_gap_ms": round(max(0.0, ms_step - kern_ms - (caller_per_step or 0.0)), 4), "gap_frac": round(max(0.0, ms_step - kern_ms - (caller_per_step or 0.0)) / ms_step, 4),
                     "GBps_on_bytes_moved": round(moved_step / (ms_step * 1e-3) / 1e9, 1), "frac_of_8TBps": round(moved_step / (ms_step * 1e-3) / 1e9 / PEAK, 4),
                     "library_GBps_on_bytes_moved": None if caller_per_step is None else round(moved_step / ((ms_step - caller_per_step) * 1e-3) / 1e9, 1),
                     "GBps_inside_kernels": round(moved_step / (kern_ms * 1e-3) / 1e9, 1) if kern_ms > 0 else None},

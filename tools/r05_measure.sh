@@ -5,7 +5,7 @@
 # Run on the GPU box from the repository root; afterwards, here: python profiles/summarise.py r05_c2 r05/c2_   (etc.)
 set -o pipefail
 R=$PWD; O=$R/gpurun_out/r05; mkdir -p $O
-git -C $R rev-parse HEAD > $O/commit.txt 2>/dev/null || echo "(snapshot without .git: see the commit that added this file's output)" > $O/commit.txt
+echo "${COMMIT:-unknown}" > $O/commit.txt
 which=${@:-c3 c2 c4}
 cd /tmp && export TMPDIR=/tmp
 for c in $which; do
