@@ -86,10 +86,11 @@ int stochqn_hip_export(const void *s_mem);
  * break moves under it whenever the allocator trims the heap.  Such a range -- and one whose pages overlap a range pinned here
  * already -- is DECLINED (return 1, "host_pins_declined"): it still works, through the runtime's pageable path.  Arrays with a
  * mapping of their own (malloc / numpy / R above the mmap threshold; anything from mmap or posix_memalign(4096, a multiple of
- * 4096)) are pinned.  "register_host" = 1 and the multi-device mode's own registrations follow the same rule.  (Not recognised:
- * a block from one of glibc's THREAD arenas -- memory malloc'ed by a thread other than the main one lives in 64 MiB heaps of its
- * own that look like any anonymous mapping, share pages among their blocks and are trimmed like the break heap.  A binding that
- * allocates its per-call arrays on worker threads should give them mappings of their own, as stochqn_amd/free.py does.)
+ * 4096)) are pinned.  "register_host" = 1 and the multi-device mode's own registrations follow the same rule.  A block from one
+ * of glibc's THREAD arenas is declined as well: memory malloc'ed below the mmap threshold by a thread other than the main one
+ * lives in 64 MiB-aligned heaps that share pages among their blocks and are trimmed like the break heap; they are recognised
+ * by the header glibc keeps at their start (runtime.cpp: inside_a_thread_arena_heap; other allocators' pools are not known to
+ * the library -- a binding on jemalloc / tcmalloc should give the arrays it pins mappings of their own, as stochqn_amd/free.py does).
  * pin: 0 = pinned now (or once more), 1 = not pinned by this call (already page-locked by other means, or declined: the range
  * stays pageable), -1 = refused (not host memory, no device).  unpin: 0, or -1 when the range was not pinned here. */
 int stochqn_hip_pin_host(void *p, size_t bytes);

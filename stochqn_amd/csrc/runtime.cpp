@@ -5,7 +5,9 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <sys/uio.h>
 #include <unistd.h>
+#include <cerrno>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -878,6 +880,7 @@ real* host_landing(DevCtx* c, int slot)
 // process twice to a GPU memory-access fault at a break-heap address.  Arrays with a mapping of their own -- what
 // malloc / numpy / R hand out above the mmap threshold, what stochqn_amd/free.py makes for its own arrays -- start on a page of
 // their own and are unmapped as a whole by their owner, after the owner has unpinned them.
+bool g_pin_probe_by_maps = false;                    // runtime.hpp: a switch for tests/hostsim (the fallback of peek_words)
 namespace {
 std::mutex g_span_mu;
 std::map<uintptr_t, uintptr_t> g_spans;            // first page -> one past the last page, of every range this library registered
@@ -896,6 +899,56 @@ uintptr_t break_heap_start()
 	if (s) start.store(s, std::memory_order_relaxed);
 	return s;
 }
+
+// glibc gives every thread but the first an arena of its own, and those grow in "heaps": anonymous mappings aligned to their
+// maximum size (64 MiB on 64-bit), each beginning with {arena, previous heap, size in use, size made read-write}.  A block
+// below the mmap threshold that a worker thread allocated lives in one: it shares its first and last page with its neighbours
+// and sits under a top that glibc gives back (madvise, or munmap of the whole heap) as it does with the break.  Recognised by
+// that header -- five conditions on four words; a wrong "yes" costs the staged copy path and nothing else, a wrong "no" is the
+// behaviour before this check.
+// four words at `at`, read without a fault if there is nothing to read: process_vm_readv on the process itself says EFAULT;
+// where that call is not allowed (EPERM / ENOSYS under some seccomp profiles) /proc/self/maps says whether the page is readable
+__attribute__((no_sanitize("address", "thread"))) bool peek_words(uintptr_t at, uintptr_t out[4])
+{
+	if (!g_pin_probe_by_maps) {
+		struct iovec local{out, 4 * sizeof(uintptr_t)}, remote{(void*) at, 4 * sizeof(uintptr_t)};
+		const ssize_t got = process_vm_readv(getpid(), &local, 1, &remote, 1, 0);
+		if (got == (ssize_t) (4 * sizeof(uintptr_t))) return true;
+		if (got >= 0 || errno == EFAULT) return false;
+	}
+	bool readable = false;
+	if (FILE* f = std::fopen("/proc/self/maps", "r")) {
+		char line[512];
+		while (std::fgets(line, sizeof line, f)) {
+			char* dash = nullptr;
+			const uintptr_t a = (uintptr_t) std::strtoull(line, &dash, 16);
+			if (!dash || *dash != '-') continue;
+			char* sp = nullptr;
+			const uintptr_t b = (uintptr_t) std::strtoull(dash + 1, &sp, 16);
+			if (at + 4096 <= a) break;                              // the list is sorted by address
+			if (a <= at && at + 4096 <= b) { readable = sp && sp[0] == ' ' && sp[1] == 'r'; break; }
+		}
+		std::fclose(f);
+	}
+	if (!readable) return false;
+	const volatile uintptr_t* h = (const volatile uintptr_t*) at;
+	for (int i = 0; i < 4; i++) out[i] = h[i];
+	return true;
+}
+
+bool inside_a_thread_arena_heap(uintptr_t lo, uintptr_t hi)
+{
+	constexpr uintptr_t kHeap = (uintptr_t) 64 << 20;
+	const uintptr_t base = lo & ~(kHeap - 1);
+	if (hi > base + kHeap) return false;                            // a block never spans two heaps
+	uintptr_t h[4];
+	if (!peek_words(base, h)) return false;
+	const uintptr_t arena = h[0], prev = h[1], size = h[2], prot = h[3];
+	const uintptr_t arena_off = arena & (kHeap - 1);
+	return arena && (arena & 7) == 0 && arena_off >= 32 && arena_off <= 256        // an arena begins right after the header of its first heap
+	       && (prev & (kHeap - 1)) == 0 && (arena - arena_off == base ? prev == 0 : true)
+	       && size && (size & 4095) == 0 && (prot & 4095) == 0 && size <= prot && prot <= kHeap && hi <= base + prot;
+}
 }  // namespace
 
 bool pinnable_in_place(const void* p, size_t bytes)
@@ -905,6 +958,10 @@ bool pinnable_in_place(const void* p, size_t bytes)
 	const uintptr_t heap = break_heap_start(), brk_now = (uintptr_t) sbrk(0);
 	bool ok = !(heap && lo < brk_now && hi > heap);
 	if (!ok && trace) std::fprintf(stderr, "stochqn: pin %p +%zu declined: inside the break heap [%#lx, %#lx)\n", p, bytes, (unsigned long) heap, (unsigned long) brk_now);
+	if (ok && inside_a_thread_arena_heap(lo, hi)) {
+		ok = false;
+		if (trace) std::fprintf(stderr, "stochqn: pin %p +%zu declined: inside a heap of one of glibc's thread arenas (at %#lx)\n", p, bytes, (unsigned long) (lo & ~(((uintptr_t) 64 << 20) - 1)));
+	}
 	if (ok) {
 		std::lock_guard<std::mutex> lk(g_span_mu);
 		auto it = g_spans.upper_bound(lo);                  // the first span that starts above lo; the one before may reach into [lo, hi)
@@ -960,7 +1017,7 @@ bool ensure_registered(DevCtx* c, const void* p, size_t bytes)
 	if (!mine) { *oldest = DevCtx::Seen{p, c->call_index}; return false; }
 	if (mine->call == c->call_index) return false;             // first sighting was in this very call
 	mine->call = c->call_index;
-	if (!pinnable_in_place(p, bytes)) return false;          // a block in the break heap, or pages shared with another pin: left to the runtime's pageable path
+	if (!pinnable_in_place(p, bytes)) return false;          // a block in a malloc heap, or pages shared with another pin: left to the runtime's pageable path
 	DevCtx::HostRange& slot = c->regs[c->reg_turn++ % (int) (sizeof(c->regs) / sizeof(c->regs[0]))];
 	if (slot.p) { if (hipHostUnregister(const_cast<void*>(slot.p)) != hipSuccess) (void) hipGetLastError(); note_unpinned(slot.p); slot = DevCtx::HostRange{}; }
 	if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
@@ -1312,7 +1369,7 @@ int stochqn_hip_pin_host(void* p, size_t bytes)
 		note_unpinned(p);
 		const int refs = it->second.refs;
 		g_pins.erase(it);
-		if (!pinnable_in_place(p, bytes)) return pin_says(p, bytes, 1, "declined: break heap or shared pages");
+		if (!pinnable_in_place(p, bytes)) return pin_says(p, bytes, 1, "declined: malloc heap or shared pages");
 		if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); return pin_says(p, bytes, -1, "hipHostRegister failed"); }
 		note_pinned(p, bytes);
 		g_pins[p] = Pin{bytes, refs + 1};
@@ -1323,7 +1380,7 @@ int stochqn_hip_pin_host(void* p, size_t bytes)
 		if (a.type == hipMemoryTypeHost) { stat_add(ST_HOST_PIN_FOREIGN); return pin_says(p, bytes, 1, "page-locked by other means"); }
 		if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) return pin_says(p, bytes, -1, "not host memory");
 	} else (void) hipGetLastError();
-	if (!pinnable_in_place(p, bytes)) return pin_says(p, bytes, 1, "declined: break heap or shared pages");                // stays pageable (works, a little slower)
+	if (!pinnable_in_place(p, bytes)) return pin_says(p, bytes, 1, "declined: malloc heap or shared pages");                // stays pageable (works, a little slower)
 	const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
 	if (e != hipSuccess) { (void) hipGetLastError(); stat_add(ST_HOST_PIN_ERRORS); return pin_says(p, bytes, -1, hipGetErrorString(e)); }
 	note_pinned(p, bytes);

@@ -213,6 +213,7 @@ void stat_add(int id, long long v = 1);
 // page with neighbours, and the break moves under them when the heap is trimmed), not one whose pages overlap a range that is
 // page-locked already.  Whatever is declined still works: the runtime's pageable path carries it (runtime.cpp).
 bool pinnable_in_place(const void* p, size_t bytes);
+extern bool g_pin_probe_by_maps;   // tests/hostsim only: look a heap header up through /proc/self/maps even where process_vm_readv works
 void note_pinned(const void* p, size_t bytes);          // bookkeeping of the ranges this library has registered, for the overlap rule
 void note_unpinned(const void* p);
 

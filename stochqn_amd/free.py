@@ -80,8 +80,8 @@ class _HostSpace:
             return                                      # the same array, declined before (break heap, pages shared, pinned by its owner)
         if (ptr & 4095) > 64:
             # an array that begins deep inside a page shares that page with whatever precedes it: a block of some heap (the library
-            # recognises the program-break heap by itself; glibc's thread arenas it cannot tell from other mappings).  Arrays with a
-            # mapping of their own begin within a malloc header of a page boundary.  Left pageable.
+            # recognises glibc's heaps by itself -- the program break, the thread arenas -- but no other allocator's pools).  Arrays
+            # with a mapping of their own begin within a malloc header of a page boundary.  Left pageable.
             self._left[ptr] = (weakref.ref(a), a.nbytes)
             return
         if self._lib.stochqn_hip_pin_host(C.c_void_p(ptr), C.c_size_t(a.nbytes)) == 0:

@@ -17,6 +17,7 @@
 #include "runtime.hpp"          // the host checksum of x (xhash_*): tested against its definition directly
 
 #include <dlfcn.h>
+#include <malloc.h>
 #include <signal.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
@@ -826,6 +827,76 @@ struct Heap {
 	}
 };
 
+// ---- what the pinning rule says about glibc's own heaps (the PLAIN build only: the sanitizers bring allocators of their own) ------------------
+// runtime.cpp: pinnable_in_place.  Every verdict is checked against what glibc itself says about the block in its chunk header
+// (the word before the block: bit 1 = IS_MMAPPED, a mapping of its own; bit 2 = NON_MAIN_ARENA, a heap of a thread's arena).
+void sc_glibc_heaps()
+{
+#if defined(__SANITIZE_ADDRESS__) || defined(__SANITIZE_THREAD__)
+	std::printf("note: glibc_heaps needs glibc's malloc; nothing checked in a sanitizer build\n");
+#else
+	const size_t bytes = 6u << 20;
+	auto head = [](const void* p) { return ((const size_t*) p)[-1]; };
+	auto declined = [&](void* p, const char* what) {
+		const long long before = stat("host_pins_declined");
+		CHECK(stochqn_hip_pin_host(p, bytes) == 1 && stat("host_pins_declined") == before + 1, "%s must be declined", what);
+		CHECK(stochqn_hip_unpin_host(p) == -1 && fakehip::live().registered_ranges == 0, "%s: a declined range is not pinned", what);
+	};
+	auto pinned = [&](void* p, const char* what) {
+		CHECK(stochqn_hip_pin_host(p, bytes) == 0 && fakehip::is_registered(p), "%s must be pinned", what);
+		CHECK(stochqn_hip_unpin_host(p) == 0 && fakehip::live().registered_ranges == 0, "%s: unpin", what);
+	};
+	// above the mmap threshold: a mapping of its own, whichever thread asks
+	mallopt(M_MMAP_THRESHOLD, 128 << 10);
+	void* own = std::malloc(bytes);
+	void* own_t = nullptr;
+	std::thread([&] { own_t = std::malloc(bytes); }).join();
+	CHECK(own && own_t && (head(own) & 2) && (head(own_t) & 2), "glibc should have mmap'ed these (%#zx, %#zx)", head(own), head(own_t));
+	pinned(own, "the main thread's block above the mmap threshold");
+	pinned(own_t, "a worker thread's block above the mmap threshold");
+	// below it: the main thread's comes from the program break, a worker's from a 64 MiB heap of its arena
+	mallopt(M_MMAP_THRESHOLD, 32 << 20);
+	void* brk_blk = std::malloc(bytes);
+	void* arena_blk = nullptr;
+	void* arena_blk2 = nullptr;
+	std::thread([&] { arena_blk = std::malloc(bytes); arena_blk2 = std::malloc(bytes); }).join();      // the second one is not at the start of the heap
+	CHECK(brk_blk && !(head(brk_blk) & 6), "glibc should have taken this one from the break (%#zx)", head(brk_blk));
+	declined(brk_blk, "a block of the break heap");
+	if (arena_blk && arena_blk2 && (head(arena_blk) & 4) && (head(arena_blk2) & 4)) {
+		for (int by_maps = 0; by_maps < 2; by_maps++) {          // the heap's header read through process_vm_readv, and looked up in /proc/self/maps
+			sqn::g_pin_probe_by_maps = by_maps != 0;
+			declined(arena_blk, "the first block of a thread arena's heap");
+			declined(arena_blk2, "a later block of a thread arena's heap");
+			pinned(own_t, "a worker thread's block above the mmap threshold, again");
+		}
+		sqn::g_pin_probe_by_maps = false;
+		// a page-aligned piece of such a block is no better (posix_memalign inside a heap looks like this)
+		void* inner = (void*) (((uintptr_t) arena_blk2 + 4095) & ~(uintptr_t) 4095);
+		const long long before = stat("host_pins_declined");
+		CHECK(stochqn_hip_pin_host(inner, bytes / 2) == 1 && stat("host_pins_declined") == before + 1, "a page-aligned range inside a thread arena's heap must be declined");
+	} else std::printf("note: this malloc gave the worker thread no arena of its own (%#zx); the thread-arena rule was not exercised\n", arena_blk ? head(arena_blk) : (size_t) 0);
+	// a caller's own anonymous mapping that happens to begin on a 64 MiB boundary and holds ordinary data is not mistaken for one
+	{
+		const size_t span = (size_t) 128 << 20;
+		char* raw = (char*) mmap(nullptr, span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+		CHECK(raw != MAP_FAILED, "mmap");
+		double* at = (double*) (((uintptr_t) raw + ((size_t) 64 << 20) - 1) & ~(((uintptr_t) 64 << 20) - 1));
+		for (int i = 0; i < 64; i++) at[i] = 1.0 + i;                    // an array of doubles from the boundary on
+		pinned(at + 8, "an array in the caller's own mapping, 64 bytes past a 64 MiB boundary");
+		// ... and one whose 64 MiB boundary is not mapped at all (the probe must come back empty-handed, not fault)
+		munmap(raw, (size_t) ((char*) at - raw) + 4096);
+		for (int by_maps = 0; by_maps < 2; by_maps++) {
+			sqn::g_pin_probe_by_maps = by_maps != 0;
+			pinned((char*) at + 8192, "an array whose 64 MiB boundary is unmapped");
+		}
+		sqn::g_pin_probe_by_maps = false;
+		munmap((char*) at + 4096, span - (size_t) ((char*) at - raw) - 4096);
+	}
+	std::free(own); std::free(own_t); std::free(brk_blk); std::free(arena_blk); std::free(arena_blk2);
+	mallopt(M_MMAP_THRESHOLD, 128 << 10);
+#endif
+}
+
 void sc_caller_heap()
 {
 	const int n = (1 << 16) + 3;
@@ -995,7 +1066,7 @@ const Scenario kScenarios[] = {
 	{"registry", sc_registry}, {"reclaim_resume", sc_reclaim_resume}, {"mirror_cap", sc_mirror_cap}, {"host_path", sc_host_path}, {"xhash", sc_xhash},
 	{"branches", sc_branches}, {"owned_and_raw", sc_owned_and_raw}, {"group_rccl", sc_group_rccl}, {"group_virtual", sc_group_virtual},
 	{"group_alloc_failures", sc_group_alloc_failures}, {"fault_sweep", sc_fault_sweep}, {"fault_sweep_group", sc_fault_sweep_group},
-	{"threads", sc_threads}, {"caller_heap", sc_caller_heap}, {"model_a_failure", sc_model_a_failure}};
+	{"threads", sc_threads}, {"caller_heap", sc_caller_heap}, {"glibc_heaps", sc_glibc_heaps}, {"model_a_failure", sc_model_a_failure}};
 
 }  // namespace
 

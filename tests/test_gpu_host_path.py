@@ -219,6 +219,22 @@ def test_the_library_pins_nothing_behind_the_callers_back(hip_backend):
     small = np.zeros(6000)                                       # 48 KB: below every mmap threshold, so in the heap of the thread that made it
     assert lib.stochqn_hip_pin_host(small.ctypes.data, small.nbytes) == 1 and stat(lib, "host_pins_declined") == declined0 + 1
     assert lib.stochqn_hip_unpin_host(small.ctypes.data) == -1   # never was pinned
+    # ... and so is a block of one of glibc's thread arenas: a numpy array a worker thread made, below the mmap threshold (which a
+    # process that has freed large arrays has long since raised to its 32 MiB ceiling: the dynamic threshold).  What glibc itself
+    # says about the block stands in the word before it: bit 1 = a mapping of its own, bit 2 = a heap of a thread's arena
+    import threading
+    made = []
+    np.empty(24 << 20, dtype=np.uint8)                           # made and freed at once: the threshold is 24 MiB (or more) from here on
+    worker = threading.Thread(target=lambda: made.extend(np.zeros(6 << 17) for _ in range(2)))      # 6 MiB each
+    worker.start()
+    worker.join()
+    for a in made:
+        head = C.c_size_t.from_address(a.ctypes.data - 8).value
+        want = 0 if head & 2 else 1                              # mapped on its own -> pinned; inside a heap (bit 2: a thread arena's; neither: the break) -> declined
+        print("a worker thread's 6 MiB array: chunk header %#x -> %s" % (head, "a mapping of its own" if head & 2 else ("a thread arena's heap" if head & 4 else "the break heap")))
+        assert lib.stochqn_hip_pin_host(a.ctypes.data, a.nbytes) == want, "chunk header %#x, expected %d" % (head, want)
+        if want == 0:
+            assert lib.stochqn_hip_unpin_host(a.ctypes.data) == 0
     big = own(2 * n)
     assert lib.stochqn_hip_pin_host(big.ctypes.data, 8 * n + 100) == 0
     assert lib.stochqn_hip_pin_host(big.ctypes.data + 8 * n + 200, 8 * n - 200) == 1      # starts in the page the first range ends in

@@ -23,6 +23,10 @@ caller waited for may legally do):
   group_rccl / group_virtual: the single-process multi-device mode with 4 worker threads over ncclCommInitAll, and over
       the host-side reducer; one shard over a real communicator (option devices_rccl_single);
   group_alloc_failures: every allocation of that mode failing in turn (NULL / -1000, no hang, no leak);
+  glibc_heaps (a third build, WITHOUT a sanitizer -- they replace malloc): which blocks of glibc's own heaps the library agrees to
+      page-lock in place -- mmap'ed blocks of either thread yes; blocks of the program break and of a worker thread's arena heap no
+      (first block, later block, a page-aligned piece) -- each verdict checked against the flags in glibc's own chunk header; the
+      heap's header read through process_vm_readv and through /proc/self/maps; unmapped and ordinary 64 MiB boundaries;
   fault_sweep / fault_sweep_group: EVERY call site of the HIP runtime failing in turn, ~850 runs: a message and -1000 or
       a correct result, never an abort, a wrong x or a leak -- the bound on round 3's unexplained abort.
 """
@@ -64,3 +68,14 @@ def test_host_logic(san, scenario, streams, built):
     assert out.returncode == 0, tail
     assert "%s (%s streams): ok" % (scenario, streams) in out.stdout, tail
     assert "ERROR: AddressSanitizer" not in out.stdout and "WARNING: ThreadSanitizer" not in out.stdout and "runtime error:" not in out.stdout, tail
+
+
+@pytest.mark.parametrize("streams", ["immediate", "per_stream"])
+def test_pinning_rule_on_glibcs_own_heaps(streams, built):
+    """runtime.cpp: pinnable_in_place against glibc's malloc itself (scenario glibc_heaps, the build without a sanitizer)."""
+    env = dict(os.environ, STOCHQN_HIP_RCCL_LIB=os.path.join(built, "libfake_rccl_plain.so"))
+    cmd = [os.path.join(built, "host_logic_plain"), "glibc_heaps"] + ([streams] if streams != "immediate" else [])
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stdout[-4000:]
+    assert "glibc_heaps (%s streams): ok" % streams in out.stdout, out.stdout[-4000:]
+    assert "the thread-arena rule was not exercised" not in out.stdout, out.stdout[-2000:]
