@@ -231,8 +231,17 @@ def test_the_library_pins_nothing_behind_the_callers_back(hip_backend):
     for a in made:
         head = C.c_size_t.from_address(a.ctypes.data - 8).value
         want = 0 if head & 2 else 1                              # mapped on its own -> pinned; inside a heap (bit 2: a thread arena's; neither: the break) -> declined
-        print("a worker thread's 6 MiB array: chunk header %#x -> %s" % (head, "a mapping of its own" if head & 2 else ("a thread arena's heap" if head & 4 else "the break heap")))
-        assert lib.stochqn_hip_pin_host(a.ctypes.data, a.nbytes) == want, "chunk header %#x, expected %d" % (head, want)
+        got = lib.stochqn_hip_pin_host(a.ctypes.data, a.nbytes)
+        said = "a worker thread's 6 MiB numpy array at %#x: glibc's chunk header %#x = %s; stochqn_hip_pin_host -> %d" % (
+            a.ctypes.data, head, "a mapping of its own" if head & 2 else ("a thread arena's heap" if head & 4 else "the break heap"), got)
+        print(said)
+        import os
+        try:                                                     # which case the box exercised, for the record of the run (gpurun_out/ is scratch)
+            with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "pin_rule_on_the_gpu_box.txt"), "a") as f:
+                f.write(said + "\n")
+        except OSError:
+            pass
+        assert got == want, said
         if want == 0:
             assert lib.stochqn_hip_unpin_host(a.ctypes.data) == 0
     big = own(2 * n)
