@@ -900,12 +900,6 @@ uintptr_t break_heap_start()
 	return s;
 }
 
-// glibc gives every thread but the first an arena of its own, and those grow in "heaps": anonymous mappings aligned to their
-// maximum size (64 MiB on 64-bit), each beginning with {arena, previous heap, size in use, size made read-write}.  A block
-// below the mmap threshold that a worker thread allocated lives in one: it shares its first and last page with its neighbours
-// and sits under a top that glibc gives back (madvise, or munmap of the whole heap) as it does with the break.  Recognised by
-// that header -- five conditions on four words; a wrong "yes" costs the staged copy path and nothing else, a wrong "no" is the
-// behaviour before this check.
 // four words at `at`, read without a fault if there is nothing to read: process_vm_readv on the process itself says EFAULT;
 // where that call is not allowed (EPERM / ENOSYS under some seccomp profiles) /proc/self/maps says whether the page is readable
 __attribute__((no_sanitize("address", "thread"))) bool peek_words(uintptr_t at, uintptr_t out[4])
@@ -936,6 +930,12 @@ __attribute__((no_sanitize("address", "thread"))) bool peek_words(uintptr_t at, 
 	return true;
 }
 
+// glibc gives every thread but the first an arena of its own, and those grow in "heaps": anonymous mappings aligned to their
+// maximum size (64 MiB on 64-bit), each beginning with {arena, previous heap, size in use, size made read-write}.  A block
+// below the mmap threshold that a worker thread allocated lives in one: it shares its first and last page with its neighbours
+// and sits under a top that glibc gives back (madvise, or munmap of the whole heap) as it does with the break.  Recognised by
+// that header -- five conditions on four words; a wrong "yes" costs the staged copy path and nothing else, a wrong "no" is the
+// behaviour before this check.
 bool inside_a_thread_arena_heap(uintptr_t lo, uintptr_t hi)
 {
 	constexpr uintptr_t kHeap = (uintptr_t) 64 << 20;
@@ -1207,11 +1207,12 @@ hipError_t wait_stream(DevCtx* c, hipStream_t s)
 	const auto t0 = std::chrono::steady_clock::now();
 	const double patience = options().reducer_patience_s;
 	const char* why = nullptr;
+	bool slow = false;
 	for (long spin = 0;; spin++) {
 		const hipError_t q = hipStreamQuery(s);
 		if (q != hipErrorNotReady) return q;
 		(void) hipGetLastError();
-		if ((spin & 255) != 255) continue;                 // the clock is read every 256 polls (a poll is ~1 us)
+		if (!slow && (spin & 255) != 255) continue;        // the clock is read every 256 polls (a poll is ~1 us)
 		const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 		if (waited > 50e-3) {                              // no step takes this long: from here on something is slow or gone -- stop burning the core
 			if (g_comm.CommGetAsyncError) {
@@ -1220,7 +1221,7 @@ hipError_t wait_stream(DevCtx* c, hipStream_t s)
 			}
 			if (waited > patience) { why = "a reduction did not complete within reducer_patience_s"; break; }
 			std::this_thread::sleep_for(std::chrono::microseconds(200));
-			spin |= 255;                                   // ... and look at the clock after every poll
+			slow = true;                                   // ... one poll per sleep from here on, the clock read every time
 		}
 	}
 	std::fprintf(stderr, "stochqn: rank %d of %d: %s -- aborting the communicator; this call and every later reduction over it fail (-1000)\n", c->red.rank, c->red.nranks, why);
@@ -1655,7 +1656,7 @@ long long stochqn_hip_stat(const char* name)
 void stochqn_hip_stats_reset(void)
 {
 	for (int i = 0; i < ST_COUNT; i++)
-		if (i != ST_HOST_UNPIN_FAILED && i != ST_WORK_IN_FLIGHT && i != ST_HOST_PIN_ERRORS && i != ST_HOST_PIN_FOREIGN) g_stats[i].store(0, std::memory_order_relaxed);       // those two are facts about the process, not rates
+		if (i != ST_HOST_UNPIN_FAILED && i != ST_WORK_IN_FLIGHT && i != ST_HOST_PIN_ERRORS && i != ST_HOST_PIN_FOREIGN) g_stats[i].store(0, std::memory_order_relaxed);       // those are facts about the process, not rates
 }
 
 int stochqn_hip_loopback_init(int nranks)

@@ -82,13 +82,17 @@ class _HostSpace:
             # an array that begins deep inside a page shares that page with whatever precedes it: a block of some heap (the library
             # recognises glibc's heaps by itself -- the program break, the thread arenas -- but no other allocator's pools).  Arrays
             # with a mapping of their own begin within a malloc header of a page boundary.  Left pageable.
-            self._left[ptr] = (weakref.ref(a), a.nbytes)
+            self._leave(ptr, a)
             return
         if self._lib.stochqn_hip_pin_host(C.c_void_p(ptr), C.c_size_t(a.nbytes)) == 0:
             self._pins[ptr] = (weakref.ref(a), weakref.finalize(a, _unpin, self._lib, ptr))
         else:
+            self._leave(ptr, a)
+
+    def _leave(self, ptr, a):
+        if len(self._left) >= 32:                       # a caller that brings a new x every call: the dead ones go
             self._left = {p: v for p, v in self._left.items() if v[0]() is not None}
-            self._left[ptr] = (weakref.ref(a), a.nbytes)
+        self._left[ptr] = (weakref.ref(a), a.nbytes)
 
     def unpin_all(self):
         for _, fin in self._pins.values():
