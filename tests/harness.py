@@ -136,6 +136,7 @@ class NoisyQuadratic:
         self.noise = noise
         self.nan_calls = set(nan_calls)
         self.f_spike_calls = set(f_spike_calls)
+        self._factors = {}                              # call -> 1 + noise (2u - 1), kept for large n: tests drive the same calls two or three times
 
     def x0(self):
         return self._x0.copy()
@@ -145,8 +146,13 @@ class NoisyQuadratic:
         return v * 10.0 if call in self.f_spike_calls else v
 
     def grad(self, x, call):
-        u = np.random.default_rng([self.seed, call]).random(self.n)
-        g = self.d * x * (1.0 + self.noise * (2.0 * u - 1.0))
+        f = self._factors.get(call)
+        if f is None:
+            u = np.random.default_rng([self.seed, call]).random(self.n)
+            f = 1.0 + self.noise * (2.0 * u - 1.0)
+            if self.n >= 1_000_000 and 8 * self.n * (len(self._factors) + 1) <= (2 << 30):
+                self._factors[call] = f
+        g = self.d * x * f                              # (d x) f: the same operations in the same order with or without the cache
         if call in self.nan_calls:
             g = g.copy()
             g[self.n // 2] = np.nan
