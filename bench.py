@@ -50,6 +50,117 @@ sys.path.insert(0, ROOT)
 
 SEED = 20240611
 PEAK = 8000.0  # GB/s, MI355X HBM3E (MI355X_MICROARCH.md)
+
+# ------------------------------------------------------------------------------------------------
+# ONE wall-clock budget for the whole command: the clock starts when this process is entered, every
+# auxiliary leg is admitted only if its measured cost still fits, every child process gets no more than what is left, and
+# the one JSON line is printed no later than the budget -- with what there is, and `legs_skipped` naming the rest.
+# ------------------------------------------------------------------------------------------------
+ENTRY_EPOCH = time.time()
+DEFAULT_BUDGET_S = 420.0
+RESERVE_S = 6.0                # printing the line, tearing the communicators down, leaving
+# Seconds each auxiliary leg took on one MI355X box (profiles/r06_bench_leg_seconds.json: the `budget.leg_seconds` of
+# default runs at N = 1 and of the 3-rank rehearsal), rounded up by a third.  A leg is admitted when this much is left.
+LEG_COST_S = {"profile": 4.0, "value_runs": 4.0, "sustained": 10.0, "reference_form": 4.0, "two_loop_micro": 4.0,
+              "host_copies": 12.0, "host_caller": 30.0, "cpu_baseline": 40.0, "live_pmc": 60.0,
+              "c5": 20.0, "strong": 12.0, "allreduce_us": 3.0, "in_process": 90.0, "c5_yardstick": 45.0}
+
+
+class Budget:
+    """What is left of the command's wall-clock budget.  The deadline is an epoch time that travels to every child process
+    through BENCH_DEADLINE_EPOCH, so that the ranks a launcher-less `--gpus N` starts, the in-process child, the yardstick
+    child and the PMC children all count down to the same moment.  `clock` is injectable (tests)."""
+
+    def __init__(self, total_s=None, entry=None, clock=time.time, costs=None, env=os.environ):
+        self.clock = clock
+        entry = ENTRY_EPOCH if entry is None else entry
+        if total_s is None:
+            total_s = float(env.get("BENCH_BUDGET_S", DEFAULT_BUDGET_S))
+        self.total_s = total_s
+        inherited = env.get("BENCH_DEADLINE_EPOCH")
+        self.deadline = float(inherited) if inherited else entry + total_s
+        self.inherited = bool(inherited)
+        self.costs = dict(LEG_COST_S if costs is None else costs)
+        self.skipped, self.spent = [], {}
+
+    def export(self, env):
+        env["BENCH_DEADLINE_EPOCH"] = repr(self.deadline)
+        return env
+
+    def left(self):
+        """Seconds that may still be spent on measuring (the reserve for printing and leaving taken off)."""
+        return self.deadline - self.clock() - RESERVE_S
+
+    def fits(self, leg, cost=None):
+        return self.left() >= (self.costs.get(leg, 0.0) if cost is None else cost)
+
+    def skip(self, leg, why=None):
+        self.skipped.append({"leg": leg, "needs_s": self.costs.get(leg), "left_s": round(self.left(), 1),
+                             "why": why or "does not fit into what is left of the budget"})
+
+    def admit(self, leg, cost=None):
+        """One rank's decision (run() makes it collective): True, or False with the leg named in `skipped`."""
+        if self.fits(leg, cost):
+            return True
+        self.skip(leg)
+        return False
+
+    def child_timeout(self, cap):
+        """A child process gets `cap` seconds or what is left, whichever is less (never less than a second: it then fails at once)."""
+        return max(1.0, min(float(cap), self.left()))
+
+    def note(self, leg, seconds):
+        self.spent[leg] = round(self.spent.get(leg, 0.0) + seconds, 2)
+
+    def report(self):
+        return {"budget_s": round(self.deadline - ENTRY_EPOCH, 1) if self.inherited else self.total_s,
+                "deadline_inherited": self.inherited,
+                "used_s": round(self.clock() - ENTRY_EPOCH, 1), "left_s": round(self.left() + RESERVE_S, 1),
+                "leg_seconds": dict(self.spent), "leg_cost_s": self.costs}
+
+
+LIVE_CHILDREN = []             # Popen objects of child processes in flight (the watchdog takes them along when it leaves)
+
+
+def run_child(cmd, env, timeout, cwd=None, quiet=False):
+    """subprocess.run with a process group of its own: at the timeout (or when the watchdog leaves) the whole group goes.
+    Returns (returncode, stdout, stderr); returncode None = timed out."""
+    import signal
+    out = subprocess.DEVNULL if quiet else subprocess.PIPE
+    p = subprocess.Popen(cmd, stdout=out, stderr=out, text=True, env=env, cwd=cwd, start_new_session=True)
+    LIVE_CHILDREN.append(p)
+    try:
+        so, se = p.communicate(timeout=timeout)
+        return p.returncode, so or "", se or ""
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        so, se = p.communicate()
+        return None, so or "", se or ""
+    finally:
+        LIVE_CHILDREN.remove(p)
+
+
+def kill_children():
+    import signal
+    for p in list(LIVE_CHILDREN):
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+
+
+RANK_ENV = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "MASTER_ADDR",
+            "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS")
+
+
+def child_env(budget):
+    """Environment of a 1-process child of rank 0: nothing of the launcher's, the same deadline."""
+    env = {k: v for k, v in os.environ.items() if k not in RANK_ENV}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return budget.export(env)
 CONFIGS = {"c3": 100_000_000, "c5": 125_000_000}
 # counter-based generator streams (stochqn_hip.h): which vector a draw belongs to
 ST_D, ST_S, ST_X0, ST_NOISE = 0, 1, 3, 4
@@ -132,6 +243,7 @@ def self_launch(args):
     cmd += [a if a != "--n" else "--vars-per-gpu" for a in sys.argv[1:]]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    Budget().export(env)                               # the ranks count down to THIS process's deadline
     child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
     for out in child.stdout:
@@ -534,155 +646,23 @@ def run(args):
     if args.dump_x:
         np.save("%s.%d.npy" % (args.dump_x, rank), x.cpu().numpy())
 
-    # ---- the K-step region again, on a gradient array that was freed and allocated anew (another placement): the spread ----
-    value_runs = None
-    if args.value_runs > 1:
-        vals = [args.steps / elapsed * n_total / 1e8]
-        for _ in range(args.value_runs - 1):
-            wl.grad = None
-            torch.cuda.empty_cache()
-            wl.pad = torch.empty(int(7 + 64 * len(vals)) << 18, dtype=f64, device=dev)     # shifts where the new array lands
-            wl.grad = torch.empty(n, dtype=f64, device=dev)
-            wl.keep_stable(L + args.steps)
-            wl.steps(L)
-            barrier(ctx)
-            tv = time.perf_counter()
-            wl.steps(args.steps)
-            barrier(ctx)
-            vals.append(args.steps / max_over_ranks(ctx, time.perf_counter() - tv) * n_total / 1e8)
-        wl.pad = None
-        sv = sorted(vals)
-        value_runs = {"values": [round(v, 3) for v in vals], "min": round(sv[0], 3), "median": round(sv[len(sv) // 2], 3), "max": round(sv[-1], 3),
-                      "note": "`value` is values[0]; before each later repetition the caller's gradient array was re-allocated"}
-
-    # ---- the same workload over seconds (K is the driver's choice and may last a quarter of a second): every rank
-    # derives the same number of steps from the max-over-ranks time of the K steps above ---------------------------------
-    sustained = None
-    if args.sustain_seconds > 0:
-        extra = max(L, int(args.sustain_seconds / (elapsed / args.steps)) // L * L)
-        extra = min(extra, wl.STABLE_STEPS - wl.warm) // L * L
-        wl.keep_stable(extra)
-        barrier(ctx)
-        ts = time.perf_counter()
-        wl.steps(extra)
-        barrier(ctx)
-        dt = max_over_ranks(ctx, time.perf_counter() - ts)
-        sustained = {"steps": extra, "seconds": round(dt, 3), "ms_per_step": round(1e3 * dt / extra, 3),
-                     "value": round(extra / dt * n_total / 1e8, 3)}
-
-    # ---- second pass, same workload, every launch bracketed by HIP events on the library's stream:
-    # per-kernel durations -> roofline of the dominant kernel --------------------------------------
-    kern, prof_elapsed, prof_steps = {}, None, 0
-    if not args.no_profile:
-        prof_steps = max(L, min(args.steps, 4 * L)) // L * L                # whole L-cycles: the pair-building calls in proportion
-        wl.keep_stable(prof_steps + 12)                                     # + the reference-form steps below
-        lib.stochqn_hip_profile_enable(1)
-        lib.stochqn_hip_profile_reset()
-        barrier(ctx)
-        t1 = time.perf_counter()
-        wl.steps(prof_steps)
-        barrier(ctx)
-        prof_elapsed = time.perf_counter() - t1
-        lib.stochqn_hip_profile_enable(0)
-        kern = kernel_table(lib)
-    detail, roof, two_loop, what = analyse_kernels(kern, n_gpu, m, bs, prof_steps, 1)
-
+    # ---- from here on the primary result is in hand: everything below is auxiliary, admitted leg by leg against the ONE
+    # wall-clock budget of the command, and the line is printed no later than that budget whatever a leg does ----------------
     steps_per_s = args.steps / elapsed
     value = steps_per_s * n_total / 1e8
-
-    # ---- outside the timed region: the same workload in the reference's own dependency structure
-    # (2m+1 dependent fused sweeps, 64*m*n algorithmic bytes) for the roofline the north star names --
-    ref_form = None
-    if "sadd" in kern and not args.no_reference_form:
-        lib.stochqn_hip_set_option(b"threepass", 0.0)
-        wl.steps(2)
-        lib.stochqn_hip_profile_enable(1)
-        lib.stochqn_hip_profile_reset()
-        barrier(ctx)
-        t1 = time.perf_counter()
-        extra = 10
-        wl.steps(extra)
-        barrier(ctx)
-        el2 = time.perf_counter() - t1
-        lib.stochqn_hip_profile_enable(0)
-        lib.stochqn_hip_set_option(b"threepass", 1.0)
-        k2 = kernel_table(lib)
-        if "bwd" in k2:
-            cnt, ms = k2["bwd"]
-            ach = 4 * n_gpu * 8 / (ms / cnt * 1e-3) / 1e9
-            tl = sum(k2[k][1] for k in ("first", "bwd", "mid", "fwd", "fwd_last") if k in k2) / extra
-            tr, src = pmc_traffic("bwd", n_gpu, m)
-            ref_form = {"note": "same workload with --opt threepass=0, %d steps after the timed region" % extra,
-                        "steps_per_s": round(extra / el2 * n_total / 1e8, 3),
-                        "two_loop_ms": round(tl, 3), "two_loop_alg_bytes": 64 * m * n_gpu,
-                        "two_loop_alg_GBps": round(64.0 * m * n_gpu / (tl * 1e-3) / 1e9, 1),
-                        "two_loop_frac_of_8TBps": round(64.0 * m * n_gpu / (tl * 1e-3) / 1e9 / PEAK, 4),
-                        "roofline": {"bound": "hbm", "kernel": "bwd (%s)" % what["bwd"], "achieved": round(ach, 1),
-                                     "peak": PEAK, "unit": "GB/s", "frac": round(ach / PEAK, 4), "traffic": tr,
-                                     "traffic_source": src, "alg_bytes_per_launch": 4 * n_gpu * 8,
-                                     "avg_launch_ms": round(ms / cnt, 4)}}
-
-    # ---- the two-loop recursion on its own (SURVEY.md 8d "two-loop micro-benchmark"): the ring as the
-    # run left it (m pairs, oldest in row mem_st_ix), H0 = NULL, h0 = 0; 3 warm-up + 20 timed calls of
-    # stochqn_hip_two_loop per form, median wall clock of the synchronous call --------------------------
-    micro = None
-    if not args.no_reference_form:
-        lib.stochqn_hip_two_loop.restype = C.c_int
-        lib.stochqn_hip_two_loop.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
-                                             C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
-        g0 = wl.uniform(torch.empty(n, dtype=f64, device=dev), 2, 0, -0.5, 1.0)          # g_i = u(i,2,t) - 0.5
-        gq = torch.empty_like(g0)
-        micro = {"note": "stochqn_hip_two_loop alone: mem_used=%d, oldest pair in row %d, H0=NULL, 3 warm-up + 20 calls, median; "
-                         "reference-form bytes = SURVEY 8d's 64*m*n (the sweeps form moves exactly those; the three-pass form moves "
-                         "(3m+5)*n*8)" % (m, wl.b.mem_st_ix)}
-        lib.stochqn_hip_set_option(b"raw_reuse_cache", 1.0)      # S and Y do not change between these calls
-        for form, three in (("three_pass", 1.0), ("sweeps", 0.0)):
-            lib.stochqn_hip_set_option(b"threepass", three)
-            ts = []
-            for rep in range(23):
-                gq.copy_(g0)
-                barrier(ctx)
-                tq = time.perf_counter()
-                rc = lib.stochqn_hip_two_loop(gq.data_ptr(), n, None, 0.0, Y.data_ptr(), S.data_ptr(), m, m, wl.b.mem_st_ix,
-                                              wl.rho_h.ctypes.data, wl.alpha_h.ctypes.data)
-                assert rc == 0
-                ts.append(time.perf_counter() - tq)
-            med = max_over_ranks(ctx, sorted(ts[3:])[10])
-            moved = {"three_pass": 3 * m + 5, "sweeps": 8 * m}[form] * n * 8        # bytes this form has to stream
-            micro[form] = {"median_ms": round(1e3 * med, 3), "bytes_moved": moved,
-                           "GBps_on_bytes_moved": round(moved / med / 1e9, 1),
-                           "frac_of_8TBps_on_bytes_moved": round(moved / med / 1e9 / PEAK, 4),
-                           "GBps_on_reference_form_bytes": round(64.0 * m * n / med / 1e9, 1)}
-        lib.stochqn_hip_set_option(b"threepass", 1.0)
-        lib.stochqn_hip_set_option(b"raw_reuse_cache", 0.0)
-        lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))      # the raw context keyed by S; the optimiser is finished
-        del g0, gq
-
-    # ---- N = 1 only: the reference's real callers own their arrays in HOST memory (R / numpy), so the same step is also
-    # timed PCIe-inclusive, and the CPU baseline runs the oracle on the host cores; both work on one host copy of the inputs --
-    host_leg, cpu = None, None
-    if rank == 0 and world == 1 and not (args.no_cpu_baseline and args.no_host_caller):
-        lib.stochqn_hip_release_all()
-        wl.fill_ring()                                         # the state the GPU leg started from
-        wl.uniform(x, ST_X0, 0, 1.0, 1.0)
-        torch.cuda.synchronize()
-        gpu = {"S": S, "Y": Y, "A": A, "d": d, "x": x, "noise": lambda t, out: wl.uniform(out, ST_NOISE, t, 0.99, 0.02)}
-        hostc = HostCopies(args, gpu, n, m, bs, need_batch=not args.no_cpu_baseline)
-        if not args.no_host_caller:
-            host_leg = host_caller_leg(args, lib, be, hostc, gpu, n, m, L, wl.step_size, two_loop)
-        if not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, gpu, hostc, n, m, L, bs, wl.step_size)
-        del hostc
-        gpu = None
-
-    # no leg after the timed region may have had a step rejected: a rejected step skips the update, and its time would be that of less work
-    assert wl.counters["bad"] == timed_counters["bad"], "a leg after the timed region had %d step(s) rejected" % (wl.counters["bad"] - timed_counters["bad"])
+    budget = Budget()
+    value_runs = sustained = ref_form = micro = host_leg = cpu = roof = two_loop = prof_elapsed = None
+    kern, detail, prof_steps, what = {}, {}, 0, {}
+    legs, legs_failed = {}, []
+    want_legs = world > 1 and not args.no_extra_legs and args.config == "c3" and args.n <= 0 and not args.strong
+    emitted, emit_lock, all_done, stage = threading.Event(), threading.Lock(), threading.Event(), {"name": "after the timed region", "since": time.time()}
     par = ("n sharded over %d GPU(s), one process per GPU; one RCCL all-reduce per dot product" % world)
     if args.rehearse:
         par = "REHEARSAL: %d ranks sharing one GPU, all-reduce over gloo -- not a measurement" % world
     elif reducer is not None and reducer != "rccl":
         par = ("n sharded over %d GPU(s), one process per GPU; RCCL COULD NOT BE BROUGHT UP: every reduction (a few dozen doubles, "
                "three per step) goes device -> host -> gloo -> device instead" % world)
+
     def build_out():
         return {
             "metric": "optimizer steps/sec + achieved HBM GB/s, two-loop at n=10^8 m=20 fp64",
@@ -731,13 +711,8 @@ def run(args):
             "cpu_baseline": cpu,
         }
 
-    # ---- N > 1 with no further flags: what BASELINE config 5 and SURVEY 8e ask for, in the same line ----
-    legs, legs_failed = {}, []
-    want_legs = world > 1 and not args.no_extra_legs and args.config == "c3" and args.n <= 0 and not args.strong
-    emitted, emit_lock, legs_done, stage = threading.Event(), threading.Lock(), threading.Event(), {"name": None}
-
-    def emit(extra_failed=(), watchdog_fired=False):
-        """THE line (once).  Normally at the very end; from the watchdog when an auxiliary leg hangs, with what there is."""
+    def emit(extra_failed=(), watchdog_fired=None):
+        """THE line (once).  Normally at the very end; from the watchdog when a leg hangs or the budget runs out, with what there is."""
         with emit_lock:
             if emitted.is_set():
                 return
@@ -749,42 +724,236 @@ def run(args):
                 why.append("the reductions of this run did not go over RCCL: %s" % reducer)
                 out["rccl_nranks"] = 0
             if watchdog_fired:
-                why.append("the watchdog cut an auxiliary leg off: the legs are incomplete")
+                why.append("the watchdog cut the run off (%s): what follows the primary result is incomplete" % watchdog_fired)
             out["degraded"] = bool(why)
             if why:
                 out["degraded_because"] = why
             if want_legs:
-                out["legs"] = legs
+                out["legs"] = dict(legs)
                 out["legs_failed"] = legs_failed + list(extra_failed)
+            out["legs_skipped"] = [s["leg"] for s in budget.skipped]
+            out["budget"] = dict(budget.report(), skipped=list(budget.skipped))
             if args.config == "c5" or n_gpu == CONFIGS["c5"]:
                 out["shard_reference_1gpu"] = shard_reference(world, steps_per_s, None)
             os.write(real_stdout, (json.dumps(out) + "\n").encode())
             emitted.set()
 
-    def watchdog(limit):
-        # the primary result is in hand; a collective of an auxiliary leg that never completes (first contact with RCCL on N > 1
-        # ranks happens on the driver's node) must not take it along: every rank leaves at the limit, rank 0 prints first -- the
-        # line says "degraded": true.  With --strict-legs there is no line and every rank leaves with code 3.
-        if legs_done.wait(limit):
-            return
-        if args.strict_legs:
-            sys.stderr.write("bench.py: rank %d: leg '%s' had not finished after %g s (--strict-legs: no result line)\n" % (rank, stage["name"], limit))
-            os._exit(3)
-        if rank == 0:
-            emit(["watchdog: leg '%s' had not finished after %g s; nothing after it was run" % (stage["name"], limit)], watchdog_fired=True)
-        else:
-            time.sleep(3.0)
-        os._exit(0)
+    def watchdog(leg_limit):
+        # The primary result is in hand.  Two things must not take it along: a collective of an auxiliary leg that never completes
+        # (first contact with RCCL on N > 1 ranks happens on the driver's node) -- no stage of the multi-rank part may last longer
+        # than `leg_limit` -- and the command's budget running out under a leg that cannot be interrupted.  Every rank leaves at
+        # that moment, rank 0 prints first: the line says "degraded": true.  With --strict-legs a hung leg means no line, code 3.
+        while not all_done.wait(0.25):
+            now = time.time()
+            hung = want_legs and stage.get("collective") and now - stage["since"] > leg_limit
+            spent = now >= budget.deadline - 2.0
+            if not (hung or spent):
+                continue
+            why = ("leg '%s' had not finished after %g s" % (stage["name"], leg_limit)) if hung else \
+                  ("the budget of %g s ran out during '%s'" % (budget.deadline - ENTRY_EPOCH, stage["name"]))
+            if hung and args.strict_legs:
+                sys.stderr.write("bench.py: rank %d: %s (--strict-legs: no result line)\n" % (rank, why))
+                kill_children()
+                os._exit(3)
+            if rank == 0:
+                if not hung:
+                    budget.skip(stage["name"], "was running when the budget ran out")
+                emit(["watchdog: %s; nothing after it was run" % why] if hung else [], watchdog_fired=why)
+            else:
+                time.sleep(3.0)
+            kill_children()
+            os._exit(0)
+
+    threading.Thread(target=watchdog, args=(float(os.environ.get("BENCH_WATCHDOG_S", "300")),), daemon=True).start()
+
+    def admitted(leg, cost=None, collective=True):
+        """Is there room for `leg`?  Every rank must take the same turn: the leg runs only when it fits on ALL ranks."""
+        ok = budget.fits(leg, cost)
+        if collective:
+            ok = all_ok(ctx, ok)
+        if not ok:
+            budget.skip(leg)
+        stage.update(name=leg, since=time.time())
+        return ok
+
+    class on_the_clock:
+        def __init__(self, leg):
+            self.leg = leg
+
+        def __enter__(self):
+            self.t = time.time()
+
+        def __exit__(self, *exc):
+            budget.note(self.leg, time.time() - self.t)
+            stage.update(name="after " + self.leg, since=time.time())
+            return False
+
+    # ---- second pass, same workload, every launch bracketed by HIP events on the library's stream:
+    # per-kernel durations -> roofline of the dominant kernel (first of the auxiliary legs: the line's contract needs it) ----
+    if not args.no_profile and admitted("profile"):
+        with on_the_clock("profile"):
+            prof_steps = max(L, min(args.steps, 4 * L)) // L * L                # whole L-cycles: the pair-building calls in proportion
+            wl.keep_stable(prof_steps + 12)                                     # + the reference-form steps below
+            lib.stochqn_hip_profile_enable(1)
+            lib.stochqn_hip_profile_reset()
+            barrier(ctx)
+            t1 = time.perf_counter()
+            wl.steps(prof_steps)
+            barrier(ctx)
+            prof_elapsed = time.perf_counter() - t1
+            lib.stochqn_hip_profile_enable(0)
+            kern = kernel_table(lib)
+    detail, roof, two_loop, what = analyse_kernels(kern, n_gpu, m, bs, prof_steps, 1, config=args.config)
+
+    # ---- the K-step region again, on a gradient array that was freed and allocated anew (another placement): the spread ----
+    if args.value_runs > 1 and admitted("value_runs"):
+        with on_the_clock("value_runs"):
+            vals = [args.steps / elapsed * n_total / 1e8]
+            for _ in range(args.value_runs - 1):
+                wl.grad = None
+                torch.cuda.empty_cache()
+                wl.pad = torch.empty(int(7 + 64 * len(vals)) << 18, dtype=f64, device=dev)     # shifts where the new array lands
+                wl.grad = torch.empty(n, dtype=f64, device=dev)
+                wl.keep_stable(L + args.steps)
+                wl.steps(L)
+                barrier(ctx)
+                tv = time.perf_counter()
+                wl.steps(args.steps)
+                barrier(ctx)
+                vals.append(args.steps / max_over_ranks(ctx, time.perf_counter() - tv) * n_total / 1e8)
+            wl.pad = None
+            sv = sorted(vals)
+            value_runs = {"values": [round(v, 3) for v in vals], "min": round(sv[0], 3), "median": round(sv[len(sv) // 2], 3), "max": round(sv[-1], 3),
+                          "note": "`value` is values[0]; before each later repetition the caller's gradient array was re-allocated"}
+
+    # ---- the same workload over seconds (K is the driver's choice and may last a quarter of a second): every rank
+    # derives the same number of steps from the max-over-ranks time of the K steps above ---------------------------------
+    if args.sustain_seconds > 0 and admitted("sustained", args.sustain_seconds + 4.0):
+        with on_the_clock("sustained"):
+            extra = max(L, int(args.sustain_seconds / (elapsed / args.steps)) // L * L)
+            extra = min(extra, wl.STABLE_STEPS - wl.warm) // L * L
+            wl.keep_stable(extra)
+            barrier(ctx)
+            ts = time.perf_counter()
+            wl.steps(extra)
+            barrier(ctx)
+            dt = max_over_ranks(ctx, time.perf_counter() - ts)
+            sustained = {"steps": extra, "seconds": round(dt, 3), "ms_per_step": round(1e3 * dt / extra, 3),
+                         "value": round(extra / dt * n_total / 1e8, 3)}
+
+    # ---- outside the timed region: the same workload in the reference's own dependency structure
+    # (2m+1 dependent fused sweeps, 64*m*n algorithmic bytes) for the roofline the north star names --
+    if "sadd" in kern and not args.no_reference_form and admitted("reference_form"):
+        with on_the_clock("reference_form"):
+            wl.keep_stable(12)
+            lib.stochqn_hip_set_option(b"threepass", 0.0)
+            wl.steps(2)
+            lib.stochqn_hip_profile_enable(1)
+            lib.stochqn_hip_profile_reset()
+            barrier(ctx)
+            t1 = time.perf_counter()
+            extra = 10
+            wl.steps(extra)
+            barrier(ctx)
+            el2 = time.perf_counter() - t1
+            lib.stochqn_hip_profile_enable(0)
+            lib.stochqn_hip_set_option(b"threepass", 1.0)
+            k2 = kernel_table(lib)
+            if "bwd" in k2:
+                cnt, ms = k2["bwd"]
+                ach = 4 * n_gpu * 8 / (ms / cnt * 1e-3) / 1e9
+                tl = sum(k2[k][1] for k in ("first", "bwd", "mid", "fwd", "fwd_last") if k in k2) / extra
+                tr, src = pmc_traffic("bwd", n_gpu, m, 4 * n_gpu * 8, config=args.config)
+                ref_form = {"note": "same workload with --opt threepass=0, %d steps after the timed region" % extra,
+                            "steps_per_s": round(extra / el2 * n_total / 1e8, 3),
+                            "two_loop_ms": round(tl, 3), "two_loop_alg_bytes": 64 * m * n_gpu,
+                            "two_loop_alg_GBps": round(64.0 * m * n_gpu / (tl * 1e-3) / 1e9, 1),
+                            "two_loop_frac_of_8TBps": round(64.0 * m * n_gpu / (tl * 1e-3) / 1e9 / PEAK, 4),
+                            "roofline": {"bound": "hbm", "kernel": "bwd (%s)" % what["bwd"], "achieved": round(ach, 1),
+                                         "peak": PEAK, "unit": "GB/s", "frac": round(ach / PEAK, 4), "traffic": tr,
+                                         "traffic_source": src, "alg_bytes_per_launch": 4 * n_gpu * 8,
+                                         "avg_launch_ms": round(ms / cnt, 4)}}
+
+    # ---- the two-loop recursion on its own (SURVEY.md 8d "two-loop micro-benchmark"): the ring as the
+    # run left it (m pairs, oldest in row mem_st_ix), H0 = NULL, h0 = 0; 3 warm-up + 20 timed calls of
+    # stochqn_hip_two_loop per form, median wall clock of the synchronous call --------------------------
+    if not args.no_reference_form and admitted("two_loop_micro"):
+        with on_the_clock("two_loop_micro"):
+            lib.stochqn_hip_two_loop.restype = C.c_int
+            lib.stochqn_hip_two_loop.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                                                 C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+            g0 = wl.uniform(torch.empty(n, dtype=f64, device=dev), 2, 0, -0.5, 1.0)          # g_i = u(i,2,t) - 0.5
+            gq = torch.empty_like(g0)
+            micro = {"note": "stochqn_hip_two_loop alone: mem_used=%d, oldest pair in row %d, H0=NULL, 3 warm-up + 20 calls, median; "
+                             "reference-form bytes = SURVEY 8d's 64*m*n (the sweeps form moves exactly those; the three-pass form moves "
+                             "(3m+5)*n*8)" % (m, wl.b.mem_st_ix)}
+            lib.stochqn_hip_set_option(b"raw_reuse_cache", 1.0)      # S and Y do not change between these calls
+            for form, three in (("three_pass", 1.0), ("sweeps", 0.0)):
+                lib.stochqn_hip_set_option(b"threepass", three)
+                ts = []
+                for rep in range(23):
+                    gq.copy_(g0)
+                    barrier(ctx)
+                    tq = time.perf_counter()
+                    rc = lib.stochqn_hip_two_loop(gq.data_ptr(), n, None, 0.0, Y.data_ptr(), S.data_ptr(), m, m, wl.b.mem_st_ix,
+                                                  wl.rho_h.ctypes.data, wl.alpha_h.ctypes.data)
+                    assert rc == 0
+                    ts.append(time.perf_counter() - tq)
+                med = max_over_ranks(ctx, sorted(ts[3:])[10])
+                moved = {"three_pass": 3 * m + 5, "sweeps": 8 * m}[form] * n * 8        # bytes this form has to stream
+                micro[form] = {"median_ms": round(1e3 * med, 3), "bytes_moved": moved,
+                               "GBps_on_bytes_moved": round(moved / med / 1e9, 1),
+                               "frac_of_8TBps_on_bytes_moved": round(moved / med / 1e9 / PEAK, 4),
+                               "GBps_on_reference_form_bytes": round(64.0 * m * n / med / 1e9, 1)}
+            lib.stochqn_hip_set_option(b"threepass", 1.0)
+            lib.stochqn_hip_set_option(b"raw_reuse_cache", 0.0)
+            lib.stochqn_hip_release(C.c_void_p(S.data_ptr()))      # the raw context keyed by S; the optimiser is finished
+            del g0, gq
+
+    # ---- N = 1 only: the reference's real callers own their arrays in HOST memory (R / numpy), so the same step is also
+    # timed PCIe-inclusive, and the CPU baseline runs the oracle on the host cores; both work on one host copy of the inputs.
+    # The CPU baseline goes first: the line's contract asks for it, the host-caller variants are extra --
+    if rank == 0 and world == 1 and not (args.no_cpu_baseline and args.no_host_caller):
+        want_cpu = not args.no_cpu_baseline and budget.fits("cpu_baseline", budget.costs["cpu_baseline"] + budget.costs["host_copies"])
+        want_host = not args.no_host_caller and budget.fits("host_caller", budget.costs["host_caller"] + budget.costs["host_copies"]
+                                                            + (budget.costs["cpu_baseline"] if want_cpu else 0.0))
+        for leg, asked, got in (("cpu_baseline", not args.no_cpu_baseline, want_cpu), ("host_caller", not args.no_host_caller, want_host)):
+            if asked and not got:
+                budget.skip(leg)
+        if want_cpu or want_host:
+            stage.update(name="host_copies", since=time.time())
+            with on_the_clock("host_copies"):
+                lib.stochqn_hip_release_all()
+                wl.fill_ring()                                         # the state the GPU leg started from
+                wl.uniform(x, ST_X0, 0, 1.0, 1.0)
+                torch.cuda.synchronize()
+                gpu = {"S": S, "Y": Y, "A": A, "d": d, "x": x, "noise": lambda t, out: wl.uniform(out, ST_NOISE, t, 0.99, 0.02)}
+                hostc = HostCopies(args, gpu, n, m, bs, need_batch=want_cpu)
+            if want_cpu:
+                stage.update(name="cpu_baseline", since=time.time())
+                with on_the_clock("cpu_baseline"):
+                    cpu = cpu_baseline(args, gpu, hostc, n, m, L, bs, wl.step_size)
+            if want_host and admitted("host_caller", collective=False):
+                with on_the_clock("host_caller"):
+                    host_leg = host_caller_leg(args, lib, be, hostc, gpu, n, m, L, wl.step_size, two_loop, budget)
+            del hostc
+            gpu = None
+
+    # no leg after the timed region may have had a step rejected: a rejected step skips the update, and its time would be that of less work
+    assert wl.counters["bad"] == timed_counters["bad"], "a leg after the timed region had %d step(s) rejected" % (wl.counters["bad"] - timed_counters["bad"])
+
+    # ---- N > 1 with no further flags: what BASELINE config 5 and SURVEY 8e ask for, in the same line (VERDICT r02 #1) ----
     wl.free()
     del x, S, Y, A, d
     if want_legs:
         leg_steps = max(20, args.steps)
 
-        threading.Thread(target=watchdog, args=(float(os.environ.get("BENCH_WATCHDOG_S", "300")),), daemon=True).start()
-
         def attempt(name, fn):
+            if not admitted(name):
+                return
+            stage["collective"] = True
             res, ok = None, True
-            stage["name"] = name
+            t_leg = time.time()
             try:
                 if os.environ.get("BENCH_TEST_HANG_LEG") == name:      # tests: a leg that never comes back
                     time.sleep(1e6)
@@ -796,68 +965,83 @@ def run(args):
             else:
                 legs[name] = res if not ok else {"error": "failed on another rank"}
                 legs_failed.append(name)
+            budget.note(name, time.time() - t_leg)
+            stage.update(name="after " + name, since=time.time())
 
         attempt("c5", lambda: timed_leg(ctx, config_n("c5"), m, L, bs, leg_steps, args.warmup,
                                         "BASELINE config 5's weak-scaling point: n = 1.25e8 per GPU (n_total = 1e9 on 8 GPUs)"))
         attempt("strong", lambda: timed_leg(ctx, config_n("c3") // world, m, L, bs, leg_steps, args.warmup,
                                             "SURVEY 8e strong scaling: the n = 1e8 problem split over the GPUs"))
         attempt("allreduce_us", lambda: allreduce_latency(ctx))
-        if "allreduce_us" not in legs_failed and forms:
+        if "allreduce_us" in legs and "allreduce_us" not in legs_failed and forms:
             legs["allreduce_us"]["allreduces_per_step"] = round(forms["allreduces"] / args.steps, 2)
 
     if dist is not None:
-        stage["name"] = "teardown of the communicators"
+        stage.update(name="teardown of the communicators", since=time.time(), collective=True)
         barrier(ctx)
         lib.stochqn_hip_comm_finalize()
         dist.destroy_process_group()
-    legs_done.set()
+    stage.update(name="after the ranks' part", since=time.time(), collective=False)
     lib.stochqn_hip_release_all()
     if rank != 0:
-        return                                                 # rank 0 alone starts the in-process child and prints
+        all_done.set()
+        return                                                 # rank 0 alone starts the children and prints
 
     if want_legs:
         # SURVEY 8e's own process model: ONE host process driving all N devices (ncclCommInitAll, one thread per device).
         # A fresh child, started when the other ranks are on their way out; this process keeps only an idle HIP context.
-        try:
-            torch.cuda.empty_cache()
-            time.sleep(3.0)
-            legs["in_process"] = in_process_leg(args, world, n_gpu, max(20, args.steps))
-        except Exception as e:
-            legs["in_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            legs_failed.append("in_process")
+        if admitted("in_process", collective=False):
+            with on_the_clock("in_process"):
+                try:
+                    torch.cuda.empty_cache()
+                    time.sleep(3.0)
+                    legs["in_process"] = in_process_leg(args, world, n_gpu, max(20, args.steps), budget)
+                except Exception as e:
+                    legs["in_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    legs_failed.append("in_process")
         # C5's yardstick -- ONE GPU at the same per-GPU shard -- measured on THIS node, now that the ranks are gone: the
         # "within 15 % of linear" verdict compares two numbers of the same box and the same minute (boxes differ by 5-8 %)
         if "c5" in legs and "c5" not in legs_failed:
             here = None
-            try:
-                here = c5_yardstick_here(args, config_n("c5"), max(20, args.steps))
-            except Exception as e:
-                here = {"error": "%s: %s" % (type(e).__name__, e)}
+            if admitted("c5_yardstick", collective=False):
+                with on_the_clock("c5_yardstick"):
+                    try:
+                        here = c5_yardstick_here(args, config_n("c5"), max(20, args.steps), budget)
+                    except Exception as e:
+                        here = {"error": "%s: %s" % (type(e).__name__, e)}
+            else:
+                here = {"error": "skipped: did not fit into what was left of the budget"}
             ref = shard_reference(world, legs["c5"]["steps_per_s"], here)
             legs["c5"]["shard_reference_1gpu"] = ref
             if ref and "steps_per_s" in ref:
                 legs["c5"]["this_run_over_reference"] = ref.get("this_run_over_reference")
                 legs["c5"]["within_15pct_of_linear"] = bool(legs["c5"]["steps_per_s"] >= ref["within_15pct_means_at_least"])
 
-    # ---- N = 1: the dominant kernel's HBM traffic counted now (PMC), not looked up ------------------------------
-    if world == 1 and roof and not args.no_live_pmc and not args.rehearse:
+    # ---- the dominant kernel's HBM traffic counted NOW (PMC), not looked up: at N = 1 in this process's own time, at N > 1 on
+    # rank 0's device once the ranks have gone (a per-GPU shard of the weak-scaling run IS the one-GPU problem) --------------
+    if roof and not args.no_live_pmc and not args.rehearse:
         dom = roof["kernel"].split()[0]
-        live = live_pmc(args, dom)
+        live = None
+        if admitted("live_pmc", collective=False):
+            with on_the_clock("live_pmc"):
+                live = live_pmc(args, dom, n_gpu, budget)
         if live:
             roof["traffic"] = live["bytes"]
             roof["traffic_source"] = live["source"]
             roof["traffic_read_bytes"], roof["traffic_write_bytes"], roof["traffic_dispatches"] = live["read_bytes"], live["write_bytes"], live["dispatches"]
             roof["traffic_over_algorithmic"] = round(live["bytes"] / roof["alg_bytes_per_launch"], 4)
         else:
-            roof["traffic_note"] = "live PMC passes unavailable here: committed profile quoted"
+            roof["traffic_note"] = "live PMC passes unavailable here (or no room left for them): " + \
+                                   ("committed profile quoted" if roof.get("traffic") else "no committed profile of this kernel instantiation passes the cross-check either")
 
     if want_legs and legs_failed and args.strict_legs:
         sys.stderr.write("bench.py: leg(s) %s failed: %s\n" % (", ".join(legs_failed), json.dumps({k: legs[k] for k in legs_failed})))
         raise SystemExit(3)
     emit()
+    all_done.set()
 
 
-def c5_yardstick_here(args, n_gpu, steps):
+def c5_yardstick_here(args, n_gpu, steps, budget):
     """`bench.py --gpus 1` at config 5's per-GPU shard as a fresh child on this node's GPU 0 (timed region only: no profiler
     pass, no PMC, no host legs): the 1-GPU point of the weak-scaling curve, from the same box as the N-GPU point."""
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--vars-per-gpu", str(n_gpu), "--steps", str(steps), "--warmup", str(args.warmup),
@@ -865,18 +1049,15 @@ def c5_yardstick_here(args, n_gpu, steps):
            "--no-live-pmc", "--no-reference-form", "--no-profile", "--sustain-seconds", "0", "--value-runs", "1"]
     for kv in args.opt:
         cmd += ["--opt", kv]
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
-                                                             "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
-    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
-    if r.returncode != 0 or not lines:
-        raise RuntimeError("exit code %d: %s" % (r.returncode, r.stderr[-600:].replace("\n", " | ")))
+    rc, so, se = run_child(cmd, child_env(budget), budget.child_timeout(300))
+    lines = [l for l in so.splitlines() if l.startswith('{"metric"')]
+    if rc != 0 or not lines:
+        raise RuntimeError("%s: %s" % ("timed out" if rc is None else "exit code %d" % rc, se[-600:].replace("\n", " | ")))
     d = json.loads(lines[0])
     return {"steps_per_s": d["steps_per_s_unnormalised"], "ms_per_step": d["ms_per_step"], "n_per_gpu": n_gpu, "steps": d["steps"]}
 
 
-def in_process_leg(args, world, n_gpu, steps):
+def in_process_leg(args, world, n_gpu, steps, budget):
     """`bench.py --gpus N --in-process` as a fresh child process: the same per-GPU problem driven by ONE host process through
     the library's single-process multi-device mode (group.cpp; SURVEY 8e's process model)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--in-process", "--vars-per-gpu", str(n_gpu),
@@ -888,13 +1069,14 @@ def in_process_leg(args, world, n_gpu, steps):
         cmd.append("--no-host-caller")
     for kv in args.opt:
         cmd += ["--opt", kv]
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
-                                                             "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=420)      # a child that hangs must not cost the line its primary result
-    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
-    if r.returncode != 0 or not lines:
-        raise RuntimeError("exit code %d: %s" % (r.returncode, r.stderr[-600:].replace("\n", " | ")))
+    # a child that hangs must not cost the line its primary result: it gets what is left of the budget, at most 420 s.  The
+    # child's host-caller part comes last and is the first thing to go when time is short
+    if not budget.fits("in_process", budget.costs["in_process"] + 30.0) and "--no-host-caller" not in cmd:
+        cmd.append("--no-host-caller")
+    rc, so, se = run_child(cmd, child_env(budget), budget.child_timeout(420))
+    lines = [l for l in so.splitlines() if l.startswith('{"metric"')]
+    if rc != 0 or not lines:
+        raise RuntimeError("%s: %s" % ("timed out" if rc is None else "exit code %d" % rc, se[-600:].replace("\n", " | ")))
     d = json.loads(lines[0])
     return {"what": "one host process, %d device shards behind the plain ABI (option devices): %s" % (world, d["config"]["parallelism"]),
             "n_per_gpu": n_gpu, "n_total": n_gpu * world, "steps": d["steps"], "ms_per_step": d["ms_per_step"],
@@ -1238,7 +1420,7 @@ def kernel_table(lib):
     return kern
 
 
-def analyse_kernels(kern, n_gpu, m, bs, prof_steps, shards):
+def analyse_kernels(kern, n_gpu, m, bs, prof_steps, shards, config="c3"):
     """Kernel table -> (per-kernel detail, roofline of the dominant kernel, two-loop summary, kernel descriptions).
     `shards` = device shards whose launches the table aggregates (1 per process except --in-process)."""
     # algorithmic n-words per launch (DESIGN.md section 3)
@@ -1264,7 +1446,7 @@ def analyse_kernels(kern, n_gpu, m, bs, prof_steps, shards):
         cnt, ms = kern[dom]
         alg = words[dom] * n_gpu * 8
         ach = alg / (ms / cnt * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(dom, n_gpu, m)
+        traffic, traffic_src = pmc_traffic(dom, n_gpu, m, alg, config=config)
         roof = {"bound": "hbm", "kernel": "%s (%s)" % (dom, what[dom]),
                 "achieved": round(ach, 1), "peak": PEAK, "unit": "GB/s", "frac": round(ach / PEAK, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
@@ -1310,44 +1492,52 @@ def shard_reference(n_gpus, steps_per_s, here):
     return None
 
 
-PMC_KEYS = {"bwd": "BwdOp", "fwd": "FwdOp<true, false, false>",
-            "sdot": "k_rows_dot_all<2, 3, true, 1", "qdot": "k_qdot<2, 3", "sadd": "k_sadd<2"}
+# Which optimiser a configuration of this file runs -- and with it which instantiation of the three-pass kernels: pass 2 is
+# k_qdot<W, NG, NT, MODE, PH> with MODE 0 (scalar H0: oLBFGS, SQN) or 2 (adaQN: four more streams, 20.0 GB instead of 17.6 GB at
+# n = 1e8, m = 20).  A committed PMC file serves a line only if it holds THAT instantiation (the adaQN
+# file's pass 2 was quoted for SQN lines -- a "wasted traffic" of 1.136 that does not exist).
+CONFIG_PROFILE = {"c3": ("c3", 0), "c5": ("c3", 0), "c2": ("c2", 0), "c4": ("c4", 2)}      # profiles/rNN_<tag>_pmc_traffic.json, k_qdot MODE
+PROFILE_N = {"c2": 10_000_000}  # problem size a configuration's committed counters were taken at (every other one: 1e8)
+PMC_RATIO_OK = (0.97, 1.06)    # bytes counted / algorithmic bytes outside this band: the file is not about this launch -- refuse it
 
 
-def live_pmc(args, kernel):
+def pmc_key(kernel, m, mode=0):
+    """The exact kernel instantiation (as rocprofv3 prints it, namespace stripped) a bench leg's `kernel` launches at ring size m:
+    W = 2 doubles per pack, NG = ceil(m / 8) row groups, non-temporal row loads, clock-phased stores."""
+    ng = (m + 7) // 8
+    return {"bwd": "BwdOp", "fwd": "FwdOp<true, false, false>",
+            "sdot": "k_rows_dot_all<2, %d, true, 1, false>" % ng,
+            "qdot": "k_qdot<2, %d, true, %d, true>" % (ng, mode),
+            "sadd": "k_sadd<2, %d, true, true, false>" % ng}.get(kernel)
+
+
+def live_pmc(args, kernel, n_gpu, budget):
     """HBM bytes per launch of `kernel` counted NOW: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE, separate runs
-    with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short child run of this very workload; FETCH_SIZE is
-    doubled (gfx950 counts wide streaming reads at half their size).  None when rocprofv3 is missing or a pass fails."""
+    with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short ONE-GPU child run of this very workload at this
+    per-GPU size (at N > 1: on rank 0's device, after the ranks have gone); FETCH_SIZE is doubled (gfx950 counts wide streaming
+    reads at half their size).  None when rocprofv3 is missing, a pass fails or the budget has no room for both passes."""
     import csv
     import glob
     import shutil
-    import signal
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe) or kernel not in PMC_KEYS:
+    key = pmc_key(kernel, args.mem, CONFIG_PROFILE.get(args.config, ("", 0))[1])
+    if not os.path.exists(exe) or key is None:
         return None
-    key = PMC_KEYS[kernel]
     tmp = tempfile.mkdtemp(prefix="sqn_pmc_", dir="/tmp")
-    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--config", args.config, "--mem", str(args.mem),
+    child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "2", "--vars-per-gpu", str(n_gpu), "--mem", str(args.mem),
              "--upd-freq", str(args.upd_freq), "--bsize", str(args.bsize), "--no-profile", "--no-cpu-baseline", "--no-host-caller",
              "--no-reference-form", "--sustain-seconds", "0", "--no-live-pmc", "--value-runs", "1"]
-    if args.n > 0:
-        child += ["--vars-per-gpu", str(args.n)]
     for kv in args.opt:
         child += ["--opt", kv]
     got = {}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            if not budget.fits("live_pmc", budget.costs["live_pmc"] / 2):
+                return None
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--"] + child
-            env = dict(os.environ, TMPDIR="/tmp")
-            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
-            try:
-                rc = p.wait(timeout=300)
-            except subprocess.TimeoutExpired:
-                os.killpg(p.pid, signal.SIGKILL)
-                p.wait()
-                return None
+            rc, _, _ = run_child(cmd, dict(child_env(budget), TMPDIR="/tmp"), budget.child_timeout(300), cwd="/tmp", quiet=True)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if rc != 0 or not files:
                 return None
@@ -1362,25 +1552,51 @@ def live_pmc(args, kernel):
     return {"bytes": int(round(b)), "read_bytes": int(round(got["FETCH_SIZE"][0] * 2048)), "write_bytes": int(round(got["WRITE_SIZE"][0] * 1024)),
             "dispatches": got["FETCH_SIZE"][1],
             "source": "counted in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over a 5-step "
-                      "child run of this workload; FETCH_SIZE x 2 (gfx950 half-count of wide streaming reads)"}
+                      "one-GPU child run of this workload (instantiation %s); FETCH_SIZE x 2 (gfx950 half-count of wide streaming reads)" % key}
 
 
-def pmc_traffic(kernel, n, m):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
-    gfx950 + WRITE_SIZE, separate passes; profiles/summarise.py).  The counters were taken at
-    n = 1e8, m = 20; the kernels are pure streams, so bytes scale with n."""
+def pmc_traffic(kernel, n, m, alg_bytes, config="c3", profiles_dir=None):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
+    passes; profiles/summarise.py), or (None, why).  The fall-back of every line whose traffic is not counted live.  Selection:
+    newest round first, and within a round the file of THIS configuration (`_c3_` for the SQN lines, `_c4_` adaQN, `_c2_` oLBFGS)
+    before an untagged one; a file serves only if it holds the exact instantiation this leg launches (pmc_key: ring size and
+    k_qdot's MODE) and its bytes, scaled from the n = 1e8 they were counted at, lie within PMC_RATIO_OK of `alg_bytes` -- a file
+    that holds some other launch of the same kernel name (another optimiser, a ring still filling) is refused, not quoted."""
     import glob
-    key = PMC_KEYS[kernel]
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
-        d = json.load(open(f))
+    import re
+    tag, mode = CONFIG_PROFILE.get(config, ("c3", 0))
+    key = pmc_key(kernel, m, mode)
+    if key is None:
+        return None, None
+    pdir = profiles_dir or os.path.join(ROOT, "profiles")
+
+    def order(f):
+        base = os.path.basename(f)
+        rnd = re.match(r"(r\d+[a-z]?)_", base)
+        cfg = re.match(r"r\d+[a-z]?_(c\d)_", base)
+        return (rnd.group(1) if rnd else "", 1 if (cfg and cfg.group(1) == tag) else 0, base)
+    refused = []
+    for f in sorted(glob.glob(os.path.join(pdir, "r*_pmc_traffic*.json")), key=order, reverse=True):
+        cfg = re.match(r"r\d+[a-z]?_(c\d)_", os.path.basename(f))
+        if cfg and cfg.group(1) != tag:
+            continue                                            # another configuration's run: never (its pass 2 is another kernel)
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
         for k, v in d.items():
-            if key in k and (m == 20 or kernel in ("bwd", "fwd")):
-                raw = v["raw"]
+            if k.replace("sqn::(anonymous namespace)::", "").replace("void ", "").startswith(key) or (kernel in ("bwd", "fwd") and key in k):
+                raw = v.get("raw", {})
                 # sdot: the same kernel also rebuilds columns of the cached block (a y row as the probe); pass 1 is the largest dispatch
                 stat = "max_KiB" if kernel == "sdot" else "median_KiB"
-                b = raw.get("FETCH_SIZE", {}).get(stat, 0.0) * 1024 * 2 + raw.get("WRITE_SIZE", {}).get(stat, 0.0) * 1024
-                return int(round(b * n / 1e8)), os.path.relpath(f, ROOT) + " (measured at n=1e8, m=20)"
-    return None, None
+                at_n = PROFILE_N.get(cfg.group(1), 100_000_000) if cfg else 100_000_000
+                b = (raw.get("FETCH_SIZE", {}).get(stat, 0.0) * 1024 * 2 + raw.get("WRITE_SIZE", {}).get(stat, 0.0) * 1024) * n / at_n
+                ratio = b / alg_bytes if alg_bytes else 0.0
+                if PMC_RATIO_OK[0] <= ratio <= PMC_RATIO_OK[1]:
+                    return int(round(b)), os.path.relpath(f, ROOT) + " (%s, measured at n=%g)" % (key, at_n)
+                refused.append("%s: %s at %.3f of the algorithmic bytes" % (os.path.basename(f), k, ratio))
+    return None, ("no committed PMC file holds %s within %.2f-%.2f of the algorithmic bytes" % (key, PMC_RATIO_OK[0], PMC_RATIO_OK[1])
+                  + ("; refused: " + "; ".join(refused[:3]) if refused else ""))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1479,7 +1695,7 @@ def pcie_probe(nbytes, device="cuda"):
     return out
 
 
-def host_caller_leg(args, lib, be, hostc, gpu, n, m, L, step_size, two_loop):
+def host_caller_leg(args, lib, be, hostc, gpu, n, m, L, step_size, two_loop, budget=None):
     """The step as the reference's own callers take it (R .Call: reference src/Rwrapper.c:98-125; Cython:
     stochqn/pywrapper.pxi:161-207): EVERY array in pageable host memory, structs rebuilt per call, x / grad / *req read and
     written on the host.  S and Y are mirrored in HBM at the first call; per step the gradient goes up and x comes down
@@ -1503,7 +1719,13 @@ def host_caller_leg(args, lib, be, hostc, gpu, n, m, L, step_size, two_loop):
     # nobody promises anything, the library compares a checksum of all of x (host threads, under the gradient's upload)
     variants = (("strict_grad_0", 0, True, {}), ("strict_grad_1", 1, True, {}), ("pageable", 0, False, {}),
                 ("vouched", 0, True, {"x_upload": 0.0, "x_prefetch": 1.0}), ("checksum", 0, True, {"x_upload": 2.0}))
+    per_variant = None
     for vname, strict, pin, opts in variants:
+        # the first variant is the library's default and always runs; a further one only while the budget has room for it
+        if budget is not None and per_variant is not None and not budget.fits("host_caller:" + vname, 1.3 * per_variant):
+            budget.skip("host_caller:" + vname)
+            continue
+        t_variant = time.time()
         lib.stochqn_hip_release_all()
         lib.stochqn_hip_stats_reset()
         assert lib.stochqn_hip_set_option(b"strict_grad", float(strict)) == 0
@@ -1574,6 +1796,7 @@ def host_caller_leg(args, lib, be, hostc, gpu, n, m, L, step_size, two_loop):
             lib.stochqn_hip_unpin_host(a.ctypes.data)
         for k in opts:
             lib.stochqn_hip_set_option(k.encode(), {"x_upload": 1.0, "x_prefetch": 0.0}[k])
+        per_variant = max(per_variant or 0.0, time.time() - t_variant)
     lib.stochqn_hip_set_option(b"strict_grad", 0.0)
     lib.stochqn_hip_release_all()
     res["note"] = ("strict_grad_0 / strict_grad_1: the library's defaults (x goes up on every step like the reference's *req = x; the library "

@@ -70,6 +70,170 @@ def test_committed_profiles_carry_the_contract():
     assert d["forms"]["three_pass"] == d["steps"] and d["host_caller"]["strict_grad_0"]["ms_per_step"] < 60
 
 
+def _walk(node, path, out):
+    if isinstance(node, dict):
+        out.append((path, node))
+        for k, v in node.items():
+            _walk(v, path + "/" + str(k), out)
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            _walk(v, "%s[%d]" % (path, i), out)
+
+
+def profile_findings(path):
+    """What is wrong with one committed profiles/*.json(l) file, as a list of strings: it must parse (every line of a .jsonl),
+    no fraction of the 8 TB/s peak may exceed 1 (by the cross-check rule a frac > 1 is not evidence: the bytes were counted
+    wrong), and wherever counted traffic stands next to algorithmic bytes the ratio lies in 0.95-1.10 unless the same object
+    explains it (`traffic_explained`)."""
+    text = open(path).read()
+    docs, bad = [], []
+    if path.endswith(".jsonl"):
+        for i, line in enumerate(l for l in text.splitlines() if l.strip()):
+            try:
+                docs.append(json.loads(line))
+            except ValueError as e:
+                bad.append("line %d does not parse: %s" % (i + 1, e))
+    else:
+        try:
+            docs.append(json.loads(text))
+        except ValueError as e:
+            bad.append("does not parse: %s" % e)
+    for doc in docs:
+        nodes = []
+        _walk(doc, "", nodes)
+        for where, d in nodes:
+            for k, v in d.items():
+                if (k == "frac" or k.startswith("frac_of_8TBps")) and isinstance(v, (int, float)) and v > 1.0:
+                    bad.append("%s/%s = %r is above the peak" % (where, k, v))
+            ratio = d.get("traffic_over_algorithmic")
+            if ratio is None and isinstance(d.get("traffic"), (int, float)) and isinstance(d.get("alg_bytes_per_launch"), (int, float)) and d["alg_bytes_per_launch"]:
+                ratio = d["traffic"] / d["alg_bytes_per_launch"]
+            if isinstance(ratio, (int, float)) and not 0.95 <= ratio <= 1.10 and not d.get("traffic_explained"):
+                bad.append("%s: counted traffic is %.3f of the algorithmic bytes, unexplained" % (where, ratio))
+    return bad
+
+
+def test_every_committed_profile_of_rounds_5_and_6_parses_and_passes_the_cross_checks():
+    """r05_other_configs.jsonl was cut mid-record and quoted 8077.8 GB/s on bytes 'moved' (above the peak: a
+    sliced pass counted once per launch), r05_c3_line.json quoted the adaQN run's traffic for SQN's pass 2 (1.136)."""
+    import glob
+    files = sorted(f for pat in ("r05_*.json", "r05_*.jsonl", "r06_*.json", "r06_*.jsonl") for f in glob.glob(os.path.join(ROOT, "profiles", pat)))
+    assert len(files) >= 12
+    findings = {os.path.basename(f): profile_findings(f) for f in files}
+    findings = {f: b for f, b in findings.items() if b}
+    assert not findings, json.dumps(findings, indent=1)
+
+
+def test_the_cross_check_catches_what_round_5_committed(tmp_path):
+    """The walker above would have failed on round 5's tree: a truncated record, a fraction above the peak, the wrong file's traffic."""
+    cut = tmp_path / "r05_cut.jsonl"
+    cut.write_text('{"config": "C3-f32", "steps_per_s": 196.8}\n{"config": "C3-host", "two_loop": {"GBps_on_bytes_moved": 8077.8, "frac_of_8TBps_on_bytes_mo')
+    assert any("does not parse" in b for b in profile_findings(str(cut)))
+    over = tmp_path / "r05_over.json"
+    over.write_text(json.dumps({"two_loop": {"frac_of_8TBps_on_bytes_moved": 1.0097}, "roofline": {"frac": 0.79}}))
+    assert profile_findings(str(over)) == ["/two_loop/frac_of_8TBps_on_bytes_moved = 1.0097 is above the peak"]
+    wrong = tmp_path / "r05_wrong.json"
+    wrong.write_text(json.dumps({"roofline": {"frac": 0.81, "traffic": 20000842496, "alg_bytes_per_launch": 17600000000}}))
+    assert any("1.136" in b for b in profile_findings(str(wrong)))
+    fine = tmp_path / "r05_fine.json"
+    fine.write_text(json.dumps({"roofline": {"frac": 0.81, "traffic": 17600551200, "alg_bytes_per_launch": 17600000000, "traffic_over_algorithmic": 1.0}}))
+    assert profile_findings(str(fine)) == []
+
+
+def test_committed_traffic_is_looked_up_by_configuration_and_kernel_instantiation(tmp_path):
+    """every line without live PMC (every multi-GPU line) quoted the lexicographically last
+    profiles/r*_pmc_traffic*.json -- the adaQN run, whose pass 2 (k_qdot<..., 2, ...>) moves 20.0 GB -- for SQN's 17.6 GB pass 2."""
+    import shutil
+    b = _bench()
+    n, m = 100_000_000, 20
+    alg = (m + 2) * n * 8
+    for kernel in ("qdot", "sadd"):
+        for config in ("c3", "c5"):
+            tr, src = b.pmc_traffic(kernel, n, m, alg, config=config)
+            assert tr is not None and abs(tr / alg - 1) < 0.01, (kernel, config, tr, src)
+            assert "_c4_" not in src and ("_c3_" in src or "_c" not in os.path.basename(src.split()[0]))
+    tr, src = b.pmc_traffic("sdot", n, m, (m + 1) * n * 8, config="c3")
+    assert abs(tr / ((m + 1) * n * 8) - 1) < 0.01
+    assert b.pmc_key("qdot", 20, 0) == "k_qdot<2, 3, true, 0, true>" and b.pmc_key("qdot", 20, 2) == "k_qdot<2, 3, true, 2, true>"
+    assert b.pmc_key("sadd", 10) == "k_sadd<2, 2, true, true, false>"
+    # the committed adaQN file alone must never serve a C3 line: not by its name, and not by its numbers either
+    only_c4 = tmp_path / "profiles"
+    only_c4.mkdir()
+    shutil.copy(os.path.join(ROOT, "profiles", "r05_c4_pmc_traffic.json"), str(only_c4 / "r05_c4_pmc_traffic.json"))
+    tr, why = b.pmc_traffic("qdot", n, m, alg, config="c3", profiles_dir=str(only_c4))
+    assert tr is None and "no committed PMC file" in why
+    shutil.copy(os.path.join(ROOT, "profiles", "r05_c4_pmc_traffic.json"), str(only_c4 / "r07_pmc_traffic.json"))      # the same counters, untagged and newest
+    tr, why = b.pmc_traffic("qdot", n, m, alg, config="c3", profiles_dir=str(only_c4))
+    assert tr is None and "no committed PMC file" in why          # another instantiation: not even looked at
+    # ... and a file that holds the right instantiation with the wrong bytes (a ring still filling: 19 pairs) is refused on the ratio
+    tr, why = b.pmc_traffic("sadd", n, m, alg, config="c4", profiles_dir=str(only_c4))
+    assert tr is None and "refused" in why and "0.95" in why
+    # scaling with n: the kernels are pure streams
+    tr5, _ = b.pmc_traffic("sadd", 125_000_000, m, (m + 2) * 125_000_000 * 8, config="c5")
+    assert abs(tr5 / ((m + 2) * 125_000_000 * 8) - 1) < 0.01
+
+
+class _FakeClock:
+    def __init__(self, t):
+        self.t = t
+
+    def __call__(self):
+        return self.t
+
+
+def test_one_wall_clock_budget_admits_skips_and_caps():
+    """a budget started at process entry; a leg runs only if its measured cost still fits, a child gets no
+    more than what is left, and what was skipped is named."""
+    b = _bench()
+    clk = _FakeClock(1000.0)
+    bud = b.Budget(total_s=100.0, entry=1000.0, clock=clk, costs={"profile": 4.0, "in_process": 90.0, "c5": 20.0}, env={})
+    assert bud.deadline == 1100.0 and not bud.inherited
+    assert abs(bud.left() - (100.0 - b.RESERVE_S)) < 1e-9
+    assert bud.admit("profile") and bud.admit("in_process") and bud.skipped == []
+    clk.t = 1030.0                                                     # 30 s in: 64 s of measuring left
+    assert bud.admit("c5") and not bud.admit("in_process")
+    assert [s["leg"] for s in bud.skipped] == ["in_process"] and bud.skipped[0]["needs_s"] == 90.0 and bud.skipped[0]["left_s"] == 64.0
+    assert bud.child_timeout(420) == 64.0 and bud.child_timeout(30) == 30.0
+    clk.t = 1099.0                                                     # past the reserve: nothing is admitted, a child fails at once
+    assert not bud.admit("profile") and bud.child_timeout(300) == 1.0
+    bud.note("c5", 12.345)
+    bud.note("c5", 1.0)
+    rep = bud.report()
+    assert rep["leg_seconds"] == {"c5": 13.35} and rep["budget_s"] == 100.0
+    # an explicit cost overrides the table (the sustained leg costs what --sustain-seconds says)
+    clk.t = 1050.0
+    assert bud.fits("sustained", 40.0) and not bud.fits("sustained", 50.0)
+    # the deadline travels to children through the environment and wins over their own entry time
+    env = bud.export({})
+    child = b.Budget(total_s=420.0, entry=1040.0, clock=clk, env=env)
+    assert child.inherited and child.deadline == 1100.0
+    # defaults: BENCH_BUDGET_S
+    assert b.Budget(entry=0.0, clock=clk, env={"BENCH_BUDGET_S": "77"}).deadline == 77.0
+    assert b.Budget(entry=0.0, clock=clk, env={}).deadline == b.DEFAULT_BUDGET_S
+    # every leg the run admits has a cost on file
+    for leg in ("profile", "value_runs", "sustained", "reference_form", "two_loop_micro", "host_copies", "host_caller", "cpu_baseline",
+                "live_pmc", "c5", "strong", "allreduce_us", "in_process", "c5_yardstick"):
+        assert b.LEG_COST_S[leg] > 0
+    assert sum(b.LEG_COST_S.values()) < b.DEFAULT_BUDGET_S             # a default run on a healthy box skips nothing
+
+
+def test_a_child_process_is_cut_off_at_its_timeout_with_its_whole_group():
+    b = _bench()
+    import time
+    t0 = time.time()
+    rc, so, se = b.run_child([sys.executable, "-c", "import subprocess,sys,time; subprocess.Popen([sys.executable,'-c','import time; time.sleep(60)']); print('up', flush=True); time.sleep(60)"],
+                             dict(os.environ), 2.0)
+    assert rc is None and "up" in so and time.time() - t0 < 20 and b.LIVE_CHILDREN == []
+    rc, so, se = b.run_child([sys.executable, "-c", "print('ok')"], dict(os.environ), 30.0)
+    assert rc == 0 and so.strip() == "ok"
+
+
+def test_sliced_passes_count_their_bytes_once_per_traversal():
+    """tools/bench_configs.py report(): a host caller's pass 1 / pass 3 run as several launches of ONE traversal."""
+    src = open(os.path.join(ROOT, "tools", "bench_configs.py")).read()
+    assert "traversals" in src and 'words[x] * k[x]["launches"] for x in chain' not in src
+
+
 def test_more_gpus_than_visible_is_refused_before_anything_runs():
     """--gpus 2 without a launcher on a machine with fewer devices: non-zero exit, no JSON line (decided before HIP is touched)."""
     import torch

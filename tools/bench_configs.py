@@ -172,11 +172,32 @@ def report(name, workload, n, m, dt, steps, calls, extra=None, kind="SQN", k_pai
             e["alg_GB"] = round(words[kn] * nb / 1e9, 3)
             e["alg_GBps"] = round(words[kn] * nb / (e["avg_ms"] * 1e-3) / 1e9, 1)
             e["frac_of_8TBps"] = round(e["alg_GBps"] / PEAK, 4)
+    # A host caller's pass 1 and pass 3 run in SLICES of one traversal (kernels.hip: Slice; each slice is a launch of its own
+    # as soon as its part of the gradient has arrived over PCIe): the pass moves its words ONCE however many launches it takes.
+    # Every step of the three-pass form has exactly one pass 1 (sdot or sdot2), one pass 2 (qdot, never sliced) and one pass 3,
+    # so traversals = launches of pass 2.  (Until round 6 the words were multiplied by the launches: 8077.8 GB/s "moved" by a
+    # sliced two-loop, above the 8 TB/s peak -- VERDICT r05 weak #5.)
+    traversals = {x: e["launches"] for x, e in k.items()}
+    if "qdot" in k:
+        passes = k["qdot"]["launches"]
+        p1 = sum(k[x]["launches"] for x in ("sdot", "sdot2") if x in k)
+        for x in ("sdot", "sdot2"):
+            if x in k and p1 > passes:
+                traversals[x] = k[x]["launches"] * passes / p1
+        if "sadd" in k and k["sadd"]["launches"] > passes:
+            traversals["sadd"] = passes
+    for kn, e in k.items():
+        if kn in words and traversals[kn] != e["launches"]:      # per-launch figures of a sliced pass: a launch moves its share of the words
+            share = traversals[kn] / e["launches"]
+            e["launches_per_traversal"] = round(1 / share, 2)
+            e["alg_GB"] = round(words[kn] * nb * share / 1e9, 3)
+            e["alg_GBps"] = round(words[kn] * nb * share / (e["avg_ms"] * 1e-3) / 1e9, 1)
+            e["frac_of_8TBps"] = round(e["alg_GBps"] / PEAK, 4)
     chain = ("first", "bwd", "mid", "fwd", "fwd_last", "sdot", "sdot2", "qdot", "sadd")
     tl = sum(k[x]["avg_ms"] * k[x]["launches"] for x in chain if x in k) / prof_steps
     form = "three-pass" if "sadd" in k else "sweeps"
-    moved_tl = sum(words[x] * k[x]["launches"] for x in chain if x in k) * nb / prof_steps
-    moved_step = sum(words[x] * e["launches"] for x, e in k.items() if x in words) * nb / prof_steps
+    moved_tl = sum(words[x] * traversals[x] for x in chain if x in k) * nb / prof_steps
+    moved_step = sum(words[x] * traversals[x] for x, e in k.items() if x in words) * nb / prof_steps
     kern_ms = sum(e["avg_ms"] * e["launches"] for e in k.values()) / prof_steps
     ms_step = 1e3 * dt / steps
     # the caller's own GPU kernels inside the step: one product per gradient request (oLBFGS: two per step), L-th steps one more
@@ -185,7 +206,7 @@ def report(name, workload, n, m, dt, steps, calls, extra=None, kind="SQN", k_pai
     dom = max(cands, key=lambda x: k[x]["avg_ms"] * k[x]["launches"]) if cands else None
     roof = None
     if dom:
-        alg = words[dom] * nb
+        alg = int(round(words[dom] * nb * traversals[dom] / k[dom]["launches"]))      # a launch of a sliced pass moves its share
         ach = alg / (k[dom]["avg_ms"] * 1e-3) / 1e9
         traffic, src = pmc_of(dom)
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK, "unit": "GB/s", "frac": round(ach / PEAK, 4),
