@@ -1916,6 +1916,37 @@ def cpu_baseline(args, gpu, hostc, n, m, L, bs, step_size):
                      "value_allcores_best = minimum). One thread: one ordinary step (%.2f s) and one pair-building step (%.2f s), "
                      "composed into a cycle."
                      % (m, L, bs, nc, t_copy, bs, threads, L, " / ".join("%.2f" % c for c in cycles), t1_ord, t1_pair)}
+    # ---- the same cycles with the reference's kind of BLAS behind the same restatement (north_star: "src/stochqn.c + BLAS";
+    # reference src/stochqn.c:676-706, 946-949 call cblas_ddot / daxpy / dscal / dnrm2 / dgemv of whatever CBLAS they were linked
+    # with): the OpenBLAS that scipy / numpy bundle on this box, all usable cores.  Both numbers are reported; `value` stays the
+    # own-loops port (kind "port"), whose threads are pinned and whose pages were first touched by the team that streams them.
+    out["blas"] = None
+    try:
+        info = oracle.find_openblas()
+        if info is None:
+            out["blas"] = {"error": "no OpenBLAS with a CBLAS interface found on this box (scipy.libs / numpy.libs / libopenblas.so)"}
+        else:
+            if hasattr(olib, "oracle_unbind_threads"):
+                olib.oracle_unbind_threads()          # the BLAS runs its own thread pool: the calling thread gets its full mask back first
+            got = oracle.use_cblas(info, threads=threads)
+            if got is None:
+                out["blas"] = {"error": "the CBLAS entry points of %s could not be resolved" % info["path"]}
+            else:
+                bc = [timed(L) for _ in range(3)]
+                b_min, b_med = min(bc), sorted(bc)[1]
+                out["blas"] = {"value": round(L / b_med * scale, 4), "value_best": round(L / b_min * scale, 4), "unit": out["unit"], "kind": "openblas",
+                               "cores": got["threads"] or threads, "library": got["library"], "config": got["config"], "ilp64": got["ilp64"],
+                               "cycles_s": [round(c, 3) for c in bc],
+                               "what": "the same oracle with v_dot / v_axpy / v_scal / v_nrm2 and the two gemv of the Hessian-vector product routed "
+                                       "through this library's cblas_ddot / daxpy / dscal / dnrm2 / dgemv (oracle_use_cblas): three whole L-cycles, "
+                                       "median; the library's own thread pool, not pinned"}
+    except Exception as e:                                   # a baseline beside the baseline: it never costs the line
+        out["blas"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        try:
+            oracle.use_cblas(None)
+        except Exception:
+            pass
     if hasattr(olib, "oracle_unbind_threads"):
         olib.oracle_unbind_threads()
     if native:

@@ -176,7 +176,10 @@ int stochqn_hip_unpin_host(void *p);
  * "kappa_max"   (default 1e6)  the three-pass form is used only while every pair in use has
  *                            |s||y| / |s'y| <= this (s almost orthogonal to y: every fp64 evaluation loses
  *                            digits); beyond, the chain of sweeps. inf = off
- * "fisher_rows" (default 16) Fisher rows one workgroup accumulates per pass (8, 16, 32)
+ * "fisher_split" (default 1) Fisher pass 1 (t = F s) with the rows divided among the waves of a workgroup: s is read once per
+ *                            128 rows; 0 = every lane accumulates "fisher_rows" rows (s re-read once per group)
+ * "fisher_split_per_cu" (default 0 = as many as fit, at most 4) workgroups per CU of that kernel
+ * "fisher_rows" (default 16) with "fisher_split" = 0: Fisher rows one workgroup accumulates per pass (8, 16, 32)
  * "verify_cache" (default 0) see "contract for callers that pass DEVICE pointers"
  * "raw_reuse_cache" (default 0)  stochqn_hip_two_loop / _take_step keep cached inner products between calls
  * "devices", "virtual_devices", "devices_min_n": single-process multi-device mode, see below

@@ -116,3 +116,63 @@ def fisher_product(F, fu, s):
     y = np.zeros(n)
     cdll().oracle_fisher_product(F.ctypes.data, fu, n, s.ctypes.data, t.ctypes.data, y.ctypes.data)
     return t, y
+
+
+# ---- "the reference's kind of BLAS" for bench.py's cpu_baseline leg (stochqn_oracle.c: oracle_use_cblas) ----------------------
+_blas_dll = None
+
+
+def find_openblas():
+    """An OpenBLAS on this box with a CBLAS interface: the one scipy bundles (32-bit integers, symbols scipy_cblas_*), the one
+    numpy bundles (64-bit integers, scipy_cblas_*64_), or a system libopenblas (cblas_*).  -> dict(path, ilp64, fmt) or None."""
+    import glob
+    import site
+    roots = []
+    for get in (getattr(site, "getsitepackages", None), lambda: [site.getusersitepackages()]):
+        try:
+            roots += list(get()) if get else []
+        except Exception:
+            pass
+    roots += [p for p in sys.path if p.endswith(("site-packages", "dist-packages"))]
+    for sub, fmt, ilp64 in (("scipy.libs", "scipy_%s", 0), ("numpy.libs", "scipy_%s64_", 1)):
+        for root in dict.fromkeys(roots):
+            for f in sorted(glob.glob(os.path.join(root, sub, "libscipy_openblas*.so"))):
+                return {"path": f, "ilp64": ilp64, "fmt": fmt}
+    for name in ("libopenblas.so.0", "libopenblas.so"):
+        try:
+            C.CDLL(name)
+            return {"path": name, "ilp64": 0, "fmt": "%s"}
+        except OSError:
+            continue
+    return None
+
+
+def use_cblas(info, threads=None):
+    """Route the oracle's ddot / daxpy / dscal / dnrm2 and the two dgemv of the Fisher product through the CBLAS of `info`
+    (find_openblas), or back to its own loops (info = None).  -> what was loaded: {library, config, threads, ilp64} or None."""
+    global _blas_dll
+    lib = cdll()
+    lib.oracle_use_cblas.restype = C.c_int
+    lib.oracle_use_cblas.argtypes = [C.c_void_p] * 5 + [C.c_int]
+    if info is None:
+        lib.oracle_use_cblas(None, None, None, None, None, 0)
+        return None
+    _blas_dll = dll = C.CDLL(info["path"])
+    fmt = info["fmt"]
+    addr = [C.cast(getattr(dll, fmt % ("cblas_" + n)), C.c_void_p).value for n in ("ddot", "daxpy", "dscal", "dnrm2", "dgemv")]
+    out = {"library": info["path"], "ilp64": bool(info["ilp64"]), "config": None, "threads": None}
+    try:
+        cfg = getattr(dll, fmt % "openblas_get_config")
+        cfg.restype = C.c_char_p
+        out["config"] = cfg().decode()
+    except AttributeError:
+        pass
+    try:
+        if threads:
+            getattr(dll, fmt % "openblas_set_num_threads")(int(threads))
+        out["threads"] = int(getattr(dll, fmt % "openblas_get_num_threads")())
+    except AttributeError:
+        pass
+    if lib.oracle_use_cblas(*addr, int(info["ilp64"])) != 1:
+        return None
+    return out

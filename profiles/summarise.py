@@ -32,7 +32,7 @@ def short(name):
     m = re.search(r"k_sweep<(\d), (\d), (\w+)(<[^>]*>)?", name)
     if m:
         return "k_sweep<W=%s,NP=%s,%s%s>" % (m.group(1), m.group(2), m.group(3), m.group(4) or "")
-    m = re.search(r"(k_rows_dot_all|k_rows_dot|k_combine|k_qdot|k_sadd|k_fisher_t|k_fisher_y|k_pair_y_diff)<([^>]*)>", name)
+    m = re.search(r"(k_rows_dot_all|k_rows_dot|k_combine|k_qdot|k_sadd|k_fisher_t_split|k_fisher_t|k_fisher_y|k_pair_y_diff|k_c2_step)<([^>]*)>", name)
     if m:
         return "%s<%s>" % (m.group(1), m.group(2))
     return re.sub(r"\(.*", "", name)[:80]

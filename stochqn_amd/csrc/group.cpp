@@ -209,10 +209,9 @@ void pin_for_all_devices(Group* g, const void* p, size_t bytes)
 	if (!pinnable_in_place(p, bytes)) return;                  // runtime.cpp: not in the break heap, no page shared with another pin
 	Group::HostRange& slot = g->regs[g->reg_turn++ % 4];
 	if (slot.p) { if (hipHostUnregister(const_cast<void*>(slot.p)) != hipSuccess) (void) hipGetLastError(); note_unpinned(slot.p); slot = Group::HostRange{}; }
-	if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); return; }
+	if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); note_unpinned(p); return; }
 	slot.p = p;
 	slot.bytes = bytes;
-	note_pinned(p, bytes);
 	stat_add(ST_HOST_REGISTERED);
 }
 

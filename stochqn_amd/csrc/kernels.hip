@@ -773,6 +773,61 @@ __global__ void __launch_bounds__(kBlock) k_fisher_t(const real* F, size_t ld_, 
 	}
 }
 
+// pass 1, row-split (round 6; default): the NW waves of a workgroup share the SAME columns and divide the rows among them --
+// wave w of row block blockIdx.y owns rows [blockIdx.y*NW*RPW + w*RPW, +RPW) -- so the pack of s that belongs to a column tile is
+// fetched from HBM once per 128 rows (NW = 8, RPW = 16): the first wave to ask misses, the other seven hit in the CU's L1 or the
+// XCD's L2.  k_fisher_t above re-reads s once per group of 16 rows: at fu = 128 eight times, PMC 108.78 GB against 103.2 GB
+// algorithmic.  A lane carries only RPW accumulators and RPW row packs in flight; the waves are kept within
+// kFisherLag column tiles of each other by a workgroup barrier (the trip count depends on blockIdx.x only, so every wave
+// reaches every barrier), which bounds how long a line of s has to survive in L2.  Same row-major gemv as reference
+// src/stochqn.c:946 (t = F s), another association of the sums than k_fisher_t (lanes own other columns): parity is held
+// against the oracle at north_star's tolerance, not against the other kernel's bits.
+constexpr int kFisherLag = 8;
+template <int W, int RPW, bool NT, int NW>
+__global__ void __launch_bounds__(64 * NW) k_fisher_t_split(const real* F, size_t ld_, uint32_t n, uint32_t fu, const real* s, double* parts)
+{
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const uint32_t row0 = blockIdx.y * (uint32_t) (NW * RPW) + (uint32_t) (wave * RPW);
+	const uint32_t nrows = row0 >= fu ? 0u : (fu - row0 < (uint32_t) RPW ? fu - row0 : (uint32_t) RPW);
+	double acc[RPW];
+	#pragma unroll
+	for (int j = 0; j < RPW; j++) acc[j] = 0;
+	const uint32_t packs = n / W, stride = gridDim.x * 64, first = blockIdx.x * 64;
+	const uint32_t trips = first < packs ? (packs - first + stride - 1) / stride : 0u;      // the same for every wave of the workgroup
+	const real* Fg = F + (size_t) row0 * ld_;
+	for (uint32_t it = 0; it < trips; it++) {
+		const uint32_t p = first + it * stride + (uint32_t) lane;
+		if (p < packs && nrows) {
+			const Pack<W> sv = ld<W, false>(s, p * W);
+			RPack<W> f[RPW];
+			#pragma unroll
+			for (int j = 0; j < RPW; j++)
+				if ((uint32_t) j < nrows) f[j] = ldr<W, NT>(Fg + (size_t) j * ld_, p * W);
+			#pragma unroll
+			for (int j = 0; j < RPW; j++)
+				if ((uint32_t) j < nrows) {
+					#pragma unroll
+					for (int e = 0; e < W; e++) acc[j] = fma((double) f[j].v[e], sv.v[e], acc[j]);
+				}
+		}
+		if ((it % kFisherLag) == kFisherLag - 1) __syncthreads();
+	}
+	if (W > 1) {
+		const uint32_t i = packs * W + (uint32_t) lane;                    // tail elements (n not a multiple of W)
+		if (blockIdx.x == gridDim.x - 1 && i < n) {
+			const double sv = (double) s[i];
+			#pragma unroll
+			for (int j = 0; j < RPW; j++)
+				if ((uint32_t) j < nrows) acc[j] = fma((double) Fg[(size_t) j * ld_ + i], sv, acc[j]);
+		}
+	}
+	#pragma unroll
+	for (int j = 0; j < RPW; j++) {
+		const double t = wave_sum(acc[j]);
+		if (lane == 0 && (uint32_t) j < nrows) parts[(size_t) (row0 + j) * kMaxGrid + blockIdx.x] = t;
+	}
+}
+
 // pass 2: y_j = (1/fu) * sum_k t_k F[k][j], rows accumulated in index order; fused with the
 // curvature dots of the new pair.  One store stream (y) among fu + 1 read streams: PH = its stores clock-phased like those
 // of passes 2 and 3 (Parked).
@@ -1550,25 +1605,54 @@ Partials launch_dots3(const Scratch& sc, int buf, size_t n, const real* s, const
 	return finish(sc, buf, 3, grid);
 }
 
+// grid of the row-split Fisher pass: a whole number of resident rounds (register-limited, like the row-split rows-dot kernel)
+template <int W, int RPW>
+static int fisher_split_launch(const Scratch& sc, size_t n, const real* F, size_t fu, const real* s)
+{
+	constexpr int NW = 8;
+	static const int per_cu = [] {
+		int blocks = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_fisher_t_split<W, RPW, true, NW>, 64 * NW, 0) != hipSuccess || blocks < 1) { (void) hipGetLastError(); blocks = 1; }
+		return blocks > 4 ? 4 : blocks;
+	}();
+	const int want = sc.fisher_split_per_cu > 0 ? sc.fisher_split_per_cu : per_cu;
+	size_t g = (size_t) sc.grid_cap * (size_t) want;
+	const size_t max_grid = (n / W + 63) / 64;           // one workgroup covers 64 packs per step
+	if (g > max_grid) g = max_grid;
+	if (g > (size_t) kMaxGrid) g = kMaxGrid;
+	if (g < 1) g = 1;
+	const dim3 grid((unsigned) g, (unsigned) ((fu + (size_t) (NW * RPW) - 1) / (size_t) (NW * RPW)));
+	hipLaunchKernelGGL((k_fisher_t_split<W, RPW, true, NW>), grid, dim3(64 * NW), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part);
+	return (int) g;
+}
+
 Partials launch_fisher(const Scratch& sc, int buf, size_t n, const real* F, size_t fu, const real* s,
                        double* t_dev, real* y_out)
 {
 	const int grid = sweep_grid(sc, n);
 	const bool vec = all_aligned(F, s, y_out);
-	// rows one workgroup accumulates per pass over its columns: s is re-read once per group of rows (fu = 128:
-	// 16 groups of 8 re-read 12.5 % on top of F, 8 groups of 16 6 %).  Measured at n = 1e8 (r02_ab_rows3_fisher.jsonl):
-	// fu = 128: 17.54 / 17.09 / 23.79 ms for 8 / 16 / 32 rows (32 rows: 64 row packs in flight per lane, the
-	// compiler serialises them); fu = 32: 4.52 / 4.45 / 6.50 ms.  Default 16.
-	const int fr = sc.fisher_rows >= 32 ? 32 : (sc.fisher_rows >= 16 ? 16 : 8);
-	const dim3 g1(grid, (unsigned) ((fu + fr - 1) / fr));
-	{
+	int grid_t = grid;
+	if (sc.fisher_split) {
+		// pass 1 with the rows divided among the waves of a workgroup: s once per 128 rows (k_fisher_t_split)
+		ProfScope ps(sc, K_FISHER_T);
+		#define SQN_FS(WW) (fu <= 16 ? fisher_split_launch<WW, 2>(sc, n, F, fu, s) : fu <= 32 ? fisher_split_launch<WW, 4>(sc, n, F, fu, s) : \
+		                    fu <= 64 ? fisher_split_launch<WW, 8>(sc, n, F, fu, s) : fisher_split_launch<WW, 16>(sc, n, F, fu, s))
+		grid_t = vec ? SQN_FS(kVec) : SQN_FS(1);
+		#undef SQN_FS
+	} else {
+		// rows one workgroup accumulates per pass over its columns: s is re-read once per group of rows (fu = 128:
+		// 16 groups of 8 re-read 12.5 % on top of F, 8 groups of 16 6 %).  Measured at n = 1e8 (r02_ab_rows3_fisher.jsonl):
+		// fu = 128: 17.54 / 17.09 / 23.79 ms for 8 / 16 / 32 rows (32 rows: 64 row packs in flight per lane, the
+		// compiler serialises them); fu = 32: 4.52 / 4.45 / 6.50 ms.  Default 16.
+		const int fr = sc.fisher_rows >= 32 ? 32 : (sc.fisher_rows >= 16 ? 16 : 8);
+		const dim3 g1(grid, (unsigned) ((fu + fr - 1) / fr));
 		ProfScope ps(sc, K_FISHER_T);
 		#define SQN_FT(WW, FR) hipLaunchKernelGGL((k_fisher_t<WW, true, FR>), g1, dim3(kBlock), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part)
 		if (vec) { if (fr == 32) SQN_FT(kVec, 32); else if (fr == 16) SQN_FT(kVec, 16); else SQN_FT(kVec, 8); }
 		else     { if (fr == 32) SQN_FT(1, 32); else if (fr == 16) SQN_FT(1, 16); else SQN_FT(1, 8); }
 		#undef SQN_FT
 	}
-	launch_fin(sc, Partials{sc.fisher_part, grid, kMaxGrid}, (int) fu, t_dev);
+	launch_fin(sc, Partials{sc.fisher_part, grid_t, kMaxGrid}, (int) fu, t_dev);
 	if (sc.allreduce) sc.allreduce(sc.user, t_dev, (int) fu, sc.stream);
 	{
 		ProfScope ps(sc, K_FISHER_Y);

@@ -78,11 +78,14 @@ void zero(DevCtx* c, real* dst, size_t count)
 void to_host(DevCtx* c, void* dst, const double* src, size_t count)      // scalars of the recursion
 {
 	if (c->async_call) return;               // stream-ordered call: nothing is read back (and nothing that would have been is used)
+	if (c->wedged) return;                   // the stream can never run again (runtime.cpp: wait_stream): the call fails, nothing is read
 	SQN_HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToHost, c->sc.stream));
 }
 
 void vec_to_host(DevCtx* c, real* dst, const real* src, size_t count)    // an n-vector
 {
+	// a copy into pageable caller memory blocks INSIDE the runtime until the stream has run: on a wedged context that is for ever
+	if (c->wedged) return;
 	SQN_HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(real), hipMemcpyDeviceToHost, c->sc.stream));
 }
 
@@ -279,7 +282,12 @@ void close_call(Call& io, bool x_changed, bool g_changed)
 	resolve_x(io);
 	// ranks of a communicator: a copy into pageable caller memory blocks INSIDE the runtime until the stream has run -- for ever if a
 	// collective on it waits for a peer that is gone.  The bounded wait comes first (runtime.cpp: wait_stream); a no-op without RCCL.
-	if (c->red.kind == Reducer::RCCL && io.host_caller && (x_changed || g_changed)) (void) wait_stream(c, c->sc.stream);
+	// Whatever the wait reports -- the patience ran out, or the stream itself failed -- fails the call (c->fault): nothing is
+	// copied into the caller's arrays behind an error that was looked away from.
+	if (c->red.kind == Reducer::RCCL && io.host_caller && (x_changed || g_changed) && wait_stream(c, c->sc.stream) != hipSuccess) {
+		(void) hipGetLastError();
+		c->fault = true;
+	}
 	// a reduction that failed while the call was being enqueued (c->fault: the call is going to return -1000) left the update
 	// working on un-reduced sums: the caller's arrays are not touched with that
 	if (x_changed && io.host_caller && io.x && !io.x_down && !io.x_pending && !c->fault) vec_to_host(c, io.x_caller, io.x, N(c));

@@ -268,9 +268,21 @@ void free_view(DevCtx* c, View& v)
 
 void destroy(DevCtx* c, bool keep_spill = false)
 {
-	SQN_HIP_OK(hipStreamSynchronize(c->sc.stream));
-	if (c->own_stream && c->own_stream != c->sc.stream) SQN_HIP_OK(hipStreamSynchronize(c->own_stream));
-	if (c->copy_stream) (void) hipStreamSynchronize(c->copy_stream);      // an upload of x started when the last call returned may still be writing the staging vector
+	// every wait of a context whose stream carries RCCL collectives is bounded (wait_stream): a context released or reclaimed
+	// while a peer is gone -- without an earlier call that timed out -- must not hang here either
+	if (!c->wedged) (void) wait_stream(c, c->sc.stream);
+	if (!c->wedged && c->own_stream && c->own_stream != c->sc.stream) (void) wait_stream(c, c->own_stream);
+	if (!c->wedged && c->copy_stream) (void) wait_stream(c, c->copy_stream);      // an upload of x started when the last call returned may still be writing the staging vector
+	if (!c->wedged && c->down_stream) (void) wait_stream(c, c->down_stream);
+	if (c->wedged) {
+		// kernels that can never end still point into this context's memory and sit on its streams: nothing of it is freed or
+		// destroyed (a leak, said out loud once, instead of a hang or a use-after-free on the device)
+		std::fprintf(stderr, "stochqn: a context whose collectives cannot be ended is abandoned with its device memory (%zu bytes of mirrors)\n", c->mirrored.load());
+		if (Spill* sp = static_cast<Spill*>(c->spill)) { delete sp; c->spill = nullptr; }
+		for (auto& r : c->regs)
+			if (r.p) { if (hipHostUnregister(const_cast<void*>(r.p)) != hipSuccess) (void) hipGetLastError(); note_unpinned(r.p); }
+		return;                                          // the DevCtx object itself stays too: the reducer's `user` pointer is in flight
+	}
 	if (Spill* sp = static_cast<Spill*>(c->spill)) {
 		// keep_spill: a resume that could not be completed (a mirror could not be had) -- the state goes back where the
 		// object's next call looks for it, instead of being lost with the half-made context
@@ -293,8 +305,8 @@ void destroy(DevCtx* c, bool keep_spill = false)
 		else std::free(c->host_stage[i]);
 	}
 	if (c->pin) SQN_HIP_OK(hipHostFree(c->pin));
-	if (c->copy_stream) { (void) hipStreamSynchronize(c->copy_stream); (void) hipStreamDestroy(c->copy_stream); }
-	if (c->down_stream) { (void) hipStreamSynchronize(c->down_stream); (void) hipStreamDestroy(c->down_stream); }
+	if (c->copy_stream) (void) hipStreamDestroy(c->copy_stream);      // idle: waited for above
+	if (c->down_stream) (void) hipStreamDestroy(c->down_stream);
 	for (hipEvent_t e : c->xup_ev) (void) hipEventDestroy(e);
 	for (hipEvent_t e : c->chunk_ev) (void) hipEventDestroy(e);
 	for (hipEvent_t e : c->up_ev) (void) hipEventDestroy(e);
@@ -372,7 +384,7 @@ bool reclaim_one(int device)
 		DevCtx* victim = nullptr;
 		for (auto& kv : g_ctx) {
 			DevCtx* c = kv.second;
-			if (c->in_call || c->no_spill || mirror_bytes(c) == 0 || (device >= 0 && c->device != device)) continue;
+			if (c->in_call || c->no_spill || c->wedged || mirror_bytes(c) == 0 || (device >= 0 && c->device != device)) continue;
 			if (!victim || c->last_use < victim->last_use) victim = c;
 		}
 		if (!victim) return false;
@@ -383,7 +395,7 @@ bool reclaim_one(int device)
 			sp->kind = victim->kind; sp->n = victim->n; sp->m = victim->m; sp->fsize = victim->fsize;
 			sp->niter = victim->last_niter; sp->section = victim->last_section;
 			// a victim whose stream reports a failure holds nothing worth keeping a copy of -- and is not touched any further
-			bool ok = hipStreamSynchronize(victim->sc.stream) == hipSuccess;
+			bool ok = !victim->wedged && wait_stream(victim, victim->sc.stream) == hipSuccess && !victim->fault;      // bounded like every wait
 			if (!ok) (void) hipGetLastError();
 			View* vs[10];
 			views_of(victim, vs);
@@ -499,6 +511,8 @@ void begin_call(DevCtx* c)
 	c->sc.reverse = g_opt.reverse;
 	c->sc.rows_split = g_opt.rows_split;
 	c->sc.fisher_rows = g_opt.fisher_rows;
+	c->sc.fisher_split = g_opt.fisher_split;
+	c->sc.fisher_split_per_cu = g_opt.fisher_split_per_cu;
 	c->sc.phase_inv = g_opt.phase_ticks > 0 ? (uint32_t) (4294967296.0 / (double) g_opt.phase_ticks) : 0u;
 	c->sc.keep_tail = g_opt.keep_tail;
 	c->sc.qdot_per_cu = g_opt.qdot_per_cu; c->sc.sadd_per_cu = g_opt.sadd_per_cu; c->sc.sdot2_per_cu = g_opt.sdot2_per_cu; c->sc.sdot_per_cu = g_opt.sdot_per_cu;
@@ -951,7 +965,12 @@ bool inside_a_thread_arena_heap(uintptr_t lo, uintptr_t hi)
 }
 }  // namespace
 
-bool pinnable_in_place(const void* p, size_t bytes)
+// The verdict and the RESERVATION of the pages are one critical section: on "yes" the span [lo, hi) is on the books
+// before anybody else can ask about a range that shares a page with it -- two threads asking at the same time about two ranges
+// with a page in common cannot both be told yes.  Who is told yes and then fails to register gives the span back
+// (note_unpinned).  `own`: a range of the asker's own that the new one REPLACES (the same array, longer now): its span does not
+// count against the new range and is taken off the books in the same breath.
+bool pinnable_in_place(const void* p, size_t bytes, const void* own)
 {
 	static const bool trace = std::getenv("STOCHQN_HIP_PIN_TRACE") != nullptr;
 	const uintptr_t lo = (uintptr_t) p & ~(uintptr_t) 4095, hi = ((uintptr_t) p + bytes + 4095) & ~(uintptr_t) 4095;
@@ -964,24 +983,24 @@ bool pinnable_in_place(const void* p, size_t bytes)
 	}
 	if (ok) {
 		std::lock_guard<std::mutex> lk(g_span_mu);
-		auto it = g_spans.upper_bound(lo);                  // the first span that starts above lo; the one before may reach into [lo, hi)
+		const uintptr_t own_lo = own ? ((uintptr_t) own & ~(uintptr_t) 4095) : 0;
 		const std::pair<const uintptr_t, uintptr_t>* hit = nullptr;
-		if (it != g_spans.end() && it->first < hi) hit = &*it;
-		if (!hit && it != g_spans.begin()) { --it; if (it->second > lo) hit = &*it; }
+		// every span that can reach into [lo, hi): the ones that start inside it, and the one before
+		auto it = g_spans.lower_bound(lo);
+		if (it != g_spans.begin()) { auto before = std::prev(it); if (before->second > lo && !(own && before->first == own_lo)) hit = &*before; }
+		for (; !hit && it != g_spans.end() && it->first < hi; ++it)
+			if (!(own && it->first == own_lo)) hit = &*it;
 		if (hit) {
 			ok = false;
 			if (trace) std::fprintf(stderr, "stochqn: pin %p +%zu declined: its pages [%#lx, %#lx) overlap the pinned range [%#lx, %#lx)\n", p, bytes,
 			                        (unsigned long) lo, (unsigned long) hi, (unsigned long) hit->first, (unsigned long) hit->second);
+		} else {
+			if (own) g_spans.erase(own_lo);
+			g_spans[lo] = hi;                               // reserved: given back by note_unpinned if the registration fails
 		}
 	}
 	if (!ok) stat_add(ST_HOST_PIN_DECLINED);
 	return ok;
-}
-
-void note_pinned(const void* p, size_t bytes)
-{
-	std::lock_guard<std::mutex> lk(g_span_mu);
-	g_spans[(uintptr_t) p & ~(uintptr_t) 4095] = ((uintptr_t) p + bytes + 4095) & ~(uintptr_t) 4095;
 }
 
 void note_unpinned(const void* p)
@@ -1022,11 +1041,11 @@ bool ensure_registered(DevCtx* c, const void* p, size_t bytes)
 	if (slot.p) { if (hipHostUnregister(const_cast<void*>(slot.p)) != hipSuccess) (void) hipGetLastError(); note_unpinned(slot.p); slot = DevCtx::HostRange{}; }
 	if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
 		(void) hipGetLastError();                        // not fatal: the runtime's staged copies still work
+		note_unpinned(p);                                // the pages pinnable_in_place reserved
 		return false;
 	}
 	slot.p = p;
 	slot.bytes = bytes;
-	note_pinned(p, bytes);
 	stat_add(ST_HOST_REGISTERED);
 	return true;
 }
@@ -1204,10 +1223,20 @@ bool ensure_copy_stream(DevCtx* c, int chunks)
 hipError_t wait_stream(DevCtx* c, hipStream_t s)
 {
 	if (c->sc.allreduce != allreduce_hook || !c->red.comm) return hipStreamSynchronize(s);
+	if (c->wedged) return hipErrorNotReady;            // its collectives can never end (below): nobody waits for this stream again
+	// A communicator that was aborted -- earlier in this very call (allreduce_hook's failure path), by another context or thread
+	// that shares it, by another shard of the group -- has been RELEASED by ncclCommAbort: it must not be handed to RCCL again
+	// (ncclCommGetAsyncError on freed memory).  Its kernels were ended by the abort, so the stream drains.
+	if (comm_is_dead(c->red.comm)) {
+		c->fault = true;
+		if (g_comm.CommAbort) return hipStreamSynchronize(s);
+		c->wedged = true;                                  // dead and never aborted (this RCCL cannot): whether this stream can drain is unknowable
+		return hipErrorNotReady;
+	}
 	const auto t0 = std::chrono::steady_clock::now();
 	const double patience = options().reducer_patience_s;
 	const char* why = nullptr;
-	bool slow = false;
+	bool slow = false, dead_meanwhile = false;
 	for (long spin = 0;; spin++) {
 		const hipError_t q = hipStreamQuery(s);
 		if (q != hipErrorNotReady) return q;
@@ -1215,25 +1244,57 @@ hipError_t wait_stream(DevCtx* c, hipStream_t s)
 		if (!slow && (spin & 255) != 255) continue;        // the clock is read every 256 polls (a poll is ~1 us)
 		const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 		if (waited > 50e-3) {                              // no step takes this long: from here on something is slow or gone -- stop burning the core
-			if (g_comm.CommGetAsyncError) {
-				ncclResult_t st = ncclSuccess;
-				if (g_comm.CommGetAsyncError((ncclComm_t) c->red.comm, &st) == ncclSuccess && st != ncclSuccess && st != ncclInProgress) { why = "the communicator reports an asynchronous error"; break; }
+			{
+				// the liveness test and the call into the communicator under ONE lock: whoever aborts does so under g_dead_mu too
+				std::lock_guard<std::mutex> lk(g_dead_mu);
+				if (std::find(g_dead_comms.begin(), g_dead_comms.end(), c->red.comm) != g_dead_comms.end()) { dead_meanwhile = true; break; }
+				if (g_comm.CommGetAsyncError) {
+					ncclResult_t st = ncclSuccess;
+					if (g_comm.CommGetAsyncError((ncclComm_t) c->red.comm, &st) == ncclSuccess && st != ncclSuccess && st != ncclInProgress) { why = "the communicator reports an asynchronous error"; break; }
+				}
 			}
 			if (waited > patience) { why = "a reduction did not complete within reducer_patience_s"; break; }
 			std::this_thread::sleep_for(std::chrono::microseconds(200));
 			slow = true;                                   // ... one poll per sleep from here on, the clock read every time
 		}
 	}
+	c->fault = true;
+	if (dead_meanwhile) {                                  // somebody else gave up on the same communicator while this context waited
+		std::fprintf(stderr, "stochqn: rank %d of %d: the communicator was given up by another context while this one waited -- the call fails (-1000)\n", c->red.rank, c->red.nranks);
+		if (g_comm.CommAbort) return hipStreamSynchronize(s);
+		c->wedged = true;
+		return hipErrorNotReady;
+	}
+	if (!g_comm.CommAbort) {
+		// This RCCL has no ncclCommAbort: nothing can end the kernels that wait for the missing peer, the stream will never drain.
+		// Saying "the call fails" and then synchronising on it would block for ever.  The communicator is dead for
+		// every later reduction, the context is WEDGED: its calls fail at once, its streams are never waited for again and its
+		// device memory is abandoned with it (the kernels in flight still point into it).
+		std::fprintf(stderr, "stochqn: rank %d of %d: %s, and this RCCL has no ncclCommAbort -- the context is abandoned; this call and every later one on it fail (-1000)\n", c->red.rank, c->red.nranks, why);
+		std::lock_guard<std::mutex> lk(g_dead_mu);
+		if (std::find(g_dead_comms.begin(), g_dead_comms.end(), c->red.comm) == g_dead_comms.end()) g_dead_comms.push_back(c->red.comm);
+		c->wedged = true;
+		return hipErrorNotReady;
+	}
 	std::fprintf(stderr, "stochqn: rank %d of %d: %s -- aborting the communicator; this call and every later reduction over it fail (-1000)\n", c->red.rank, c->red.nranks, why);
 	{
 		std::lock_guard<std::mutex> lk(g_dead_mu);
 		if (std::find(g_dead_comms.begin(), g_dead_comms.end(), c->red.comm) == g_dead_comms.end()) {
 			g_dead_comms.push_back(c->red.comm);
-			if (g_comm.CommAbort) (void) g_comm.CommAbort((ncclComm_t) c->red.comm);       // ends the kernels that wait for the missing peer
+			(void) g_comm.CommAbort((ncclComm_t) c->red.comm);       // ends the kernels that wait for the missing peer
 		}
 	}
-	c->fault = true;
 	return hipStreamSynchronize(s);                    // what was enqueued behind the collective drains now
+}
+
+// the arrival counter of the pair kernels' last-workgroup verdict must be zero when such a kernel starts, and only the workgroup
+// that draws the last ticket puts it back: a launch that faulted or was cut short leaves it non-zero, no workgroup of the NEXT
+// pair would draw grid-1, report[4..7] would keep the previous pair's sums and the host would decide on those.
+// Whenever a call ends in a fault the counter is cleared on the (now idle) stream before anything else is enqueued.
+static void reset_ticket(DevCtx* c)
+{
+	if (c->wedged || !c->sc.ticket) return;
+	if (hipMemsetAsync(c->sc.ticket, 0, sizeof(unsigned), c->sc.stream) != hipSuccess) (void) hipGetLastError();
 }
 
 void sync(DevCtx* c)
@@ -1248,9 +1309,11 @@ void sync(DevCtx* c)
 	}
 	hipError_t e = wait_stream(c, c->sc.stream);
 	if (c->copy_busy) {                                  // slices of x still on their way to the host
+		// the copy streams wait for events of the compute stream: behind a collective whose peer is gone they are just as stuck,
+		// so they are waited for with the same bound
 		for (hipStream_t s : {c->copy_stream, c->down_stream}) {
 			if (!s) continue;
-			const hipError_t e2 = hipStreamSynchronize(s);
+			const hipError_t e2 = wait_stream(c, s);
 			if (e == hipSuccess) e = e2;
 		}
 		c->copy_busy = false;
@@ -1261,7 +1324,8 @@ void sync(DevCtx* c)
 		std::fprintf(stderr, "stochqn: device work failed: %s\n", hipGetErrorString(e != hipSuccess ? e : l));
 		c->fault = true;
 	}
-	if (c->sc.prof) c->prof.collect();
+	if (c->fault) reset_ticket(c);
+	if (c->sc.prof && !c->wedged) c->prof.collect();
 }
 
 // The reducer a context created by the calling thread gets: the thread's own binding when one was
@@ -1317,14 +1381,15 @@ bool comm_init_all(int ndev, const int* devices, void** comms_out)
 	return true;
 }
 
-static bool forget_dead(void* comm)             // true: the communicator was aborted (ncclCommAbort released it): not to be destroyed again
+// true: the communicator is not to be destroyed -- it was aborted (ncclCommAbort released it), or it is dead and COULD not be
+// aborted (an RCCL without ncclCommAbort): collectives that can never end still refer to it, so it is left where it is
+static bool forget_dead(void* comm)
 {
 	std::lock_guard<std::mutex> lk(g_dead_mu);
 	auto it = std::find(g_dead_comms.begin(), g_dead_comms.end(), comm);
 	if (it == g_dead_comms.end()) return false;
-	const bool aborted = g_comm.CommAbort != nullptr;
 	g_dead_comms.erase(it);
-	return aborted;
+	return true;
 }
 
 void comm_destroy(void* comm)
@@ -1366,14 +1431,23 @@ int stochqn_hip_pin_host(void* p, size_t bytes)
 	auto it = g_pins.find(p);
 	if (it != g_pins.end() && it->second.bytes >= bytes) { it->second.refs++; return pin_says(p, bytes, 0, "pinned here already: once more"); }
 	if (it != g_pins.end()) {                                  // the same array, longer now: pinned anew
+		// the verdict on the longer range FIRST (its own shorter span does not count against it): a decline leaves the shorter pin
+		// and every holder's reference where they were -- their later unpin still finds them
+		const size_t old_bytes = it->second.bytes;
+		if (!pinnable_in_place(p, bytes, p)) return pin_says(p, bytes, 1, "declined: malloc heap or shared pages (the shorter pin stays)");
 		if (hipHostUnregister(p) != hipSuccess) (void) hipGetLastError();
-		note_unpinned(p);
-		const int refs = it->second.refs;
-		g_pins.erase(it);
-		if (!pinnable_in_place(p, bytes)) return pin_says(p, bytes, 1, "declined: malloc heap or shared pages");
-		if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); return pin_says(p, bytes, -1, "hipHostRegister failed"); }
-		note_pinned(p, bytes);
-		g_pins[p] = Pin{bytes, refs + 1};
+		if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) {
+			(void) hipGetLastError();
+			note_unpinned(p);
+			// back to what the holders had: the shorter range, if the runtime still takes it
+			if (pinnable_in_place(p, old_bytes) && hipHostRegister(p, old_bytes, hipHostRegisterPortable) == hipSuccess) return pin_says(p, bytes, -1, "hipHostRegister of the longer range failed: the shorter pin is back");
+			(void) hipGetLastError();
+			note_unpinned(p);
+			g_pins.erase(it);
+			return pin_says(p, bytes, -1, "hipHostRegister failed");
+		}
+		it->second.bytes = bytes;
+		it->second.refs++;
 		return pin_says(p, bytes, 0, "pinned anew, longer");
 	}
 	hipPointerAttribute_t a;                                   // ordinary memory: an error (older runtimes) or "unregistered" (ROCm 6+)
@@ -1383,8 +1457,7 @@ int stochqn_hip_pin_host(void* p, size_t bytes)
 	} else (void) hipGetLastError();
 	if (!pinnable_in_place(p, bytes)) return pin_says(p, bytes, 1, "declined: malloc heap or shared pages");                // stays pageable (works, a little slower)
 	const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
-	if (e != hipSuccess) { (void) hipGetLastError(); stat_add(ST_HOST_PIN_ERRORS); return pin_says(p, bytes, -1, hipGetErrorString(e)); }
-	note_pinned(p, bytes);
+	if (e != hipSuccess) { (void) hipGetLastError(); note_unpinned(p); stat_add(ST_HOST_PIN_ERRORS); return pin_says(p, bytes, -1, hipGetErrorString(e)); }
 	g_pins[p] = Pin{bytes, 1};
 	stat_add(ST_HOST_REGISTERED);
 	return pin_says(p, bytes, 0, "pinned");
@@ -1480,6 +1553,8 @@ int stochqn_hip_set_option(const char* name, double value)
 	}
 	else if (!std::strcmp(name, "rows_split")) g_opt.rows_split = value != 0;
 	else if (!std::strcmp(name, "fisher_rows")) g_opt.fisher_rows = (int) value;
+	else if (!std::strcmp(name, "fisher_split")) g_opt.fisher_split = value != 0;
+	else if (!std::strcmp(name, "fisher_split_per_cu")) g_opt.fisher_split_per_cu = value < 0 ? 0 : (value > 8 ? 8 : (int) value);
 	// 0 = off; otherwise at least 64 ticks (640 ns): the kernels multiply 2^32 / ticks by the number of output streams of the pass
 	// (up to 4, adaQN's pass 2) in 32 bits, which a period of 2 or 3 ticks would wrap to a period that never ends
 	else if (!std::strcmp(name, "phase_ticks")) g_opt.phase_ticks = value < 2 ? 0 : (value < 64 ? 64 : (value > 1e8 ? 100000000 : (int) value));

@@ -33,7 +33,11 @@ struct Options {
 	// 1: the three-pass form (S twice, Y once: (3k+5) n words) when the ring has <= kPairsMax3 pairs and every pair in use is
 	// tame ("kappa_max"); 0: always the reference's chain of dependent sweeps (8k n words)
 	bool threepass = true;
-	int fisher_rows = 16;        // Fisher rows per workgroup pass (8, 16, 32)
+	int fisher_rows = 16;        // Fisher rows per workgroup pass (8, 16, 32) of the all-rows-per-lane kernel (fisher_split = 0)
+	// Fisher pass 1 (t = F s) with the rows divided among the 8 waves of a workgroup, which share the columns: s is fetched from
+	// HBM once per 128 rows instead of once per 16 (kernels.hip: k_fisher_t_split; PMC 103.2 GB against 108.8 GB at fu = 128)
+	bool fisher_split = true;
+	int fisher_split_per_cu = 0;
 	int qdot_per_cu = 0, sadd_per_cu = 0, sdot2_per_cu = 0, sdot_per_cu = 0;
 	// three-pass form: fraction of r0 / r stored with the default (cacheable) policy -- the part the next pass, which walks
 	// the other way, reads first; the rest leaves with sc1 nt.  Rounds 2 - 3 (every pack stored at once): 0.25-0.5 measured 1 % ahead
@@ -182,6 +186,7 @@ struct DevCtx {
 	// does not continue from there belongs to a different optimiser object at the same address
 	bool attached = false;             // the reducer was bound and n_global agreed (first call on this context)
 	bool fault = false;                // a launch or the stream reported an error: the call that saw it fails loudly
+	bool wedged = false;               // a collective of this context can never end (peer gone, RCCL without ncclCommAbort): every call fails, no stream of it is waited for again, its memory is abandoned (runtime.cpp: wait_stream)
 	bool has_last = false;
 	size_t last_niter = 0;
 	int last_section = 0;
@@ -212,7 +217,9 @@ void stat_add(int id, long long v = 1);
 // itself for as long as it lives: not one inside the program-break heap (malloc'ed blocks there share their first and last
 // page with neighbours, and the break moves under them when the heap is trimmed), not one whose pages overlap a range that is
 // page-locked already.  Whatever is declined still works: the runtime's pageable path carries it (runtime.cpp).
-bool pinnable_in_place(const void* p, size_t bytes);
+// "Yes" RESERVES the pages in the same critical section (two askers with a page in common cannot both be told yes): who then
+// fails to register gives them back with note_unpinned(p).  own: a range of the asker that the new one replaces.
+bool pinnable_in_place(const void* p, size_t bytes, const void* own = nullptr);
 extern bool g_pin_probe_by_maps;   // tests/hostsim only: look a heap header up through /proc/self/maps even where process_vm_readv works
 void note_pinned(const void* p, size_t bytes);          // bookkeeping of the ranges this library has registered, for the overlap rule
 void note_unpinned(const void* p);

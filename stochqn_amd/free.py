@@ -104,7 +104,8 @@ class _HostSpace:
         n = int(n)
         nbytes = n * np.dtype(self.dtype).itemsize
         if self._lib is not None and nbytes >= self.PIN_MIN_BYTES:
-            return np.frombuffer(mmap.mmap(-1, nbytes), dtype=self.dtype, count=n)      # a mapping of its own, zero-filled by the kernel
+            return np.frombuffer(mmap.mmap(-1, nbytes, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, prot=mmap.PROT_READ | mmap.PROT_WRITE),
+                                 dtype=self.dtype, count=n)      # a PRIVATE anonymous mapping of its own, zero-filled by the kernel (the default of mmap.mmap(-1, ...) is MAP_SHARED: a fork()ed child would share and mutate the parent's optimiser state)
         return np.zeros(n, dtype=self.dtype)
 
     zeros = empty

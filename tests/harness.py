@@ -43,7 +43,7 @@ def own_mapping(a):
     (stochqn_amd/csrc/runtime.cpp: pinnable_in_place)."""
     import mmap
     a = np.ascontiguousarray(a)
-    out = np.frombuffer(mmap.mmap(-1, max(a.nbytes, 1)), dtype=a.dtype, count=a.size).reshape(a.shape)
+    out = np.frombuffer(mmap.mmap(-1, max(a.nbytes, 1), flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, prot=mmap.PROT_READ | mmap.PROT_WRITE), dtype=a.dtype, count=a.size).reshape(a.shape)
     out[...] = a
     return out
 

@@ -2,6 +2,7 @@
 // (TEST INFRASTRUCTURE ONLY; see fake_hip.hpp).  Signatures come from the real <hip/hip_runtime_api.h>, the
 // definitions here take libamdhip64's place at link time in tests/hostsim's sanitizer builds.
 #include "fake_hip.hpp"
+#include <execinfo.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -212,6 +213,12 @@ void drain_all_of(const void* s)
 		{
 			std::lock_guard<std::recursive_mutex> fl(g_flush_mu);
 			if (drain(s, -1)) return;
+		}
+		if (spins == 10000 && std::getenv("FAKE_HIP_TRACE_STUCK")) {         // 2 s without progress: who is waiting? (debugging aid)
+			void* frames[48];
+			const int nf = backtrace(frames, 48);
+			std::fprintf(stderr, "fake_hip: a wait for stream %p has made no progress for 2 s; the waiter:\n", s);
+			backtrace_symbols_fd(frames, nf, 2);
 		}
 		if (spins > 600000) { violation("a stream never finished: an operation on it waited for something that did not come"); return; }
 		std::this_thread::sleep_for(std::chrono::microseconds(200));

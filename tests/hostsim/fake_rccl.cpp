@@ -230,7 +230,11 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
 	return ncclSuccess;
 }
 
-// ends the collectives of this communicator that wait on their streams and releases it (the caller does not destroy it afterwards)
+// ends the collectives of this communicator that wait on their streams and releases it (the caller does not destroy it afterwards).
+// -DFAKE_RCCL_NO_ABORT (libfake_rccl_noabort_*.so): an RCCL that does not export the symbol -- nothing can end a collective then.
+#ifdef FAKE_RCCL_NO_ABORT
+__attribute__((visibility("hidden")))
+#endif
 ncclResult_t ncclCommAbort(ncclComm_t comm)
 {
 	if (!comm) return ncclInvalidArgument;
@@ -245,7 +249,8 @@ ncclResult_t ncclCommAbort(ncclComm_t comm)
 ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* state)
 {
 	if (!comm || !state) return ncclInvalidArgument;
-	*state = ncclSuccess;
+	// reads the communicator, like the real one: on a communicator that ncclCommAbort has released the address sanitizer speaks up
+	*state = comm->aborted.load() ? ncclInternalError : ncclSuccess;
 	return ncclSuccess;
 }
 

@@ -988,10 +988,16 @@ void sc_caller_heap()
 // rank 1 returns -1000 from that call; ranks 0 and 2, which are waiting on their streams for a contribution that will never be
 // posted, give up after reducer_patience_s (runtime.cpp: wait_stream aborts the communicator) and return -1000 FROM THE SAME
 // CALL; every later call of every rank fails at once (the communicator is dead); nobody hangs.
-void sc_model_a_failure()
+// can_abort = false (scenario model_a_no_abort, with libfake_rccl_noabort_*.so): the same story over an RCCL that does not export
+// ncclCommAbort -- nothing can end the collectives that wait.  The waiting ranks must STILL return -1000 from that call after
+// the patience (not synchronise on a stream that can never drain: ADVICE r05), fail every later call at once, and get through
+// stochqn_hip_release_all / stochqn_hip_comm_finalize without hanging: their contexts are abandoned (wedged), nothing of them is
+// freed under the kernels that still wait, the dead communicator is not destroyed.
+void model_a(bool can_abort)
 {
 	void* handle = nullptr;
 	use_fake_rccl(&handle);
+	CHECK((dlsym(handle, "ncclCommAbort") != nullptr) == can_abort, "this scenario wants an RCCL stand-in %s ncclCommAbort", can_abort ? "with" : "WITHOUT");
 	auto shared_bytes = (size_t (*)(void)) dlsym(handle, "fake_rccl_shared_bytes");
 	auto shared_init = (void (*)(void*, int)) dlsym(handle, "fake_rccl_shared_init");
 	auto shared_script = (void (*)(int, int, long)) dlsym(handle, "fake_rccl_shared_script");
@@ -1058,15 +1064,19 @@ void sc_model_a_failure()
 	      "the waiting ranks give up after the patience (1.5 s): %.2f s, %.2f s", res[0].seconds_of_failing_call, res[2].seconds_of_failing_call);
 	munmap(mem, bytes);
 	opt("reducer_patience_s", 120);
-	leak_check("model_a_failure");
+	leak_check(can_abort ? "model_a_failure" : "model_a_no_abort");
 }
+
+void sc_model_a_failure() { model_a(true); }
+void sc_model_a_no_abort() { model_a(false); }
 
 struct Scenario { const char* name; void (*fn)(); };
 const Scenario kScenarios[] = {
 	{"registry", sc_registry}, {"reclaim_resume", sc_reclaim_resume}, {"mirror_cap", sc_mirror_cap}, {"host_path", sc_host_path}, {"xhash", sc_xhash},
 	{"branches", sc_branches}, {"owned_and_raw", sc_owned_and_raw}, {"group_rccl", sc_group_rccl}, {"group_virtual", sc_group_virtual},
 	{"group_alloc_failures", sc_group_alloc_failures}, {"fault_sweep", sc_fault_sweep}, {"fault_sweep_group", sc_fault_sweep_group},
-	{"threads", sc_threads}, {"caller_heap", sc_caller_heap}, {"glibc_heaps", sc_glibc_heaps}, {"model_a_failure", sc_model_a_failure}};
+	{"threads", sc_threads}, {"caller_heap", sc_caller_heap}, {"glibc_heaps", sc_glibc_heaps}, {"model_a_failure", sc_model_a_failure},
+	{"model_a_no_abort", sc_model_a_no_abort}};
 
 }  // namespace
 

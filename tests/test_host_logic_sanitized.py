@@ -13,6 +13,8 @@ caller waited for may legally do):
       one process per GPU over ncclCommInitRank -- three forked ranks, rank-dependent delays, rank 1's 17th all-reduce fails at
       the call: every rank returns -1000 FROM THE SAME CALL (the waiting ones after reducer_patience_s: runtime.cpp wait_stream
       aborts the communicator), every later call fails at once, nobody hangs;
+  model_a_no_abort: the same over an RCCL without ncclCommAbort (libfake_rccl_noabort_*.so): the waiting ranks still return -1000
+      after the patience, every later call fails at once, release / finalize do not hang -- the contexts are abandoned, not freed;
   caller_heap: a caller whose arrays live in a garbage-collected heap (reference src/Rwrapper.c:106-123, stochqn/pywrapper.pxi:
       161-172) -- x, grad and hess_vec are replaced by new arrays between calls, the old ones unpinned, poisoned and kept out of
       circulation; no copy through host memory may be queued on ANY stream when a call returns, none may ever go through a dead
@@ -51,7 +53,8 @@ def built():
     return os.path.join(SIM, "build")
 
 
-CASES = [(sc, st) for sc in SCENARIOS for st in ("immediate", "lazy")] + [(sc, "per_stream") for sc in PER_STREAM] + [("model_a_failure", "per_stream")]
+CASES = ([(sc, st) for sc in SCENARIOS for st in ("immediate", "lazy")] + [(sc, "per_stream") for sc in PER_STREAM]
+         + [("model_a_failure", "per_stream"), ("model_a_no_abort", "per_stream")])
 
 
 @pytest.mark.parametrize("scenario,streams", CASES)
@@ -59,7 +62,10 @@ CASES = [(sc, st) for sc in SCENARIOS for st in ("immediate", "lazy")] + [(sc, "
 def test_host_logic(san, scenario, streams, built):
     if san == "tsan" and scenario == "caller_heap" and streams != "per_stream":
         pytest.skip("caller_heap is single-threaded: under TSan (40 s a run) it runs with the stream model it was written for only")
-    env = dict(os.environ, STOCHQN_HIP_RCCL_LIB=os.path.join(built, "libfake_rccl_%s.so" % san),
+    # model_a_no_abort: an RCCL that does not export ncclCommAbort (round 6, ADVICE r05: the bounded wait must fail the call, not
+    # synchronise on a stream that can never drain)
+    rccl = "libfake_rccl_noabort_%s.so" if scenario == "model_a_no_abort" else "libfake_rccl_%s.so"
+    env = dict(os.environ, STOCHQN_HIP_RCCL_LIB=os.path.join(built, rccl % san),
                ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
                TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
     cmd = [os.path.join(built, "host_logic_%s" % san), scenario] + ([streams] if streams != "immediate" else [])
