@@ -61,9 +61,13 @@ DEFAULT_BUDGET_S = 420.0
 RESERVE_S = 6.0                # printing the line, tearing the communicators down, leaving
 # Seconds each auxiliary leg took on one MI355X box (profiles/r06_bench_leg_seconds.json: the `budget.leg_seconds` of
 # default runs at N = 1 and of the 3-rank rehearsal), rounded up by a third.  A leg is admitted when this much is left.
-LEG_COST_S = {"profile": 4.0, "value_runs": 4.0, "sustained": 10.0, "reference_form": 4.0, "two_loop_micro": 4.0,
-              "host_copies": 12.0, "host_caller": 30.0, "cpu_baseline": 40.0, "live_pmc": 60.0,
-              "c5": 20.0, "strong": 12.0, "allreduce_us": 3.0, "in_process": 90.0, "c5_yardstick": 45.0}
+LEG_COST_S = {"profile": 2.0, "value_runs": 6.0, "sustained": 10.0, "reference_form": 2.0, "two_loop_micro": 2.0,
+              "host_copies": 6.0, "host_caller": 45.0, "cpu_baseline": 60.0, "live_pmc": 10.0,
+              "c5": 6.0, "strong": 4.0, "allreduce_us": 2.0, "in_process": 40.0, "c5_yardstick": 15.0}
+# (measured, round 6, gpurun_out/r06/s2_*: N = 1 default run: profile 0.4, value_runs 4.3, sustained 6.0, reference_form 0.3,
+#  two_loop_micro 0.7, host_copies 4.0, host_caller 32.5, live_pmc 5.2 s; cpu_baseline 92 s with the thread team packed on two
+#  core complexes -- it now probes the placement and sizes itself to the budget; 3-rank rehearsal at n / 50: c5 0.4, strong 0.3,
+#  all-reduce 0.1, in_process 5.6, yardstick 1.5 s, which scale to what is written above at full size.)
 
 
 class Budget:
@@ -932,7 +936,7 @@ def run(args):
             if want_cpu:
                 stage.update(name="cpu_baseline", since=time.time())
                 with on_the_clock("cpu_baseline"):
-                    cpu = cpu_baseline(args, gpu, hostc, n, m, L, bs, wl.step_size)
+                    cpu = cpu_baseline(args, gpu, hostc, n, m, L, bs, wl.step_size, budget)
             if want_host and admitted("host_caller", collective=False):
                 with on_the_clock("host_caller"):
                     host_leg = host_caller_leg(args, lib, be, hostc, gpu, n, m, L, wl.step_size, two_loop, budget)
@@ -1811,7 +1815,7 @@ def host_caller_leg(args, lib, be, hostc, gpu, n, m, L, step_size, two_loop, bud
     return res
 
 
-def cpu_baseline(args, gpu, hostc, n, m, L, bs, step_size):
+def cpu_baseline(args, gpu, hostc, n, m, L, bs, step_size, budget=None):
     """The same SQN workload (same inputs, copied from the GPU; Hessian-vector product A'(Av)/bs through
     oracle_fisher_product) on the CPU oracle (kind 'port'), at n itself when host memory allows.  Timed:
     the seconds spent inside the oracle (run_SQN + the Hessian-vector product), not the caller's gradient.
@@ -1831,8 +1835,25 @@ def cpu_baseline(args, gpu, hostc, n, m, L, bs, step_size):
     S, Y, A, d = hostc.S, hostc.Y, hostc.A, hostc.d
     t_copy = hostc.seconds
     oracle.set_threads(threads)
-    # the team stays where it is put (0.56 vs 1.42 steps/s on the same CPU model with floating threads)
-    bound = olib.oracle_bind_threads() if hasattr(olib, "oracle_bind_threads") else 0
+    # the team stays where it is put (0.56 vs 1.42 steps/s on the same CPU model with floating threads) -- and
+    # WHERE decides as much: 16 CPUs' worth of quota over 256 allowed CPUs, packed on the first 16 (two core complexes) streamed
+    # 0.59 steps/s, 2.33 on another box of the same model (round 5 / round 6 default runs).  Both placements are probed with one
+    # dot product over two rows of S (1.6 GB at n = 1e8) and the faster one is kept; the probe's rates are in the line.
+    bound, placement = 0, None
+    if hasattr(olib, "oracle_bind_threads_how") and hasattr(olib, "oracle_probe_dot_GBps"):
+        olib.oracle_bind_threads_how.argtypes = [C.c_int]
+        olib.oracle_probe_dot_GBps.restype = C.c_double
+        olib.oracle_probe_dot_GBps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rates = {}
+        for how, name in ((0, "packed"), (1, "spread")):
+            olib.oracle_bind_threads_how(how)
+            rates[name] = round(olib.oracle_probe_dot_GBps(S.ctypes.data, S.ctypes.data + 8 * nc, nc, 3), 1)
+        best = max(rates, key=rates.get)
+        bound = olib.oracle_bind_threads_how(1 if best == "spread" else 0)
+        placement = {"chosen": best, "probe_dot_GBps": rates,
+                     "how": "packed: thread t on the t-th allowed CPU; spread: on allowed CPU t * (allowed / threads)"}
+    elif hasattr(olib, "oracle_bind_threads"):
+        bound = olib.oracle_bind_threads()
 
     def team_array(src=None):
         """An n-vector whose pages are first touched by the thread team that will stream it (static schedule, like every
@@ -1861,6 +1882,7 @@ def cpu_baseline(args, gpu, hostc, n, m, L, bs, step_size):
 
     clock = {"lib": 0.0}
     tstep = [0]
+    room = lambda seconds: budget is None or budget.left() >= seconds      # is there this much of the command's budget left?
 
     def one_step():
         # one iteration INCLUDING the pair-building calls it triggers (they follow the niter increment), so
@@ -1887,59 +1909,70 @@ def cpu_baseline(args, gpu, hostc, n, m, L, bs, step_size):
 
     # niter starts at L.  All cores: three whole cycles (the first also warms the caches and the page tables up);
     # one thread: the first ordinary step and the pair-building step of a fourth cycle, the steps between them on all cores.
-    cycles = [timed(L) for _ in range(3)]
-    oracle.set_threads(1)
-    t1_ord = timed(1)
-    oracle.set_threads(threads)
-    timed(L - 2)
-    oracle.set_threads(1)
-    t1_pair = timed(1)
-    oracle.set_threads(threads)
-    cycle_1t = (L - 1) * t1_ord + t1_pair
+    # The budget of the command decides how much of that is done: one cycle always; the second and third, the one-thread steps
+    # (a pair-building step on one thread takes as long as a whole cycle on all) and the BLAS cycles only while there is room.
+    cycles = [timed(L)]
+    while len(cycles) < 3 and room(1.5 * cycles[-1] + 5.0):
+        cycles.append(timed(L))
+    t1_ord = t1_pair = cycle_1t = None
+    if room(4.0 * cycles[-1] + 5.0):
+        oracle.set_threads(1)
+        t1_ord = timed(1)
+        oracle.set_threads(threads)
+        timed(L - 2)
+        oracle.set_threads(1)
+        t1_pair = timed(1)
+        oracle.set_threads(threads)
+        cycle_1t = (L - 1) * t1_ord + t1_pair
     scale = nc / 1e8
-    c_min, c_med = min(cycles), sorted(cycles)[1]
+    c_min, c_med = min(cycles), sorted(cycles)[len(cycles) // 2]
     out = {"value": round(L / c_med * scale, 4), "unit": "steps/s at n=1e8" + ("" if nc == 100_000_000 else " (measured at n=%g, scaled by n/1e8)" % nc),
            "cores": threads, "kind": "port",
            "value_allcores": round(L / c_med * scale, 4), "value_allcores_best": round(L / c_min * scale, 4),
-           "value_1thread": round(L / cycle_1t * scale, 4),
+           "value_1thread": None if cycle_1t is None else round(L / cycle_1t * scale, 4),
            "n_measured": nc, "cpu_model": model, "nproc": os.cpu_count(), "cgroup_cpu_max": quota,
            "host_mem_available_GB": None if avail is None else round(avail / 1e9, 1),
            "allcores_cycles_s": [round(c, 3) for c in cycles], "allcores_cycle_s": round(c_med, 3),
-           "one_thread_ordinary_step_s": round(t1_ord, 3), "one_thread_pair_step_s": round(t1_pair, 3),
-           "omp": {"threads_pinned": bound, "how": "thread t of the team on the t-th allowed CPU (sched_setaffinity, oracle_bind_threads)",
+           "one_thread_ordinary_step_s": None if t1_ord is None else round(t1_ord, 3), "one_thread_pair_step_s": None if t1_pair is None else round(t1_pair, 3),
+           "omp": {"threads_pinned": bound, "how": "every thread of the team on a CPU of its own (sched_setaffinity, oracle_bind_threads_how)", "placement": placement,
                    "first_touch": "thread team" if hasattr(olib, "oracle_first_touch") else "one thread"},
            "build": flags,
            "sample": "oracle/stochqn_oracle.c (CPU restatement of the reference; " + flags + "; own BLAS-1 loops, no BLAS library), "
                      "SQN m=%d L=%d bsize=%d at n=%g, the GPU leg's own inputs copied to the host (%.1f s); seconds inside "
                      "run_SQN + the Hessian-vector product A'(Av)/%d (oracle_fisher_product), caller's gradient excluded. "
-                     "All usable cores (%d threads, pinned): three whole L-cycles of %d steps incl. one pair each (%s s; value = median, "
-                     "value_allcores_best = minimum). One thread: one ordinary step (%.2f s) and one pair-building step (%.2f s), "
-                     "composed into a cycle."
-                     % (m, L, bs, nc, t_copy, bs, threads, L, " / ".join("%.2f" % c for c in cycles), t1_ord, t1_pair)}
+                     "All usable cores (%d threads, pinned): %d whole L-cycle(s) of %d steps incl. one pair each (%s s; value = median, "
+                     "value_allcores_best = minimum; three when the command's budget has room). One thread: %s"
+                     % (m, L, bs, nc, t_copy, bs, threads, len(cycles), L, " / ".join("%.2f" % c for c in cycles),
+                        "skipped (no room in the budget)" if t1_ord is None else
+                        "one ordinary step (%.2f s) and one pair-building step (%.2f s), composed into a cycle." % (t1_ord, t1_pair))}
     # ---- the same cycles with the reference's kind of BLAS behind the same restatement (north_star: "src/stochqn.c + BLAS";
     # reference src/stochqn.c:676-706, 946-949 call cblas_ddot / daxpy / dscal / dnrm2 / dgemv of whatever CBLAS they were linked
     # with): the OpenBLAS that scipy / numpy bundle on this box, all usable cores.  Both numbers are reported; `value` stays the
     # own-loops port (kind "port"), whose threads are pinned and whose pages were first touched by the team that streams them.
     out["blas"] = None
     try:
-        info = oracle.find_openblas()
-        if info is None:
+        blas_info = oracle.find_openblas()
+        if blas_info is None:
             out["blas"] = {"error": "no OpenBLAS with a CBLAS interface found on this box (scipy.libs / numpy.libs / libopenblas.so)"}
+        elif not room(4.0 * cycles[-1] + 5.0):
+            out["blas"] = {"skipped": "no room left in the command's budget (a cycle of the port took %.1f s)" % cycles[-1]}
         else:
             if hasattr(olib, "oracle_unbind_threads"):
                 olib.oracle_unbind_threads()          # the BLAS runs its own thread pool: the calling thread gets its full mask back first
-            got = oracle.use_cblas(info, threads=threads)
+            got = oracle.use_cblas(blas_info, threads=threads)
             if got is None:
-                out["blas"] = {"error": "the CBLAS entry points of %s could not be resolved" % info["path"]}
+                out["blas"] = {"error": "the CBLAS entry points of %s could not be resolved" % blas_info["path"]}
             else:
-                bc = [timed(L) for _ in range(3)]
-                b_min, b_med = min(bc), sorted(bc)[1]
+                bc = [timed(L)]
+                while len(bc) < 3 and room(1.5 * bc[-1] + 5.0):
+                    bc.append(timed(L))
+                b_min, b_med = min(bc), sorted(bc)[len(bc) // 2]
                 out["blas"] = {"value": round(L / b_med * scale, 4), "value_best": round(L / b_min * scale, 4), "unit": out["unit"], "kind": "openblas",
                                "cores": got["threads"] or threads, "library": got["library"], "config": got["config"], "ilp64": got["ilp64"],
                                "cycles_s": [round(c, 3) for c in bc],
                                "what": "the same oracle with v_dot / v_axpy / v_scal / v_nrm2 and the two gemv of the Hessian-vector product routed "
-                                       "through this library's cblas_ddot / daxpy / dscal / dnrm2 / dgemv (oracle_use_cblas): three whole L-cycles, "
-                                       "median; the library's own thread pool, not pinned"}
+                                       "through this library's cblas_ddot / daxpy / dscal / dnrm2 / dgemv (oracle_use_cblas): up to three whole "
+                                       "L-cycles, median; the library's own thread pool, not pinned"}
     except Exception as e:                                   # a baseline beside the baseline: it never costs the line
         out["blas"] = {"error": "%s: %s" % (type(e).__name__, e)}
     finally:

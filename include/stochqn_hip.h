@@ -179,6 +179,7 @@ int stochqn_hip_unpin_host(void *p);
  * "fisher_split" (default 1) Fisher pass 1 (t = F s) with the rows divided among the waves of a workgroup: s is read once per
  *                            128 rows; 0 = every lane accumulates "fisher_rows" rows (s re-read once per group)
  * "fisher_split_per_cu" (default 0 = as many as fit, at most 4) workgroups per CU of that kernel
+ * "fisher_lag" (default 8)   its waves meet at a workgroup barrier every this many column tiles (0 = never)
  * "fisher_rows" (default 16) with "fisher_split" = 0: Fisher rows one workgroup accumulates per pass (8, 16, 32)
  * "verify_cache" (default 0) see "contract for callers that pass DEVICE pointers"
  * "raw_reuse_cache" (default 0)  stochqn_hip_two_loop / _take_step keep cached inner products between calls

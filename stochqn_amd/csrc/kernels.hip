@@ -778,13 +778,12 @@ __global__ void __launch_bounds__(kBlock) k_fisher_t(const real* F, size_t ld_, 
 // fetched from HBM once per 128 rows (NW = 8, RPW = 16): the first wave to ask misses, the other seven hit in the CU's L1 or the
 // XCD's L2.  k_fisher_t above re-reads s once per group of 16 rows: at fu = 128 eight times, PMC 108.78 GB against 103.2 GB
 // algorithmic.  A lane carries only RPW accumulators and RPW row packs in flight; the waves are kept within
-// kFisherLag column tiles of each other by a workgroup barrier (the trip count depends on blockIdx.x only, so every wave
+// `lag` column tiles of each other (option "fisher_lag", default 8) by a workgroup barrier (the trip count depends on blockIdx.x only, so every wave
 // reaches every barrier), which bounds how long a line of s has to survive in L2.  Same row-major gemv as reference
 // src/stochqn.c:946 (t = F s), another association of the sums than k_fisher_t (lanes own other columns): parity is held
 // against the oracle at north_star's tolerance, not against the other kernel's bits.
-constexpr int kFisherLag = 8;
 template <int W, int RPW, bool NT, int NW>
-__global__ void __launch_bounds__(64 * NW) k_fisher_t_split(const real* F, size_t ld_, uint32_t n, uint32_t fu, const real* s, double* parts)
+__global__ void __launch_bounds__(64 * NW) k_fisher_t_split(const real* F, size_t ld_, uint32_t n, uint32_t fu, const real* s, double* parts, uint32_t lag)
 {
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const uint32_t row0 = blockIdx.y * (uint32_t) (NW * RPW) + (uint32_t) (wave * RPW);
@@ -810,7 +809,7 @@ __global__ void __launch_bounds__(64 * NW) k_fisher_t_split(const real* F, size_
 					for (int e = 0; e < W; e++) acc[j] = fma((double) f[j].v[e], sv.v[e], acc[j]);
 				}
 		}
-		if ((it % kFisherLag) == kFisherLag - 1) __syncthreads();
+		if (lag && (it % lag) == lag - 1) __syncthreads();
 	}
 	if (W > 1) {
 		const uint32_t i = packs * W + (uint32_t) lane;                    // tail elements (n not a multiple of W)
@@ -1622,7 +1621,7 @@ static int fisher_split_launch(const Scratch& sc, size_t n, const real* F, size_
 	if (g > (size_t) kMaxGrid) g = kMaxGrid;
 	if (g < 1) g = 1;
 	const dim3 grid((unsigned) g, (unsigned) ((fu + (size_t) (NW * RPW) - 1) / (size_t) (NW * RPW)));
-	hipLaunchKernelGGL((k_fisher_t_split<W, RPW, true, NW>), grid, dim3(64 * NW), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part);
+	hipLaunchKernelGGL((k_fisher_t_split<W, RPW, true, NW>), grid, dim3(64 * NW), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part, (uint32_t) (sc.fisher_lag < 0 ? 0 : sc.fisher_lag));
 	return (int) g;
 }
 

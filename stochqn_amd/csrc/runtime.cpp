@@ -513,6 +513,7 @@ void begin_call(DevCtx* c)
 	c->sc.fisher_rows = g_opt.fisher_rows;
 	c->sc.fisher_split = g_opt.fisher_split;
 	c->sc.fisher_split_per_cu = g_opt.fisher_split_per_cu;
+	c->sc.fisher_lag = g_opt.fisher_lag;
 	c->sc.phase_inv = g_opt.phase_ticks > 0 ? (uint32_t) (4294967296.0 / (double) g_opt.phase_ticks) : 0u;
 	c->sc.keep_tail = g_opt.keep_tail;
 	c->sc.qdot_per_cu = g_opt.qdot_per_cu; c->sc.sadd_per_cu = g_opt.sadd_per_cu; c->sc.sdot2_per_cu = g_opt.sdot2_per_cu; c->sc.sdot_per_cu = g_opt.sdot_per_cu;
@@ -1554,6 +1555,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "rows_split")) g_opt.rows_split = value != 0;
 	else if (!std::strcmp(name, "fisher_rows")) g_opt.fisher_rows = (int) value;
 	else if (!std::strcmp(name, "fisher_split")) g_opt.fisher_split = value != 0;
+	else if (!std::strcmp(name, "fisher_lag")) g_opt.fisher_lag = value < 0 ? 0 : (value > 1e6 ? 1000000 : (int) value);
 	else if (!std::strcmp(name, "fisher_split_per_cu")) g_opt.fisher_split_per_cu = value < 0 ? 0 : (value > 8 ? 8 : (int) value);
 	// 0 = off; otherwise at least 64 ticks (640 ns): the kernels multiply 2^32 / ticks by the number of output streams of the pass
 	// (up to 4, adaQN's pass 2) in 32 bits, which a period of 2 or 3 ticks would wrap to a period that never ends

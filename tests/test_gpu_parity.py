@@ -124,10 +124,17 @@ CONFIGS = [
 ]
 
 
-# Free-running trajectories whose two-loop is ill-conditioned (rank-deficient Fisher pairs) amplify
-# last-bit differences by up to 10x per call (measured: 1e-16 per call -> 7e-9 after 45 calls); the
-# per-call bar of 1e-10 is enforced for them by the lock-step test below.
-FREE_RUN_TOL = {"adaqn_fisher_adagrad_nomaxincr": 1e-7, "adaqn_ring25": 1e-7, "adaqn_ring20": 1e-7}
+# Free-running trajectories that amplify last-bit differences: the bar is what TWO LEGAL EVALUATIONS OF THE REFERENCE'S OWN
+# ARITHMETIC keep between them, measured on the CPU with the kernels out of the question (round 6):
+# profiles/r06_oracle_vs_oracle_sensitivity.json is the oracle against itself with nothing changed but the order in which its
+# dot products are summed (8 / 4 / 1 interleaved partial sums, OpenBLAS: every one an order a BLAS may choose), same
+# configurations, same sizes; profiles/r06_free_run_device_vs_oracle.json is the library on an MI355X against the oracle.
+#   adaqn_fisher_adagrad_nomaxincr  oracle vs oracle up to 1.0e-7 (n = 70001; 7.8e-9 at n = 4097), device vs oracle 5.9e-8 / 4.3e-9
+#   adaqn_ring20                    oracle vs oracle up to 2.1e-10 (n = 4097), device vs oracle 2.4e-10: held to 2e-9 (was 1e-7)
+#   adaqn_ring25                    oracle vs oracle 1.6e-12, device vs oracle 9.2e-13: held to 1e-10 like everything else (was 1e-7)
+# -- the device sits where any other summation order sits, configuration by configuration and size by size; the per-call bar
+# of 1e-10 is enforced for all of them by the lock-step test below.  tests/test_oracle_sensitivity.py keeps this table honest.
+FREE_RUN_TOL = {"adaqn_fisher_adagrad_nomaxincr": 1e-7, "adaqn_ring20": 2e-9}
 
 
 def both_traces(cfg, n, space, hip_backend, oracle_backend):
@@ -2000,6 +2007,48 @@ def test_bench_keeps_its_primary_result_when_an_auxiliary_leg_hangs():
     strict = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rehearse", "--strict-legs"] + short, capture_output=True,
                             text=True, timeout=600, cwd=root, env=env)
     assert strict.returncode != 0 and not [l for l in strict.stdout.splitlines() if l.startswith('{"metric"')], strict.stdout[-1000:]
+
+
+def test_bench_prints_its_one_line_inside_its_budget_and_names_what_it_left_out():
+    """ONE wall-clock budget for the whole command (BENCH_BUDGET_S, started at process entry and handed on to every
+    child process): an auxiliary leg runs only if its measured cost still fits, and whatever happens the line is printed no later
+    than the budget.  (a) 45 s for the 3-rank rehearsal of the driver's N > 1 command: the in-process child (cost on file: 40 s
+    ... at full size, more than what is left) is skipped and NAMED, every leg that fits still runs, one line, on time.
+    (b) a leg that hangs while the per-leg watchdog is far away (300 s): the budget itself cuts the run off -- the line comes at the
+    deadline with the primary result, `degraded`, and the leg that was running named in `legs_skipped`."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_DEADLINE_EPOCH")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rehearse"], capture_output=True, text=True,
+                         timeout=600, cwd=root, env=dict(env, BENCH_BUDGET_S="45"))
+    took = time.time() - t0
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert took < 45 + 15, took
+    assert d["n_gpus"] == 3 and d["value"] > 0 and d["roofline"] is not None
+    assert "in_process" in d["legs_skipped"] and d["legs_failed"] == []
+    sk = {s["leg"]: s for s in d["budget"]["skipped"]}
+    assert sk["in_process"]["needs_s"] > sk["in_process"]["left_s"] and d["budget"]["deadline_inherited"] is True
+    assert {"c5", "strong", "allreduce_us"} <= set(d["legs"]) and "in_process" not in d["legs"]      # what fits still runs
+    assert d["budget"]["leg_seconds"]["c5"] > 0 and d["budget"]["used_s"] <= 45
+    # (b) the budget runs out under a leg that never comes back
+    short = ["--steps", "20", "--warmup", "2", "--sustain-seconds", "0", "--value-runs", "1", "--no-reference-form"]
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rehearse"] + short, capture_output=True, text=True,
+                         timeout=600, cwd=root, env=dict(env, BENCH_BUDGET_S="45", BENCH_TEST_HANG_LEG="strong", BENCH_WATCHDOG_S="300"))
+    took = time.time() - t0
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert 30 < took < 45 + 15, took
+    assert d["value"] > 0 and d["degraded"] is True and any("budget" in w for w in d["degraded_because"])
+    assert "strong" in d["legs_skipped"] and "c5" in d["legs"] and "strong" not in d["legs"]
 
 
 def _host_memory_available():
