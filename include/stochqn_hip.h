@@ -95,6 +95,17 @@ int stochqn_hip_export(const void *s_mem);
  * stays pageable), -1 = refused (not host memory, no device).  unpin: 0, or -1 when the range was not pinned here. */
 int stochqn_hip_pin_host(void *p, size_t bytes);
 int stochqn_hip_unpin_host(void *p);
+/* The one supported way for a caller that does NOT control its allocator (an R .Call shim, a numpy caller, a C program on
+ * jemalloc / tcmalloc) to get arrays that the rule above will always pin: `bytes` of zero-filled host memory in a private
+ * anonymous mapping of its own (mmap: page-aligned, its pages shared with nothing, unmapped as a whole), page-locked for the
+ * device through stochqn_hip_pin_host.  Use it for x, grad, hess_vec and the workspace vectors the caller reads requests from
+ * (reference src/Rwrapper.c:106-123 takes them from R vectors, stochqn/pywrapper.pxi:161-172 from numpy arrays: wrap the
+ * pointer -- an ALTREP / external-pointer vector in R, np.frombuffer / np.ctypeslib.as_array in Python -- INTEGRATION.md).
+ * Returns NULL when the mapping cannot be had; when only the pin is declined or fails (no device) the memory is still returned,
+ * pageable, and *pinned (nullable) says 0.  free: unpins and unmaps; `bytes` as given to alloc.  Returns 0, or -1 for a pointer
+ * that did not come from stochqn_hip_alloc_host. */
+void *stochqn_hip_alloc_host(size_t bytes, int *pinned);
+int stochqn_hip_free_host(void *p, size_t bytes);
 
 /* ---- options -------------------------------------------------------------------------------------
  * "nontemporal" (default 1)  stream pair / Fisher rows with non-temporal loads
@@ -106,7 +117,7 @@ int stochqn_hip_unpin_host(void *p);
  *                            used for m > 48 and for ill-conditioned pairs, "kappa_max").  (Round 1's two-pass form -- [S;Y]g,
  *                            a recursion over Gram blocks, one combine pass: (4m+3)n words -- was retired in round 4 together
  *                            with its options: the three-pass form dominated it on bytes, time and accuracy.)
- * "rows_split", "sdot_per_cu", "sdot2_per_cu", "qdot_per_cu", "sadd_per_cu": kernel-shape knobs (rows of pass 1 split over the
+ * "rows_split", "sdot_per_cu", "sdot2_per_cu", "qdot_per_cu", "sadd_per_cu", "pair_per_cu": kernel-shape knobs (rows of pass 1 split over the
  *                            waves of a workgroup; grid sizes in workgroups per compute unit); the defaults are the measured
  *                            optima, DESIGN.md 3.0.  With "phase_ticks" on, passes 2 and 3 (and the second Fisher pass) hold
  *                            ~150 KB of LDS per workgroup, so ONE workgroup is resident per compute unit whatever these say:

@@ -1565,7 +1565,7 @@ void launch_apply(const Scratch& sc, size_t n, double n_global, Partials guard, 
 void launch_pair_s(const Scratch& sc, size_t n, real* x_sum, double inv_L, bool scale, const real* x_avg_prev,
                    real* s_out)
 {
-	const int grid = sweep_grid(sc, n);
+	const int grid = sweep_grid(sc, n, sc.pair_per_cu > 0 ? sc.pair_per_cu : 1);
 	const bool vec = all_aligned(x_sum, x_avg_prev, s_out);
 	run_sweep<0>(sc, K_PAIR_S, n, vec, PairSOp{x_sum, inv_L, scale, x_avg_prev, s_out}, nullptr, grid);
 }
@@ -1573,7 +1573,7 @@ void launch_pair_s(const Scratch& sc, size_t n, real* x_sum, double inv_L, bool 
 Partials launch_pair_y_diff(const Scratch& sc, int buf, size_t n, const real* g, const real* g_prev,
                             const real* s, double lambda, real* y_out, const VerdictArgs* verdict)
 {
-	const int grid = sweep_grid(sc, n);
+	const int grid = sweep_grid(sc, n, sc.pair_per_cu > 0 ? sc.pair_per_cu : 1);
 	const bool vec = all_aligned(g, g_prev, s, y_out);
 	if (verdict && !sc.allreduce && sc.ticket) {               // the last workgroup takes the verdict: no second launch
 		run_sweep_verdict(sc, K_PAIR_Y_DIFF, n, vec, PairYDiffOp{g, g_prev, s, lambda, y_out}, sc.part[buf], grid, *verdict);
@@ -1586,7 +1586,7 @@ Partials launch_pair_y_diff(const Scratch& sc, int buf, size_t n, const real* g,
 Partials launch_pair_y_hv(const Scratch& sc, int buf, size_t n, const real* hv, const real* s, real* y_out,
                           real* x_sum, real* x_avg_prev, const VerdictArgs* verdict)
 {
-	const int grid = sweep_grid(sc, n);
+	const int grid = sweep_grid(sc, n, sc.pair_per_cu > 0 ? sc.pair_per_cu : 1);
 	const bool vec = all_aligned(hv, s, y_out, x_sum, x_avg_prev);
 	if (verdict && !sc.allreduce && sc.ticket) {
 		run_sweep_verdict(sc, K_PAIR_Y_HV, n, vec, PairYHvOp{hv, s, y_out, x_sum, x_avg_prev}, sc.part[buf], grid, *verdict);

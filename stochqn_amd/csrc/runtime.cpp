@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <sys/mman.h>
 #include <sys/uio.h>
 #include <unistd.h>
 #include <cerrno>
@@ -517,6 +518,7 @@ void begin_call(DevCtx* c)
 	c->sc.phase_inv = g_opt.phase_ticks > 0 ? (uint32_t) (4294967296.0 / (double) g_opt.phase_ticks) : 0u;
 	c->sc.keep_tail = g_opt.keep_tail;
 	c->sc.qdot_per_cu = g_opt.qdot_per_cu; c->sc.sadd_per_cu = g_opt.sadd_per_cu; c->sc.sdot2_per_cu = g_opt.sdot2_per_cu; c->sc.sdot_per_cu = g_opt.sdot_per_cu;
+	c->sc.pair_per_cu = g_opt.pair_per_cu;
 	c->sc.prof = g_profile ? &c->prof : nullptr;
 	c->sc.phase = &c->phase;
 	c->phase = 1;
@@ -1491,6 +1493,43 @@ int stochqn_hip_unpin_host(void* p)
 	return 0;
 }
 
+// ---- host arrays the library hands out: a mapping of their own, pinned (include/stochqn_hip.h) ----------------------------
+namespace {
+std::mutex g_host_alloc_mu;
+std::unordered_map<const void*, size_t> g_host_allocs;      // what stochqn_hip_alloc_host gave out -> bytes mapped
+}
+
+void* stochqn_hip_alloc_host(size_t bytes, int* pinned)
+{
+	if (pinned) *pinned = 0;
+	if (bytes == 0) return nullptr;
+	const size_t mapped = (bytes + 4095) & ~(size_t) 4095;
+	void* p = mmap(nullptr, mapped, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+	if (p == MAP_FAILED) return nullptr;
+	{
+		std::lock_guard<std::mutex> lk(g_host_alloc_mu);
+		g_host_allocs[p] = mapped;
+	}
+	const int rc = stochqn_hip_pin_host(p, mapped);          // 0 pinned; 1 declined / foreign; -1 no device: the memory works either way
+	if (pinned) *pinned = rc == 0;
+	return p;
+}
+
+int stochqn_hip_free_host(void* p, size_t bytes)
+{
+	(void) bytes;                                            // the mapped size is on the books
+	size_t mapped = 0;
+	{
+		std::lock_guard<std::mutex> lk(g_host_alloc_mu);
+		auto it = g_host_allocs.find(p);
+		if (it == g_host_allocs.end()) return -1;
+		mapped = it->second;
+		g_host_allocs.erase(it);
+	}
+	(void) stochqn_hip_unpin_host(p);                        // -1 when the pin was declined: nothing to undo
+	return munmap(p, mapped) == 0 ? 0 : -1;
+}
+
 void stochqn_hip_invalidate(const void* s_mem)
 {
 	if (group_invalidate(s_mem)) return;
@@ -1564,6 +1603,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "x_prefetch")) g_opt.x_prefetch = value != 0;
 	else if (!std::strcmp(name, "keep_tail")) g_opt.keep_tail = value < 0 ? 0 : (value > 1 ? 1 : value);
 	else if (!std::strcmp(name, "qdot_per_cu")) g_opt.qdot_per_cu = (int) value;
+	else if (!std::strcmp(name, "pair_per_cu")) g_opt.pair_per_cu = value < 0 ? 0 : (value > 8 ? 8 : (int) value);
 	else if (!std::strcmp(name, "sadd_per_cu")) g_opt.sadd_per_cu = (int) value;
 	else if (!std::strcmp(name, "sdot2_per_cu")) g_opt.sdot2_per_cu = (int) value;
 	else if (!std::strcmp(name, "sdot_per_cu")) g_opt.sdot_per_cu = (int) value;

@@ -40,6 +40,7 @@ struct Options {
 	int fisher_split_per_cu = 0;
 	int fisher_lag = 8;          // the waves of such a workgroup meet at a barrier every this many column tiles (0 = never): how long a line of s must survive in L2
 	int qdot_per_cu = 0, sadd_per_cu = 0, sdot2_per_cu = 0, sdot_per_cu = 0;
+	int pair_per_cu = 0;         // workgroups per CU of the pair kernels (0 = 1)
 	// three-pass form: fraction of r0 / r stored with the default (cacheable) policy -- the part the next pass, which walks
 	// the other way, reads first; the rest leaves with sc1 nt.  Rounds 2 - 3 (every pack stored at once): 0.25-0.5 measured 1 % ahead
 	// of 0 and of 1 (profiles/r03_ab_fold_tail.jsonl).  With the clock-phased stores a write-back store is a store out of phase:

@@ -109,6 +109,7 @@ struct Scratch {
 	int fisher_split_per_cu; // workgroups per CU of that kernel (0 = what the occupancy query says, at most 4)
 	int fisher_lag;       // column tiles the waves of such a workgroup may drift apart before a barrier brings them together (0 = no barrier)
 	int qdot_per_cu, sadd_per_cu, sdot2_per_cu, sdot_per_cu;   // workgroups per CU of the three-pass kernels (0 = default)
+	int pair_per_cu;      // workgroups per CU of the pair kernels (s, y = g - g_prev, y = Hv; 0 = default: 1)
 	double keep_tail;     // three-pass form: fraction of r0 / r (the part written last) stored with the default policy instead of sc1 nt
 	uint32_t phase_inv;   // pass 2 / pass 3: 2^32 / (ticks of the 100 MHz clock per store phase), 0 = every pack stored at once (kernels.hip: Parked)
 	bool nontemporal;     // stream S/Y/F rows with nt loads

@@ -107,6 +107,31 @@ def test_no_gpu_means_loud_failure_not_fallback(capfd):
     assert lib.stochqn_hip_two_loop(g.ctypes.data, 4, None, 0.0, g.ctypes.data, g.ctypes.data, 1, 1, 0, None, None) == -1000
 
 
+def test_host_arrays_from_the_library_work_without_a_device_too():
+    """stochqn_hip_alloc_host / _free_host (include/stochqn_hip.h): a private anonymous mapping of its own, zero-filled, pinned when a
+    device is there -- and plain pageable memory when none is (this container): the pointer is usable either way."""
+    lib = stochqn_amd.cdll()
+    lib.stochqn_hip_alloc_host.restype = C.c_void_p
+    lib.stochqn_hip_alloc_host.argtypes = [C.c_size_t, C.POINTER(C.c_int)]
+    lib.stochqn_hip_free_host.argtypes = [C.c_void_p, C.c_size_t]
+    pinned = C.c_int(-7)
+    n = 100_003
+    p = lib.stochqn_hip_alloc_host(8 * n, C.byref(pinned))
+    assert p and p % 4096 == 0 and pinned.value in (0, 1)
+    if lib.stochqn_hip_available() != 1:
+        assert pinned.value == 0
+    a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), (n,))
+    assert not a.any()
+    a[:] = np.arange(n)
+    assert a[-1] == n - 1
+    del a
+    assert lib.stochqn_hip_free_host(p, 8 * n) == 0
+    assert lib.stochqn_hip_free_host(p, 8 * n) == -1                     # not (any longer) one of the library's
+    assert lib.stochqn_hip_alloc_host(0, None) is None
+    q = lib.stochqn_hip_alloc_host(4096, None)                            # `pinned` is optional
+    assert q and lib.stochqn_hip_free_host(q, 4096) == 0
+
+
 def test_product_package_never_touches_the_oracle():
     """The product path must not import, link or dlopen anything under oracle/."""
     pkg = os.path.join(ROOT, "stochqn_amd")

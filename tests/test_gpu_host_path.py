@@ -253,6 +253,64 @@ def test_the_library_pins_nothing_behind_the_callers_back(hip_backend):
     lib.stochqn_hip_release_all()
 
 
+def test_host_arrays_handed_out_by_the_library_are_pinned_and_carry_a_whole_run(hip_backend, oracle_backend):
+    """stochqn_hip_alloc_host: the supported way for a caller that does not control its allocator (R, numpy, jemalloc ...) to get
+    x / grad / hess_vec / x_sum / x_avg_prev that the pinning rule always accepts.  The arrays come back pinned, a 40-call SQN run
+    over them (structs rebuilt on the stack every call, *req read on the host: reference src/Rwrapper.c:106-123) matches the oracle
+    at 1e-10, and stochqn_hip_free_host takes every pin with it."""
+    from stochqn_amd import _abi
+    lib = _lib()
+    lib.stochqn_hip_alloc_host.restype = C.c_void_p
+    lib.stochqn_hip_alloc_host.argtypes = [C.c_size_t, C.POINTER(C.c_int)]
+    lib.stochqn_hip_free_host.argtypes = [C.c_void_p, C.c_size_t]
+    lib.stochqn_hip_stat.argtypes = [C.c_char_p]
+    lib.stochqn_hip_stat.restype = C.c_longlong
+    n, m, L, calls = 3_000_001, 4, 3, 40
+    live0 = lib.stochqn_hip_stat(b"host_pins_live")
+    ptrs = []
+
+    def lib_array(count):
+        pinned = C.c_int(0)
+        p = lib.stochqn_hip_alloc_host(8 * count, C.byref(pinned))
+        assert p and pinned.value == 1
+        ptrs.append((p, 8 * count))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), (count,))
+
+    d = 0.5 + np.random.default_rng(2).random(n)
+    x0 = 1.0 + np.random.default_rng(3).random(n)
+
+    def run(backend, alloc):
+        S, Y = np.zeros(m * n), np.zeros(m * n)
+        x, grad, hv, x_sum, x_avg_prev = (alloc(n) for _ in range(5))
+        x[:] = x0
+        rho, alpha, dummy = np.zeros(m), np.zeros(m), np.zeros(1)
+        b = _abi.bfgs_mem(S.ctypes.data, Y.ctypes.data, rho.ctypes.data, alpha.ctypes.data, dummy.ctypes.data, dummy.ctypes.data, m, 0, 0, L, 0.0, 0.0)
+        w = _abi.workspace_SQN(C.pointer(b), dummy.ctypes.data, x_sum.ctypes.data, x_avg_prev.ctypes.data, 0, 0, 0, 1, 1, n)
+        req, req_vec, task, info = C.c_void_p(x.ctypes.data), C.c_void_p(), C.c_int(101), C.c_int(200)
+        view = lambda p: np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), (n,))
+        log = []
+        for _ in range(calls):
+            if task.value == 104:
+                np.multiply(d, view(req_vec.value), out=hv)
+            else:
+                np.multiply(d, view(req.value), out=grad)
+            rc = backend.run_SQN(0.05, x.ctypes.data, grad.ctypes.data, hv.ctypes.data, C.byref(req), C.byref(req_vec), C.byref(task), C.byref(w), C.byref(info))
+            assert rc in (0, 1)
+            log.append((rc, task.value, info.value, w.niter, w.section, b.mem_used, b.mem_st_ix))
+        out = x.copy()
+        if backend is hip_backend:
+            lib.stochqn_hip_release(C.c_void_p(S.ctypes.data))
+        return out, log
+
+    want, log_w = run(oracle_backend, lambda k: np.zeros(k))
+    got, log_g = run(hip_backend, lib_array)
+    assert log_g == log_w and rel_err(got, want) <= 1e-10
+    assert lib.stochqn_hip_stat(b"host_pins_live") == live0 + 5
+    for p, nbytes in ptrs:
+        assert lib.stochqn_hip_free_host(p, nbytes) == 0
+    assert lib.stochqn_hip_stat(b"host_pins_live") == live0
+
+
 def test_x_edited_by_the_caller_between_calls_is_seen(hip_backend, oracle_backend):
     """The skipped upload must not turn x into the library's private variable: a caller that rescales / projects x between
     two calls gets its x used.  (The reference forbids touching *req -- include/stochqn.h:364-366 -- which is x after an

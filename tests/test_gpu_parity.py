@@ -858,11 +858,12 @@ def test_steps_match_the_oracle_at_full_size(optname, n, kw, iters, step, tol, h
 
 def test_adaqn_trajectory_at_full_size_in_lockstep_with_the_oracle(hip_backend, oracle_backend):
     """A whole adaQN trajectory at the C4 size (n = 1e8, m = 20, Fisher pairs, RMSProp diagonal) held to the oracle at
-    1e-10.  adaQN's Fisher pairs amplify last-bit differences ~10x per call, so a free-running comparison can only be held
-    to 1e-7 (FREE_RUN_TOL); here the device state is put back on the oracle's every K = 5 iterations -- x, G, H0, the
+    1e-10.  adaQN's Fisher pairs can amplify last-bit differences (FREE_RUN_TOL above: up to 1e-7 between two summation orders
+    of the ORACLE on one of the small configurations); here the device state is put back on the oracle's every K = 5 iterations -- x, G, H0, the
     averages and the rows of S, Y and F written since the last sync: n-vectors, not the rings -- so the amplification cannot
     accumulate, and at every sync point x, G, H0 and those rows are compared at the north-star tolerance.  A second device
-    optimiser runs free beside them and ends within 1e-7 of the oracle (the old assertion).  22 iterations: the ring of 20
+    optimiser runs free beside them and ends within 1e-10 of the oracle too (measured 3.3e-16: over these 22 iterations nothing is
+    amplified yet; until round 6 the bar was 1e-7).  22 iterations: the ring of 20
     fills and wraps, the Fisher ring of 16 wraps.  Reference: src/stochqn.c:1170-1239 (the step), :936-952 (the pair)."""
     import stochqn_amd
     torch = torch_cuda()
@@ -944,7 +945,7 @@ def test_adaqn_trajectory_at_full_size_in_lockstep_with_the_oracle(hip_backend, 
         close("the final x", x_lock, x_ref)
         x_ref_d = to_dev(x_ref)
         e_free = float(torch.linalg.vector_norm(x_free - x_ref_d) / torch.linalg.vector_norm(x_ref_d))
-        assert e_free <= 1e-7, e_free                                        # free-running: FREE_RUN_TOL
+        assert e_free <= TOL, e_free                                         # free-running over these 22 iterations: measured 3.3e-16 (round 6), held to 1e-10 (was 1e-7)
         assert rel_err(x_ref, x0_h) > 1e-4                                   # and the run went somewhere
         print("adaQN at n = 1e8 in lock-step every %d iterations: worst relative error of x / G / H0 / F at a sync point %.2e; free-running %.2e" % (K, worst, e_free))
     finally:
@@ -955,9 +956,11 @@ def test_adaqn_trajectory_at_full_size_in_lockstep_with_the_oracle(hip_backend, 
 @pytest.mark.parametrize("optname,kw,iters,step,tol", [
     ("SQN", dict(mem_size=20, bfgs_upd_freq=1, min_curvature=None), 30, 0.05, TOL),
     ("oLBFGS", dict(mem_size=20, min_curvature=None), 30, 0.05, TOL),
-    # adaQN's Fisher pairs make the free-running trajectory amplify last-bit differences (FREE_RUN_TOL above)
+    # adaQN's Fisher pairs make the free-running trajectory amplify last-bit differences: after these 26 iterations at n = 1e8 two
+    # summation orders of the ORACLE's dot products end 1.2e-9 apart (profiles/r06_oracle_vs_oracle_sensitivity.json:
+    # full_size_n_1e8), the two forms on the device 2.8e-9: held to 2e-8 (was 1e-7)
     ("adaQN", dict(mem_size=20, fisher_size=16, bfgs_upd_freq=1, max_incr=None, min_curvature=None, rmsprop_weight=0.9),
-     26, 0.002, 1e-7),
+     26, 0.002, 2e-8),
 ])
 def test_full_size_steps_agree_between_the_two_forms(optname, kw, iters, step, tol, hip_backend):
     """n = 1e8, m = 20 (BASELINE size), whole optimiser steps: the three-pass form and the chain of
@@ -1001,6 +1004,7 @@ def test_full_size_steps_agree_between_the_two_forms(optname, kw, iters, step, t
     assert la == lb
     assert la[-1][3] == 20                                     # the ring did fill up
     err = float(torch.linalg.norm(xa - xb) / torch.linalg.norm(xb))
+    print("%s at n = 1e8, %d iterations: the two forms of the recursion end %.2e apart (held to %.1e)" % (optname, iters, err, tol))
     assert err <= tol, err
     assert float(torch.linalg.norm(xa - x0) / torch.linalg.norm(x0)) > 1e-4     # and the run went somewhere
 

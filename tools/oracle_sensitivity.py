@@ -80,7 +80,40 @@ def sensitivity(name, seed=7):
     return out
 
 
+def full_size(n=100_000_000, calls=27):
+    """The C4-shaped instance at n = 1e8 itself: 26 iterations (the length of test_full_size_steps_agree_between_the_two_forms'
+    adaQN case), the oracle's default order against 4 interleaved partial sums.  ~60 GB of host memory, minutes on 16 cores:
+    run where there is room (the GPU box), not in the test suite."""
+    optname, kw, step, _ = CONFIGS["c4_lockstep_instance"]
+    oracle.set_threads(oracle.usable_cpus())
+    rng = np.random.default_rng(99)
+    d = 0.5 + rng.random(n)
+    dn = [d * (1 + 0.01 * (2 * rng.random(n) - 1)) for _ in range(2)]
+    x0 = 1 + rng.random(n)
+    xs = {}
+    for lanes in (8, 4):
+        oracle.cdll().oracle_set_lanes(lanes)
+        opt = OPTIMIZERS[optname](backend=oracle.bound(), space="host", **kw)
+        x, t = x0.copy(), 0
+        for _ in range(calls):
+            r = opt.run_optimizer(x, step)
+            assert r["task"] == "calc_grad"
+            np.multiply(dn[t % 2], r["requested_on"], out=opt.gradient)
+            t += 1
+        xs[lanes] = (x, opt.niter, opt.BFGS_mem.mem_used)
+        sys.stderr.write("n = %g, lanes %d: %d iterations done\n" % (n, lanes, opt.niter))
+    oracle.cdll().oracle_set_lanes(8)
+    (xa, ia, ma), (xb, ib, mb) = xs[8], xs[4]
+    return {"config": "c4_lockstep_instance", "n": n, "variant": "lanes4", "calls": calls, "iterations": ia,
+            "discrete_outputs_identical": bool(ia == ib and ma == mb), "final_rel_err": rel_err(xb, xa),
+            "moved": rel_err(xa, x0)}
+
+
 if __name__ == "__main__":
+    if sys.argv[1:2] == ["full_size"]:
+        json.dump(full_size(int(float(sys.argv[2])) if len(sys.argv) > 2 else 100_000_000), sys.stdout)
+        sys.stdout.write("\n")
+        sys.exit(0)
     which = sys.argv[1:] or list(CONFIGS)
     oracle.set_threads(2)
     res = []
