@@ -70,6 +70,26 @@ def test_committed_profiles_carry_the_contract():
     assert d["forms"]["three_pass"] == d["steps"] and d["host_caller"]["strict_grad_0"]["ms_per_step"] < 60
 
 
+def test_this_rounds_default_run_carries_the_contract_and_the_budget():
+    """`python bench.py` as the driver starts it, round 6 (profiles/r06_bench_default_run_session3.json): the contract's keys, the two
+    objects (`roofline` with counted traffic, `cpu_baseline` with the BLAS figure beside the port), and what the budget saw."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_default_run_session3.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "legs_skipped", "budget"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["degraded"] is False and d["legs_skipped"] == []
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.7 < r["frac"] < 1.0
+    assert "counted in this run" in r["traffic_source"] and abs(r["traffic_over_algorithmic"] - 1) < 0.01
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["omp"]["placement"]["chosen"] in ("packed", "spread")
+    assert c["blas"]["kind"] == "openblas" and c["blas"]["value"] > 0 and "OpenBLAS" in c["blas"]["config"]
+    b = d["budget"]
+    assert b["budget_s"] == 420.0 and b["used_s"] < b["budget_s"] and b["skipped"] == []
+    assert {"profile", "cpu_baseline", "host_caller", "live_pmc"} <= set(b["leg_seconds"])
+    assert d["forms"]["three_pass"] == d["steps"] and d["config"]["rejected_steps"] == 0
+
+
 def _walk(node, path, out):
     if isinstance(node, dict):
         out.append((path, node))
