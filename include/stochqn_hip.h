@@ -117,6 +117,8 @@ int stochqn_hip_free_host(void *p, size_t bytes);
  *                            used for m > 48 and for ill-conditioned pairs, "kappa_max").  (Round 1's two-pass form -- [S;Y]g,
  *                            a recursion over Gram blocks, one combine pass: (4m+3)n words -- was retired in round 4 together
  *                            with its options: the three-pass form dominated it on bytes, time and accuracy.)
+ * "sdot_tile" (default 2)    pass 1 with a single probe over at most 24 rows: adjacent column tiles a workgroup takes per iteration
+ *                            (1 or 2: with 2 a lane holds the packs p and p + 256 of every row)
  * "rows_split", "sdot_per_cu", "sdot2_per_cu", "qdot_per_cu", "sadd_per_cu", "pair_per_cu": kernel-shape knobs (rows of pass 1 split over the
  *                            waves of a workgroup; grid sizes in workgroups per compute unit); the defaults are the measured
  *                            optima, DESIGN.md 3.0.  With "phase_ticks" on, passes 2 and 3 (and the second Fisher pass) hold
@@ -190,6 +192,7 @@ int stochqn_hip_free_host(void *p, size_t bytes);
  * "fisher_split" (default 1) Fisher pass 1 (t = F s) with the rows divided among the waves of a workgroup: s is read once per
  *                            128 rows; 0 = every lane accumulates "fisher_rows" rows (s re-read once per group)
  * "fisher_split_per_cu" (default 0 = as many as fit, at most 4) workgroups per CU of that kernel
+ * "fisher_tile" (default 2)  column tiles of 64 packs such a workgroup takes per trip (1 or 2)
  * "fisher_lag" (default 8)   its waves meet at a workgroup barrier every this many column tiles (0 = never)
  * "fisher_rows" (default 16) with "fisher_split" = 0: Fisher rows one workgroup accumulates per pass (8, 16, 32)
  * "verify_cache" (default 0) see "contract for callers that pass DEVICE pointers"

@@ -782,7 +782,10 @@ __global__ void __launch_bounds__(kBlock) k_fisher_t(const real* F, size_t ld_, 
 // reaches every barrier), which bounds how long a line of s has to survive in L2.  Same row-major gemv as reference
 // src/stochqn.c:946 (t = F s), another association of the sums than k_fisher_t (lanes own other columns): parity is held
 // against the oracle at north_star's tolerance, not against the other kernel's bits.
-template <int W, int RPW, bool NT, int NW>
+// U: column tiles of 64 packs a workgroup takes per trip (option "fisher_tile", default 2): with U = 2 a wave reads 2 KB of every row
+// of its share back to back (2 x RPW row packs in flight per lane): 15.67 against 16.19 - 16.28 ms at fu = 128, n = 1e8
+// (profiles/r06_c4_ab_fisher_tile.jsonl).
+template <int W, int RPW, bool NT, int NW, int U>
 __global__ void __launch_bounds__(64 * NW) k_fisher_t_split(const real* F, size_t ld_, uint32_t n, uint32_t fu, const real* s, double* parts, uint32_t lag)
 {
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -791,23 +794,36 @@ __global__ void __launch_bounds__(64 * NW) k_fisher_t_split(const real* F, size_
 	double acc[RPW];
 	#pragma unroll
 	for (int j = 0; j < RPW; j++) acc[j] = 0;
-	const uint32_t packs = n / W, stride = gridDim.x * 64, first = blockIdx.x * 64;
+	const uint32_t packs = n / W, stride = gridDim.x * (uint32_t) (64 * U), first = blockIdx.x * (uint32_t) (64 * U);
 	const uint32_t trips = first < packs ? (packs - first + stride - 1) / stride : 0u;      // the same for every wave of the workgroup
 	const real* Fg = F + (size_t) row0 * ld_;
 	for (uint32_t it = 0; it < trips; it++) {
-		const uint32_t p = first + it * stride + (uint32_t) lane;
-		if (p < packs && nrows) {
-			const Pack<W> sv = ld<W, false>(s, p * W);
-			RPack<W> f[RPW];
+		const uint32_t p0 = first + it * stride + (uint32_t) lane;
+		if (nrows) {
+			Pack<W> sv[U];
+			RPack<W> f[U][RPW];
 			#pragma unroll
-			for (int j = 0; j < RPW; j++)
-				if ((uint32_t) j < nrows) f[j] = ldr<W, NT>(Fg + (size_t) j * ld_, p * W);
-			#pragma unroll
-			for (int j = 0; j < RPW; j++)
-				if ((uint32_t) j < nrows) {
+			for (int u = 0; u < U; u++) {
+				const uint32_t p = p0 + (uint32_t) (64 * u);
+				if (p < packs) {
+					sv[u] = ld<W, false>(s, p * W);
 					#pragma unroll
-					for (int e = 0; e < W; e++) acc[j] = fma((double) f[j].v[e], sv.v[e], acc[j]);
+					for (int j = 0; j < RPW; j++)
+						if ((uint32_t) j < nrows) f[u][j] = ldr<W, NT>(Fg + (size_t) j * ld_, p * W);
 				}
+			}
+			#pragma unroll
+			for (int u = 0; u < U; u++) {
+				const uint32_t p = p0 + (uint32_t) (64 * u);
+				if (p < packs) {
+					#pragma unroll
+					for (int j = 0; j < RPW; j++)
+						if ((uint32_t) j < nrows) {
+							#pragma unroll
+							for (int e = 0; e < W; e++) acc[j] = fma((double) f[u][j].v[e], sv[u].v[e], acc[j]);
+						}
+				}
+			}
 		}
 		if (lag && (it % lag) == lag - 1) __syncthreads();
 	}
@@ -915,42 +931,58 @@ struct Slice {
 
 // SL = false is the pass as one launch (the slice argument is ignored: the device-resident path keeps its register budget --
 // 145 VGPRs and three waves per SIMD for the two-probe variant against 203 and two with the carry code in)
-template <int W, int NG, bool NT, int NPR, bool SL>
+// U (round 6): adjacent column tiles a workgroup takes per iteration.  With U = 2 a lane holds the packs p and p + kBlock of every
+// row: 8 KB of a row per workgroup and iteration instead of 4, 2 x (k + 1) loads in flight per lane -- the read-only pass 1 then
+// streams 3 - 4 % faster (2.48 - 2.53 against 2.59 - 2.69 ms at n = 1e8, k = 20, interleaved; 0.87 of the HBM peak on the bare shape:
+// profiles/src/tune17.hip), where the passes that also store gain nothing, nor does the two-probe variant (fewer registers left: 0.2205
+// against 0.2003 ms at the C2 shape).  A lane adds its terms in the order of the traversal (tile 0, then tile 1), slices are whole
+// rounds of grid x kBlock x U packs, so a sliced pass is still bit-identical to the unsliced one.
+template <int W, int NG, bool NT, int NPR, bool SL, int U>
 __global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, Probes pr, real* copy_out, uint32_t n, int rev,
                                                          double* parts, Slice sl)
 {
 	__shared__ double sh[NPR * NG * 8 * kWaves];
 	double acc[NPR][NG * 8];
-	const uint32_t packs = n / W, stride = gridDim.x * kBlock, last = packs - 1;
-	const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t packs = n / W, lanes = gridDim.x * kBlock, stride = lanes * (uint32_t) U, last = packs - 1;
+	const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;                      // this lane among the lanes of the grid (carry slot)
+	const uint32_t first = blockIdx.x * (uint32_t) (kBlock * U) + threadIdx.x;     // its first pack of a round
 	#pragma unroll
 	for (int q = 0; q < NPR; q++)
 		#pragma unroll
 		for (int j = 0; j < NG * 8; j++) {
-			if constexpr (SL) acc[q][j] = (!sl.first && j < rs.count) ? sl.carry[(size_t) (q * rs.count + j) * stride + gtid] : 0.0;
+			if constexpr (SL) acc[q][j] = (!sl.first && j < rs.count) ? sl.carry[(size_t) (q * rs.count + j) * lanes + gtid] : 0.0;
 			else acc[q][j] = 0;
 		}
 	const uint32_t p_end = SL ? sl.p_end : packs;
-	for (uint32_t p = (SL ? sl.p_begin : 0u) + gtid; p < p_end; p += stride) {
-		const uint32_t i = (rev ? last - p : p) * W;
-		Pack<W> pv[NPR];
+	for (uint32_t p0 = (SL ? sl.p_begin : 0u) + first; p0 < p_end; p0 += stride) {
+		Pack<W> pv[U][NPR];
+		RPack<W> f[U][NG * 8];
 		#pragma unroll
-		for (int q = 0; q < NPR; q++) pv[q] = ld<W, false>(pr.p[q], i);
-		if (copy_out) st<W>(copy_out, i, pv[0]);
+		for (int t = 0; t < U; t++) {
+			const uint32_t p = p0 + (uint32_t) (t * kBlock);
+			if (U == 1 || p < p_end) {
+				const uint32_t i = (rev ? last - p : p) * W;
+				#pragma unroll
+				for (int q = 0; q < NPR; q++) pv[t][q] = ld<W, false>(pr.p[q], i);
+				if (copy_out) st<W>(copy_out, i, pv[t][0]);
+				#pragma unroll
+				for (int j = 0; j < NG * 8; j++)
+					if (j < rs.count) f[t][j] = ldr<W, NT>(rs.row[j], i);
+			}
+		}
 		#pragma unroll
-		for (int g = 0; g < NG; g++) {
-			RPack<W> f[8];
-			#pragma unroll
-			for (int u = 0; u < 8; u++)
-				if (g * 8 + u < rs.count) f[u] = ldr<W, NT>(rs.row[g * 8 + u], i);
-			#pragma unroll
-			for (int u = 0; u < 8; u++)
-				if (g * 8 + u < rs.count) {
-					#pragma unroll
-					for (int q = 0; q < NPR; q++)
+		for (int t = 0; t < U; t++) {
+			const uint32_t p = p0 + (uint32_t) (t * kBlock);
+			if (U == 1 || p < p_end) {
+				#pragma unroll
+				for (int j = 0; j < NG * 8; j++)
+					if (j < rs.count) {
 						#pragma unroll
-						for (int k = 0; k < W; k++) acc[q][g * 8 + u] = fma((double) f[u].v[k], pv[q].v[k], acc[q][g * 8 + u]);
-				}
+						for (int q = 0; q < NPR; q++)
+							#pragma unroll
+							for (int k = 0; k < W; k++) acc[q][j] = fma((double) f[t][j].v[k], pv[t][q].v[k], acc[q][j]);
+					}
+			}
 		}
 	}
 	if constexpr (SL) {
@@ -959,7 +991,7 @@ __global__ void __launch_bounds__(kBlock) k_rows_dot_all(RowSet rs, Probes pr, r
 			for (int q = 0; q < NPR; q++)
 				#pragma unroll
 				for (int j = 0; j < NG * 8; j++)
-					if (j < rs.count) sl.carry[(size_t) (q * rs.count + j) * stride + gtid] = acc[q][j];
+					if (j < rs.count) sl.carry[(size_t) (q * rs.count + j) * lanes + gtid] = acc[q][j];
 			return;
 		}
 	}
@@ -1605,23 +1637,23 @@ Partials launch_dots3(const Scratch& sc, int buf, size_t n, const real* s, const
 }
 
 // grid of the row-split Fisher pass: a whole number of resident rounds (register-limited, like the row-split rows-dot kernel)
-template <int W, int RPW>
+template <int W, int RPW, int U>
 static int fisher_split_launch(const Scratch& sc, size_t n, const real* F, size_t fu, const real* s)
 {
 	constexpr int NW = 8;
 	static const int per_cu = [] {
 		int blocks = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_fisher_t_split<W, RPW, true, NW>, 64 * NW, 0) != hipSuccess || blocks < 1) { (void) hipGetLastError(); blocks = 1; }
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_fisher_t_split<W, RPW, true, NW, U>, 64 * NW, 0) != hipSuccess || blocks < 1) { (void) hipGetLastError(); blocks = 1; }
 		return blocks > 4 ? 4 : blocks;
 	}();
 	const int want = sc.fisher_split_per_cu > 0 ? sc.fisher_split_per_cu : per_cu;
 	size_t g = (size_t) sc.grid_cap * (size_t) want;
-	const size_t max_grid = (n / W + 63) / 64;           // one workgroup covers 64 packs per step
+	const size_t max_grid = (n / W + (size_t) (64 * U) - 1) / (size_t) (64 * U);      // one workgroup covers 64 * U packs per trip
 	if (g > max_grid) g = max_grid;
 	if (g > (size_t) kMaxGrid) g = kMaxGrid;
 	if (g < 1) g = 1;
 	const dim3 grid((unsigned) g, (unsigned) ((fu + (size_t) (NW * RPW) - 1) / (size_t) (NW * RPW)));
-	hipLaunchKernelGGL((k_fisher_t_split<W, RPW, true, NW>), grid, dim3(64 * NW), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part, (uint32_t) (sc.fisher_lag < 0 ? 0 : sc.fisher_lag));
+	hipLaunchKernelGGL((k_fisher_t_split<W, RPW, true, NW, U>), grid, dim3(64 * NW), 0, sc.stream, F, n, (uint32_t) n, (uint32_t) fu, s, sc.fisher_part, (uint32_t) (sc.fisher_lag < 0 ? 0 : sc.fisher_lag));
 	return (int) g;
 }
 
@@ -1634,9 +1666,10 @@ Partials launch_fisher(const Scratch& sc, int buf, size_t n, const real* F, size
 	if (sc.fisher_split) {
 		// pass 1 with the rows divided among the waves of a workgroup: s once per 128 rows (k_fisher_t_split)
 		ProfScope ps(sc, K_FISHER_T);
-		#define SQN_FS(WW) (fu <= 16 ? fisher_split_launch<WW, 2>(sc, n, F, fu, s) : fu <= 32 ? fisher_split_launch<WW, 4>(sc, n, F, fu, s) : \
-		                    fu <= 64 ? fisher_split_launch<WW, 8>(sc, n, F, fu, s) : fisher_split_launch<WW, 16>(sc, n, F, fu, s))
-		grid_t = vec ? SQN_FS(kVec) : SQN_FS(1);
+		#define SQN_FS(WW, UU) (fu <= 16 ? fisher_split_launch<WW, 2, UU>(sc, n, F, fu, s) : fu <= 32 ? fisher_split_launch<WW, 4, UU>(sc, n, F, fu, s) : \
+		                        fu <= 64 ? fisher_split_launch<WW, 8, UU>(sc, n, F, fu, s) : fisher_split_launch<WW, 16, UU>(sc, n, F, fu, s))
+		if (sc.fisher_tile >= 2) grid_t = vec ? SQN_FS(kVec, 2) : SQN_FS(1, 2);
+		else                     grid_t = vec ? SQN_FS(kVec, 1) : SQN_FS(1, 1);
 		#undef SQN_FS
 	} else {
 		// rows one workgroup accumulates per pass over its columns: s is re-read once per group of rows (fu = 128:
@@ -1704,13 +1737,30 @@ static int rows_dot_dispatch(const Scratch& sc, size_t max_grid, int rpw, const 
 	return grid;
 }
 
+// column tiles per iteration of the all-rows pass: two for the single-probe pass over at most 24 rows (option "sdot_tile", default 2:
+// the registers of 2 x 24 row packs fit the one wave per SIMD the pass runs with), one otherwise
+static int sdot_tiles(const Scratch& sc, int ng, bool two_probes)
+{
+	return (!two_probes && ng <= 3 && sc.sdot_tile >= 2) ? 2 : 1;
+}
+
 template <int W, int NPR>
 static void rows_dot_all_dispatch(const Scratch& sc, int slot, int grid, int ng, const RowSet& rows, const Probes& probe,
                                   real* copy_out, uint32_t n, int rev, const Slice* slice = nullptr)
 {
 	const Slice sl = slice ? *slice : Slice{0u, n / (uint32_t) W, nullptr, 1, 1};
-	#define SQN_RA(NG) { if (slice) hipLaunchKernelGGL((k_rows_dot_all<W, NG, true, NPR, true>), dim3(grid), dim3(kBlock), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[slot], sl); \
-	                     else hipLaunchKernelGGL((k_rows_dot_all<W, NG, true, NPR, false>), dim3(grid), dim3(kBlock), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[slot], sl); }
+	#define SQN_RA_U(NG, UU) { if (slice) hipLaunchKernelGGL((k_rows_dot_all<W, NG, true, NPR, true, UU>), dim3(grid), dim3(kBlock), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[slot], sl); \
+	                           else hipLaunchKernelGGL((k_rows_dot_all<W, NG, true, NPR, false, UU>), dim3(grid), dim3(kBlock), 0, sc.stream, rows, probe, copy_out, n, rev, sc.rows_part[slot], sl); }
+	#define SQN_RA(NG) SQN_RA_U(NG, 1)
+	if constexpr (NPR == 1) {
+		if (sdot_tiles(sc, ng, false) == 2) {
+			switch (ng) {
+			case 1: SQN_RA_U(1, 2); return;
+			case 2: SQN_RA_U(2, 2); return;
+			default: SQN_RA_U(3, 2); return;
+			}
+		}
+	}
 	switch (ng) {
 	case 1: SQN_RA(1); break;
 	case 2: SQN_RA(2); break;
@@ -1720,6 +1770,7 @@ static void rows_dot_all_dispatch(const Scratch& sc, int slot, int grid, int ng,
 	default: SQN_RA(6); break;
 	}
 	#undef SQN_RA
+	#undef SQN_RA_U
 }
 
 // pass 1 without a second probe as the row-split kernel (option "rows_split": the float build's default); one launch, never sliced.
@@ -1764,12 +1815,12 @@ Partials launch_sdot(const Scratch& sc, size_t n, const RowSet& s_rows, const re
 	const int rev = (sc.reverse && sc.phase) ? ((*sc.phase)++ & 1) : 0;
 	const Probes pr{{g, probe_y}};
 	const int ng = (s_rows.count + 7) / 8;
-	const size_t packs = n / kVec, round = (size_t) grid * kBlock;
+	const size_t packs = n / kVec, round = (size_t) grid * kBlock * (size_t) sdot_tiles(sc, ng, probe_y != nullptr);
 	if (!probe_y && sc.rows_split) {
 		if (feed) feed->arrive(feed->user, 0, n, 0);
 		grid = sdot_row_split(sc, n, s_rows, g, copy_out, rev);
 	} else if (feed && vec && feed->slices >= 2 && packs >= 2 * round && feed->carry &&
-	           feed->carry_count >= (size_t) (probe_y ? 2 : 1) * (size_t) s_rows.count * round) {
+	           feed->carry_count >= (size_t) (probe_y ? 2 : 1) * (size_t) s_rows.count * (size_t) grid * kBlock) {      // one accumulator per quantity and LANE
 		// the pass in slices of whole grid rounds; before slice s its part of g is sent for (feed->arrive), and the kernel of
 		// that slice is what the stream runs once it has landed
 		size_t per = (packs + (size_t) feed->slices - 1) / (size_t) feed->slices;

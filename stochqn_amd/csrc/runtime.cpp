@@ -515,10 +515,12 @@ void begin_call(DevCtx* c)
 	c->sc.fisher_split = g_opt.fisher_split;
 	c->sc.fisher_split_per_cu = g_opt.fisher_split_per_cu;
 	c->sc.fisher_lag = g_opt.fisher_lag;
+	c->sc.fisher_tile = g_opt.fisher_tile;
 	c->sc.phase_inv = g_opt.phase_ticks > 0 ? (uint32_t) (4294967296.0 / (double) g_opt.phase_ticks) : 0u;
 	c->sc.keep_tail = g_opt.keep_tail;
 	c->sc.qdot_per_cu = g_opt.qdot_per_cu; c->sc.sadd_per_cu = g_opt.sadd_per_cu; c->sc.sdot2_per_cu = g_opt.sdot2_per_cu; c->sc.sdot_per_cu = g_opt.sdot_per_cu;
 	c->sc.pair_per_cu = g_opt.pair_per_cu;
+	c->sc.sdot_tile = g_opt.sdot_tile;
 	c->sc.prof = g_profile ? &c->prof : nullptr;
 	c->sc.phase = &c->phase;
 	c->phase = 1;
@@ -1594,6 +1596,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "rows_split")) g_opt.rows_split = value != 0;
 	else if (!std::strcmp(name, "fisher_rows")) g_opt.fisher_rows = (int) value;
 	else if (!std::strcmp(name, "fisher_split")) g_opt.fisher_split = value != 0;
+	else if (!std::strcmp(name, "fisher_tile")) g_opt.fisher_tile = value >= 2 ? 2 : 1;
 	else if (!std::strcmp(name, "fisher_lag")) g_opt.fisher_lag = value < 0 ? 0 : (value > 1e6 ? 1000000 : (int) value);
 	else if (!std::strcmp(name, "fisher_split_per_cu")) g_opt.fisher_split_per_cu = value < 0 ? 0 : (value > 8 ? 8 : (int) value);
 	// 0 = off; otherwise at least 64 ticks (640 ns): the kernels multiply 2^32 / ticks by the number of output streams of the pass
@@ -1603,6 +1606,7 @@ int stochqn_hip_set_option(const char* name, double value)
 	else if (!std::strcmp(name, "x_prefetch")) g_opt.x_prefetch = value != 0;
 	else if (!std::strcmp(name, "keep_tail")) g_opt.keep_tail = value < 0 ? 0 : (value > 1 ? 1 : value);
 	else if (!std::strcmp(name, "qdot_per_cu")) g_opt.qdot_per_cu = (int) value;
+	else if (!std::strcmp(name, "sdot_tile")) g_opt.sdot_tile = value >= 2 ? 2 : 1;
 	else if (!std::strcmp(name, "pair_per_cu")) g_opt.pair_per_cu = value < 0 ? 0 : (value > 8 ? 8 : (int) value);
 	else if (!std::strcmp(name, "sadd_per_cu")) g_opt.sadd_per_cu = (int) value;
 	else if (!std::strcmp(name, "sdot2_per_cu")) g_opt.sdot2_per_cu = (int) value;

@@ -38,8 +38,10 @@ struct Options {
 	// HBM once per 128 rows instead of once per 16 (kernels.hip: k_fisher_t_split; PMC 103.2 GB against 108.8 GB at fu = 128)
 	bool fisher_split = true;
 	int fisher_split_per_cu = 0;
+	int fisher_tile = 2;         // column tiles of 64 packs per trip of such a workgroup (1 or 2): 2 KB of every row back to back, 15.67 against 16.2 ms at fu = 128
 	int fisher_lag = 8;          // the waves of such a workgroup meet at a barrier every this many column tiles (0 = never): how long a line of s must survive in L2
 	int qdot_per_cu = 0, sadd_per_cu = 0, sdot2_per_cu = 0, sdot_per_cu = 0;
+	int sdot_tile = 2;           // pass 1 with one probe over <= 24 rows takes two adjacent column tiles per iteration (8 KB of a row per workgroup): 3 - 4 % faster
 	int pair_per_cu = 0;         // workgroups per CU of the pair kernels (0 = 1)
 	// three-pass form: fraction of r0 / r stored with the default (cacheable) policy -- the part the next pass, which walks
 	// the other way, reads first; the rest leaves with sc1 nt.  Rounds 2 - 3 (every pack stored at once): 0.25-0.5 measured 1 % ahead

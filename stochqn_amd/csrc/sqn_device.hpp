@@ -107,8 +107,10 @@ struct Scratch {
 	int fisher_rows;      // Fisher rows one workgroup accumulates per pass over its columns: 8, 16 or 32 (the all-rows-per-lane kernel: fisher_split = 0)
 	bool fisher_split;    // Fisher pass 1 with the rows divided among the 8 waves of a workgroup: s is fetched once per 128 rows (default)
 	int fisher_split_per_cu; // workgroups per CU of that kernel (0 = what the occupancy query says, at most 4)
+	int fisher_tile;      // column tiles of 64 packs such a workgroup takes per trip: 1 or 2
 	int fisher_lag;       // column tiles the waves of such a workgroup may drift apart before a barrier brings them together (0 = no barrier)
 	int qdot_per_cu, sadd_per_cu, sdot2_per_cu, sdot_per_cu;   // workgroups per CU of the three-pass kernels (0 = default)
+	int sdot_tile;        // pass 1 (single probe, <= 24 rows): adjacent column tiles a workgroup takes per iteration, 1 or 2 (kernels.hip: k_rows_dot_all U)
 	int pair_per_cu;      // workgroups per CU of the pair kernels (s, y = g - g_prev, y = Hv; 0 = default: 1)
 	double keep_tail;     // three-pass form: fraction of r0 / r (the part written last) stored with the default policy instead of sc1 nt
 	uint32_t phase_inv;   // pass 2 / pass 3: 2^32 / (ticks of the 100 MHz clock per store phase), 0 = every pack stored at once (kernels.hip: Parked)
