@@ -1505,12 +1505,13 @@ PROFILE_N = {"c2": 10_000_000}  # problem size a configuration's committed count
 PMC_RATIO_OK = (0.97, 1.06)    # bytes counted / algorithmic bytes outside this band: the file is not about this launch -- refuse it
 
 
-def pmc_key(kernel, m, mode=0):
+def pmc_key(kernel, m, mode=0, older=False):
     """The exact kernel instantiation (as rocprofv3 prints it, namespace stripped) a bench leg's `kernel` launches at ring size m:
-    W = 2 doubles per pack, NG = ceil(m / 8) row groups, non-temporal row loads, clock-phased stores."""
+    W = 2 doubles per pack, NG = ceil(m / 8) row groups, non-temporal row loads, clock-phased stores; pass 1 since round 6 with
+    U = 2 adjacent column tiles per iteration for rings of up to 24 pairs (`older`: its name in the profiles of rounds 2 - 5)."""
     ng = (m + 7) // 8
-    return {"bwd": "BwdOp", "fwd": "FwdOp<true, false, false>",
-            "sdot": "k_rows_dot_all<2, %d, true, 1, false>" % ng,
+    sdot = "k_rows_dot_all<2, %d, true, 1, false>" % ng if older else "k_rows_dot_all<2, %d, true, 1, false, %d>" % (ng, 2 if ng <= 3 else 1)
+    return {"bwd": "BwdOp", "fwd": "FwdOp<true, false, false>", "sdot": sdot,
             "qdot": "k_qdot<2, %d, true, %d, true>" % (ng, mode),
             "sadd": "k_sadd<2, %d, true, true, false>" % ng}.get(kernel)
 
@@ -1572,6 +1573,7 @@ def pmc_traffic(kernel, n, m, alg_bytes, config="c3", profiles_dir=None):
     key = pmc_key(kernel, m, mode)
     if key is None:
         return None, None
+    keys = [key] + ([pmc_key(kernel, m, mode, older=True)] if kernel == "sdot" else [])
     pdir = profiles_dir or os.path.join(ROOT, "profiles")
 
     def order(f):
@@ -1589,7 +1591,7 @@ def pmc_traffic(kernel, n, m, alg_bytes, config="c3", profiles_dir=None):
         except (OSError, ValueError):
             continue
         for k, v in d.items():
-            if k.replace("sqn::(anonymous namespace)::", "").replace("void ", "").startswith(key) or (kernel in ("bwd", "fwd") and key in k):
+            if k.replace("sqn::(anonymous namespace)::", "").replace("void ", "").startswith(tuple(keys)) or (kernel in ("bwd", "fwd") and key in k):
                 raw = v.get("raw", {})
                 # sdot: the same kernel also rebuilds columns of the cached block (a y row as the probe); pass 1 is the largest dispatch
                 stat = "max_KiB" if kernel == "sdot" else "median_KiB"
