@@ -71,9 +71,11 @@ def test_committed_profiles_carry_the_contract():
 
 
 def test_this_rounds_default_run_carries_the_contract_and_the_budget():
-    """`python bench.py` as the driver starts it, round 6 (profiles/r06_bench_default_run_session3.json): the contract's keys, the two
-    objects (`roofline` with counted traffic, `cpu_baseline` with the BLAS figure beside the port), and what the budget saw."""
-    d = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_default_run_session3.json")))
+    """`python3 bench.py --gpus 1 --steps 20 --warmup 5` -- the driver's own command -- with the round's final library
+    (profiles/r06_bench_driver_like_run.json): the contract's keys, the two objects (`roofline` with counted traffic, `cpu_baseline`
+    with the BLAS figure beside the port), and what the budget saw."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_driver_like_run.json")))
+    assert d["steps"] == 20 and d["warmup"] == 5
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline", "legs_skipped", "budget"):
         assert k in d, k
