@@ -575,7 +575,23 @@ def run(args):
                 if lib.stochqn_hip_comm_unique_id(buf) == 0:
                     uid = torch.tensor(list(buf) + [1], dtype=torch.uint8)
             dist.broadcast(uid, 0)
-            rc = lib.stochqn_hip_comm_init(rank, world, bytes(uid[:128].tolist())) if int(uid[128]) == 1 else -1
+            # First contact with RCCL on N > 1 ranks happens on the driver's node.  ncclCommInitRank is a rendezvous: if a peer
+            # or the fabric never answers it does not return -- and there is no result yet that a watchdog could print.  So it
+            # runs on a thread of its own and gets BENCH_RCCL_INIT_S seconds (90); a rank that has not come back by then says so,
+            # the ranks agree (MIN below) and the whole run goes over the gloo reducer instead: degraded, but a measurement.
+            box = {"rc": None}
+
+            def comm_init():
+                if os.environ.get("BENCH_TEST_RCCL_INIT_HANGS"):     # tests: an init that never returns
+                    time.sleep(1e6)
+                box["rc"] = lib.stochqn_hip_comm_init(rank, world, bytes(uid[:128].tolist())) if int(uid[128]) == 1 else -1
+            th = threading.Thread(target=comm_init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("BENCH_RCCL_INIT_S", "90")))
+            rc = box["rc"] if box["rc"] is not None else -2
+            if rc == -2:
+                sys.stderr.write("bench.py: rank %d: stochqn_hip_comm_init (ncclCommInitRank) had not returned after %s s\n"
+                                 % (rank, os.environ.get("BENCH_RCCL_INIT_S", "90")))
             if os.environ.get("BENCH_TEST_RCCL_FAILS"):              # tests: the fall-back below
                 rc = -1
             up = torch.tensor([1.0 if rc == 0 else 0.0], dtype=torch.float64)
@@ -583,7 +599,10 @@ def run(args):
             if float(up.item()) < 0.5:
                 sys.stderr.write("bench.py: rank %d: the library's RCCL communicator could not be set up (rc %d here): the reductions of this "
                                  "run go over gloo on the host instead -- three sums of a few dozen doubles per step\n" % (rank, rc))
-                lib.stochqn_hip_comm_finalize()
+                if rc != -2:                                         # (a rank whose init never returned has nothing to finalise -- and must not wait for it)
+                    fin = threading.Thread(target=lib.stochqn_hip_comm_finalize, daemon=True)
+                    fin.start()
+                    fin.join(20.0)
                 reducer = "gloo (the library's RCCL communicator could not be set up)"
         if reducer != "rccl":
             hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))   # the runtime already loaded

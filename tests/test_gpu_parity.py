@@ -1983,6 +1983,14 @@ def test_bench_falls_back_to_the_host_reducer_when_rccl_cannot_be_set_up():
                  "--no-live-pmc", "--sustain-seconds", "0"], timeout=600)
     d2 = json.loads([l for l in ok.stdout.splitlines() if l.startswith('{"metric"')][0])
     assert d2["reducer"] == "rccl" and d2["rccl_nranks"] == 1 and d2["degraded"] is False
+    # ... and when the communicator's set-up never RETURNS (ncclCommInitRank is a rendezvous: a peer or a fabric that does not answer
+    # at first contact): the init runs on a thread of its own under BENCH_RCCL_INIT_S, the ranks agree, the run goes over gloo
+    hung = _bench(["--force-dist", "--vars-per-gpu", "3000000", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-host-caller",
+                   "--no-live-pmc", "--sustain-seconds", "0"], timeout=600, env=dict(os.environ, BENCH_TEST_RCCL_INIT_HANGS="1", BENCH_RCCL_INIT_S="3"))
+    assert hung.returncode == 0, hung.stderr[-3000:]
+    d3 = json.loads([l for l in hung.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert d3["reducer"].startswith("gloo (the library") and d3["rccl_nranks"] == 0 and d3["degraded"] is True and d3["value"] > 0
+    assert "had not returned after 3 s" in hung.stderr
 
 
 def test_bench_keeps_its_primary_result_when_an_auxiliary_leg_hangs():
