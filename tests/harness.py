@@ -361,7 +361,8 @@ class library_options:
     """`with library_options(lib, x_upload=0, register_host=1): ...` -- stochqn_hip_set_option for the block, the library's
     defaults (include/stochqn_hip.h) back afterwards."""
     DEFAULTS = {"x_upload": 1.0, "x_prefetch": 0.0, "register_host": 0.0, "register_min_bytes": float(4 << 20), "spec_x": 1.0,
-                "apply_chunks": 8.0, "upload_slices": 8.0, "hash_threads": 0.0, "host_slice_min": float(1 << 21), "threepass": 1.0, "kappa_max": 1e6, "phase_ticks": 8000.0}
+                "apply_chunks": 8.0, "upload_slices": 8.0, "hash_threads": 0.0, "host_slice_min": float(1 << 21), "threepass": 1.0, "kappa_max": 1e6, "phase_ticks": 8000.0,
+                "sdot_tile": 2.0, "fisher_tile": 2.0, "fisher_split": 1.0}
 
     def __init__(self, lib, **kw):
         import ctypes as C
