@@ -26,9 +26,11 @@ struct View {
 struct Options {
 	bool nontemporal = true;
 	int grid_cap = 0;            // 0 = one workgroup per compute unit (measured optimum)
-	// pass 1 without a second probe: every lane keeps all rows (fp64: 5.1-5.2 ms; the row-split form is within
-	// +-3 % of it depending on the device) or the waves of a workgroup split the rows (fp32: 2.5 vs 5.9 ms)
-	bool rows_split = sizeof(real) == 4;
+	// pass 1 without a second probe: every lane keeps all rows (the default in both builds since round 6), or the waves of a
+	// workgroup split the rows (k_rows_dot: 1 KB of a row per workgroup and trip).  Rounds 1 - 5 used the row-split form in the float
+	// build (round 1's all-rows kernel: 5.9 against 2.5 ms); with the kernel as it is now the all-rows form is 9 % ahead there too
+	// (1.31 against 1.43 ms at n = 1e8, k = 20, interleaved: profiles/r06_f32_ab_rows_split.log)
+	bool rows_split = false;
 	bool reverse = true;
 	// 1: the three-pass form (S twice, Y once: (3k+5) n words) when the ring has <= kPairsMax3 pairs and every pair in use is
 	// tame ("kappa_max"); 0: always the reference's chain of dependent sweeps (8k n words)
