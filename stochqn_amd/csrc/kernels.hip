@@ -1261,7 +1261,15 @@ __global__ void __launch_bounds__(kBlock) k_qdot(RowSet ys, Fold3 fo, real* g, D
 		for (int j = 0; j < NG * 8; j++)
 			if (j < k) {
 				#pragma unroll
-				for (int e = 0; e < W; e++) acc[j] = fma((double) f[j].v[e], q.v[e], acc[j]);
+				for (int e = 0; e < W; e++) {
+					if constexpr (W > 2) {
+						// float build: the row value is widened AGAIN for its second use.  Left to itself the compiler keeps all 4 x k doubles
+						// of the chain above alive (256 VGPRs + 126 AGPRs of copies: pass 2 at 0.69 of peak where pass 3 runs at 0.83)
+						real fv = f[j].v[e];
+						asm volatile("" : "+v"(fv));
+						acc[j] = fma((double) fv, q.v[e], acc[j]);
+					} else acc[j] = fma((double) f[j].v[e], q.v[e], acc[j]);
+				}
 			}
 		// the part of r0 this pass writes last is what pass 3 (opposite direction) reads first: those packs are stored with
 		// the default policy so that they may still sit in the Infinity Cache, the rest streams past it (keep_from)
