@@ -396,6 +396,15 @@ class Workload:
         self.t_idx += 1
 
     def steps(self, k):
+        if os.environ.get("BENCH_STEP_TIMES"):                     # diagnostic: wall time of every step (each run_SQN is synchronous), on stderr
+            ts = []
+            for _ in range(k):
+                t0 = time.perf_counter()
+                self.one_step()
+                ts.append(round(1e3 * (time.perf_counter() - t0), 3))
+            sys.stderr.write("bench.py: %d steps, ms each: %s\n" % (k, ts))
+            self.steps_done += k
+            return
         for _ in range(k):
             self.one_step()
         self.steps_done += k
